@@ -1,0 +1,426 @@
+// Fp2 / Fp6 / Fp12 tower for BLS12-381:  Fp2 = Fp[u]/(u^2+1),  Fp6 = Fp2[v]/(v^3 - xi),  xi = 1 + u,
+// Fp12 = Fp6[w]/(w^2 - v).  An Fp12 element c0 + c1 w holds the w-power coefficients
+//   w^0 = c0.a0, w^1 = c1.a0, w^2 = c0.a1, w^3 = c1.a1, w^4 = c0.a2, w^5 = c1.a2.
+// Replaces the Fp2/Fp6/Fp12 arithmetic of the reference's un-vendored blst backend
+// (call sites: reference src/helpers.rs:44,50,56,62).
+#pragma once
+#include "fp.cuh"
+
+// ------------------------------------------------------------------ Fp2
+struct fp2 {
+  fp c0, c1;
+};
+
+BLS_FN void fp2_load(fp2& r, const uint32_t* c) {
+  fp_load(r.c0, c);
+  fp_load(r.c1, c + 12);
+}
+BLS_FN void fp2_store(uint32_t* c, const fp2& a) {
+  fp_store(c, a.c0);
+  fp_store(c + 12, a.c1);
+}
+BLS_FN void fp2_zero(fp2& r) {
+  fp_zero(r.c0);
+  fp_zero(r.c1);
+}
+BLS_FN void fp2_one(fp2& r) {
+  fp_one(r.c0);
+  fp_zero(r.c1);
+}
+BLS_FN bool fp2_is_zero(const fp2& a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1); }
+BLS_FN bool fp2_eq(const fp2& a, const fp2& b) { return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1); }
+BLS_FN void fp2_cmov(fp2& r, const fp2& a, bool c) {
+  fp_cmov(r.c0, a.c0, c);
+  fp_cmov(r.c1, a.c1, c);
+}
+BLS_FN void fp2_add(fp2& r, const fp2& a, const fp2& b) {
+  fp_add(r.c0, a.c0, b.c0);
+  fp_add(r.c1, a.c1, b.c1);
+}
+BLS_FN void fp2_sub(fp2& r, const fp2& a, const fp2& b) {
+  fp_sub(r.c0, a.c0, b.c0);
+  fp_sub(r.c1, a.c1, b.c1);
+}
+BLS_FN void fp2_neg(fp2& r, const fp2& a) {
+  fp_neg(r.c0, a.c0);
+  fp_neg(r.c1, a.c1);
+}
+BLS_FN void fp2_dbl(fp2& r, const fp2& a) {
+  fp_dbl(r.c0, a.c0);
+  fp_dbl(r.c1, a.c1);
+}
+BLS_FN void fp2_conj(fp2& r, const fp2& a) {
+  r.c0 = a.c0;
+  fp_neg(r.c1, a.c1);
+}
+// Karatsuba: 3 Fp multiplications
+BLS_NOINLINE void fp2_mul(fp2& r, const fp2& a, const fp2& b) {
+  fp t0, t1, s0, s1, m;
+  fp_mul(t0, a.c0, b.c0);
+  fp_mul(t1, a.c1, b.c1);
+  fp_add(s0, a.c0, a.c1);
+  fp_add(s1, b.c0, b.c1);
+  fp_mul(m, s0, s1);
+  fp_sub(m, m, t0);
+  fp_sub(r.c1, m, t1);
+  fp_sub(r.c0, t0, t1);
+}
+// complex squaring: 2 Fp multiplications
+BLS_NOINLINE void fp2_sqr(fp2& r, const fp2& a) {
+  fp s, d, m;
+  fp_add(s, a.c0, a.c1);
+  fp_sub(d, a.c0, a.c1);
+  fp_mul(m, a.c0, a.c1);
+  fp_mul(r.c0, s, d);
+  fp_dbl(r.c1, m);
+}
+BLS_FN void fp2_mul_fp(fp2& r, const fp2& a, const fp& k) {
+  fp_mul(r.c0, a.c0, k);
+  fp_mul(r.c1, a.c1, k);
+}
+// multiply by xi = 1 + u
+BLS_FN void fp2_mul_xi(fp2& r, const fp2& a) {
+  fp t;
+  fp_sub(t, a.c0, a.c1);
+  fp_add(r.c1, a.c0, a.c1);
+  r.c0 = t;
+}
+BLS_FN void fp2_inv(fp2& r, const fp2& a) {
+  fp n, t;
+  fp_sqr(n, a.c0);
+  fp_sqr(t, a.c1);
+  fp_add(n, n, t);
+  fp_inv(n, n);
+  fp_mul(r.c0, a.c0, n);
+  fp_mul(t, a.c1, n);
+  fp_neg(r.c1, t);
+}
+BLS_FN bool fp2_is_square(const fp2& a) {
+  fp n, t;
+  fp_sqr(n, a.c0);
+  fp_sqr(t, a.c1);
+  fp_add(n, n, t);
+  return fp_is_square(n);
+}
+// some square root (complex method); false if a is not a square.  Callers fix the sign.
+BLS_FN bool fp2_sqrt(fp2& r, const fp2& a) {
+  if (fp_is_zero(a.c1)) {
+    fp s;
+    if (fp_sqrt(s, a.c0)) {
+      r.c0 = s;
+      fp_zero(r.c1);
+      return true;
+    }
+    fp na;
+    fp_neg(na, a.c0);
+    bool ok = fp_sqrt(s, na);  // sqrt(-1) = u
+    fp_zero(r.c0);
+    r.c1 = s;
+    return ok;
+  }
+  fp n, t, half, s;
+  fp_sqr(n, a.c0);
+  fp_sqr(t, a.c1);
+  fp_add(n, n, t);
+  if (!fp_sqrt(n, n)) return false;
+  fp two;
+  fp_one(half);
+  fp_dbl(two, half);
+  fp_inv(half, two);
+  fp_add(t, a.c0, n);
+  fp_mul(t, t, half);
+  if (!fp_sqrt(s, t)) {
+    fp_sub(t, a.c0, n);
+    fp_mul(t, t, half);
+    if (!fp_sqrt(s, t)) return false;
+  }
+  fp d;
+  fp_dbl(d, s);
+  fp_inv(d, d);
+  r.c0 = s;
+  fp_mul(r.c1, a.c1, d);
+  fp2 chk;
+  fp2_sqr(chk, r);
+  return fp2_eq(chk, a);
+}
+// RFC 9380 sgn0 for m = 2
+BLS_FN uint32_t fp2_sgn0(const fp2& a) {
+  fp t0, t1;
+  fp_from_mont(t0, a.c0);
+  fp_from_mont(t1, a.c1);
+  uint32_t s0 = t0.l[0] & 1, z0 = fp_is_zero(t0) ? 1u : 0u, s1 = t1.l[0] & 1;
+  return s0 | (z0 & s1);
+}
+BLS_FN bool fp2_lex_largest(const fp2& a) {
+  if (!fp_is_zero(a.c1)) return fp_lex_largest(a.c1);
+  return fp_lex_largest(a.c0);
+}
+
+// ------------------------------------------------------------------ Fp6
+struct fp6 {
+  fp2 a0, a1, a2;
+};
+
+BLS_FN void fp6_zero(fp6& r) {
+  fp2_zero(r.a0);
+  fp2_zero(r.a1);
+  fp2_zero(r.a2);
+}
+BLS_FN void fp6_add(fp6& r, const fp6& a, const fp6& b) {
+  fp2_add(r.a0, a.a0, b.a0);
+  fp2_add(r.a1, a.a1, b.a1);
+  fp2_add(r.a2, a.a2, b.a2);
+}
+BLS_FN void fp6_sub(fp6& r, const fp6& a, const fp6& b) {
+  fp2_sub(r.a0, a.a0, b.a0);
+  fp2_sub(r.a1, a.a1, b.a1);
+  fp2_sub(r.a2, a.a2, b.a2);
+}
+BLS_FN void fp6_neg(fp6& r, const fp6& a) {
+  fp2_neg(r.a0, a.a0);
+  fp2_neg(r.a1, a.a1);
+  fp2_neg(r.a2, a.a2);
+}
+// multiply by v: (a0, a1, a2) -> (xi a2, a0, a1)
+BLS_FN void fp6_mul_v(fp6& r, const fp6& a) {
+  fp2 t;
+  fp2_mul_xi(t, a.a2);
+  r.a2 = a.a1;
+  r.a1 = a.a0;
+  r.a0 = t;
+}
+// Karatsuba: 6 Fp2 multiplications
+BLS_FN void fp6_mul(fp6& r, const fp6& a, const fp6& b) {
+  fp2 v0, v1, v2, s, t, m;
+  fp2_mul(v0, a.a0, b.a0);
+  fp2_mul(v1, a.a1, b.a1);
+  fp2_mul(v2, a.a2, b.a2);
+  fp6 o;
+  // c0 = v0 + xi((a1+a2)(b1+b2) - v1 - v2)
+  fp2_add(s, a.a1, a.a2);
+  fp2_add(t, b.a1, b.a2);
+  fp2_mul(m, s, t);
+  fp2_sub(m, m, v1);
+  fp2_sub(m, m, v2);
+  fp2_mul_xi(m, m);
+  fp2_add(o.a0, m, v0);
+  // c1 = (a0+a1)(b0+b1) - v0 - v1 + xi v2
+  fp2_add(s, a.a0, a.a1);
+  fp2_add(t, b.a0, b.a1);
+  fp2_mul(m, s, t);
+  fp2_sub(m, m, v0);
+  fp2_sub(m, m, v1);
+  fp2_mul_xi(t, v2);
+  fp2_add(o.a1, m, t);
+  // c2 = (a0+a2)(b0+b2) - v0 - v2 + v1
+  fp2_add(s, a.a0, a.a2);
+  fp2_add(t, b.a0, b.a2);
+  fp2_mul(m, s, t);
+  fp2_sub(m, m, v0);
+  fp2_sub(m, m, v2);
+  fp2_add(o.a2, m, v1);
+  r = o;
+}
+BLS_FN void fp6_inv(fp6& r, const fp6& a) {
+  fp2 t0, t1, t2, m, d;
+  fp2_sqr(t0, a.a0);
+  fp2_mul(m, a.a1, a.a2);
+  fp2_mul_xi(m, m);
+  fp2_sub(t0, t0, m);  // a0^2 - xi a1 a2
+  fp2_sqr(t1, a.a2);
+  fp2_mul_xi(t1, t1);
+  fp2_mul(m, a.a0, a.a1);
+  fp2_sub(t1, t1, m);  // xi a2^2 - a0 a1
+  fp2_sqr(t2, a.a1);
+  fp2_mul(m, a.a0, a.a2);
+  fp2_sub(t2, t2, m);  // a1^2 - a0 a2
+  fp2_mul(d, a.a0, t0);
+  fp2 e;
+  fp2_mul(m, a.a2, t1);
+  fp2_mul(e, a.a1, t2);
+  fp2_add(m, m, e);
+  fp2_mul_xi(m, m);
+  fp2_add(d, d, m);
+  fp2_inv(d, d);
+  fp2_mul(r.a0, t0, d);
+  fp2_mul(r.a1, t1, d);
+  fp2_mul(r.a2, t2, d);
+}
+
+// ------------------------------------------------------------------ Fp12
+struct fp12 {
+  fp6 c0, c1;
+};
+
+BLS_FN void fp12_one(fp12& r) {
+  fp6_zero(r.c0);
+  fp6_zero(r.c1);
+  fp2_one(r.c0.a0);
+}
+BLS_FN bool fp12_is_one(const fp12& a) {
+  fp2 one;
+  fp2_one(one);
+  return fp2_eq(a.c0.a0, one) && fp2_is_zero(a.c0.a1) && fp2_is_zero(a.c0.a2) && fp2_is_zero(a.c1.a0) &&
+         fp2_is_zero(a.c1.a1) && fp2_is_zero(a.c1.a2);
+}
+BLS_FN void fp12_conj(fp12& r, const fp12& a) {
+  r.c0 = a.c0;
+  fp6_neg(r.c1, a.c1);
+}
+// Karatsuba over Fp6: 18 Fp2 multiplications
+BLS_FN void fp12_mul(fp12& r, const fp12& a, const fp12& b) {
+  fp6 t0, t1, s, t, m;
+  fp6_mul(t0, a.c0, b.c0);
+  fp6_mul(t1, a.c1, b.c1);
+  fp6_add(s, a.c0, a.c1);
+  fp6_add(t, b.c0, b.c1);
+  fp6_mul(m, s, t);
+  fp6_sub(m, m, t0);
+  fp6_sub(r.c1, m, t1);
+  fp6_mul_v(t1, t1);
+  fp6_add(r.c0, t0, t1);
+}
+// complex squaring: 12 Fp2 multiplications
+BLS_FN void fp12_sqr(fp12& r, const fp12& a) {
+  fp6 t, s0, s1, m;
+  fp6_mul(t, a.c0, a.c1);
+  fp6_add(s0, a.c0, a.c1);
+  fp6_mul_v(s1, a.c1);
+  fp6_add(s1, s1, a.c0);
+  fp6_mul(m, s0, s1);
+  fp6_sub(m, m, t);
+  fp6_mul_v(s0, t);
+  fp6_sub(r.c0, m, s0);
+  fp6_add(r.c1, t, t);
+}
+BLS_FN void fp12_inv(fp12& r, const fp12& a) {
+  fp6 t0, t1;
+  fp6_mul(t0, a.c0, a.c0);
+  fp6_mul(t1, a.c1, a.c1);
+  fp6_mul_v(t1, t1);
+  fp6_sub(t0, t0, t1);
+  fp6_inv(t0, t0);
+  fp6_mul(r.c0, a.c0, t0);
+  fp6_mul(t1, a.c1, t0);
+  fp6_neg(r.c1, t1);
+}
+// a^(p^J), J = 1 or 2:  coefficient of w^k -> conj^J(c_k) * FROBJ[k]
+template <int J>
+BLS_FN void fp12_frob(fp12& r, const fp12& a) {
+  const uint32_t(*tab)[24] = (J == 1) ? FROB1 : FROB2;
+  fp2 g, c;
+#define FROB_ONE(dst, src, k)        \
+  if (J == 1) fp2_conj(c, src);      \
+  else c = src;                      \
+  if (k == 0) dst = c;               \
+  else {                             \
+    fp2_load(g, tab[k]);             \
+    fp2_mul(dst, c, g);              \
+  }
+  FROB_ONE(r.c0.a0, a.c0.a0, 0)
+  FROB_ONE(r.c1.a0, a.c1.a0, 1)
+  FROB_ONE(r.c0.a1, a.c0.a1, 2)
+  FROB_ONE(r.c1.a1, a.c1.a1, 3)
+  FROB_ONE(r.c0.a2, a.c0.a2, 4)
+  FROB_ONE(r.c1.a2, a.c1.a2, 5)
+#undef FROB_ONE
+}
+
+// Granger-Scott squaring, valid in the cyclotomic subgroup (after the easy part of the final exponentiation)
+BLS_FN void fp4_sqr(fp2& c0, fp2& c1, const fp2& a, const fp2& b) {
+  fp2 t0, t1, t2;
+  fp2_sqr(t0, a);
+  fp2_sqr(t1, b);
+  fp2_mul_xi(t2, t1);
+  fp2_add(c0, t2, t0);
+  fp2_add(t2, a, b);
+  fp2_sqr(t2, t2);
+  fp2_sub(t2, t2, t0);
+  fp2_sub(c1, t2, t1);
+}
+BLS_FN void fp12_cyclotomic_sqr(fp12& r, const fp12& f) {
+  fp2 z0 = f.c0.a0, z4 = f.c0.a1, z3 = f.c0.a2, z2 = f.c1.a0, z1 = f.c1.a1, z5 = f.c1.a2;
+  fp2 t0, t1, t2, t3;
+  fp4_sqr(t0, t1, z0, z1);
+  fp2_sub(z0, t0, z0);
+  fp2_dbl(z0, z0);
+  fp2_add(z0, z0, t0);
+  fp2_add(z1, t1, z1);
+  fp2_dbl(z1, z1);
+  fp2_add(z1, z1, t1);
+  fp4_sqr(t0, t1, z2, z3);
+  fp4_sqr(t2, t3, z4, z5);
+  fp2_sub(z4, t0, z4);
+  fp2_dbl(z4, z4);
+  fp2_add(z4, z4, t0);
+  fp2_add(z5, t1, z5);
+  fp2_dbl(z5, z5);
+  fp2_add(z5, z5, t1);
+  fp2_mul_xi(t0, t3);
+  fp2_add(z2, t0, z2);
+  fp2_dbl(z2, z2);
+  fp2_add(z2, z2, t0);
+  fp2_sub(z3, t2, z3);
+  fp2_dbl(z3, z3);
+  fp2_add(z3, z3, t2);
+  r.c0.a0 = z0;
+  r.c0.a1 = z4;
+  r.c0.a2 = z3;
+  r.c1.a0 = z2;
+  r.c1.a1 = z1;
+  r.c1.a2 = z5;
+}
+
+// f * (l0 + l2 w^2 + l3 w^3): the sparse line value of the Miller loop.  13 Fp2 multiplications.
+BLS_FN void fp12_mul_by_line(fp12& f, const fp2& l0, const fp2& l2, const fp2& l3) {
+  // L0 = (l0, l2, 0), L1 = (0, l3, 0) in Fp6
+  fp6 t0, t1, s, m;
+  fp2 x, y, z;
+  // t0 = f.c0 * (l0 + l2 v): Karatsuba on the two non-zero coefficients, 5 mul
+  {
+    const fp6& a = f.c0;
+    fp2 v0, v1;
+    fp2_mul(v0, a.a0, l0);
+    fp2_mul(v1, a.a1, l2);
+    fp2_mul(x, a.a2, l2);  // a2 l2 v^3 = xi a2 l2
+    fp2_mul_xi(x, x);
+    fp2_add(t0.a0, v0, x);
+    fp2_add(y, a.a0, a.a1);
+    fp2_add(z, l0, l2);
+    fp2_mul(y, y, z);
+    fp2_sub(y, y, v0);
+    fp2_sub(t0.a1, y, v1);  // a0 l2 + a1 l0
+    fp2_mul(z, a.a2, l0);
+    fp2_add(t0.a2, z, v1);  // a2 l0 + a1 l2
+  }
+  // t1 = f.c1 * (l3 v) = (xi a2 l3, a0 l3, a1 l3), 3 mul
+  {
+    const fp6& a = f.c1;
+    fp2_mul(x, a.a2, l3);
+    fp2_mul_xi(t1.a0, x);
+    fp2_mul(t1.a1, a.a0, l3);
+    fp2_mul(t1.a2, a.a1, l3);
+  }
+  // m = (f.c0 + f.c1) * (l0 + (l2 + l3) v), 5 mul
+  fp6_add(s, f.c0, f.c1);
+  {
+    fp2 l23, v0, v1;
+    fp2_add(l23, l2, l3);
+    fp2_mul(v0, s.a0, l0);
+    fp2_mul(v1, s.a1, l23);
+    fp2_mul(x, s.a2, l23);
+    fp2_mul_xi(x, x);
+    fp2_add(m.a0, v0, x);
+    fp2_add(y, s.a0, s.a1);
+    fp2_add(z, l0, l23);
+    fp2_mul(y, y, z);
+    fp2_sub(y, y, v0);
+    fp2_sub(m.a1, y, v1);
+    fp2_mul(z, s.a2, l0);
+    fp2_add(m.a2, z, v1);
+  }
+  fp6_sub(m, m, t0);
+  fp6_sub(f.c1, m, t1);
+  fp6_mul_v(t1, t1);
+  fp6_add(f.c0, t0, t1);
+}

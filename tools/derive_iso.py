@@ -1,6 +1,6 @@
 """Derive the RFC 9380 isogeny maps E' -> E for BLS12-381 G1 (11-isogeny) and G2 (3-isogeny).
 
-ORACLE tooling (test infrastructure).  The reference crate gets these tables from the un-vendored
+Build-time tooling shared by the oracle tables and the device constant header.  The reference crate gets these tables from the un-vendored
 `blst` dependency (reference call sites src/impls/g1.rs:18, src/impls/g2.rs:16); there is no copy of
 them anywhere on this machine, so they are *computed*:
 
@@ -13,7 +13,8 @@ them anywhere on this machine, so they are *computed*:
      k_(1,11)/k_(3,15) [G1] and k_(1,3)/k_(3,3) [G2]; final confirmation = RFC 9380 J.9.1 / J.10.1
      hash_to_curve vectors and, for G2, the reference's C++ known-answer signatures (check_kats.py).
 
-Run:  python -m oracle.py.derive_iso  > oracle/py/iso_consts.py   (takes ~1 min)
+Run:  python tools/derive_iso.py > oracle/py/iso_consts.py   (about 10 s); tools/gen_consts.py reads the same file's
+values through tools/iso_tables.py (an identical generated copy kept outside oracle/).
 """
 import random
 import sys
@@ -335,7 +336,7 @@ def main():
     B1 = 0x12e2908d11688030018b12e8753eee3b2016c1f0f24f4070a0b9c14fcef35ef55a23215a316ceaa5d1cc48e98e172be0
     # RFC 9380 8.8.2: E'2: A' = 240 u, B' = 1012 (1 + u), Z = -(2 + u)
     A2, B2 = (0, 240), (1012, 1012)
-    print('"""GENERATED by oracle/py/derive_iso.py -- do not edit.  RFC 9380 8.8 SSWU curves and the derived')
+    print('"""GENERATED by tools/derive_iso.py -- do not edit.  RFC 9380 8.8 SSWU curves and the derived')
     print('isogeny tables (x_num, x_den, y_num, y_den), coefficients low -> high."""')
     print('G1_A = 0x%x' % A1)
     print('G1_B = 0x%x' % B1)

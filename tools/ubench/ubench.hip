@@ -1,0 +1,185 @@
+// Microbenchmarks that size the integer-VALU roofline of the path ("the integer MAD rate is not in the
+// guides, must be measured"): cycles per wave-instruction for the candidate multiply primitives at 1/2/4 waves per
+// SIMD, and Fp-multiplication throughput of the candidate fp_mul formulations.
+// Build: hipcc --offload-arch=gfx950 -O3 -o ubench tools/ubench/ubench.hip ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <algorithm>
+#include "../../agora-blsful_amd/csrc/fp.cuh"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+#define REP8(X) X X X X X X X X
+#define ITERS 512
+
+enum { I_ADD32, I_MAD64, I_MULLO, I_MULHI, I_MAD24, I_LSHLADD64, I_FMA64, I_FMA32, I_ADDC, I_MADCARRY, I_N };
+static const char* NAMES[] = {"v_add_u32", "v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_lshl_add_u64",
+                              "v_fma_f64", "v_fma_f32", "v_addc_co_u32(3 chains)", "mad_u64+addc(grp3)"};
+
+template <int KIND>
+__global__ void __launch_bounds__(256) k_rate(uint64_t* cycles, uint32_t* sink, uint32_t seed) {
+  uint32_t x0 = threadIdx.x + seed, x1 = x0 * 3 + 1, x2 = x0 * 5 + 7, x3 = x0 * 7 + 3;
+  uint64_t a0 = x0, a1 = x1, a2 = x2, a3 = x3, a4 = x0 + 9, a5 = x1 + 9, a6 = x2 + 9, a7 = x3 + 9;
+  double d0 = x0, d1 = x1, d2 = x2, d3 = x3, d4 = 1.5, d5 = 2.5, d6 = 3.5, d7 = 4.5;
+  float f0 = x0, f1 = x1, f2 = x2, f3 = x3, f4 = 1.5f, f5 = 2.5f, f6 = 3.5f, f7 = 4.5f;
+  uint32_t w0 = x0, w1 = x1, w2 = x2, w3 = x3, w4 = x0 ^ 5, w5 = x1 ^ 5, w6 = x2 ^ 5, w7 = x3 ^ 5;
+  uint64_t s0, s1, s2;
+  uint64_t t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < ITERS; it++) {
+    if (KIND == I_ADD32) {
+      REP8(asm volatile("v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n"
+                        "v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8"
+                        : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "+v"(w6), "+v"(w7) : "v"(x0));)
+    } else if (KIND == I_MAD64) {
+      REP8(asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_mad_u64_u32 %2, vcc, %8, %9, %2\n"
+                        "v_mad_u64_u32 %3, vcc, %8, %9, %3\n v_mad_u64_u32 %4, vcc, %8, %9, %4\n v_mad_u64_u32 %5, vcc, %8, %9, %5\n"
+                        "v_mad_u64_u32 %6, vcc, %8, %9, %6\n v_mad_u64_u32 %7, vcc, %8, %9, %7"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x0), "v"(x1) : "vcc");)
+    } else if (KIND == I_MULLO) {
+      REP8(asm volatile("v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n"
+                        "v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8"
+                        : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "+v"(w6), "+v"(w7) : "v"(x1));)
+    } else if (KIND == I_MULHI) {
+      REP8(asm volatile("v_mul_hi_u32 %0, %0, %8\n v_mul_hi_u32 %1, %1, %8\n v_mul_hi_u32 %2, %2, %8\n v_mul_hi_u32 %3, %3, %8\n"
+                        "v_mul_hi_u32 %4, %4, %8\n v_mul_hi_u32 %5, %5, %8\n v_mul_hi_u32 %6, %6, %8\n v_mul_hi_u32 %7, %7, %8"
+                        : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "+v"(w6), "+v"(w7) : "v"(x1));)
+    } else if (KIND == I_MAD24) {
+      REP8(asm volatile("v_mad_u32_u24 %0, %0, %8, %0\n v_mad_u32_u24 %1, %1, %8, %1\n v_mad_u32_u24 %2, %2, %8, %2\n v_mad_u32_u24 %3, %3, %8, %3\n"
+                        "v_mad_u32_u24 %4, %4, %8, %4\n v_mad_u32_u24 %5, %5, %8, %5\n v_mad_u32_u24 %6, %6, %8, %6\n v_mad_u32_u24 %7, %7, %8, %7"
+                        : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "+v"(w6), "+v"(w7) : "v"(x1));)
+    } else if (KIND == I_LSHLADD64) {
+      REP8(asm volatile("v_lshl_add_u64 %0, %0, 0, %8\n v_lshl_add_u64 %1, %1, 0, %8\n v_lshl_add_u64 %2, %2, 0, %8\n v_lshl_add_u64 %3, %3, 0, %8\n"
+                        "v_lshl_add_u64 %4, %4, 0, %8\n v_lshl_add_u64 %5, %5, 0, %8\n v_lshl_add_u64 %6, %6, 0, %8\n v_lshl_add_u64 %7, %7, 0, %8"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(a0));)
+    } else if (KIND == I_FMA64) {
+      REP8(asm volatile("v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9\n"
+                        "v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9"
+                        : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(d0), "v"(d1));)
+    } else if (KIND == I_FMA32) {
+      REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                        "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9"
+                        : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7) : "v"(f0), "v"(f1));)
+    } else if (KIND == I_ADDC) {
+      // three interleaved carry chains on three SGPR pairs: 2 wait states between dependent links, no s_nop needed
+      REP8(asm volatile("v_addc_co_u32 %0, %3, %0, %6, %3\n v_addc_co_u32 %1, %4, %1, %6, %4\n v_addc_co_u32 %2, %5, %2, %6, %5\n"
+                        "v_addc_co_u32 %0, %3, %0, %6, %3\n v_addc_co_u32 %1, %4, %1, %6, %4\n v_addc_co_u32 %2, %5, %2, %6, %5\n"
+                        "v_addc_co_u32 %0, %3, %0, %6, %3\n v_addc_co_u32 %1, %4, %1, %6, %4"
+                        : "+v"(w0), "+v"(w1), "+v"(w2), "+s"(s0), "+s"(s1), "+s"(s2) : "v"(x1));)
+    } else if (KIND == I_MADCARRY) {
+      // the fp_mul inner pattern: 3 mads then 3 addc (6 instructions)
+      REP8(asm volatile("v_mad_u64_u32 %0, %2, %5, %6, %0\n v_mad_u64_u32 %0, %3, %5, %7, %0\n v_mad_u64_u32 %0, %4, %6, %7, %0\n"
+                        "v_addc_co_u32 %1, %2, 0, %1, %2\n v_addc_co_u32 %1, %3, 0, %1, %3\n v_addc_co_u32 %1, %4, 0, %1, %4"
+                        : "+v"(a0), "+v"(w0), "=&s"(s0), "=&s"(s1), "=&s"(s2) : "v"(x1), "v"(x2), "v"(x3));)
+    }
+  }
+  uint64_t t1 = __builtin_amdgcn_s_memtime();
+  uint32_t r = w0 ^ w1 ^ w2 ^ w3 ^ w4 ^ w5 ^ w6 ^ w7 ^ (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) ^
+               (uint32_t)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7) ^ (uint32_t)(f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7);
+  if (r == 0x12345) sink[0] = r;
+  if ((threadIdx.x & 63) == 0) cycles[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+}
+
+// ---- fp_mul variants: NCH independent dependent-chains per lane
+template <int VAR, int NCH>
+__global__ void __launch_bounds__(256) k_fpmul(uint32_t* out, const uint32_t* in, int iters, uint64_t* cycles) {
+  int id = blockIdx.x * blockDim.x + threadIdx.x;
+  fp x[NCH], y;
+  for (int c = 0; c < NCH; c++) fp_load(x[c], in + 12 * ((id + c * 7) & 1023));
+  fp_load(y, in + 12 * ((id + 3) & 1023));
+  uint64_t t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      if (VAR == 0) fp_mul_c(x[c], x[c], y);
+      else fp_mul_asm(x[c], x[c], y);
+    }
+  }
+  uint64_t t1 = __builtin_amdgcn_s_memtime();
+  fp acc = x[0];
+  for (int c = 1; c < NCH; c++) fp_add(acc, acc, x[c]);
+  fp_store(out + 12 * id, acc);
+  if ((threadIdx.x & 63) == 0) cycles[id >> 6] = t1 - t0;
+}
+
+static double median_cycles(std::vector<uint64_t>& v) {
+  std::sort(v.begin(), v.end());
+  return (double)v[v.size() / 2];
+}
+
+template <int KIND>
+static void run_rate(int wps, uint64_t* dcy, uint32_t* dsink) {
+  int blocks = 256 * wps;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  k_rate<KIND><<<blocks, 256>>>(dcy, dsink, 1);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  k_rate<KIND><<<blocks, 256>>>(dcy, dsink, 2);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  std::vector<uint64_t> cy(blocks * 4);
+  CK(hipMemcpy(cy.data(), dcy, cy.size() * 8, hipMemcpyDeviceToHost));
+  double med = median_cycles(cy);
+  int per_iter = (KIND == I_MADCARRY) ? 48 : 64;
+  double n_inst = (double)ITERS * per_iter;
+  // cycles per wave-instruction as seen by one wave; x waves-per-SIMD sharing the SIMD => SIMD issue interval = that / wps
+  printf("%-26s wps=%d  cyc/inst(wave)=%7.2f  SIMD-interval=%6.2f cyc  wall=%.3f ms  chip rate=%.2f T lane-op/s\n", NAMES[KIND], wps,
+         med / n_inst, med / n_inst / wps, ms, (double)blocks * 256 * n_inst / (ms * 1e-3) / 1e12);
+}
+
+template <int VAR, int NCH>
+static void run_fpmul(int wps, uint32_t* dout, uint32_t* din, uint64_t* dcy, std::vector<uint32_t>& ref_out, bool check) {
+  int blocks = 256 * wps, iters = 200;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  k_fpmul<VAR, NCH><<<blocks, 256>>>(dout, din, iters, dcy);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  k_fpmul<VAR, NCH><<<blocks, 256>>>(dout, din, iters, dcy);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  std::vector<uint64_t> cy(blocks * 4);
+  CK(hipMemcpy(cy.data(), dcy, cy.size() * 8, hipMemcpyDeviceToHost));
+  double med = median_cycles(cy);
+  std::vector<uint32_t> o(12 * 1024);
+  CK(hipMemcpy(o.data(), dout, o.size() * 4, hipMemcpyDeviceToHost));
+  const char* ok = "";
+  if (check) ok = (o == ref_out) ? " [matches variant 0]" : " [MISMATCH vs variant 0]";
+  else ref_out = o;
+  double nmul = (double)iters * NCH;
+  printf("fp_mul var=%d chains=%d wps=%d  cyc/mul(wave)=%8.1f  wall=%.3f ms  chip=%.2f G fp_mul/s%s\n", VAR, NCH, wps, med / nmul, ms,
+         (double)blocks * 256 * nmul / (ms * 1e-3) / 1e9, ok);
+}
+
+int main() {
+  hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+  printf("device %s  CUs=%d  clock=%d kHz\n", prop.name, prop.multiProcessorCount, prop.clockRate);
+  uint64_t* dcy; uint32_t *dsink, *din, *dout;
+  CK(hipMalloc(&dcy, 8 * 4 * 256 * 8)); CK(hipMalloc(&dsink, 64));
+  CK(hipMalloc(&din, 12 * 4 * 1024)); CK(hipMalloc(&dout, 12 * 4 * 256 * 256 * 8));
+  std::vector<uint32_t> hin(12 * 1024);
+  srand(7);
+  for (int i = 0; i < 1024; i++) {
+    for (int j = 0; j < 12; j++) hin[12 * i + j] = ((uint32_t)rand() << 16) ^ rand();
+    hin[12 * i + 11] &= 0x0fffffff;  // < p
+  }
+  CK(hipMemcpy(din, hin.data(), hin.size() * 4, hipMemcpyHostToDevice));
+  for (int wps = 1; wps <= 4; wps *= 2) {
+    run_rate<I_ADD32>(wps, dcy, dsink); run_rate<I_MAD64>(wps, dcy, dsink); run_rate<I_MULLO>(wps, dcy, dsink);
+    run_rate<I_MULHI>(wps, dcy, dsink); run_rate<I_MAD24>(wps, dcy, dsink); run_rate<I_LSHLADD64>(wps, dcy, dsink);
+    run_rate<I_FMA64>(wps, dcy, dsink); run_rate<I_FMA32>(wps, dcy, dsink); run_rate<I_ADDC>(wps, dcy, dsink);
+    run_rate<I_MADCARRY>(wps, dcy, dsink);
+  }
+  std::vector<uint32_t> ref1, ref2;
+  for (int wps = 1; wps <= 4; wps *= 2) {
+    run_fpmul<0, 1>(wps, dout, din, dcy, ref1, false);
+    run_fpmul<1, 1>(wps, dout, din, dcy, ref1, true);
+    run_fpmul<0, 3>(wps, dout, din, dcy, ref2, false);
+    run_fpmul<1, 3>(wps, dout, din, dcy, ref2, true);
+  }
+  return 0;
+}
