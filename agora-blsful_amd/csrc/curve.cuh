@@ -1,0 +1,292 @@
+// G1 (over Fp) and G2 (over Fp2, the M-twist y^2 = x^3 + 4(1+u)) group arithmetic in Jacobian coordinates
+// (x = X/Z^2, y = Y/Z^3, infinity = Z == 0) -- the coordinate system of blst's blst_p1/blst_p2, which is what the
+// reference's G1Projective/G2Projective hold in memory, so RAW_PROJ buffers are consumed as they are.
+// Replaces: `+`, `-`, `* scalar`, `to_affine`, `is_identity`, `to_compressed` of the un-vendored backend
+// (reference call sites src/traits/pk_multi.rs:10, src/secure_aggregation.rs:42,203, src/helpers.rs:44,56).
+#pragma once
+#include "tower.cuh"
+
+// ---- uniform field interface so point code is written once
+BLS_FN void fe_add(fp& r, const fp& a, const fp& b) { fp_add(r, a, b); }
+BLS_FN void fe_sub(fp& r, const fp& a, const fp& b) { fp_sub(r, a, b); }
+BLS_FN void fe_mul(fp& r, const fp& a, const fp& b) { fp_mul(r, a, b); }
+BLS_FN void fe_sqr(fp& r, const fp& a) { fp_sqr(r, a); }
+BLS_FN void fe_neg(fp& r, const fp& a) { fp_neg(r, a); }
+BLS_FN void fe_dbl(fp& r, const fp& a) { fp_dbl(r, a); }
+BLS_FN void fe_inv(fp& r, const fp& a) { fp_inv(r, a); }
+BLS_FN bool fe_is_zero(const fp& a) { return fp_is_zero(a); }
+BLS_FN bool fe_eq(const fp& a, const fp& b) { return fp_eq(a, b); }
+BLS_FN void fe_zero(fp& r) { fp_zero(r); }
+BLS_FN void fe_one(fp& r) { fp_one(r); }
+BLS_FN void fe_cmov(fp& r, const fp& a, bool c) { fp_cmov(r, a, c); }
+
+BLS_FN void fe_add(fp2& r, const fp2& a, const fp2& b) { fp2_add(r, a, b); }
+BLS_FN void fe_sub(fp2& r, const fp2& a, const fp2& b) { fp2_sub(r, a, b); }
+BLS_FN void fe_mul(fp2& r, const fp2& a, const fp2& b) { fp2_mul(r, a, b); }
+BLS_FN void fe_sqr(fp2& r, const fp2& a) { fp2_sqr(r, a); }
+BLS_FN void fe_neg(fp2& r, const fp2& a) { fp2_neg(r, a); }
+BLS_FN void fe_dbl(fp2& r, const fp2& a) { fp2_dbl(r, a); }
+BLS_FN void fe_inv(fp2& r, const fp2& a) { fp2_inv(r, a); }
+BLS_FN bool fe_is_zero(const fp2& a) { return fp2_is_zero(a); }
+BLS_FN bool fe_eq(const fp2& a, const fp2& b) { return fp2_eq(a, b); }
+BLS_FN void fe_zero(fp2& r) { fp2_zero(r); }
+BLS_FN void fe_one(fp2& r) { fp2_one(r); }
+BLS_FN void fe_cmov(fp2& r, const fp2& a, bool c) { fp2_cmov(r, a, c); }
+
+template <class F>
+struct jac {
+  F x, y, z;
+};
+template <class F>
+struct aff {
+  F x, y;
+  bool inf;
+};
+typedef jac<fp> g1_jac;
+typedef jac<fp2> g2_jac;
+typedef aff<fp> g1_aff;
+typedef aff<fp2> g2_aff;
+
+template <class F>
+BLS_FN void jac_set_inf(jac<F>& r) {
+  fe_one(r.x);
+  fe_one(r.y);
+  fe_zero(r.z);
+}
+template <class F>
+BLS_FN bool jac_is_inf(const jac<F>& a) {
+  return fe_is_zero(a.z);
+}
+template <class F>
+BLS_FN void jac_neg(jac<F>& r, const jac<F>& a) {
+  r.x = a.x;
+  fe_neg(r.y, a.y);
+  r.z = a.z;
+}
+template <class F>
+BLS_FN void jac_from_aff(jac<F>& r, const aff<F>& a) {
+  if (a.inf) {
+    jac_set_inf(r);
+    return;
+  }
+  r.x = a.x;
+  r.y = a.y;
+  fe_one(r.z);
+}
+
+// doubling on y^2 = x^3 + b (a = 0), dbl-2009-l: 2M + 5S
+template <class F>
+BLS_FN void jac_dbl(jac<F>& r, const jac<F>& p) {
+  F A, B, C, D, E, Fq, t;
+  fe_sqr(A, p.x);
+  fe_sqr(B, p.y);
+  fe_sqr(C, B);
+  fe_add(t, p.x, B);
+  fe_sqr(t, t);
+  fe_sub(t, t, A);
+  fe_sub(t, t, C);
+  fe_dbl(D, t);
+  fe_dbl(E, A);
+  fe_add(E, E, A);
+  fe_sqr(Fq, E);
+  F z3;
+  fe_mul(z3, p.y, p.z);
+  fe_dbl(z3, z3);
+  fe_dbl(t, D);
+  fe_sub(r.x, Fq, t);
+  fe_sub(t, D, r.x);
+  fe_mul(t, E, t);
+  fe_dbl(C, C);
+  fe_dbl(C, C);
+  fe_dbl(C, C);
+  fe_sub(r.y, t, C);
+  r.z = z3;
+}
+
+// general addition, add-2007-bl with the exceptional cases handled (inputs are attacker-chosen: equal or opposite
+// points do occur, e.g. duplicated public keys in an aggregate)
+template <class F>
+BLS_FN void jac_add(jac<F>& r, const jac<F>& p, const jac<F>& q) {
+  if (jac_is_inf(p)) {
+    r = q;
+    return;
+  }
+  if (jac_is_inf(q)) {
+    r = p;
+    return;
+  }
+  F z1z1, z2z2, u1, u2, s1, s2, h, i, j, rr, v, t;
+  fe_sqr(z1z1, p.z);
+  fe_sqr(z2z2, q.z);
+  fe_mul(u1, p.x, z2z2);
+  fe_mul(u2, q.x, z1z1);
+  fe_mul(s1, p.y, q.z);
+  fe_mul(s1, s1, z2z2);
+  fe_mul(s2, q.y, p.z);
+  fe_mul(s2, s2, z1z1);
+  fe_sub(h, u2, u1);
+  fe_sub(rr, s2, s1);
+  if (fe_is_zero(h)) {
+    if (fe_is_zero(rr)) {
+      jac_dbl(r, p);
+    } else {
+      jac_set_inf(r);
+    }
+    return;
+  }
+  fe_dbl(rr, rr);
+  fe_dbl(i, h);
+  fe_sqr(i, i);
+  fe_mul(j, h, i);
+  fe_mul(v, u1, i);
+  F x3, y3, z3;
+  fe_sqr(x3, rr);
+  fe_sub(x3, x3, j);
+  fe_dbl(t, v);
+  fe_sub(x3, x3, t);
+  fe_sub(t, v, x3);
+  fe_mul(y3, rr, t);
+  fe_mul(t, s1, j);
+  fe_dbl(t, t);
+  fe_sub(y3, y3, t);
+  fe_add(z3, p.z, q.z);
+  fe_sqr(z3, z3);
+  fe_sub(z3, z3, z1z1);
+  fe_sub(z3, z3, z2z2);
+  fe_mul(z3, z3, h);
+  r.x = x3;
+  r.y = y3;
+  r.z = z3;
+}
+
+// mixed addition with an affine second operand (Z2 = 1)
+template <class F>
+BLS_FN void jac_add_aff(jac<F>& r, const jac<F>& p, const aff<F>& q) {
+  jac<F> qq;
+  jac_from_aff(qq, q);
+  jac_add(r, p, qq);
+}
+
+template <class F>
+BLS_FN void jac_to_aff(aff<F>& r, const jac<F>& p) {
+  if (jac_is_inf(p)) {
+    r.inf = true;
+    fe_zero(r.x);
+    fe_zero(r.y);
+    return;
+  }
+  F zi, zi2;
+  fe_inv(zi, p.z);
+  fe_sqr(zi2, zi);
+  fe_mul(r.x, p.x, zi2);
+  fe_mul(zi2, zi2, zi);
+  fe_mul(r.y, p.y, zi2);
+  r.inf = false;
+}
+
+// [k] P for a 64-bit public scalar (left-to-right; k is the same in every lane: no divergence)
+template <class F>
+BLS_FN void jac_mul_u64(jac<F>& r, const jac<F>& p, uint64_t k) {
+  jac<F> acc;
+  jac_set_inf(acc);
+  for (int i = 63; i >= 0; i--) {
+    jac_dbl(acc, acc);
+    if ((k >> i) & 1) jac_add(acc, acc, p);
+  }
+  r = acc;
+}
+
+// [k] P for a 256-bit scalar given as 8 little-endian 32-bit words (per-lane scalars: the branch diverges)
+template <class F>
+BLS_FN void jac_mul_scalar(jac<F>& r, const jac<F>& p, const uint32_t* k) {
+  jac<F> acc;
+  jac_set_inf(acc);
+  for (int i = 255; i >= 0; i--) {
+    jac_dbl(acc, acc);
+    if ((k[i >> 5] >> (i & 31)) & 1) jac_add(acc, acc, p);
+  }
+  r = acc;
+}
+
+// ---- psi (untwist-Frobenius-twist) on G2, Jacobian form: (conj X * cx, conj Y * cy, conj Z)
+BLS_FN void g2_psi(g2_jac& r, const g2_jac& p) {
+  fp2 cx, cy, t;
+  fp2_load(cx, PSI_CX);
+  fp2_load(cy, PSI_CY);
+  fp2_conj(t, p.x);
+  fp2_mul(r.x, t, cx);
+  fp2_conj(t, p.y);
+  fp2_mul(r.y, t, cy);
+  fp2_conj(r.z, p.z);
+}
+// psi^2: (X * cx2, Y * cy2, Z) with cx2, cy2 in Fp
+BLS_FN void g2_psi2(g2_jac& r, const g2_jac& p) {
+  fp cx2, cy2;
+  fp_load(cx2, PSI2_CX);
+  fp_load(cy2, PSI2_CY);
+  fp2_mul_fp(r.x, p.x, cx2);
+  fp2_mul_fp(r.y, p.y, cy2);
+  r.z = p.z;
+}
+
+// RFC 9380 Appendix G.3 clear_cofactor_bls12381_g2 (x is negative: [x]P = -[|x|]P)
+BLS_FN void g2_clear_cofactor(g2_jac& r, const g2_jac& p) {
+  g2_jac t1, t2, t3, n;
+  jac_mul_u64(t1, p, BLS_X_ABS);
+  jac_neg(t1, t1);  // t1 = x P
+  g2_psi(t2, p);    // t2 = psi(P)
+  jac_dbl(t3, p);
+  g2_psi2(t3, t3);  // t3 = psi^2(2P)
+  jac_neg(n, t2);
+  jac_add(t3, t3, n);  // t3 - t2
+  jac_add(t2, t1, t2);  // t1 + t2
+  jac_mul_u64(t2, t2, BLS_X_ABS);
+  jac_neg(t2, t2);      // x (t1 + t2)
+  jac_add(t3, t3, t2);
+  jac_neg(n, t1);
+  jac_add(t3, t3, n);
+  jac_neg(n, p);
+  jac_add(r, t3, n);
+}
+
+// ---- ZCash compressed encoding (modern); `legacy` applies the Dash header transcode of
+// reference src/impls/legacy.rs:19-35
+BLS_FN void fp_to_be48(uint8_t* out, const fp& a_mont) {
+  fp t;
+  fp_from_mont(t, a_mont);
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    uint32_t w = t.l[11 - i];
+    out[4 * i + 0] = (uint8_t)(w >> 24);
+    out[4 * i + 1] = (uint8_t)(w >> 16);
+    out[4 * i + 2] = (uint8_t)(w >> 8);
+    out[4 * i + 3] = (uint8_t)w;
+  }
+}
+BLS_FN void header_to_legacy(uint8_t* b) {
+  if (b[0] == 0xc0) return;
+  uint8_t ys = b[0] & 0x20;
+  b[0] &= 0x1f;
+  if (ys) b[0] |= 0x80;
+}
+BLS_FN void g1_compress(uint8_t* out, const g1_aff& a, bool legacy) {
+  if (a.inf) {
+    for (int i = 0; i < 48; i++) out[i] = 0;
+    out[0] = 0xc0;
+    return;
+  }
+  fp_to_be48(out, a.x);
+  out[0] |= 0x80 | (fp_lex_largest(a.y) ? 0x20 : 0);
+  if (legacy) header_to_legacy(out);
+}
+BLS_FN void g2_compress(uint8_t* out, const g2_aff& a, bool legacy) {
+  if (a.inf) {
+    for (int i = 0; i < 96; i++) out[i] = 0;
+    out[0] = 0xc0;
+    return;
+  }
+  fp_to_be48(out, a.x.c1);
+  fp_to_be48(out + 48, a.x.c0);
+  out[0] |= 0x80 | (fp2_lex_largest(a.y) ? 0x20 : 0);
+  if (legacy) header_to_legacy(out);
+}

@@ -160,7 +160,7 @@ BLS_FN void fp_mul_c(fp& r, const fp& a, const fp& b) {
   fp_reduce_once(r, tt);
 }
 
-#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIPCC__)
 // gfx950: product-scanning form, one v_mad_u64_u32 + one v_addc_co_u32 per partial product.  Measured on
 // MI355X (profiles/ubench_r01.txt): 58 G fp_mul/s chip-wide at 4 waves/SIMD vs 40 G for the C form.
 #include "fp_mul_gfx950.inc"
@@ -212,8 +212,9 @@ BLS_FN bool fp_sqrt(fp& r, const fp& a) {
   fp_pow(t, a, EXP_PM3D4, EXP_PM3D4_BITS);  // a^((p-3)/4)
   fp_mul(s, t, a);                           // a^((p+1)/4)
   fp_sqr(c, s);
+  bool ok = fp_eq(c, a);  // before writing r: r may alias a
   r = s;
-  return fp_eq(c, a);
+  return ok;
 }
 
 // canonical-integer predicates (argument in Montgomery form)

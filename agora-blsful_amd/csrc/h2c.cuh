@@ -1,0 +1,319 @@
+// RFC 9380 hash_to_curve for the suites BLS12381G1_XMD:SHA-256_SSWU_RO_ and BLS12381G2_XMD:SHA-256_SSWU_RO_:
+// expand_message_xmd(SHA-256) -> hash_to_field -> simplified SWU on the isogenous curve -> isogeny -> add ->
+// clear cofactor.  Replaces `G1Projective::hash::<ExpandMsgXmd<Sha256>>` / `G2Projective::hash` of the un-vendored
+// backend (reference call sites src/impls/g1.rs:18 and src/impls/g2.rs:16; DST passed in by the scheme traits).
+#pragma once
+#include "curve.cuh"
+
+// ------------------------------------------------------------------ SHA-256 (streaming, one lane = one hash)
+struct sha256_ctx {
+  uint32_t h[8];
+  uint32_t w[16];
+  uint32_t fill;    // bytes in w
+  uint32_t total;   // total bytes (messages < 512 MiB)
+};
+
+BLS_CONST uint32_t SHA256_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+BLS_FN uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+
+BLS_NOINLINE void sha256_compress(uint32_t* h, uint32_t* w) {
+  uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+  for (int i = 0; i < 64; i++) {
+    uint32_t wi;
+    if (i < 16) {
+      wi = w[i];
+    } else {
+      uint32_t w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
+      uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+      uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+      wi = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
+      w[i & 15] = wi;
+    }
+    uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+    uint32_t ch = (e & f) ^ (~e & g);
+    uint32_t t1 = hh + S1 + ch + SHA256_K[i] + wi;
+    uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+    uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+    uint32_t t2 = S0 + mj;
+    hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+  }
+  h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+
+BLS_FN void sha256_init(sha256_ctx& c) {
+  c.h[0] = 0x6a09e667; c.h[1] = 0xbb67ae85; c.h[2] = 0x3c6ef372; c.h[3] = 0xa54ff53a;
+  c.h[4] = 0x510e527f; c.h[5] = 0x9b05688c; c.h[6] = 0x1f83d9ab; c.h[7] = 0x5be0cd19;
+  for (int i = 0; i < 16; i++) c.w[i] = 0;
+  c.fill = 0;
+  c.total = 0;
+}
+BLS_FN void sha256_byte(sha256_ctx& c, uint8_t b) {
+  uint32_t idx = c.fill >> 2, sh = 24 - 8 * (c.fill & 3);
+  c.w[idx] |= (uint32_t)b << sh;
+  c.fill++;
+  c.total++;
+  if (c.fill == 64) {
+    sha256_compress(c.h, c.w);
+    for (int i = 0; i < 16; i++) c.w[i] = 0;
+    c.fill = 0;
+  }
+}
+BLS_FN void sha256_update(sha256_ctx& c, const uint8_t* p, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++) sha256_byte(c, p[i]);
+}
+BLS_FN void sha256_final(sha256_ctx& c, uint8_t* out) {
+  uint32_t bits_lo = c.total << 3, bits_hi = c.total >> 29;
+  sha256_byte(c, 0x80);
+  while (c.fill != 56) sha256_byte(c, 0);
+  c.w[14] = bits_hi;
+  c.w[15] = bits_lo;
+  sha256_compress(c.h, c.w);
+  for (int i = 0; i < 8; i++) {
+    out[4 * i] = (uint8_t)(c.h[i] >> 24);
+    out[4 * i + 1] = (uint8_t)(c.h[i] >> 16);
+    out[4 * i + 2] = (uint8_t)(c.h[i] >> 8);
+    out[4 * i + 3] = (uint8_t)c.h[i];
+  }
+}
+
+// ------------------------------------------------------------------ expand_message_xmd + hash_to_field
+// msg = pre (optional prefix, the Aug scheme's public-key bytes) || m.  NOUT = 128 (G1) or 256 (G2).  dst_len <= 255.
+template <int NOUT>
+BLS_FN void expand_message_xmd(uint8_t* out, const uint8_t* pre, uint32_t pre_len, const uint8_t* m, uint32_t m_len,
+                               const uint8_t* dst, uint32_t dst_len) {
+  sha256_ctx c;
+  uint8_t b0[32], bi[32];
+  sha256_init(c);
+  for (int i = 0; i < 64; i++) sha256_byte(c, 0);
+  sha256_update(c, pre, pre_len);
+  sha256_update(c, m, m_len);
+  sha256_byte(c, (uint8_t)(NOUT >> 8));
+  sha256_byte(c, (uint8_t)NOUT);
+  sha256_byte(c, 0);
+  sha256_update(c, dst, dst_len);
+  sha256_byte(c, (uint8_t)dst_len);
+  sha256_final(c, b0);
+  for (int i = 0; i < 32; i++) bi[i] = 0;
+  for (int blk = 1; blk <= NOUT / 32; blk++) {
+    sha256_init(c);
+    for (int i = 0; i < 32; i++) sha256_byte(c, b0[i] ^ bi[i]);
+    sha256_byte(c, (uint8_t)blk);
+    sha256_update(c, dst, dst_len);
+    sha256_byte(c, (uint8_t)dst_len);
+    sha256_final(c, bi);
+    for (int i = 0; i < 32; i++) out[32 * (blk - 1) + i] = bi[i];
+  }
+}
+
+// 64 big-endian bytes -> Fp (Montgomery): (lo48 + hi16 * 2^384) mod p = lo48 * R2/R + hi16 * R3/R
+BLS_FN void fp_from_be64(fp& r, const uint8_t* b) {
+  fp lo, hi, t;
+  fp_zero(hi);
+  for (int i = 0; i < 4; i++) {
+    const uint8_t* q = b + 4 * (3 - i);
+    hi.l[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+  }
+  for (int i = 0; i < 12; i++) {
+    const uint8_t* q = b + 16 + 4 * (11 - i);
+    lo.l[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+  }
+  fp k;
+  fp_load(k, FP_R2);
+  fp_mul(t, k, lo);   // unreduced operand second (see fp_mul_c bound)
+  fp_load(k, FP_R3);
+  fp_mul(hi, k, hi);
+  fp_add(r, t, hi);
+}
+
+// ------------------------------------------------------------------ G1: simplified SWU (RFC 9380 F.2, straight line)
+// returns x = xn/xd and y on E'1
+BLS_FN void sswu_g1(fp& xn, fp& xd, fp& y, const fp& u) {
+  fp A, B, Z, tv1, tv2, tv3, tv4, tv5, tv6, x, y1, t;
+  fp_load(A, SSWU1_A);
+  fp_load(B, SSWU1_B);
+  fp_load(Z, SSWU1_Z);
+  fp_sqr(tv1, u);
+  fp_mul(tv1, Z, tv1);
+  fp_sqr(tv2, tv1);
+  fp_add(tv2, tv2, tv1);
+  fp_one(t);
+  fp_add(tv3, tv2, t);
+  fp_mul(tv3, B, tv3);
+  fp_neg(tv4, tv2);
+  fp_cmov(tv4, Z, fp_is_zero(tv2));
+  fp_mul(tv4, A, tv4);
+  fp_sqr(tv2, tv3);
+  fp_sqr(tv6, tv4);
+  fp_mul(tv5, A, tv6);
+  fp_add(tv2, tv2, tv5);
+  fp_mul(tv2, tv2, tv3);
+  fp_mul(tv6, tv6, tv4);
+  fp_mul(tv5, B, tv6);
+  fp_add(tv2, tv2, tv5);
+  fp_mul(x, tv1, tv3);
+  // sqrt_ratio_3mod4(tv2, tv6)
+  fp s1, s2, s3, y2, c2;
+  fp_sqr(s1, tv6);
+  fp_mul(s2, tv2, tv6);
+  fp_mul(s1, s1, s2);
+  fp_pow(y1, s1, EXP_PM3D4, EXP_PM3D4_BITS);
+  fp_mul(y1, y1, s2);
+  fp_load(c2, SSWU1_C2);
+  fp_mul(y2, y1, c2);
+  fp_sqr(s3, y1);
+  fp_mul(s3, s3, tv6);
+  bool is_qr = fp_eq(s3, tv2);
+  // y = tv1 * u * y2-branch value when gx1 is not a square
+  fp_mul(y, tv1, u);
+  fp_mul(y, y, y2);
+  fp_cmov(x, tv3, is_qr);
+  fp_cmov(y, y1, is_qr);
+  fp ny;
+  fp_neg(ny, y);
+  fp_cmov(y, ny, fp_parity(u) != fp_parity(y));
+  xn = x;
+  xd = tv4;
+}
+
+// homogenised Horner: sum_i k_i xn^i xd^(D-i), zp[j] = xd^j
+BLS_FN void iso1_poly(fp& r, const uint32_t (*k)[12], int deg, const fp& xn, const fp* zp) {
+  fp acc, c, t;
+  fp_load(acc, k[deg]);
+  for (int i = deg - 1; i >= 0; i--) {
+    fp_mul(acc, acc, xn);
+    fp_load(c, k[i]);
+    fp_mul(t, c, zp[deg - i]);
+    fp_add(acc, acc, t);
+  }
+  r = acc;
+}
+
+// 11-isogeny E'1 -> E1 applied to (xn/xd, y); Jacobian output
+BLS_FN void iso_map_g1(g1_jac& r, const fp& xn, const fp& xd, const fp& y) {
+  fp zp[16];
+  fp_one(zp[0]);
+  zp[1] = xd;
+  for (int i = 2; i < 16; i++) fp_mul(zp[i], zp[i - 1], xd);
+  fp XN, XD, YN, YD, zx, t, yd2;
+  iso1_poly(XN, ISO1_XNUM, 11, xn, zp);
+  iso1_poly(XD, ISO1_XDEN, 10, xn, zp);
+  iso1_poly(YN, ISO1_YNUM, 15, xn, zp);
+  iso1_poly(YD, ISO1_YDEN, 15, xn, zp);
+  fp_mul(zx, XD, xd);     // x_out = XN / zx,  y_out = y YN / YD
+  fp_mul(r.z, zx, YD);    // Z = zx YD
+  fp_sqr(yd2, YD);
+  fp_mul(t, XN, zx);
+  fp_mul(r.x, t, yd2);    // X = XN zx YD^2
+  fp_sqr(t, zx);
+  fp_mul(t, t, zx);
+  fp_mul(t, t, yd2);
+  fp_mul(t, t, YN);
+  fp_mul(r.y, t, y);      // Y = y YN zx^3 YD^2
+}
+
+BLS_FN void hash_to_g1(g1_jac& r, const uint8_t* pre, uint32_t pre_len, const uint8_t* m, uint32_t m_len,
+                       const uint8_t* dst, uint32_t dst_len) {
+  uint8_t ub[128];
+  expand_message_xmd<128>(ub, pre, pre_len, m, m_len, dst, dst_len);
+  fp u0, u1, xn, xd, y;
+  fp_from_be64(u0, ub);
+  fp_from_be64(u1, ub + 64);
+  g1_jac q0, q1;
+  sswu_g1(xn, xd, y, u0);
+  iso_map_g1(q0, xn, xd, y);
+  sswu_g1(xn, xd, y, u1);
+  iso_map_g1(q1, xn, xd, y);
+  jac_add(q0, q0, q1);
+  // clear cofactor: h_eff = 1 - x = 1 + |x|
+  jac_mul_u64(q1, q0, BLS_X_ABS);
+  jac_add(r, q1, q0);
+}
+
+// ------------------------------------------------------------------ G2: simplified SWU (RFC 9380 6.6.2, generic form)
+BLS_FN void fp2_curve_rhs_iso(fp2& r, const fp2& x) {  // x^3 + A' x + B' on E'2
+  fp2 A, B, t;
+  fp2_load(A, SSWU2_A);
+  fp2_load(B, SSWU2_B);
+  fp2_sqr(t, x);
+  fp2_add(t, t, A);
+  fp2_mul(t, t, x);
+  fp2_add(r, t, B);
+}
+BLS_FN void sswu_g2(fp2& x, fp2& y, const fp2& u) {
+  fp2 Z, zu2, tv1, x1, gx, one, t;
+  fp2_load(Z, SSWU2_Z);
+  fp2_sqr(zu2, u);
+  fp2_mul(zu2, Z, zu2);
+  fp2_sqr(tv1, zu2);
+  fp2_add(tv1, tv1, zu2);
+  if (fp2_is_zero(tv1)) {
+    fp2_load(x1, SSWU2_BZA);
+  } else {
+    fp2_inv(t, tv1);
+    fp2_one(one);
+    fp2_add(t, t, one);
+    fp2_load(x1, SSWU2_NBA);
+    fp2_mul(x1, x1, t);
+  }
+  fp2_curve_rhs_iso(gx, x1);
+  if (fp2_is_square(gx)) {
+    x = x1;
+    fp2_sqrt(y, gx);
+  } else {
+    fp2_mul(x, zu2, x1);
+    fp2_curve_rhs_iso(gx, x);
+    fp2_sqrt(y, gx);
+  }
+  if (fp2_sgn0(u) != fp2_sgn0(y)) fp2_neg(y, y);
+}
+BLS_FN void iso2_poly(fp2& r, const uint32_t (*k)[24], int deg, const fp2& x) {
+  fp2 acc, c;
+  fp2_load(acc, k[deg]);
+  for (int i = deg - 1; i >= 0; i--) {
+    fp2_mul(acc, acc, x);
+    fp2_load(c, k[i]);
+    fp2_add(acc, acc, c);
+  }
+  r = acc;
+}
+BLS_FN void iso_map_g2(g2_jac& r, const fp2& x, const fp2& y) {
+  fp2 XN, XD, YN, YD, t, yd2;
+  iso2_poly(XN, ISO2_XNUM, 3, x);
+  iso2_poly(XD, ISO2_XDEN, 2, x);
+  iso2_poly(YN, ISO2_YNUM, 3, x);
+  iso2_poly(YD, ISO2_YDEN, 3, x);
+  fp2_mul(r.z, XD, YD);
+  fp2_sqr(yd2, YD);
+  fp2_mul(t, XN, XD);
+  fp2_mul(r.x, t, yd2);
+  fp2_sqr(t, XD);
+  fp2_mul(t, t, XD);
+  fp2_mul(t, t, yd2);
+  fp2_mul(t, t, YN);
+  fp2_mul(r.y, t, y);
+}
+BLS_FN void hash_to_g2(g2_jac& r, const uint8_t* pre, uint32_t pre_len, const uint8_t* m, uint32_t m_len,
+                       const uint8_t* dst, uint32_t dst_len) {
+  uint8_t ub[256];
+  expand_message_xmd<256>(ub, pre, pre_len, m, m_len, dst, dst_len);
+  fp2 u0, u1, x, y;
+  fp_from_be64(u0.c0, ub);
+  fp_from_be64(u0.c1, ub + 64);
+  fp_from_be64(u1.c0, ub + 128);
+  fp_from_be64(u1.c1, ub + 192);
+  g2_jac q0, q1;
+  sswu_g2(x, y, u0);
+  iso_map_g2(q0, x, y);
+  sswu_g2(x, y, u1);
+  iso_map_g2(q1, x, y);
+  jac_add(q0, q0, q1);
+  g2_clear_cofactor(r, q0);
+}

@@ -1,0 +1,168 @@
+// Optimal-ate Miller loop and final exponentiation for BLS12-381 (x = -0xd201000000010000).
+// Replaces `multi_miller_loop(..).final_exponentiation()` + `Gt::is_identity` of the un-vendored backend
+// (reference call sites src/helpers.rs:50,62 and src/traits/sig_core.rs:138-141,173).  Only the verdict
+// "product of pairings == 1" is consumed by the reference's verify path, so line values are scaled freely by
+// proper-subfield factors (they vanish in the final exponentiation) and the final exponentiation computes the
+// cube of the canonical value (gcd(3, r) = 1: same verdict).
+#pragma once
+#include "curve.cuh"
+
+// homogeneous projective point on the twist, used only inside the Miller loop
+struct g2_hom {
+  fp2 x, y, z;
+};
+
+BLS_FN void fp2_mul_3b(fp2& r, const fp2& a) {  // a * 3b' = a * 12 (1 + u)
+  fp2 t, t2;
+  fp2_mul_xi(t, a);
+  fp2_dbl(t2, t);   // 2
+  fp2_add(t, t2, t);  // 3
+  fp2_dbl(t, t);    // 6
+  fp2_dbl(r, t);    // 12
+}
+
+// T <- 2T and the tangent line at T evaluated at P = (xp, yp):
+//   l0 = Y^2 - 3b'Z^2,  l2 = -3X^2 xp,  l3 = 2YZ yp     (coefficients of w^0, w^2, w^3)
+BLS_FN void miller_dbl_step(g2_hom& t, fp2& l0, fp2& l2, fp2& l3, const fp& xp, const fp& yp) {
+  fp2 a, b, c, e, f, h, g, s;
+  fp2_mul(a, t.x, t.y);  // XY
+  fp2_sqr(b, t.y);       // B = Y^2
+  fp2_sqr(c, t.z);       // C = Z^2
+  fp2_mul_3b(e, c);      // E = 3b'C
+  fp2_dbl(f, e);
+  fp2_add(f, f, e);      // F = 3E
+  fp2_add(h, t.y, t.z);
+  fp2_sqr(h, h);
+  fp2_sub(h, h, b);
+  fp2_sub(h, h, c);      // H = 2YZ
+  fp2_sqr(s, t.x);       // X^2
+  // line
+  fp2_sub(l0, b, e);
+  fp2_dbl(g, s);
+  fp2_add(g, g, s);      // 3X^2
+  fp2_neg(g, g);
+  fp2_mul_fp(l2, g, xp);
+  fp2_mul_fp(l3, h, yp);
+  // point: X3 = 2XY(B - F), Y3 = (B + F)^2 - 12E^2, Z3 = 4BH
+  fp2_sub(g, b, f);
+  fp2_mul(g, a, g);
+  fp2_dbl(t.x, g);
+  fp2_add(g, b, f);
+  fp2_sqr(g, g);
+  fp2_sqr(s, e);
+  fp2_dbl(a, s);
+  fp2_add(a, a, s);      // 3E^2
+  fp2_dbl(a, a);
+  fp2_dbl(a, a);         // 12E^2
+  fp2_sub(t.y, g, a);
+  fp2_mul(g, b, h);
+  fp2_dbl(g, g);
+  fp2_dbl(t.z, g);
+}
+
+// T <- T + Q and the chord line through T and Q evaluated at P:
+//   l0 = theta xq - lambda yq,  l2 = -theta xp,  l3 = lambda yp
+BLS_FN void miller_add_step(g2_hom& t, fp2& l0, fp2& l2, fp2& l3, const fp2& xq, const fp2& yq, const fp& xp,
+                            const fp& yp) {
+  fp2 th, la, c, d, e, f, g, h, s;
+  fp2_mul(th, yq, t.z);
+  fp2_sub(th, t.y, th);  // theta = Y - yq Z
+  fp2_mul(la, xq, t.z);
+  fp2_sub(la, t.x, la);  // lambda = X - xq Z
+  fp2_mul(l0, th, xq);
+  fp2_mul(s, la, yq);
+  fp2_sub(l0, l0, s);
+  fp2_neg(s, th);
+  fp2_mul_fp(l2, s, xp);
+  fp2_mul_fp(l3, la, yp);
+  fp2_sqr(c, th);
+  fp2_sqr(d, la);
+  fp2_mul(e, la, d);
+  fp2_mul(f, t.z, c);
+  fp2_mul(g, t.x, d);
+  fp2_add(h, e, f);
+  fp2_sub(h, h, g);
+  fp2_sub(h, h, g);
+  fp2_mul(t.x, la, h);
+  fp2_sub(s, g, h);
+  fp2_mul(s, th, s);
+  fp2_mul(g, e, t.y);
+  fp2_sub(t.y, s, g);
+  fp2_mul(t.z, t.z, e);
+}
+
+// f <- conj( prod_i f_{|x|,Q_i}(P_i) ).  Pairs with a point at infinity contribute 1.
+template <int N>
+BLS_FN void miller_loop(fp12& f, const g1_aff* P, const g2_aff* Q) {
+  g2_hom T[N];
+  bool skip[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    skip[k] = P[k].inf || Q[k].inf;
+    T[k].x = Q[k].x;
+    T[k].y = Q[k].y;
+    fp2_one(T[k].z);
+  }
+  fp12_one(f);
+  fp2 l0, l2, l3;
+  for (int i = 62; i >= 0; i--) {
+    if (i != 62) fp12_sqr(f, f);
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      if (!skip[k]) {
+        miller_dbl_step(T[k], l0, l2, l3, P[k].x, P[k].y);
+        fp12_mul_by_line(f, l0, l2, l3);
+      }
+    }
+    if ((BLS_X_ABS >> i) & 1) {
+#pragma unroll
+      for (int k = 0; k < N; k++) {
+        if (!skip[k]) {
+          miller_add_step(T[k], l0, l2, l3, Q[k].x, Q[k].y, P[k].x, P[k].y);
+          fp12_mul_by_line(f, l0, l2, l3);
+        }
+      }
+    }
+  }
+  fp12_conj(f, f);
+}
+
+// a^x for a in the cyclotomic subgroup (x < 0: conjugate of a^|x|)
+BLS_FN void fp12_pow_x(fp12& r, const fp12& a) {
+  fp12 acc = a;
+  for (int i = 62; i >= 0; i--) {
+    fp12_cyclotomic_sqr(acc, acc);
+    if ((BLS_X_ABS >> i) & 1) fp12_mul(acc, acc, a);
+  }
+  fp12_conj(r, acc);
+}
+
+// f^(3 (p^12 - 1)/r), using 3 (p^4 - p^2 + 1)/r = (x-1)^2 (x+p) (x^2+p^2-1) + 3
+BLS_FN void final_exponentiation(fp12& r, const fp12& fin) {
+  fp12 f, t, u, v;
+  // easy part: f^((p^6 - 1)(p^2 + 1))
+  fp12_inv(t, fin);
+  fp12_conj(f, fin);
+  fp12_mul(f, f, t);
+  fp12_frob<2>(t, f);
+  fp12_mul(f, t, f);
+  // hard part
+  fp12_pow_x(t, f);
+  fp12_conj(u, f);
+  fp12_mul(t, t, u);  // f^(x-1)
+  fp12_pow_x(u, t);
+  fp12_conj(v, t);
+  fp12_mul(t, u, v);  // f^((x-1)^2)
+  fp12_pow_x(u, t);
+  fp12_frob<1>(v, t);
+  fp12_mul(t, u, v);  // ^(x+p)
+  fp12_pow_x(u, t);
+  fp12_pow_x(u, u);   // t^(x^2)
+  fp12_frob<2>(v, t);
+  fp12_mul(u, u, v);
+  fp12_conj(v, t);
+  fp12_mul(t, u, v);  // ^(x^2+p^2-1)
+  fp12_cyclotomic_sqr(u, f);
+  fp12_mul(u, u, f);  // f^3
+  fp12_mul(r, t, u);
+}

@@ -1,0 +1,134 @@
+// Per-item pieces of the reference's core_verify (src/traits/sig_core.rs:120-146), shared by every kernel:
+//   prepare  : identity checks (signature first, then public key), to-affine, optional Aug prefix, hash-to-curve
+//   pairs    : (H(m), pk), (sig, -g)   with the G1 member first, as src/helpers.rs:41-63 arranges them
+// SIG_GROUP = 1: Bls12381G1Impl (sig in G1, pk in G2, src/impls/g1.rs);  = 2: Bls12381G2Impl (src/impls/g2.rs).
+#pragma once
+#include "h2c.cuh"
+#include "pairing.cuh"
+
+// status codes of the C ABI (include/blsgpu.h)
+#define BLS_OK 0
+#define BLS_ERR_INVALID_SIGNATURE 1
+#define BLS_ERR_SIG_IDENTITY 2
+#define BLS_ERR_PK_IDENTITY 3
+#define BLS_ERR_DUPLICATE_MESSAGE 4
+#define BLS_ERR_INVALID_COEFFICIENT 5
+#define BLS_ERR_BAD_LENGTH 6
+#define BLS_ERR_BAD_ENCODING 7
+#define BLS_ERR_LEGACY_FORMAT 8
+
+// 1/a, 1/b, 1/c with one inversion (all three non-zero)
+BLS_FN void fp_inv3(fp& a, fp& b, fp& c) {
+  fp ab, abc, t;
+  fp_mul(ab, a, b);
+  fp_mul(abc, ab, c);
+  fp_inv(abc, abc);
+  fp_mul(t, abc, ab);   // 1/c
+  fp_mul(abc, abc, c);  // 1/(ab)
+  c = t;
+  fp_mul(t, abc, b);    // 1/a
+  fp_mul(b, abc, a);    // 1/b
+  a = t;
+}
+BLS_FN void fp_inv2(fp& a, fp& b) {
+  fp ab, t;
+  fp_mul(ab, a, b);
+  fp_inv(ab, ab);
+  fp_mul(t, ab, b);
+  fp_mul(b, ab, a);
+  a = t;
+}
+BLS_FN void g1_apply_zinv(g1_aff& r, const g1_jac& p, const fp& zi) {
+  fp zi2;
+  fp_sqr(zi2, zi);
+  fp_mul(r.x, p.x, zi2);
+  fp_mul(zi2, zi2, zi);
+  fp_mul(r.y, p.y, zi2);
+  r.inf = false;
+}
+// 1/z for z in Fp2 given 1/norm(z)
+BLS_FN void g2_apply_ninv(g2_aff& r, const g2_jac& p, const fp& ni) {
+  fp2 zi, zi2;
+  fp_mul(zi.c0, p.z.c0, ni);
+  fp_mul(zi.c1, p.z.c1, ni);
+  fp_neg(zi.c1, zi.c1);
+  fp2_sqr(zi2, zi);
+  fp2_mul(r.x, p.x, zi2);
+  fp2_mul(zi2, zi2, zi);
+  fp2_mul(r.y, p.y, zi2);
+  r.inf = false;
+}
+BLS_FN void fp2_norm(fp& n, const fp2& a) {
+  fp t;
+  fp_sqr(n, a.c0);
+  fp_sqr(t, a.c1);
+  fp_add(n, n, t);
+}
+
+// both of (pk, sig) to affine with one inversion; neither is infinity
+BLS_FN void g1g2_to_aff(g1_aff& a1, g2_aff& a2, const g1_jac& p1, const g2_jac& p2) {
+  fp z1 = p1.z, n2;
+  fp2_norm(n2, p2.z);
+  fp_inv2(z1, n2);
+  g1_apply_zinv(a1, p1, z1);
+  g2_apply_ninv(a2, p2, n2);
+}
+
+BLS_FN void g1_neg_gen(g1_aff& r) {
+  fp_load(r.x, G1_GEN_X);
+  fp y;
+  fp_load(y, G1_GEN_Y);
+  fp_neg(r.y, y);
+  r.inf = false;
+}
+BLS_FN void g2_neg_gen(g2_aff& r) {
+  fp2_load(r.x, G2_GEN_X);
+  fp2 y;
+  fp2_load(y, G2_GEN_Y);
+  fp2_neg(r.y, y);
+  r.inf = false;
+}
+
+// Bls12381G1Impl: builds P[0] = H(m), Q[0] = pk, P[1] = sig, Q[1] = -g2
+BLS_FN int prepare_g1impl(g1_aff* P, g2_aff* Q, const g2_jac& pk, const g1_jac& sig, bool aug, const uint8_t* msg,
+                          uint32_t msg_len, const uint8_t* dst, uint32_t dst_len) {
+  if (jac_is_inf(sig)) return BLS_ERR_SIG_IDENTITY;
+  if (jac_is_inf(pk)) return BLS_ERR_PK_IDENTITY;
+  g1g2_to_aff(P[1], Q[0], sig, pk);
+  uint8_t pre[96];
+  uint32_t pre_len = 0;
+  if (aug) {
+    g2_compress(pre, Q[0], false);
+    pre_len = 96;
+  }
+  g1_jac h;
+  hash_to_g1(h, pre, pre_len, msg, msg_len, dst, dst_len);
+  jac_to_aff(P[0], h);
+  g2_neg_gen(Q[1]);
+  return BLS_OK;
+}
+
+// Bls12381G2Impl: P[0] = pk, Q[0] = H(m), P[1] = -g1, Q[1] = sig
+BLS_FN int prepare_g2impl(g1_aff* P, g2_aff* Q, const g1_jac& pk, const g2_jac& sig, bool aug, const uint8_t* msg,
+                          uint32_t msg_len, const uint8_t* dst, uint32_t dst_len) {
+  if (jac_is_inf(sig)) return BLS_ERR_SIG_IDENTITY;
+  if (jac_is_inf(pk)) return BLS_ERR_PK_IDENTITY;
+  g1g2_to_aff(P[0], Q[1], pk, sig);
+  uint8_t pre[48];
+  uint32_t pre_len = 0;
+  if (aug) {
+    g1_compress(pre, P[0], false);
+    pre_len = 48;
+  }
+  g2_jac h;
+  hash_to_g2(h, pre, pre_len, msg, msg_len, dst, dst_len);
+  jac_to_aff(Q[0], h);
+  g1_neg_gen(P[1]);
+  return BLS_OK;
+}
+
+BLS_FN int pairing_verdict(const fp12& f) {
+  fp12 e;
+  final_exponentiation(e, f);
+  return fp12_is_one(e) ? BLS_OK : BLS_ERR_INVALID_SIGNATURE;
+}

@@ -1,0 +1,117 @@
+// TEST-ONLY harness: compiles the device arithmetic headers (agora-blsful_amd/csrc/*.cuh) as plain host C++ so that
+// the `-m "not gpu"` suite can check every per-item device function against the oracle without a GPU.
+// It is never linked into libblsgpu.so and is not a CPU fallback: the product library has no host compute path.
+#include <string.h>
+#include "../../agora-blsful_amd/csrc/verify.cuh"
+
+static void load_g1_jac(g1_jac& p, const uint32_t* w) { fp_load(p.x, w); fp_load(p.y, w + 12); fp_load(p.z, w + 24); }
+static void load_g2_jac(g2_jac& p, const uint32_t* w) { fp2_load(p.x, w); fp2_load(p.y, w + 24); fp2_load(p.z, w + 48); }
+static void store_fp12_plain(uint32_t* out, const fp12& f) {
+  // w-power order: k = 2 j + i for c_i . a_j
+  const fp2* c[6] = {&f.c0.a0, &f.c1.a0, &f.c0.a1, &f.c1.a1, &f.c0.a2, &f.c1.a2};
+  for (int k = 0; k < 6; k++) {
+    fp t;
+    fp_from_mont(t, c[k]->c0); fp_store(out + 24 * k, t);
+    fp_from_mont(t, c[k]->c1); fp_store(out + 24 * k + 12, t);
+  }
+}
+
+extern "C" {
+void hs_fp_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  fp x, y, z; fp_load(x, a); fp_load(y, b); fp_mul(z, x, y); fp_store(out, z);
+}
+void hs_fp_ops(const uint32_t* a, const uint32_t* b, uint32_t* out) {  // add, sub, neg, inv, sqrt-flag
+  fp x, y, z; fp_load(x, a); fp_load(y, b);
+  fp_add(z, x, y); fp_store(out, z);
+  fp_sub(z, x, y); fp_store(out + 12, z);
+  fp_neg(z, x); fp_store(out + 24, z);
+  fp_inv(z, x); fp_store(out + 36, z);
+  out[48] = fp_sqrt(z, x) ? 1 : 0; fp_store(out + 49, z);
+  out[61] = fp_lex_largest(x) ? 1 : 0;
+}
+void hs_fp12_check(const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  // a, b: fp12 as 6 fp2 in w-power order, Montgomery.  out: mul, sqr(a), inv(a), frob1(a), frob2(a) plain w-order
+  fp12 x, y, z;
+  fp2* cx[6] = {&x.c0.a0, &x.c1.a0, &x.c0.a1, &x.c1.a1, &x.c0.a2, &x.c1.a2};
+  fp2* cy[6] = {&y.c0.a0, &y.c1.a0, &y.c0.a1, &y.c1.a1, &y.c0.a2, &y.c1.a2};
+  for (int k = 0; k < 6; k++) { fp2_load(*cx[k], a + 24 * k); fp2_load(*cy[k], b + 24 * k); }
+  fp12_mul(z, x, y); store_fp12_plain(out, z);
+  fp12_sqr(z, x); store_fp12_plain(out + 144, z);
+  fp12_inv(z, x); store_fp12_plain(out + 288, z);
+  fp12_frob<1>(z, x); store_fp12_plain(out + 432, z);
+  fp12_frob<2>(z, x); store_fp12_plain(out + 576, z);
+}
+void hs_hash_to_g1(const uint8_t* msg, uint32_t len, const uint8_t* dst, uint32_t dlen, uint8_t* out48) {
+  g1_jac h; g1_aff a;
+  hash_to_g1(h, nullptr, 0, msg, len, dst, dlen);
+  jac_to_aff(a, h);
+  g1_compress(out48, a, false);
+}
+void hs_hash_to_g2(const uint8_t* msg, uint32_t len, const uint8_t* dst, uint32_t dlen, uint8_t* out96) {
+  g2_jac h; g2_aff a;
+  hash_to_g2(h, nullptr, 0, msg, len, dst, dlen);
+  jac_to_aff(a, h);
+  g2_compress(out96, a, false);
+}
+// k * P for raw Jacobian inputs; compressed outputs.  also P + Q
+void hs_g1_mul_add(const uint32_t* p, const uint32_t* q, const uint32_t* k, uint8_t* out_mul, uint8_t* out_add, int legacy) {
+  g1_jac a, b, r; g1_aff f;
+  load_g1_jac(a, p); load_g1_jac(b, q);
+  jac_mul_scalar(r, a, k); jac_to_aff(f, r); g1_compress(out_mul, f, legacy);
+  jac_add(r, a, b); jac_to_aff(f, r); g1_compress(out_add, f, legacy);
+}
+void hs_g2_mul_add(const uint32_t* p, const uint32_t* q, const uint32_t* k, uint8_t* out_mul, uint8_t* out_add) {
+  g2_jac a, b, r; g2_aff f;
+  load_g2_jac(a, p); load_g2_jac(b, q);
+  jac_mul_scalar(r, a, k); jac_to_aff(f, r); g2_compress(out_mul, f, false);
+  jac_add(r, a, b); jac_to_aff(f, r); g2_compress(out_add, f, false);
+}
+void hs_g2_clear_cofactor(const uint32_t* p, uint8_t* out) {
+  g2_jac a, r; g2_aff f;
+  load_g2_jac(a, p); g2_clear_cofactor(r, a); jac_to_aff(f, r); g2_compress(out, f, false);
+}
+// final_exponentiation(miller_loop(pairs)) with affine Montgomery inputs (x, y), n = 1 or 2
+void hs_pairing(int n, const uint32_t* g1s, const uint32_t* g2s, uint32_t* out_plain, uint32_t* out_miller_plain) {
+  g1_aff P[2]; g2_aff Q[2];
+  for (int i = 0; i < n; i++) {
+    fp_load(P[i].x, g1s + 24 * i); fp_load(P[i].y, g1s + 24 * i + 12); P[i].inf = false;
+    fp2_load(Q[i].x, g2s + 48 * i); fp2_load(Q[i].y, g2s + 48 * i + 24); Q[i].inf = false;
+  }
+  fp12 f, e;
+  if (n == 1) miller_loop<1>(f, P, Q); else miller_loop<2>(f, P, Q);
+  if (out_miller_plain) store_fp12_plain(out_miller_plain, f);
+  final_exponentiation(e, f);
+  store_fp12_plain(out_plain, e);
+}
+// cyclotomic squaring vs generic squaring on an element of the cyclotomic subgroup
+int hs_cyclotomic_check(int n, const uint32_t* g1s, const uint32_t* g2s) {
+  g1_aff P[1]; g2_aff Q[1];
+  fp_load(P[0].x, g1s); fp_load(P[0].y, g1s + 12); P[0].inf = false;
+  fp2_load(Q[0].x, g2s); fp2_load(Q[0].y, g2s + 24); Q[0].inf = false;
+  fp12 f, e, a, b;
+  miller_loop<1>(f, P, Q);
+  final_exponentiation(e, f);
+  fp12_cyclotomic_sqr(a, e);
+  fp12_sqr(b, e);
+  uint32_t wa[144], wb[144];
+  store_fp12_plain(wa, a); store_fp12_plain(wb, b);
+  (void)n;
+  return memcmp(wa, wb, sizeof wa) == 0;
+}
+int hs_verify(int sig_group, const uint32_t* pk, const uint32_t* sig, int aug, const uint8_t* msg, uint32_t len,
+              const uint8_t* dst, uint32_t dlen) {
+  g1_aff P[2]; g2_aff Q[2];
+  int st;
+  if (sig_group == 1) {
+    g2_jac k; g1_jac s; load_g2_jac(k, pk); load_g1_jac(s, sig);
+    st = prepare_g1impl(P, Q, k, s, aug != 0, msg, len, dst, dlen);
+  } else {
+    g1_jac k; g2_jac s; load_g1_jac(k, pk); load_g2_jac(s, sig);
+    st = prepare_g2impl(P, Q, k, s, aug != 0, msg, len, dst, dlen);
+  }
+  if (st != BLS_OK) return st;
+  fp12 f;
+  miller_loop<2>(f, P, Q);
+  return pairing_verdict(f);
+}
+}

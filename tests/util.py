@@ -1,0 +1,81 @@
+"""Test helpers: oracle <-> raw-buffer conversions (blst-layout Montgomery limbs) and library loading."""
+import ctypes
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle.py import bls381 as c  # noqa: E402
+from oracle.py import blsful_ref as ref  # noqa: E402
+
+P = c.P
+RM = 1 << 384
+
+
+def fp_raw(v):
+    """Fp value -> 48 bytes, Montgomery form, little-endian limbs (blst `blst_fp`)."""
+    return (v % P * RM % P).to_bytes(48, 'little')
+
+
+def fp2_raw(v):
+    return fp_raw(v[0]) + fp_raw(v[1])
+
+
+def fp_from_raw(b):
+    return int.from_bytes(b, 'little') * pow(RM, -1, P) % P
+
+
+def g1_raw(pt, rng=None):
+    """Affine oracle point -> 144-byte Jacobian RAW_PROJ (random Z when rng is given; Z = 0 for infinity)."""
+    if pt is None:
+        return fp_raw(0) + fp_raw(1) + fp_raw(0) if rng is None else fp_raw(rng.randrange(1, P)) + fp_raw(rng.randrange(1, P)) + fp_raw(0)
+    z = 1 if rng is None else rng.randrange(1, P)
+    return fp_raw(pt[0] * z * z) + fp_raw(pt[1] * z * z * z) + fp_raw(z)
+
+
+def g2_raw(pt, rng=None):
+    if pt is None:
+        return fp2_raw((0, 0)) + fp2_raw((1, 0)) + fp2_raw((0, 0))
+    z = (1, 0) if rng is None else (rng.randrange(1, P), rng.randrange(P))
+    z2 = c.f2_sqr(z)
+    z3 = c.f2_mul(z2, z)
+    return fp2_raw(c.f2_mul(pt[0], z2)) + fp2_raw(c.f2_mul(pt[1], z3)) + fp2_raw(z)
+
+
+def g1_aff_raw(pt):
+    return fp_raw(pt[0]) + fp_raw(pt[1])
+
+
+def g2_aff_raw(pt):
+    return fp2_raw(pt[0]) + fp2_raw(pt[1])
+
+
+def f12_from_plain_words(buf):
+    """144 little-endian u32 words (6 Fp2 in w-power order, plain integers) -> oracle f12 tuple."""
+    out = []
+    for k in range(6):
+        c0 = int.from_bytes(buf[96 * k:96 * k + 48], 'little')
+        c1 = int.from_bytes(buf[96 * k + 48:96 * k + 96], 'little')
+        out.append((c0, c1))
+    return tuple(out)
+
+
+def f12_raw(f):
+    return b''.join(fp2_raw(x) for x in f)
+
+
+def scalar_raw(k):
+    return (k % (1 << 256)).to_bytes(32, 'little')
+
+
+def build_hostsim():
+    src = os.path.join(ROOT, 'tests', 'hostsim', 'hostsim.cpp')
+    so = os.path.join(ROOT, 'tests', 'hostsim', 'libhostsim.so')
+    deps = [src] + [os.path.join(ROOT, 'agora-blsful_amd', 'csrc', f) for f in os.listdir(os.path.join(ROOT, 'agora-blsful_amd', 'csrc')) if f.endswith('.cuh')]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        import subprocess
+        subprocess.check_call(['g++', '-O2', '-shared', '-fPIC', '-o', so, src])
+    return ctypes.CDLL(so)
