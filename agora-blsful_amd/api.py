@@ -1,0 +1,323 @@
+"""Host-side mirror of the reference's verify-path interface over the C ABI of libblsgpu.so (include/blsgpu.h).
+
+The reference is a Rust crate and no Rust toolchain exists in this image, so this module plays the role of the
+`hip`-feature shim of INTEGRATION.md: same names, argument meaning and error behaviour as
+
+    Signature::verify / verify_secure / verify_secure_with_mode     reference src/signature.rs:130-138,177-197,256-276
+    MultiSignature::verify + MultiPublicKey::from_public_keys      src/multi_signature.rs:127-135, src/multi_public_key.rs:79-83
+    AggregateSignature::verify                                     src/aggregate_signature.rs:230-239
+    BlsError                                                       src/error.rs:5-55
+
+so that the parity tests read like the reference's own tests.  Points are held as RAW_PROJ byte strings (the
+blst in-memory layout the Rust types wrap).  All compute happens in the HIP library; if it cannot be loaded or finds
+no gfx950 device, every call raises -- there is no CPU path here.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libblsgpu.so')
+
+FMT_RAW_PROJ, FMT_RAW_AFFINE, FMT_COMPRESSED, FMT_LEGACY = 0, 1, 2, 3
+BASIC, AUG, POP = 0, 1, 2
+MODERN, LEGACY = 0, 1
+
+OK, INVALID_SIGNATURE, SIG_IDENTITY, PK_IDENTITY, DUPLICATE_MESSAGE, INVALID_COEFFICIENT, BAD_LENGTH, BAD_ENCODING, \
+    LEGACY_FORMAT = range(9)
+
+EXPORTS = [
+    'blsgpu_init', 'blsgpu_shutdown', 'blsgpu_last_error', 'blsgpu_verify_batch', 'blsgpu_multi_verify',
+    'blsgpu_aggregate_verify', 'blsgpu_verify_secure', 'blsgpu_secure_coefficients', 'blsgpu_hash_to_g1',
+    'blsgpu_hash_to_g2', 'blsgpu_sum_g1', 'blsgpu_sum_g2', 'blsgpu_msm_g1', 'blsgpu_msm_g2',
+    'blsgpu_pairing_product_is_one', 'blsgpu_serialize',
+]
+
+
+class BlsGpuRuntimeError(RuntimeError):
+    """A negative return code of the C ABI (HIP failure, missing device, bad argument)."""
+
+
+class BlsError(Exception):
+    """Mirror of the reference's BlsError variants reachable on the verify path (src/error.rs:5-55)."""
+
+    def __init__(self, kind, msg=''):
+        super().__init__(f'{kind}: {msg}' if msg else kind)
+        self.kind, self.msg = kind, msg
+
+    def __eq__(self, o):
+        return isinstance(o, BlsError) and (self.kind, self.msg) == (o.kind, o.msg)
+
+    def __hash__(self):
+        return hash((self.kind, self.msg))
+
+
+def error_from_status(st, aux=(0, 0), aggregate=False):
+    """Status code -> the exact BlsError value the reference returns (strings from src/traits/sig_core.rs:126-176,
+    src/traits/sig_basic.rs:51-55, src/secure_aggregation.rs:99,193)."""
+    if st == OK:
+        return None
+    if st == INVALID_SIGNATURE:
+        return BlsError('InvalidSignature')
+    if st == SIG_IDENTITY:
+        return BlsError('InvalidInputs', 'signature is the identity point')
+    if st == PK_IDENTITY:
+        if aggregate:
+            return BlsError('InvalidInputs', 'public key at %d is the identity point' % aux[0])
+        return BlsError('InvalidInputs', 'public key is the identity point')
+    if st == DUPLICATE_MESSAGE:
+        return BlsError('InvalidInputs', 'duplicate messages detected at %d and %d' % (aux[0], aux[1]))
+    if st == INVALID_COEFFICIENT:
+        return BlsError('InvalidCoefficient')
+    if st == BAD_LENGTH:
+        return BlsError('InvalidLength')
+    if st == BAD_ENCODING:
+        return BlsError('DeserializationError')
+    if st == LEGACY_FORMAT:
+        return BlsError('LegacyFormatError')
+    return BlsError('Unknown', str(st))
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libblsgpu.so (no device needed for this).  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise BlsGpuRuntimeError(f'{p} not found: build it with __graft_entry__.build(); there is no CPU fallback')
+        lib = ctypes.CDLL(p)
+        vp, u8p, u64p, i32p, u32p, sz, ci = (ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int)
+        lib.blsgpu_init.argtypes = [ci]
+        lib.blsgpu_shutdown.restype = None
+        lib.blsgpu_last_error.argtypes = [ctypes.c_char_p, sz]
+        lib.blsgpu_last_error.restype = sz
+        lib.blsgpu_verify_batch.argtypes = [ci, ci, vp, vp, u8p, u64p, sz, ci, i32p]
+        lib.blsgpu_multi_verify.argtypes = [ci, ci, vp, sz, vp, u8p, sz, ci, i32p]
+        lib.blsgpu_aggregate_verify.argtypes = [ci, ci, vp, u8p, u64p, sz, vp, ci, i32p, u64p]
+        lib.blsgpu_verify_secure.argtypes = [ci, ci, vp, sz, vp, u8p, sz, ci, ci, i32p]
+        lib.blsgpu_secure_coefficients.argtypes = [u8p, sz, sz, u32p, u8p, i32p]
+        lib.blsgpu_hash_to_g1.argtypes = [u8p, u64p, sz, u8p, sz, vp]
+        lib.blsgpu_hash_to_g2.argtypes = [u8p, u64p, sz, u8p, sz, vp]
+        for nm in ('blsgpu_sum_g1', 'blsgpu_sum_g2'):
+            getattr(lib, nm).argtypes = [vp, sz, ci, vp]
+        for nm in ('blsgpu_msm_g1', 'blsgpu_msm_g2'):
+            getattr(lib, nm).argtypes = [vp, u8p, sz, ci, vp]
+        lib.blsgpu_pairing_product_is_one.argtypes = [vp, vp, sz, ci, i32p]
+        lib.blsgpu_serialize.argtypes = [ci, vp, sz, ci, ci, vp, i32p]
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        buf = ctypes.create_string_buffer(1024)
+        _lib.blsgpu_last_error(buf, 1024)
+        raise BlsGpuRuntimeError('libblsgpu rc=%d: %s' % (rc, buf.value.decode(errors='replace')))
+
+
+def init(device=-1):
+    lib = load_library()
+    _check(lib.blsgpu_init(device))
+    return lib
+
+
+def _offsets(msgs):
+    offs = (ctypes.c_uint64 * (len(msgs) + 1))()
+    t = 0
+    for i, m in enumerate(msgs):
+        offs[i] = t
+        t += len(m)
+    offs[len(msgs)] = t
+    return offs, b''.join(msgs)
+
+
+def _ptr(b):
+    """bytes / int (device address) -> c_void_p value"""
+    if isinstance(b, int):
+        return ctypes.c_void_p(b)
+    return ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p)
+
+
+# ------------------------------------------------------------------ flat (array) calls
+def verify_batch(sig_group, scheme, pks, sigs, msgs, fmt=FMT_RAW_PROJ):
+    """status list of Signature::verify for n independent (pk, msg, sig) items."""
+    lib = init()
+    n = len(msgs)
+    offs, blob = _offsets(msgs)
+    st = (ctypes.c_int32 * n)()
+    pkb, sgb = b''.join(pks), b''.join(sigs)
+    _check(lib.blsgpu_verify_batch(sig_group, scheme, _ptr(pkb), _ptr(sgb), _ptr(blob), ctypes.cast(offs, ctypes.c_void_p), n, fmt,
+                                   ctypes.cast(st, ctypes.c_void_p)))
+    return list(st)
+
+
+def multi_verify(sig_group, scheme, pks, sig, msg, fmt=FMT_RAW_PROJ):
+    lib = init()
+    st = ctypes.c_int32(-99)
+    pkb = b''.join(pks)
+    _check(lib.blsgpu_multi_verify(sig_group, scheme, _ptr(pkb), len(pks), _ptr(sig), _ptr(msg), len(msg), fmt, ctypes.byref(st)))
+    return st.value
+
+
+def aggregate_verify(sig_group, scheme, pks, msgs, sig, fmt=FMT_RAW_PROJ):
+    lib = init()
+    offs, blob = _offsets(msgs)
+    st = ctypes.c_int32(-99)
+    aux = (ctypes.c_uint64 * 2)()
+    pkb = b''.join(pks)
+    _check(lib.blsgpu_aggregate_verify(sig_group, scheme, _ptr(pkb), _ptr(blob), ctypes.cast(offs, ctypes.c_void_p), len(pks), _ptr(sig), fmt,
+                                       ctypes.byref(st), ctypes.cast(aux, ctypes.c_void_p)))
+    return st.value, (aux[0], aux[1])
+
+
+def verify_secure(sig_group, scheme, pks, sig, msg, ser_format=MODERN, fmt=FMT_RAW_PROJ):
+    lib = init()
+    st = ctypes.c_int32(-99)
+    pkb = b''.join(pks)
+    _check(lib.blsgpu_verify_secure(sig_group, scheme, _ptr(pkb), len(pks), _ptr(sig), _ptr(msg), len(msg), ser_format, fmt, ctypes.byref(st)))
+    return st.value
+
+
+def secure_coefficients(key_bytes_list):
+    lib = init()
+    n = len(key_bytes_list)
+    width = len(key_bytes_list[0]) if n else 48
+    perm = (ctypes.c_uint32 * max(n, 1))()
+    scal = ctypes.create_string_buffer(32 * max(n, 1))
+    st = ctypes.c_int32(-99)
+    blob = b''.join(key_bytes_list)
+    _check(lib.blsgpu_secure_coefficients(_ptr(blob), n, width, ctypes.cast(perm, ctypes.c_void_p), ctypes.cast(scal, ctypes.c_void_p),
+                                          ctypes.byref(st)))
+    return st.value, list(perm)[:n], [int.from_bytes(scal.raw[32 * i:32 * i + 32], 'little') for i in range(n)]
+
+
+def hash_to_point(group, msgs, dst):
+    lib = init()
+    n = len(msgs)
+    offs, blob = _offsets(msgs)
+    sz = 144 if group == 1 else 288
+    out = ctypes.create_string_buffer(sz * n)
+    fn = lib.blsgpu_hash_to_g1 if group == 1 else lib.blsgpu_hash_to_g2
+    _check(fn(_ptr(blob), ctypes.cast(offs, ctypes.c_void_p), n, _ptr(dst), len(dst), ctypes.cast(out, ctypes.c_void_p)))
+    return [out.raw[sz * i:sz * (i + 1)] for i in range(n)]
+
+
+def point_sum(group, pts, scalars=None, fmt=FMT_RAW_PROJ):
+    lib = init()
+    sz = 144 if group == 1 else 288
+    out = ctypes.create_string_buffer(sz)
+    blob = b''.join(pts)
+    if scalars is None:
+        fn = lib.blsgpu_sum_g1 if group == 1 else lib.blsgpu_sum_g2
+        _check(fn(_ptr(blob), len(pts), fmt, ctypes.cast(out, ctypes.c_void_p)))
+    else:
+        fn = lib.blsgpu_msm_g1 if group == 1 else lib.blsgpu_msm_g2
+        sb = b''.join(int(s).to_bytes(32, 'little') for s in scalars)
+        _check(fn(_ptr(blob), _ptr(sb), len(pts), fmt, ctypes.cast(out, ctypes.c_void_p)))
+    return out.raw
+
+
+def pairing_product_is_one(g1s, g2s, fmt=FMT_RAW_PROJ):
+    lib = init()
+    r = ctypes.c_int32(-99)
+    a, b = b''.join(g1s), b''.join(g2s)
+    _check(lib.blsgpu_pairing_product_is_one(_ptr(a), _ptr(b), len(g1s), fmt, ctypes.byref(r)))
+    return bool(r.value)
+
+
+def serialize(group, pts, fmt_in=FMT_RAW_PROJ, legacy=False):
+    lib = init()
+    n = len(pts)
+    osz = 48 if group == 1 else 96
+    out = ctypes.create_string_buffer(osz * max(n, 1))
+    blob = b''.join(pts)
+    _check(lib.blsgpu_serialize(group, _ptr(blob), n, fmt_in, FMT_LEGACY if legacy else FMT_COMPRESSED, ctypes.cast(out, ctypes.c_void_p), None))
+    return [out.raw[osz * i:osz * (i + 1)] for i in range(n)]
+
+
+# ------------------------------------------------------------------ reference-shaped wrapper types
+class Impl:
+    def __init__(self, sig_group):
+        self.sig_group = sig_group
+        self.name = 'Bls12381G%dImpl' % sig_group
+
+
+Bls12381G1Impl = Impl(1)
+Bls12381G2Impl = Impl(2)
+
+
+class PublicKey:
+    """PublicKey<C>(pub C::PublicKey): reference src/public_key.rs:5-11.  `raw` = RAW_PROJ bytes."""
+
+    def __init__(self, impl, raw):
+        self.impl, self.raw = impl, bytes(raw)
+
+
+class Signature:
+    """Signature<C> {Basic, MessageAugmentation, ProofOfPossession}: reference src/signature.rs:25-44."""
+
+    def __init__(self, impl, scheme, raw):
+        self.impl, self.scheme, self.raw = impl, scheme, bytes(raw)
+
+    def verify(self, pk, msg):
+        """reference src/signature.rs:130-138; raises BlsError on failure, returns None on Ok(())."""
+        st = verify_batch(self.impl.sig_group, self.scheme, [pk.raw], [self.raw], [bytes(msg)])[0]
+        e = error_from_status(st)
+        if e:
+            raise e
+
+    def verify_secure(self, public_keys, msg):
+        """reference src/signature.rs:177-197."""
+        st = verify_secure(self.impl.sig_group, self.scheme, [p.raw for p in public_keys], self.raw, bytes(msg), MODERN)
+        e = error_from_status(st)
+        if e:
+            raise e
+
+    def verify_secure_with_mode(self, public_keys, msg, fmt):
+        """reference src/signature.rs:256-276."""
+        st = verify_secure(self.impl.sig_group, self.scheme, [p.raw for p in public_keys], self.raw, bytes(msg), fmt)
+        e = error_from_status(st)
+        if e:
+            raise e
+
+
+class MultiPublicKey:
+    """reference src/multi_public_key.rs:5-11; built lazily: the sum runs on the GPU inside MultiSignature.verify."""
+
+    def __init__(self, impl, keys):
+        self.impl, self.keys = impl, list(keys)
+
+    @staticmethod
+    def from_public_keys(keys):
+        return MultiPublicKey(keys[0].impl, keys)
+
+
+class MultiSignature:
+    """reference src/multi_signature.rs:6-25."""
+
+    def __init__(self, impl, scheme, raw):
+        self.impl, self.scheme, self.raw = impl, scheme, bytes(raw)
+
+    def verify(self, mpk, msg):
+        """reference src/multi_signature.rs:127-135."""
+        st = multi_verify(self.impl.sig_group, self.scheme, [k.raw for k in mpk.keys], self.raw, bytes(msg))
+        e = error_from_status(st)
+        if e:
+            raise e
+
+
+class AggregateSignature:
+    """reference src/aggregate_signature.rs:33-52."""
+
+    def __init__(self, impl, scheme, raw):
+        self.impl, self.scheme, self.raw = impl, scheme, bytes(raw)
+
+    def verify(self, data):
+        """data: [(PublicKey, msg)]; reference src/aggregate_signature.rs:230-239."""
+        st, aux = aggregate_verify(self.impl.sig_group, self.scheme, [p.raw for p, _ in data], [bytes(m) for _, m in data], self.raw)
+        e = error_from_status(st, aux, aggregate=True)
+        if e:
+            raise e

@@ -1,0 +1,693 @@
+// libblsgpu.so: host side of the C ABI declared in include/blsgpu.h.  HIP runtime only (no torch types).
+// There is no CPU compute path in this library: without a gfx950 device every entry point fails loudly.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/blsgpu.h"
+#include "kernels.cuh"
+#include "host_sha256.h"
+
+namespace {
+
+thread_local std::string t_err;
+
+struct Ctx {
+  int dev = -1;
+  hipStream_t stream = nullptr;
+  uint8_t* arena = nullptr;
+  size_t arena_cap = 0, arena_off = 0;
+  std::mutex mu;
+};
+Ctx* g_ctx = nullptr;
+std::mutex g_init_mu;
+
+int fail(int code, const std::string& msg) {
+  t_err = msg;
+  return code;
+}
+#define HIPCK(x)                                                                                   \
+  do {                                                                                             \
+    hipError_t e_ = (x);                                                                           \
+    if (e_ != hipSuccess) {                                                                        \
+      (void)hipGetLastError();                                                                     \
+      return fail(BLSGPU_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_));                 \
+    }                                                                                              \
+  } while (0)
+
+bool is_device_ptr(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t a;
+  hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+// ---- bump arena in device memory, reset per call
+int arena_reserve(Ctx* c, size_t bytes) {
+  if (bytes <= c->arena_cap) return 0;
+  HIPCK(hipStreamSynchronize(c->stream));
+  if (c->arena) HIPCK(hipFree(c->arena));
+  c->arena = nullptr;
+  c->arena_cap = 0;
+  size_t cap = bytes + bytes / 8 + (1u << 20);
+  HIPCK(hipMalloc((void**)&c->arena, cap));
+  c->arena_cap = cap;
+  return 0;
+}
+void* arena_take(Ctx* c, size_t bytes) {
+  size_t off = (c->arena_off + 255) & ~(size_t)255;
+  if (off + bytes > c->arena_cap) return nullptr;
+  c->arena_off = off + bytes;
+  return c->arena + off;
+}
+size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// device view of an input buffer: device pointers pass through, host buffers are staged into the arena
+int stage_in(Ctx* c, const void* p, size_t bytes, const void** out) {
+  if (bytes == 0) {
+    *out = c->arena;
+    return 0;
+  }
+  if (is_device_ptr(p)) {
+    *out = p;
+    return 0;
+  }
+  void* d = arena_take(c, bytes);
+  if (!d) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  HIPCK(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, c->stream));
+  *out = d;
+  return 0;
+}
+int copy_out(Ctx* c, void* dst, const void* dsrc, size_t bytes) {
+  if (bytes == 0) return 0;
+  HIPCK(hipMemcpyAsync(dst, dsrc, bytes, is_device_ptr(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+  return 0;
+}
+
+size_t g1_size(int fmt) { return fmt == BLSGPU_FMT_RAW_PROJ ? 144 : fmt == BLSGPU_FMT_RAW_AFFINE ? 96 : 48; }
+size_t g2_size(int fmt) { return fmt == BLSGPU_FMT_RAW_PROJ ? 288 : fmt == BLSGPU_FMT_RAW_AFFINE ? 192 : 96; }
+size_t pk_size(int sg, int fmt) { return sg == 1 ? g2_size(fmt) : g1_size(fmt); }
+size_t sig_size(int sg, int fmt) { return sg == 1 ? g1_size(fmt) : g2_size(fmt); }
+
+const char* DST_TABLE[2][3] = {
+    {"BLS_SIG_BLS12381G1_XMD:SHA-256_SSWU_RO_NUL_", "BLS_SIG_BLS12381G1_XMD:SHA-256_SSWU_RO_AUG_",
+     "BLS_SIG_BLS12381G1_XMD:SHA-256_SSWU_RO_POP_"},  // reference src/impls/g1.rs:110,114,118
+    {"BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_", "BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_AUG_",
+     "BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_"},  // reference src/impls/g2.rs:108,112,116
+};
+dst_arg make_dst(const uint8_t* d, size_t n) {
+  dst_arg a;
+  memset(&a, 0, sizeof a);
+  memcpy(a.b, d, n);
+  a.len = (uint32_t)n;
+  return a;
+}
+dst_arg scheme_dst(int sg, int scheme) {
+  const char* s = DST_TABLE[sg - 1][scheme];
+  return make_dst((const uint8_t*)s, strlen(s));
+}
+
+int check_common(int sg, int scheme, int fmt) {
+  if (!g_ctx) return fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)");
+  if (sg != 1 && sg != 2) return fail(BLSGPU_E_ARG, "sig_group must be 1 (Bls12381G1Impl) or 2 (Bls12381G2Impl)");
+  if (scheme < 0 || scheme > 2) return fail(BLSGPU_E_ARG, "scheme must be 0 (Basic), 1 (MessageAugmentation) or 2 (ProofOfPossession)");
+  if (fmt != BLSGPU_FMT_RAW_PROJ && fmt != BLSGPU_FMT_RAW_AFFINE)
+    return fail(BLSGPU_E_ARG, "this entry point takes BLSGPU_FMT_RAW_PROJ or BLSGPU_FMT_RAW_AFFINE points");
+  return 0;
+}
+
+unsigned blocks_for(size_t n) { return (unsigned)((n + BLS_BLOCK - 1) / BLS_BLOCK); }
+
+// ---- shared device pipelines (stream-ordered; caller holds the context mutex) ------------------------
+
+// one core_verify per item: statuses end up in d_status (device)
+int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_t* d_sigs, int fmt, const uint8_t* d_msgs,
+                     const uint64_t* d_offs, int single_msg, const dst_arg& dst, size_t n, uint32_t* d_pairs, uint32_t* d_f,
+                     int32_t* d_status) {
+  if (n == 0) return 0;
+  unsigned nb = blocks_for(n);
+  if (sg == 1)
+    hipLaunchKernelGGL(k_prepare<1>, dim3(nb), dim3(BLS_BLOCK), 0, c->stream, n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status);
+  else
+    hipLaunchKernelGGL(k_prepare<2>, dim3(nb), dim3(BLS_BLOCK), 0, c->stream, n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status);
+  hipLaunchKernelGGL(k_miller2, dim3(nb), dim3(BLS_BLOCK), 0, c->stream, n, d_pairs, d_status, d_f);
+  hipLaunchKernelGGL(k_finalexp, dim3(nb), dim3(BLS_BLOCK), 0, c->stream, n, d_f, d_status);
+  HIPCK(hipGetLastError());
+  return 0;
+}
+
+// product of m Fp12 values in a workspace (stride given) folded into item 0, then verdict
+int run_f12_product_verdict(Ctx* c, uint32_t* d_f, size_t m, size_t stride, int32_t* d_verdict) {
+  size_t cur = m;
+  while (cur > 1) {
+    size_t half = (cur + 1) / 2;
+    hipLaunchKernelGGL(k_f12_fold, dim3(blocks_for(half)), dim3(BLS_BLOCK), 0, c->stream, cur, half, d_f, stride);
+    cur = half;
+  }
+  hipLaunchKernelGGL(k_finalexp_one, dim3(1), dim3(64), 0, c->stream, d_f, stride, d_verdict);
+  HIPCK(hipGetLastError());
+  return 0;
+}
+
+size_t accumulate_lanes(size_t n) {
+  size_t t = n / 4;
+  if (t < 64) t = 64;
+  if (t > 65536) t = 65536;
+  return (t + 63) & ~(size_t)63;
+}
+
+// sum (or sum of scalar multiples) of n points of group G into partials[0] (RAW_PROJ, device)
+template <int G>
+int run_point_sum(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_scalars, const uint32_t* d_perm, size_t n,
+                  uint8_t* d_partials, size_t T) {
+  unsigned nb = blocks_for(T);
+  if (d_scalars)
+    hipLaunchKernelGGL((k_accumulate<G, 1>), dim3(nb), dim3(BLS_BLOCK), 0, c->stream, n, d_pts, fmt, d_scalars, d_perm, d_partials, T);
+  else
+    hipLaunchKernelGGL((k_accumulate<G, 0>), dim3(nb), dim3(BLS_BLOCK), 0, c->stream, n, d_pts, fmt, d_scalars, d_perm, d_partials, T);
+  size_t cur = T;
+  while (cur > 1) {
+    size_t half = (cur + 1) / 2;
+    hipLaunchKernelGGL(k_point_fold<G>, dim3(blocks_for(half)), dim3(BLS_BLOCK), 0, c->stream, cur, half, d_partials);
+    cur = half;
+  }
+  HIPCK(hipGetLastError());
+  return 0;
+}
+
+// 256-bit big-endian hash -> scalar mod r, 32 bytes little-endian; returns false when the result is zero.
+// Restates `int_BE(hash) mod r` of reference src/secure_aggregation.rs:61-100.
+const uint32_t R_LIMBS[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+bool hash_to_scalar_le(const uint8_t hash[32], uint8_t out[32]) {
+  uint32_t v[8];
+  for (int i = 0; i < 8; i++) {
+    const uint8_t* q = hash + 4 * (7 - i);
+    v[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+  }
+  for (int round = 0; round < 3; round++) {  // hash < 2^256 < 3r
+    uint32_t d[8];
+    uint64_t bw = 0;
+    for (int i = 0; i < 8; i++) {
+      uint64_t s = (uint64_t)v[i] - R_LIMBS[i] - bw;
+      d[i] = (uint32_t)s;
+      bw = (s >> 63) & 1;
+    }
+    if (bw) break;
+    memcpy(v, d, sizeof v);
+  }
+  uint32_t nz = 0;
+  for (int i = 0; i < 8; i++) {
+    nz |= v[i];
+    out[4 * i] = (uint8_t)v[i];
+    out[4 * i + 1] = (uint8_t)(v[i] >> 8);
+    out[4 * i + 2] = (uint8_t)(v[i] >> 16);
+    out[4 * i + 3] = (uint8_t)(v[i] >> 24);
+  }
+  return nz != 0;
+}
+
+// host part of hash_public_keys_with_sorted (reference src/secure_aggregation.rs:41-103): stable sort by serialised
+// bytes, H = SHA-256(concat), t_i = SHA-256(BE32(i) || H) mod r.  Returns BLSGPU_OK or BLSGPU_INVALID_COEFFICIENT.
+int secure_coefficients_host(const uint8_t* kb, size_t n, size_t width, std::vector<uint32_t>& perm, std::vector<uint8_t>& scalars) {
+  perm.resize(n);
+  std::iota(perm.begin(), perm.end(), 0u);
+  std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return memcmp(kb + (size_t)a * width, kb + (size_t)b * width, width) < 0; });
+  host_sha256 h;
+  for (size_t i = 0; i < n; i++) h.update(kb + (size_t)perm[i] * width, width);
+  uint8_t H[32];
+  h.final(H);
+  scalars.resize(32 * n);
+  for (size_t i = 0; i < n; i++) {
+    uint8_t buf[36] = {(uint8_t)(i >> 24), (uint8_t)(i >> 16), (uint8_t)(i >> 8), (uint8_t)i};
+    memcpy(buf + 4, H, 32);
+    uint8_t d[32];
+    host_sha256 hi;
+    hi.update(buf, 36);
+    hi.final(d);
+    if (!hash_to_scalar_le(d, &scalars[32 * i])) return BLSGPU_INVALID_COEFFICIENT;
+  }
+  return BLSGPU_OK;
+}
+
+}  // namespace
+
+// =========================================================================================================
+extern "C" {
+
+int blsgpu_init(int device) {
+  std::lock_guard<std::mutex> lk(g_init_mu);
+  if (g_ctx) return 0;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    (void)hipGetLastError();
+    return fail(BLSGPU_E_NO_DEVICE, "no HIP device available: libblsgpu has no CPU fallback");
+  }
+  if (device < 0) {
+    if (hipGetDevice(&device) != hipSuccess) device = 0;
+  }
+  if (device >= ndev) return fail(BLSGPU_E_ARG, "device ordinal out of range");
+  HIPCK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCK(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return fail(BLSGPU_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 (MI355X) only");
+  Ctx* c = new Ctx();
+  c->dev = device;
+  HIPCK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  g_ctx = c;
+  return 0;
+}
+
+void blsgpu_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_init_mu);
+  if (!g_ctx) return;
+  (void)hipSetDevice(g_ctx->dev);
+  (void)hipStreamSynchronize(g_ctx->stream);
+  if (g_ctx->arena) (void)hipFree(g_ctx->arena);
+  (void)hipStreamDestroy(g_ctx->stream);
+  delete g_ctx;
+  g_ctx = nullptr;
+}
+
+size_t blsgpu_last_error(char* buf, size_t cap) {
+  if (buf && cap) {
+    size_t k = std::min(cap - 1, t_err.size());
+    memcpy(buf, t_err.data(), k);
+    buf[k] = 0;
+  }
+  return t_err.size();
+}
+
+int blsgpu_verify_batch(int sig_group, int scheme, const void* pks, const void* sigs, const uint8_t* msgs,
+                        const uint64_t* msg_offsets, size_t n, int fmt, int32_t* status) {
+  int rc = check_common(sig_group, scheme, fmt);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  if (!pks || !sigs || !msg_offsets || !status) return fail(BLSGPU_E_ARG, "null argument");
+  Ctx* c = g_ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCK(hipSetDevice(c->dev));
+  // total message bytes: last offset (read it from wherever it lives)
+  uint64_t total = 0;
+  if (is_device_ptr(msg_offsets)) HIPCK(hipMemcpy(&total, msg_offsets + n, 8, hipMemcpyDeviceToHost));
+  else total = msg_offsets[n];
+  const size_t pkb = pk_size(sig_group, fmt) * n, sgb = sig_size(sig_group, fmt) * n;
+  size_t need = pad256(pkb) + pad256(sgb) + pad256(total) + pad256(8 * (n + 1)) + pad256(4 * n) + 2 * pad256((size_t)WS_PAIRS_WORDS * 4 * n) + 4096;
+  rc = arena_reserve(c, need);
+  if (rc) return rc;
+  c->arena_off = 0;
+  const void *d_pks, *d_sigs, *d_msgs, *d_offs;
+  if ((rc = stage_in(c, pks, pkb, &d_pks))) return rc;
+  if ((rc = stage_in(c, sigs, sgb, &d_sigs))) return rc;
+  if ((rc = stage_in(c, msgs, total, &d_msgs))) return rc;
+  if ((rc = stage_in(c, msg_offsets, 8 * (n + 1), &d_offs))) return rc;
+  int32_t* d_status = (int32_t*)arena_take(c, 4 * n);
+  uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)WS_PAIRS_WORDS * 4 * n);
+  uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * n);
+  if (!d_status || !d_pairs || !d_f) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  rc = run_verify_items(c, sig_group, scheme == BLSGPU_SCHEME_AUG, (const uint8_t*)d_pks, (const uint8_t*)d_sigs, fmt,
+                        (const uint8_t*)d_msgs, (const uint64_t*)d_offs, 0, scheme_dst(sig_group, scheme), n, d_pairs, d_f, d_status);
+  if (rc) return rc;
+  if ((rc = copy_out(c, status, d_status, 4 * n))) return rc;
+  HIPCK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// shared tail of multi_verify / verify_secure: one core_verify of (d_pk RAW_PROJ on device, caller's sig, msg)
+static int verify_one_tail(Ctx* c, int sig_group, int scheme, const uint8_t* d_pk_proj, const void* sig, int fmt, const uint8_t* msg,
+                           size_t msg_len, int32_t* status) {
+  int rc;
+  // bring the signature to RAW_PROJ next to the key so one k_prepare call (single fmt) serves both
+  const void* d_sig_in;
+  if ((rc = stage_in(c, sig, sig_size(sig_group, fmt), &d_sig_in))) return rc;
+  const void* d_msg;
+  if ((rc = stage_in(c, msg, msg_len, &d_msg))) return rc;
+  uint64_t offs_h[2] = {0, (uint64_t)msg_len};
+  uint64_t* d_offs = (uint64_t*)arena_take(c, 16);
+  int32_t* d_status = (int32_t*)arena_take(c, 4);
+  uint32_t* d_pairs = (uint32_t*)arena_take(c, WS_PAIRS_WORDS * 4);
+  uint32_t* d_f = (uint32_t*)arena_take(c, WS_F_WORDS * 4);
+  uint8_t* d_sig_proj = (uint8_t*)arena_take(c, 288);
+  if (!d_offs || !d_status || !d_pairs || !d_f || !d_sig_proj) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  HIPCK(hipMemcpyAsync(d_offs, offs_h, 16, hipMemcpyHostToDevice, c->stream));
+  // normalise the signature to RAW_PROJ with a 1-point "sum"
+  if (sig_group == 1) rc = run_point_sum<1>(c, (const uint8_t*)d_sig_in, fmt, nullptr, nullptr, 1, d_sig_proj, 1);
+  else rc = run_point_sum<2>(c, (const uint8_t*)d_sig_in, fmt, nullptr, nullptr, 1, d_sig_proj, 1);
+  if (rc) return rc;
+  rc = run_verify_items(c, sig_group, scheme == BLSGPU_SCHEME_AUG, d_pk_proj, d_sig_proj, BLSGPU_FMT_RAW_PROJ, (const uint8_t*)d_msg, d_offs, 1,
+                        scheme_dst(sig_group, scheme), 1, d_pairs, d_f, d_status);
+  if (rc) return rc;
+  if ((rc = copy_out(c, status, d_status, 4))) return rc;
+  HIPCK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int blsgpu_multi_verify(int sig_group, int scheme, const void* pks, size_t n, const void* sig, const uint8_t* msg,
+                        size_t msg_len, int fmt, int32_t* status) {
+  int rc = check_common(sig_group, scheme, fmt);
+  if (rc) return rc;
+  if (!sig || !status || (n && !pks)) return fail(BLSGPU_E_ARG, "null argument");
+  Ctx* c = g_ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCK(hipSetDevice(c->dev));
+  const size_t psz = pk_size(sig_group, fmt), T = accumulate_lanes(n);
+  size_t need = pad256(psz * n) + pad256(288 * T) + pad256(msg_len) + 8192;
+  if ((rc = arena_reserve(c, need))) return rc;
+  c->arena_off = 0;
+  const void* d_pks;
+  if ((rc = stage_in(c, pks, psz * n, &d_pks))) return rc;
+  uint8_t* d_part = (uint8_t*)arena_take(c, 288 * T);
+  if (!d_part) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  // MultiPublicKey::from_public_keys: the serial `g += key` of reference src/traits/pk_multi.rs:7-13 as a tree sum
+  if (sig_group == 1) rc = run_point_sum<2>(c, (const uint8_t*)d_pks, fmt, nullptr, nullptr, n, d_part, T);
+  else rc = run_point_sum<1>(c, (const uint8_t*)d_pks, fmt, nullptr, nullptr, n, d_part, T);
+  if (rc) return rc;
+  return verify_one_tail(c, sig_group, scheme, d_part, sig, fmt, msg, msg_len, status);
+}
+
+int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const uint8_t* msgs, const uint64_t* msg_offsets,
+                            size_t n, const void* sig, int fmt, int32_t* status, uint64_t* aux) {
+  int rc = check_common(sig_group, scheme, fmt);
+  if (rc) return rc;
+  if (!sig || !status || !msg_offsets || (n && !pks)) return fail(BLSGPU_E_ARG, "null argument");
+  Ctx* c = g_ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCK(hipSetDevice(c->dev));
+  uint64_t aux_h[2] = {0, 0};
+  // host views of offsets (and of messages for the Basic duplicate check)
+  std::vector<uint64_t> offs_h(n + 1);
+  if (is_device_ptr(msg_offsets)) HIPCK(hipMemcpy(offs_h.data(), msg_offsets, 8 * (n + 1), hipMemcpyDeviceToHost));
+  else memcpy(offs_h.data(), msg_offsets, 8 * (n + 1));
+  const uint64_t total = offs_h[n];
+  int32_t st = BLSGPU_OK;
+  if (scheme == BLSGPU_SCHEME_BASIC) {
+    // reference src/traits/sig_basic.rs:46-58: first i whose message equals an earlier one, runs before anything else
+    std::vector<uint8_t> tmp;
+    const uint8_t* mh = msgs;
+    if (is_device_ptr(msgs)) {
+      tmp.resize(total);
+      HIPCK(hipMemcpy(tmp.data(), msgs, total, hipMemcpyDeviceToHost));
+      mh = tmp.data();
+    }
+    std::unordered_map<std::string, uint64_t> seen;
+    seen.reserve(n * 2);
+    for (size_t i = 0; i < n && st == BLSGPU_OK; i++) {
+      std::string key((const char*)mh + offs_h[i], (size_t)(offs_h[i + 1] - offs_h[i]));
+      auto it = seen.find(key);
+      if (it != seen.end()) {
+        st = BLSGPU_DUPLICATE_MESSAGE;
+        aux_h[0] = it->second;
+        aux_h[1] = i;
+      } else {
+        seen.emplace(std::move(key), i);
+      }
+    }
+  }
+  if (st == BLSGPU_OK) {
+    const size_t m = n + 1, psz = pk_size(sig_group, fmt);
+    size_t need = pad256(psz * n) + pad256(sig_size(sig_group, fmt)) + pad256(total) + pad256(8 * m) + pad256(4 * m) +
+                  2 * pad256((size_t)WS_PAIRS_WORDS * 4 * m) + 8192;
+    if ((rc = arena_reserve(c, need))) return rc;
+    c->arena_off = 0;
+    const void *d_pks, *d_sig, *d_msgs, *d_offs;
+    if ((rc = stage_in(c, pks, psz * n, &d_pks))) return rc;
+    if ((rc = stage_in(c, sig, sig_size(sig_group, fmt), &d_sig))) return rc;
+    if ((rc = stage_in(c, msgs, total, &d_msgs))) return rc;
+    if ((rc = stage_in(c, msg_offsets, 8 * m, &d_offs))) return rc;
+    int32_t* d_bad = (int32_t*)arena_take(c, 4 * m);
+    int32_t* d_verdict = (int32_t*)arena_take(c, 4);
+    uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)72 * 4 * m);
+    uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * m);
+    if (!d_bad || !d_verdict || !d_pairs || !d_f) return fail(BLSGPU_E_HIP, "internal: arena too small");
+    dst_arg dst = scheme_dst(sig_group, scheme);
+    int aug = scheme == BLSGPU_SCHEME_AUG;
+    if (sig_group == 1)
+      hipLaunchKernelGGL(k_prepare_agg<1>, dim3(blocks_for(m)), dim3(BLS_BLOCK), 0, c->stream, n, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, aug,
+                         (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad);
+    else
+      hipLaunchKernelGGL(k_prepare_agg<2>, dim3(blocks_for(m)), dim3(BLS_BLOCK), 0, c->stream, n, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, aug,
+                         (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad);
+    HIPCK(hipGetLastError());
+    std::vector<int32_t> bad(m);
+    HIPCK(hipMemcpyAsync(bad.data(), d_bad, 4 * m, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    // reference src/traits/sig_core.rs:155-167: signature identity first, then the first identity key (1-based)
+    if (bad[n]) {
+      st = BLSGPU_SIG_IDENTITY;
+    } else {
+      for (size_t i = 0; i < n; i++)
+        if (bad[i]) {
+          st = BLSGPU_PK_IDENTITY;
+          aux_h[0] = i + 1;
+          break;
+        }
+    }
+    if (st == BLSGPU_OK) {
+      hipLaunchKernelGGL(k_miller1, dim3(blocks_for(m)), dim3(BLS_BLOCK), 0, c->stream, m, d_pairs, d_bad, d_f);
+      if ((rc = run_f12_product_verdict(c, d_f, m, m, d_verdict))) return rc;
+      HIPCK(hipMemcpyAsync(&st, d_verdict, 4, hipMemcpyDeviceToHost, c->stream));
+      HIPCK(hipStreamSynchronize(c->stream));
+    }
+  }
+  if (is_device_ptr(status)) HIPCK(hipMemcpy(status, &st, 4, hipMemcpyHostToDevice));
+  else *status = st;
+  if (aux) {
+    if (is_device_ptr(aux)) HIPCK(hipMemcpy(aux, aux_h, 16, hipMemcpyHostToDevice));
+    else memcpy(aux, aux_h, 16);
+  }
+  return 0;
+}
+
+int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, const void* sig, const uint8_t* msg,
+                         size_t msg_len, int ser_format, int fmt, int32_t* status) {
+  int rc = check_common(sig_group, scheme, fmt);
+  if (rc) return rc;
+  if (!sig || !status || (n && !pks)) return fail(BLSGPU_E_ARG, "null argument");
+  if (ser_format != 0 && ser_format != 1) return fail(BLSGPU_E_ARG, "ser_format must be 0 (Modern) or 1 (Legacy)");
+  if (ser_format == 1 && sig_group != 2)
+    return fail(BLSGPU_E_ARG, "Legacy serialization exists only for Bls12381G2Impl (48-byte keys), reference src/signature.rs:201-204");
+  Ctx* c = g_ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCK(hipSetDevice(c->dev));
+  const size_t psz = pk_size(sig_group, fmt), width = sig_group == 1 ? 96 : 48, T = accumulate_lanes(n);
+  size_t need = pad256(psz * n) + pad256(width * n) + pad256(4 * n) + pad256(32 * n) + pad256(288 * T) + pad256(msg_len) + 16384;
+  if ((rc = arena_reserve(c, need))) return rc;
+  c->arena_off = 0;
+  int32_t st = BLSGPU_OK;
+  if (n == 0) {
+    // reference src/secure_aggregation.rs:189-195: Ok iff the signature is the identity
+    const void* d_sig;
+    if ((rc = stage_in(c, sig, sig_size(sig_group, fmt), &d_sig))) return rc;
+    uint8_t* d_proj = (uint8_t*)arena_take(c, 288);
+    std::vector<uint8_t> h(288);
+    if (sig_group == 1) rc = run_point_sum<1>(c, (const uint8_t*)d_sig, fmt, nullptr, nullptr, 1, d_proj, 1);
+    else rc = run_point_sum<2>(c, (const uint8_t*)d_sig, fmt, nullptr, nullptr, 1, d_proj, 1);
+    if (rc) return rc;
+    HIPCK(hipMemcpyAsync(h.data(), d_proj, 288, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    const size_t zoff = sig_group == 1 ? 96 : 192, zlen = sig_group == 1 ? 48 : 96;
+    bool inf = true;
+    for (size_t k = 0; k < zlen; k++) inf = inf && h[zoff + k] == 0;
+    st = inf ? BLSGPU_OK : BLSGPU_INVALID_SIGNATURE;
+  } else {
+    const void* d_pks;
+    if ((rc = stage_in(c, pks, psz * n, &d_pks))) return rc;
+    uint8_t* d_bytes = (uint8_t*)arena_take(c, width * n);
+    uint32_t* d_perm = (uint32_t*)arena_take(c, 4 * n);
+    uint8_t* d_scal = (uint8_t*)arena_take(c, 32 * n);
+    uint8_t* d_part = (uint8_t*)arena_take(c, 288 * T);
+    if (!d_bytes || !d_perm || !d_scal || !d_part) return fail(BLSGPU_E_HIP, "internal: arena too small");
+    // PublicKey::to_bytes / to_bytes_with_mode of every key (reference src/secure_aggregation.rs:42,47; public_key.rs:146-151)
+    if (sig_group == 1)
+      hipLaunchKernelGGL(k_compress<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), 0, c->stream, n, (const uint8_t*)d_pks, fmt, ser_format, d_bytes);
+    else
+      hipLaunchKernelGGL(k_compress<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), 0, c->stream, n, (const uint8_t*)d_pks, fmt, ser_format, d_bytes);
+    HIPCK(hipGetLastError());
+    std::vector<uint8_t> kb(width * n);
+    HIPCK(hipMemcpyAsync(kb.data(), d_bytes, width * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> perm;
+    std::vector<uint8_t> scal;
+    st = secure_coefficients_host(kb.data(), n, width, perm, scal);
+    if (st == BLSGPU_OK) {
+      HIPCK(hipMemcpyAsync(d_perm, perm.data(), 4 * n, hipMemcpyHostToDevice, c->stream));
+      HIPCK(hipMemcpyAsync(d_scal, scal.data(), 32 * n, hipMemcpyHostToDevice, c->stream));
+      // aggregated_pk = sum t_i * pk_sorted[i]   (reference src/secure_aggregation.rs:201-204)
+      if (sig_group == 1) rc = run_point_sum<2>(c, (const uint8_t*)d_pks, fmt, d_scal, d_perm, n, d_part, T);
+      else rc = run_point_sum<1>(c, (const uint8_t*)d_pks, fmt, d_scal, d_perm, n, d_part, T);
+      if (rc) return rc;
+      return verify_one_tail(c, sig_group, scheme, d_part, sig, fmt, msg, msg_len, status);
+    }
+  }
+  if (is_device_ptr(status)) HIPCK(hipMemcpy(status, &st, 4, hipMemcpyHostToDevice));
+  else *status = st;
+  return 0;
+}
+
+int blsgpu_secure_coefficients(const uint8_t* key_bytes, size_t n, size_t width, uint32_t* out_perm, uint8_t* out_scalars,
+                               int32_t* status) {
+  if (!g_ctx) return fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)");
+  if (width != 48 && width != 96) return fail(BLSGPU_E_ARG, "width must be 48 or 96");
+  if (!status || (n && (!key_bytes || !out_perm || !out_scalars))) return fail(BLSGPU_E_ARG, "null argument");
+  std::vector<uint8_t> tmp;
+  const uint8_t* kb = key_bytes;
+  if (is_device_ptr(key_bytes)) {
+    tmp.resize(n * width);
+    HIPCK(hipMemcpy(tmp.data(), key_bytes, n * width, hipMemcpyDeviceToHost));
+    kb = tmp.data();
+  }
+  std::vector<uint32_t> perm;
+  std::vector<uint8_t> scal;
+  int32_t st = secure_coefficients_host(kb, n, width, perm, scal);
+  if (st == BLSGPU_OK && n) {
+    HIPCK(hipMemcpy(out_perm, perm.data(), 4 * n, is_device_ptr(out_perm) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+    HIPCK(hipMemcpy(out_scalars, scal.data(), 32 * n, is_device_ptr(out_scalars) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+  }
+  if (is_device_ptr(status)) HIPCK(hipMemcpy(status, &st, 4, hipMemcpyHostToDevice));
+  else *status = st;
+  return 0;
+}
+
+static int hash_to_group(int group, const uint8_t* msgs, const uint64_t* msg_offsets, size_t n, const uint8_t* dst, size_t dst_len, void* out) {
+  if (!g_ctx) return fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)");
+  if (dst_len > 255) return fail(BLSGPU_E_ARG, "dst longer than 255 bytes is not supported");
+  if (n == 0) return 0;
+  if (!msg_offsets || !out || !dst) return fail(BLSGPU_E_ARG, "null argument");
+  Ctx* c = g_ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCK(hipSetDevice(c->dev));
+  uint64_t total = 0;
+  if (is_device_ptr(msg_offsets)) HIPCK(hipMemcpy(&total, msg_offsets + n, 8, hipMemcpyDeviceToHost));
+  else total = msg_offsets[n];
+  const size_t osz = group == 1 ? 144 : 288;
+  int rc = arena_reserve(c, pad256(total) + pad256(8 * (n + 1)) + pad256(osz * n) + 4096);
+  if (rc) return rc;
+  c->arena_off = 0;
+  const void *d_msgs, *d_offs;
+  if ((rc = stage_in(c, msgs, total, &d_msgs))) return rc;
+  if ((rc = stage_in(c, msg_offsets, 8 * (n + 1), &d_offs))) return rc;
+  uint8_t* d_out = is_device_ptr(out) ? (uint8_t*)out : (uint8_t*)arena_take(c, osz * n);
+  if (!d_out) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  dst_arg d = make_dst(dst, dst_len);
+  if (group == 1) hipLaunchKernelGGL(k_hash_to_g1, dim3(blocks_for(n)), dim3(BLS_BLOCK), 0, c->stream, n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out);
+  else hipLaunchKernelGGL(k_hash_to_g2, dim3(blocks_for(n)), dim3(BLS_BLOCK), 0, c->stream, n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out);
+  HIPCK(hipGetLastError());
+  if (d_out != out && (rc = copy_out(c, out, d_out, osz * n))) return rc;
+  HIPCK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int blsgpu_hash_to_g1(const uint8_t* msgs, const uint64_t* msg_offsets, size_t n, const uint8_t* dst, size_t dst_len, void* out) {
+  return hash_to_group(1, msgs, msg_offsets, n, dst, dst_len, out);
+}
+int blsgpu_hash_to_g2(const uint8_t* msgs, const uint64_t* msg_offsets, size_t n, const uint8_t* dst, size_t dst_len, void* out) {
+  return hash_to_group(2, msgs, msg_offsets, n, dst, dst_len, out);
+}
+
+static int point_sum_entry(int group, const void* pts, const uint8_t* scalars, size_t n, int fmt, void* out) {
+  if (!g_ctx) return fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)");
+  if (fmt != BLSGPU_FMT_RAW_PROJ && fmt != BLSGPU_FMT_RAW_AFFINE) return fail(BLSGPU_E_ARG, "fmt must be RAW_PROJ or RAW_AFFINE");
+  if (!out || (n && !pts)) return fail(BLSGPU_E_ARG, "null argument");
+  Ctx* c = g_ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCK(hipSetDevice(c->dev));
+  const size_t psz = group == 1 ? g1_size(fmt) : g2_size(fmt), osz = group == 1 ? 144 : 288, T = accumulate_lanes(n);
+  int rc = arena_reserve(c, pad256(psz * n) + pad256(32 * n) + pad256(288 * T) + 4096);
+  if (rc) return rc;
+  c->arena_off = 0;
+  const void *d_pts, *d_scal = nullptr;
+  if ((rc = stage_in(c, pts, psz * n, &d_pts))) return rc;
+  if (scalars && (rc = stage_in(c, scalars, 32 * n, &d_scal))) return rc;
+  uint8_t* d_part = (uint8_t*)arena_take(c, 288 * T);
+  if (!d_part) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  if (group == 1) rc = run_point_sum<1>(c, (const uint8_t*)d_pts, fmt, (const uint8_t*)d_scal, nullptr, n, d_part, T);
+  else rc = run_point_sum<2>(c, (const uint8_t*)d_pts, fmt, (const uint8_t*)d_scal, nullptr, n, d_part, T);
+  if (rc) return rc;
+  if ((rc = copy_out(c, out, d_part, osz))) return rc;
+  HIPCK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int blsgpu_sum_g1(const void* pts, size_t n, int fmt, void* out) { return point_sum_entry(1, pts, nullptr, n, fmt, out); }
+int blsgpu_sum_g2(const void* pts, size_t n, int fmt, void* out) { return point_sum_entry(2, pts, nullptr, n, fmt, out); }
+int blsgpu_msm_g1(const void* pts, const uint8_t* scalars, size_t n, int fmt, void* out) {
+  if (n && !scalars) return fail(BLSGPU_E_ARG, "null scalars");
+  return point_sum_entry(1, pts, scalars, n, fmt, out);
+}
+int blsgpu_msm_g2(const void* pts, const uint8_t* scalars, size_t n, int fmt, void* out) {
+  if (n && !scalars) return fail(BLSGPU_E_ARG, "null scalars");
+  return point_sum_entry(2, pts, scalars, n, fmt, out);
+}
+
+int blsgpu_pairing_product_is_one(const void* g1s, const void* g2s, size_t n, int fmt, int32_t* is_one) {
+  if (!g_ctx) return fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)");
+  if (fmt != BLSGPU_FMT_RAW_PROJ && fmt != BLSGPU_FMT_RAW_AFFINE) return fail(BLSGPU_E_ARG, "fmt must be RAW_PROJ or RAW_AFFINE");
+  if (!is_one || (n && (!g1s || !g2s))) return fail(BLSGPU_E_ARG, "null argument");
+  int32_t verdict = BLSGPU_OK;
+  if (n > 0) {
+    Ctx* c = g_ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCK(hipSetDevice(c->dev));
+    int rc = arena_reserve(c, pad256(g1_size(fmt) * n) + pad256(g2_size(fmt) * n) + pad256(4 * n) + 2 * pad256((size_t)WS_F_WORDS * 4 * n) + 4096);
+    if (rc) return rc;
+    c->arena_off = 0;
+    const void *d1, *d2;
+    if ((rc = stage_in(c, g1s, g1_size(fmt) * n, &d1))) return rc;
+    if ((rc = stage_in(c, g2s, g2_size(fmt) * n, &d2))) return rc;
+    int32_t* d_skip = (int32_t*)arena_take(c, 4 * n + 4);
+    uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)72 * 4 * n);
+    uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * n);
+    if (!d_skip || !d_pairs || !d_f) return fail(BLSGPU_E_HIP, "internal: arena too small");
+    hipLaunchKernelGGL(k_pairs_to_affine, dim3(blocks_for(n)), dim3(BLS_BLOCK), 0, c->stream, n, (const uint8_t*)d1, (const uint8_t*)d2, fmt, d_pairs, d_skip);
+    hipLaunchKernelGGL(k_miller1, dim3(blocks_for(n)), dim3(BLS_BLOCK), 0, c->stream, n, d_pairs, d_skip, d_f);
+    if ((rc = run_f12_product_verdict(c, d_f, n, n, d_skip + n))) return rc;
+    HIPCK(hipMemcpyAsync(&verdict, d_skip + n, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+  }
+  int32_t one = verdict == BLSGPU_OK ? 1 : 0;
+  if (is_device_ptr(is_one)) HIPCK(hipMemcpy(is_one, &one, 4, hipMemcpyHostToDevice));
+  else *is_one = one;
+  return 0;
+}
+
+int blsgpu_serialize(int group, const void* pts, size_t n, int fmt_in, int fmt_out, void* out, int32_t* status) {
+  if (!g_ctx) return fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)");
+  if (group != 1 && group != 2) return fail(BLSGPU_E_ARG, "group must be 1 or 2");
+  if ((fmt_in != BLSGPU_FMT_RAW_PROJ && fmt_in != BLSGPU_FMT_RAW_AFFINE) || (fmt_out != BLSGPU_FMT_COMPRESSED && fmt_out != BLSGPU_FMT_LEGACY))
+    return fail(BLSGPU_E_ARG, "supported conversions: RAW_PROJ/RAW_AFFINE -> COMPRESSED/LEGACY");
+  if (n == 0) return 0;
+  if (!pts || !out) return fail(BLSGPU_E_ARG, "null argument");
+  Ctx* c = g_ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCK(hipSetDevice(c->dev));
+  const size_t psz = group == 1 ? g1_size(fmt_in) : g2_size(fmt_in), osz = group == 1 ? 48 : 96;
+  int rc = arena_reserve(c, pad256(psz * n) + pad256(osz * n) + 4096);
+  if (rc) return rc;
+  c->arena_off = 0;
+  const void* d_pts;
+  if ((rc = stage_in(c, pts, psz * n, &d_pts))) return rc;
+  uint8_t* d_out = is_device_ptr(out) ? (uint8_t*)out : (uint8_t*)arena_take(c, osz * n);
+  if (!d_out) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  int legacy = fmt_out == BLSGPU_FMT_LEGACY;
+  if (group == 1) hipLaunchKernelGGL(k_compress<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), 0, c->stream, n, (const uint8_t*)d_pts, fmt_in, legacy, d_out);
+  else hipLaunchKernelGGL(k_compress<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), 0, c->stream, n, (const uint8_t*)d_pts, fmt_in, legacy, d_out);
+  HIPCK(hipGetLastError());
+  if (d_out != out && (rc = copy_out(c, out, d_out, osz * n))) return rc;
+  HIPCK(hipStreamSynchronize(c->stream));
+  if (status) {
+    std::vector<int32_t> z(n, 0);
+    HIPCK(hipMemcpy(status, z.data(), 4 * n, is_device_ptr(status) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,387 @@
+// __global__ kernels of the verify path.  One lane = one item; intermediates live in HBM workspaces laid out
+// word-major (word k of item i at ws[k * stride + i]) so that every workspace access is a coalesced dword stream.
+#pragma once
+#include "verify.cuh"
+
+#define BLS_BLOCK 64           // one wave per workgroup: 65,536 items = 1,024 waves = one per SIMD
+#define WS_PAIRS_WORDS 144     // P0(24) Q0(48) P1(24) Q1(48), affine Montgomery
+#define WS_F_WORDS 144         // Fp12
+
+struct dst_arg {
+  uint8_t b[256];
+  uint32_t len;
+};
+
+// ---- word-major workspace accessors
+__device__ __forceinline__ void ws_ld_fp(fp& r, const uint32_t* ws, size_t stride, size_t i, int w0) {
+#pragma unroll
+  for (int k = 0; k < 12; k++) r.l[k] = ws[(size_t)(w0 + k) * stride + i];
+}
+__device__ __forceinline__ void ws_st_fp(uint32_t* ws, size_t stride, size_t i, int w0, const fp& a) {
+#pragma unroll
+  for (int k = 0; k < 12; k++) ws[(size_t)(w0 + k) * stride + i] = a.l[k];
+}
+__device__ __forceinline__ void ws_ld_fp2(fp2& r, const uint32_t* ws, size_t stride, size_t i, int w0) {
+  ws_ld_fp(r.c0, ws, stride, i, w0);
+  ws_ld_fp(r.c1, ws, stride, i, w0 + 12);
+}
+__device__ __forceinline__ void ws_st_fp2(uint32_t* ws, size_t stride, size_t i, int w0, const fp2& a) {
+  ws_st_fp(ws, stride, i, w0, a.c0);
+  ws_st_fp(ws, stride, i, w0 + 12, a.c1);
+}
+__device__ __forceinline__ void ws_ld_fp12(fp12& f, const uint32_t* ws, size_t stride, size_t i) {
+  ws_ld_fp2(f.c0.a0, ws, stride, i, 0);
+  ws_ld_fp2(f.c0.a1, ws, stride, i, 24);
+  ws_ld_fp2(f.c0.a2, ws, stride, i, 48);
+  ws_ld_fp2(f.c1.a0, ws, stride, i, 72);
+  ws_ld_fp2(f.c1.a1, ws, stride, i, 96);
+  ws_ld_fp2(f.c1.a2, ws, stride, i, 120);
+}
+__device__ __forceinline__ void ws_st_fp12(uint32_t* ws, size_t stride, size_t i, const fp12& f) {
+  ws_st_fp2(ws, stride, i, 0, f.c0.a0);
+  ws_st_fp2(ws, stride, i, 24, f.c0.a1);
+  ws_st_fp2(ws, stride, i, 48, f.c0.a2);
+  ws_st_fp2(ws, stride, i, 72, f.c1.a0);
+  ws_st_fp2(ws, stride, i, 96, f.c1.a1);
+  ws_st_fp2(ws, stride, i, 120, f.c1.a2);
+}
+__device__ __forceinline__ void ws_st_pair(uint32_t* ws, size_t stride, size_t i, int slot, const g1_aff& p, const g2_aff& q) {
+  const int w0 = slot * 72;
+  ws_st_fp(ws, stride, i, w0, p.x);
+  ws_st_fp(ws, stride, i, w0 + 12, p.y);
+  ws_st_fp2(ws, stride, i, w0 + 24, q.x);
+  ws_st_fp2(ws, stride, i, w0 + 48, q.y);
+}
+__device__ __forceinline__ void ws_ld_pair(g1_aff& p, g2_aff& q, const uint32_t* ws, size_t stride, size_t i, int slot) {
+  const int w0 = slot * 72;
+  ws_ld_fp(p.x, ws, stride, i, w0);
+  ws_ld_fp(p.y, ws, stride, i, w0 + 12);
+  ws_ld_fp2(q.x, ws, stride, i, w0 + 24);
+  ws_ld_fp2(q.y, ws, stride, i, w0 + 48);
+  p.inf = false;
+  q.inf = false;
+}
+
+// ---- caller-format point loads (array of structs, one struct per item)
+__device__ __forceinline__ bool words_all_zero(const uint32_t* w, int n) {
+  uint32_t o = 0;
+  for (int k = 0; k < n; k++) o |= w[k];
+  return o == 0;
+}
+__device__ __forceinline__ void load_g1_pt(g1_jac& p, const uint8_t* base, size_t i, int fmt) {
+  if (fmt == 0) {
+    const uint32_t* w = (const uint32_t*)(base + i * 144);
+    fp_load(p.x, w);
+    fp_load(p.y, w + 12);
+    fp_load(p.z, w + 24);
+  } else {
+    const uint32_t* w = (const uint32_t*)(base + i * 96);
+    if (words_all_zero(w, 24)) {
+      jac_set_inf(p);
+    } else {
+      fp_load(p.x, w);
+      fp_load(p.y, w + 12);
+      fp_one(p.z);
+    }
+  }
+}
+__device__ __forceinline__ void load_g2_pt(g2_jac& p, const uint8_t* base, size_t i, int fmt) {
+  if (fmt == 0) {
+    const uint32_t* w = (const uint32_t*)(base + i * 288);
+    fp2_load(p.x, w);
+    fp2_load(p.y, w + 24);
+    fp2_load(p.z, w + 48);
+  } else {
+    const uint32_t* w = (const uint32_t*)(base + i * 192);
+    if (words_all_zero(w, 48)) {
+      jac_set_inf(p);
+    } else {
+      fp2_load(p.x, w);
+      fp2_load(p.y, w + 24);
+      fp2_one(p.z);
+    }
+  }
+}
+__device__ __forceinline__ void store_g1_pt(uint8_t* base, size_t i, const g1_jac& p) {
+  uint32_t* w = (uint32_t*)(base + i * 144);
+  fp_store(w, p.x);
+  fp_store(w + 12, p.y);
+  fp_store(w + 24, p.z);
+}
+__device__ __forceinline__ void store_g2_pt(uint8_t* base, size_t i, const g2_jac& p) {
+  uint32_t* w = (uint32_t*)(base + i * 288);
+  fp2_store(w, p.x);
+  fp2_store(w + 24, p.y);
+  fp2_store(w + 48, p.z);
+}
+
+// =====================================================================================================
+// verify_batch stage 1: identity checks, to-affine, Aug prefix, hash-to-curve  ->  two affine pairs per item.
+// single_msg != 0: every item uses message [offs[0], offs[1]) (multi_verify / verify_secure tail).
+template <int SG>
+__global__ void __launch_bounds__(BLS_BLOCK) k_prepare(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int aug,
+                                                     const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst,
+                                                     uint32_t* pairs, int32_t* status) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  size_t mi = single_msg ? 0 : i;
+  const uint8_t* m = msgs + offs[mi];
+  uint32_t mlen = (uint32_t)(offs[mi + 1] - offs[mi]);
+  g1_aff P[2];
+  g2_aff Q[2];
+  int st;
+  if (SG == 1) {
+    g2_jac pk;
+    g1_jac sig;
+    load_g2_pt(pk, pks, i, fmt);
+    load_g1_pt(sig, sigs, i, fmt);
+    st = prepare_g1impl(P, Q, pk, sig, aug != 0, m, mlen, dst.b, dst.len);
+  } else {
+    g1_jac pk;
+    g2_jac sig;
+    load_g1_pt(pk, pks, i, fmt);
+    load_g2_pt(sig, sigs, i, fmt);
+    st = prepare_g2impl(P, Q, pk, sig, aug != 0, m, mlen, dst.b, dst.len);
+  }
+  status[i] = st;
+  if (st != BLS_OK) return;
+  ws_st_pair(pairs, n, i, 0, P[0], Q[0]);
+  ws_st_pair(pairs, n, i, 1, P[1], Q[1]);
+}
+
+// stage 2: two-pair Miller loop per item
+__global__ void __launch_bounds__(BLS_BLOCK) k_miller2(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (status[i] != BLS_OK) return;
+  g1_aff P[2];
+  g2_aff Q[2];
+  ws_ld_pair(P[0], Q[0], pairs, n, i, 0);
+  ws_ld_pair(P[1], Q[1], pairs, n, i, 1);
+  fp12 f;
+  miller_loop<2>(f, P, Q);
+  ws_st_fp12(fws, n, i, f);
+}
+
+// stage 3: final exponentiation and verdict per item
+__global__ void __launch_bounds__(BLS_BLOCK) k_finalexp(size_t n, const uint32_t* fws, int32_t* status) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (status[i] != BLS_OK) return;
+  fp12 f;
+  ws_ld_fp12(f, fws, n, i);
+  status[i] = pairing_verdict(f);
+}
+
+// =====================================================================================================
+// aggregate verify / pairing product: one pair per item, then a product tree over the Fp12 values.
+// mode 0: (g1s[i], g2s[i]) given by the caller (pairing_product_is_one)
+// mode 1: aggregate verify: pk[i] + message i -> pair (H(m_i), pk_i) in the G1-first order of src/helpers.rs;
+//         item n (the extra lane) carries (sig, -g).  bad[i] = 1 when pk_i is the identity.
+template <int SG>
+__global__ void __launch_bounds__(BLS_BLOCK) k_prepare_agg(size_t n, const uint8_t* pks, const uint8_t* sig, int fmt, int aug,
+                                                         const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint32_t* pairs,
+                                                         int32_t* bad) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  const size_t stride = n + 1;
+  g1_aff P;
+  g2_aff Q;
+  if (i == n) {  // the signature pair
+    if (SG == 1) {
+      g1_jac s;
+      load_g1_pt(s, sig, 0, fmt);
+      bad[i] = jac_is_inf(s) ? 1 : 0;
+      if (bad[i]) return;
+      jac_to_aff(P, s);
+      g2_neg_gen(Q);
+    } else {
+      g2_jac s;
+      load_g2_pt(s, sig, 0, fmt);
+      bad[i] = jac_is_inf(s) ? 1 : 0;
+      if (bad[i]) return;
+      jac_to_aff(Q, s);
+      g1_neg_gen(P);
+    }
+    ws_st_pair(pairs, stride, i, 0, P, Q);
+    return;
+  }
+  const uint8_t* m = msgs + offs[i];
+  uint32_t mlen = (uint32_t)(offs[i + 1] - offs[i]);
+  if (SG == 1) {
+    g2_jac pk;
+    load_g2_pt(pk, pks, i, fmt);
+    bad[i] = jac_is_inf(pk) ? 1 : 0;
+    if (bad[i]) return;
+    jac_to_aff(Q, pk);
+    uint8_t pre[96];
+    uint32_t pre_len = 0;
+    if (aug) {
+      g2_compress(pre, Q, false);
+      pre_len = 96;
+    }
+    g1_jac h;
+    hash_to_g1(h, pre, pre_len, m, mlen, dst.b, dst.len);
+    jac_to_aff(P, h);
+  } else {
+    g1_jac pk;
+    load_g1_pt(pk, pks, i, fmt);
+    bad[i] = jac_is_inf(pk) ? 1 : 0;
+    if (bad[i]) return;
+    jac_to_aff(P, pk);
+    uint8_t pre[48];
+    uint32_t pre_len = 0;
+    if (aug) {
+      g1_compress(pre, P, false);
+      pre_len = 48;
+    }
+    g2_jac h;
+    hash_to_g2(h, pre, pre_len, m, mlen, dst.b, dst.len);
+    jac_to_aff(Q, h);
+  }
+  ws_st_pair(pairs, stride, i, 0, P, Q);
+}
+
+// caller-supplied pairs -> affine workspace; pairs with an identity member are flagged and contribute 1
+__global__ void __launch_bounds__(BLS_BLOCK) k_pairs_to_affine(size_t n, const uint8_t* g1s, const uint8_t* g2s, int fmt,
+                                                             uint32_t* pairs, int32_t* skip) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  g1_jac a;
+  g2_jac b;
+  load_g1_pt(a, g1s, i, fmt);
+  load_g2_pt(b, g2s, i, fmt);
+  skip[i] = (jac_is_inf(a) || jac_is_inf(b)) ? 1 : 0;
+  if (skip[i]) return;
+  g1_aff P;
+  g2_aff Q;
+  g1g2_to_aff(P, Q, a, b);
+  ws_st_pair(pairs, n, i, 0, P, Q);
+}
+
+// one-pair Miller loop per item; skipped items write 1
+__global__ void __launch_bounds__(BLS_BLOCK) k_miller1(size_t n, const uint32_t* pairs, const int32_t* skip, uint32_t* fws) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fp12 f;
+  if (skip[i]) {
+    fp12_one(f);
+  } else {
+    g1_aff P[1];
+    g2_aff Q[1];
+    ws_ld_pair(P[0], Q[0], pairs, n, i, 0);
+    miller_loop<1>(f, P, Q);
+  }
+  ws_st_fp12(fws, n, i, f);
+}
+
+// product tree step: f[i] *= f[i + half] for i + half < m   (stride = workspace stride)
+__global__ void __launch_bounds__(BLS_BLOCK) k_f12_fold(size_t m, size_t half, uint32_t* fws, size_t stride) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i + half >= m || i >= half) return;
+  fp12 a, b;
+  ws_ld_fp12(a, fws, stride, i);
+  ws_ld_fp12(b, fws, stride, i + half);
+  fp12_mul(a, a, b);
+  ws_st_fp12(fws, stride, i, a);
+}
+
+// final exponentiation of item 0 of a workspace -> *verdict (BLS_OK / BLS_ERR_INVALID_SIGNATURE)
+__global__ void k_finalexp_one(const uint32_t* fws, size_t stride, int32_t* verdict) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  fp12 f;
+  ws_ld_fp12(f, fws, stride, 0);
+  *verdict = pairing_verdict(f);
+}
+
+// =====================================================================================================
+// hash_to_point batches
+__global__ void __launch_bounds__(BLS_BLOCK) k_hash_to_g1(size_t n, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint8_t* out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  g1_jac h;
+  hash_to_g1(h, nullptr, 0, msgs + offs[i], (uint32_t)(offs[i + 1] - offs[i]), dst.b, dst.len);
+  store_g1_pt(out, i, h);
+}
+__global__ void __launch_bounds__(BLS_BLOCK) k_hash_to_g2(size_t n, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint8_t* out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  g2_jac h;
+  hash_to_g2(h, nullptr, 0, msgs + offs[i], (uint32_t)(offs[i + 1] - offs[i]), dst.b, dst.len);
+  store_g2_pt(out, i, h);
+}
+
+// =====================================================================================================
+// point sums and multi-scalar multiplication.  Partials are RAW_PROJ structs in a workspace array.
+// Stage 1: lane t accumulates items t, t + T, t + 2T, ... (optionally scaled by their scalars).
+template <int G, int WITH_SCALARS>
+__global__ void __launch_bounds__(BLS_BLOCK) k_accumulate(size_t n, const uint8_t* pts, int fmt, const uint8_t* scalars,
+                                                        const uint32_t* perm, uint8_t* partials, size_t T) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  if (G == 1) {
+    g1_jac acc, p;
+    jac_set_inf(acc);
+    for (size_t i = t; i < n; i += T) {
+      size_t src = perm ? perm[i] : i;
+      load_g1_pt(p, pts, src, fmt);
+      if (WITH_SCALARS) jac_mul_scalar(p, p, (const uint32_t*)(scalars + 32 * i));
+      jac_add(acc, acc, p);
+    }
+    store_g1_pt(partials, t, acc);
+  } else {
+    g2_jac acc, p;
+    jac_set_inf(acc);
+    for (size_t i = t; i < n; i += T) {
+      size_t src = perm ? perm[i] : i;
+      load_g2_pt(p, pts, src, fmt);
+      if (WITH_SCALARS) jac_mul_scalar(p, p, (const uint32_t*)(scalars + 32 * i));
+      jac_add(acc, acc, p);
+    }
+    store_g2_pt(partials, t, acc);
+  }
+}
+// Stage 2: partial[i] += partial[i + half]
+template <int G>
+__global__ void __launch_bounds__(BLS_BLOCK) k_point_fold(size_t m, size_t half, uint8_t* partials) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i + half >= m || i >= half) return;
+  if (G == 1) {
+    g1_jac a, b;
+    load_g1_pt(a, partials, i, 0);
+    load_g1_pt(b, partials, i + half, 0);
+    jac_add(a, a, b);
+    store_g1_pt(partials, i, a);
+  } else {
+    g2_jac a, b;
+    load_g2_pt(a, partials, i, 0);
+    load_g2_pt(b, partials, i + half, 0);
+    jac_add(a, a, b);
+    store_g2_pt(partials, i, a);
+  }
+}
+
+// =====================================================================================================
+// serialisation: any raw format -> compressed (modern or legacy) bytes
+template <int G>
+__global__ void __launch_bounds__(BLS_BLOCK) k_compress(size_t n, const uint8_t* pts, int fmt, int legacy, uint8_t* out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (G == 1) {
+    g1_jac p;
+    g1_aff a;
+    load_g1_pt(p, pts, i, fmt);
+    jac_to_aff(a, p);
+    uint8_t b[48];
+    g1_compress(b, a, legacy != 0);
+    for (int k = 0; k < 48; k++) out[i * 48 + k] = b[k];
+  } else {
+    g2_jac p;
+    g2_aff a;
+    load_g2_pt(p, pts, i, fmt);
+    jac_to_aff(a, p);
+    uint8_t b[96];
+    g2_compress(b, a, legacy != 0);
+    for (int k = 0; k < 96; k++) out[i * 96 + k] = b[k];
+  }
+}

@@ -1,0 +1,137 @@
+/* blsgpu.h -- C ABI of libblsgpu.so: MI355X-native batch BLS12-381 signature verification.
+ *
+ * This is the drop-in boundary for the verify path of dashpay/agora-blsful (`blsful` 3.0.0-pre8).  Each entry
+ * point names the reference interface it replaces (file:line relative to the reference crate); INTEGRATION.md
+ * shows the Rust binding a maintainer adds behind a `hip` cargo feature.
+ *
+ * Conventions
+ *   - Every buffer is caller-owned and borrowed for the duration of the call.  Pointers may be host pointers or
+ *     HIP device pointers; the library detects which (hipPointerGetAttributes) and stages host buffers itself.
+ *   - All calls are blocking, thread-safe (one internal stream guarded by a mutex) and deterministic.
+ *   - Return value: 0 = the call ran (look at the status outputs), < 0 = runtime failure (HIP error, bad argument);
+ *     blsgpu_last_error() then gives a message.  There is NO CPU fallback: without a usable gfx950 device every
+ *     compute entry point fails with BLSGPU_E_NO_DEVICE.
+ *   - sig_group selects the reference's backend type: 1 = Bls12381G1Impl (signature in G1, public key in G2,
+ *     src/impls/g1.rs), 2 = Bls12381G2Impl (signature in G2, public key in G1, src/impls/g2.rs).
+ *   - scheme = SignatureSchemes (src/sig_types.rs:6-13): 0 Basic, 1 MessageAugmentation, 2 ProofOfPossession.
+ *   - Point formats (fmt):
+ *       BLSGPU_FMT_RAW_PROJ    Jacobian (X, Y, Z), Montgomery form, little-endian limbs: the in-memory layout of
+ *                              blst_p1 (144 B) / blst_p2 (288 B) that G1Projective / G2Projective wrap; Z = 0 is
+ *                              the identity.  A `&[PublicKey<C>]` slice can be passed as it is.
+ *       BLSGPU_FMT_RAW_AFFINE  (x, y) Montgomery, 96 B / 192 B; all-zero = identity.
+ *       BLSGPU_FMT_COMPRESSED  ZCash compressed encoding 48 B / 96 B (modern), checked on decode.
+ *       BLSGPU_FMT_LEGACY      Dash legacy header variant of the same (src/impls/legacy.rs:9-67).
+ *   - Scalars are 32 bytes little-endian.
+ *   - Status codes mirror BlsError (src/error.rs:5-55) on this path; the shim maps them back to the exact
+ *     variants and strings.
+ */
+#ifndef BLSGPU_H
+#define BLSGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLSGPU_FMT_RAW_PROJ 0
+#define BLSGPU_FMT_RAW_AFFINE 1
+#define BLSGPU_FMT_COMPRESSED 2
+#define BLSGPU_FMT_LEGACY 3
+
+#define BLSGPU_SCHEME_BASIC 0
+#define BLSGPU_SCHEME_AUG 1
+#define BLSGPU_SCHEME_POP 2
+
+/* per-item / per-call status (>= 0) */
+#define BLSGPU_OK 0                  /* Ok(()) */
+#define BLSGPU_INVALID_SIGNATURE 1   /* BlsError::InvalidSignature            sig_core.rs:144,176; secure_aggregation.rs:193 */
+#define BLSGPU_SIG_IDENTITY 2        /* InvalidInputs("signature is the identity point")        sig_core.rs:127,156 */
+#define BLSGPU_PK_IDENTITY 3         /* InvalidInputs("public key is the identity point") :132; aggregate form
+                                        "public key at {aux0} is the identity point" (1-based)   sig_core.rs:163-166 */
+#define BLSGPU_DUPLICATE_MESSAGE 4   /* InvalidInputs("duplicate messages detected at {aux0} and {aux1}") sig_basic.rs:51-55 */
+#define BLSGPU_INVALID_COEFFICIENT 5 /* BlsError::InvalidCoefficient           secure_aggregation.rs:99,326 */
+#define BLSGPU_BAD_LENGTH 6          /* BlsError::InvalidLength                public_key.rs:159-164 */
+#define BLSGPU_BAD_ENCODING 7        /* BlsError::DeserializationError         legacy.rs:76-78,110,121 */
+#define BLSGPU_LEGACY_FORMAT 8       /* BlsError::LegacyFormatError            legacy.rs:54-57 */
+
+/* runtime failures (< 0) */
+#define BLSGPU_E_NO_DEVICE (-1)
+#define BLSGPU_E_HIP (-2)
+#define BLSGPU_E_ARG (-3)
+#define BLSGPU_E_NOT_INIT (-4)
+
+/* Library life cycle.  device = HIP ordinal, or -1 for the current device.  Idempotent. */
+int blsgpu_init(int device);
+void blsgpu_shutdown(void);
+/* copies the last error message of the calling thread's most recent failing call; returns its length */
+size_t blsgpu_last_error(char* buf, size_t cap);
+
+/* NEW additive API (no batch entry exists in the reference: every reference call verifies one signature).
+ * status[i] = verdict of  Signature::<C>::verify(&pk[i], msg[i])              src/signature.rs:130-138
+ *   -> BlsSignature{Basic,MessageAugmentation,Pop}::verify                    src/traits/sig_basic.rs:36-38,
+ *                                                                             sig_aug.rs:20-24, sig_pop.rs:37-39
+ *   -> BlsSignatureCore::core_verify                                          src/traits/sig_core.rs:120-146
+ * msgs is the concatenation of all messages, msg_offsets has n + 1 entries. */
+int blsgpu_verify_batch(int sig_group, int scheme, const void* pks, const void* sigs, const uint8_t* msgs,
+                        const uint64_t* msg_offsets, size_t n, int fmt, int32_t* status);
+
+/* MultiSignature::<C>::verify(MultiPublicKey::from_public_keys(pks), msg)     src/multi_signature.rs:127-135,
+ * src/multi_public_key.rs:79-83 -> BlsMultiKey::from_public_keys (serial sum) src/traits/pk_multi.rs:7-13;
+ * fused form BlsSignaturePop::multi_sig_verify                                src/traits/sig_pop.rs:42-49. */
+int blsgpu_multi_verify(int sig_group, int scheme, const void* pks, size_t n, const void* sig, const uint8_t* msg,
+                        size_t msg_len, int fmt, int32_t* status);
+
+/* AggregateSignature::<C>::verify(&[(pk, msg)])                               src/aggregate_signature.rs:230-239
+ *   -> scheme aggregate_verify (Basic: duplicate-message rejection)           src/traits/sig_basic.rs:41-64,
+ *                                                                             sig_aug.rs:27-38, sig_pop.rs:52-58
+ *   -> BlsSignatureCore::core_aggregate_verify                                src/traits/sig_core.rs:149-178
+ * aux[0], aux[1] receive the indices that the reference formats into its error strings (see status codes). */
+int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const uint8_t* msgs,
+                            const uint64_t* msg_offsets, size_t n, const void* sig, int fmt, int32_t* status,
+                            uint64_t* aux);
+
+/* Signature::<C>::verify_secure(&pks, msg)                                    src/signature.rs:177-197
+ * and verify_secure_with_mode(&pks, msg, format)                              src/signature.rs:256-276
+ *   -> verify_secure_with_dst_internal                                        src/secure_aggregation.rs:173-208
+ *   -> hash_public_keys_with_sorted[_mode]                                    src/secure_aggregation.rs:37-106,269-335
+ * ser_format: 0 = Modern, 1 = Legacy (only sig_group 2 has 48-byte keys).  n == 0: Ok iff sig is the identity. */
+int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, const void* sig, const uint8_t* msg,
+                         size_t msg_len, int ser_format, int fmt, int32_t* status);
+
+/* The coefficient step of hash_public_keys_with_sorted on already-serialised keys (width = 48 or 96 bytes each):
+ * out_perm[i] = input index of the i-th key in sorted order; out_scalars[i] = t_i (32 B LE).
+ * src/secure_aggregation.rs:41-103. */
+int blsgpu_secure_coefficients(const uint8_t* key_bytes, size_t n, size_t width, uint32_t* out_perm,
+                               uint8_t* out_scalars, int32_t* status);
+
+/* HashToPoint::hash_to_point(msg, dst)                                        src/traits/hash_to_point.rs:11,
+ * impls src/impls/g1.rs:17-19 (group 1) and src/impls/g2.rs:15-17 (group 2).  out: RAW_PROJ points. */
+int blsgpu_hash_to_g1(const uint8_t* msgs, const uint64_t* msg_offsets, size_t n, const uint8_t* dst, size_t dst_len,
+                      void* out);
+int blsgpu_hash_to_g2(const uint8_t* msgs, const uint64_t* msg_offsets, size_t n, const uint8_t* dst, size_t dst_len,
+                      void* out);
+
+/* BlsSignatureCore::aggregate_public_keys / aggregate_signatures              src/traits/sig_core.rs:38-59
+ * (= BlsMultiKey::from_public_keys, src/traits/pk_multi.rs:7-13).  out: one RAW_PROJ point. */
+int blsgpu_sum_g1(const void* pts, size_t n, int fmt, void* out);
+int blsgpu_sum_g2(const void* pts, size_t n, int fmt, void* out);
+
+/* sum_i scalars[i] * pts[i]: the loop `aggregated_pk += pk.0 * *coeff`        src/secure_aggregation.rs:201-204
+ * (and the sign-side loop :163-166).  out: one RAW_PROJ point. */
+int blsgpu_msm_g1(const void* pts, const uint8_t* scalars, size_t n, int fmt, void* out);
+int blsgpu_msm_g2(const void* pts, const uint8_t* scalars, size_t n, int fmt, void* out);
+
+/* Pairing::pairing(&[(a_i, b_i)]).is_identity()                               src/traits/pairings.rs:50,
+ * glue src/helpers.rs:41-63 (G1 member first).  *is_one = 1 iff the product of pairings is the identity. */
+int blsgpu_pairing_product_is_one(const void* g1s, const void* g2s, size_t n, int fmt, int32_t* is_one);
+
+/* point codec: to_bytes / from_bytes [_with_mode]                             src/public_key.rs:58-74,146-171,
+ * src/impls/legacy.rs:85-170.  group = 1 (G1, 48 B) or 2 (G2, 96 B).  status[i]: 0 or BAD_ENCODING/LEGACY_FORMAT. */
+int blsgpu_serialize(int group, const void* pts, size_t n, int fmt_in, int fmt_out, void* out, int32_t* status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLSGPU_H */
