@@ -29,7 +29,8 @@ EXPORTS = [
     'blsgpu_init', 'blsgpu_shutdown', 'blsgpu_last_error', 'blsgpu_verify_batch', 'blsgpu_multi_verify',
     'blsgpu_aggregate_verify', 'blsgpu_verify_secure', 'blsgpu_secure_coefficients', 'blsgpu_hash_to_g1',
     'blsgpu_hash_to_g2', 'blsgpu_sum_g1', 'blsgpu_sum_g2', 'blsgpu_msm_g1', 'blsgpu_msm_g2',
-    'blsgpu_pairing_product_is_one', 'blsgpu_serialize',
+    'blsgpu_pairing_product_is_one', 'blsgpu_serialize', 'blsgpu_sign_batch',
+    'blsgpu_profile_enable', 'blsgpu_profile_count', 'blsgpu_profile_get',
 ]
 
 
@@ -107,6 +108,9 @@ def load_library(path=None):
             getattr(lib, nm).argtypes = [vp, u8p, sz, ci, vp]
         lib.blsgpu_pairing_product_is_one.argtypes = [vp, vp, sz, ci, i32p]
         lib.blsgpu_serialize.argtypes = [ci, vp, sz, ci, ci, vp, i32p]
+        lib.blsgpu_sign_batch.argtypes = [ci, ci, u8p, u8p, u64p, sz, vp, vp]
+        lib.blsgpu_profile_enable.argtypes = [ci]
+        lib.blsgpu_profile_get.argtypes = [ci, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
         _lib = lib
     return _lib
 
@@ -236,6 +240,37 @@ def serialize(group, pts, fmt_in=FMT_RAW_PROJ, legacy=False):
     blob = b''.join(pts)
     _check(lib.blsgpu_serialize(group, _ptr(blob), n, fmt_in, FMT_LEGACY if legacy else FMT_COMPRESSED, ctypes.cast(out, ctypes.c_void_p), None))
     return [out.raw[osz * i:osz * (i + 1)] for i in range(n)]
+
+
+def sign_batch(sig_group, scheme, sks, msgs):
+    """(pks, sigs) as RAW_PROJ byte strings for integer secret keys `sks` (sign side; builds test/bench inputs)."""
+    lib = init()
+    n = len(msgs)
+    offs, blob = _offsets(msgs)
+    pksz, sgsz = (288, 144) if sig_group == 1 else (144, 288)
+    opk = ctypes.create_string_buffer(pksz * max(n, 1))
+    osg = ctypes.create_string_buffer(sgsz * max(n, 1))
+    skb = b''.join(int(s).to_bytes(32, 'little') for s in sks)
+    _check(lib.blsgpu_sign_batch(sig_group, scheme, _ptr(skb), _ptr(blob), ctypes.cast(offs, ctypes.c_void_p), n,
+                                 ctypes.cast(opk, ctypes.c_void_p), ctypes.cast(osg, ctypes.c_void_p)))
+    return ([opk.raw[pksz * i:pksz * (i + 1)] for i in range(n)], [osg.raw[sgsz * i:sgsz * (i + 1)] for i in range(n)])
+
+
+def profile_enable(on=True):
+    _check(init().blsgpu_profile_enable(1 if on else 0))
+
+
+def profile_read():
+    """{kernel name: (total device ms, launches)} accumulated since profile_enable()."""
+    lib = init()
+    out = {}
+    for k in range(lib.blsgpu_profile_count()):
+        name = ctypes.create_string_buffer(64)
+        ms, cnt = ctypes.c_double(0), ctypes.c_uint64(0)
+        _check(lib.blsgpu_profile_get(k, name, 64, ctypes.byref(ms), ctypes.byref(cnt)))
+        if cnt.value:
+            out[name.value.decode()] = (ms.value, cnt.value)
+    return out
 
 
 # ------------------------------------------------------------------ reference-shaped wrapper types

@@ -18,12 +18,26 @@ namespace {
 
 thread_local std::string t_err;
 
+enum {
+  KID_PREPARE, KID_MILLER2, KID_FINALEXP, KID_PREPARE_AGG, KID_PAIRS_AFF, KID_MILLER1, KID_F12_FOLD, KID_FINALEXP_ONE,
+  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_COUNT
+};
+const char* KID_NAMES[KID_COUNT] = {"k_prepare", "k_miller2", "k_finalexp", "k_prepare_agg", "k_pairs_to_affine", "k_miller1", "k_f12_fold",
+                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign"};
+
 struct Ctx {
   int dev = -1;
   hipStream_t stream = nullptr;
   uint8_t* arena = nullptr;
   size_t arena_cap = 0, arena_off = 0;
   std::mutex mu;
+  // optional per-kernel timing with HIP events on `stream` (blsgpu_profile_*)
+  bool prof_on = false;
+  struct Pending { int kid; hipEvent_t e0, e1; };
+  std::vector<Pending> prof_pending;
+  std::vector<hipEvent_t> prof_pool;
+  double prof_ms[KID_COUNT] = {0};
+  uint64_t prof_cnt[KID_COUNT] = {0};
 };
 Ctx* g_ctx = nullptr;
 std::mutex g_init_mu;
@@ -126,6 +140,53 @@ int check_common(int sg, int scheme, int fmt) {
   return 0;
 }
 
+hipEvent_t prof_event(Ctx* c) {
+  if (!c->prof_pool.empty()) {
+    hipEvent_t e = c->prof_pool.back();
+    c->prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+void prof_pre(Ctx* c, int kid) {
+  if (!c->prof_on) return;
+  Ctx::Pending p{kid, prof_event(c), prof_event(c)};
+  (void)hipEventRecord(p.e0, c->stream);
+  c->prof_pending.push_back(p);
+}
+void prof_post(Ctx* c) {
+  if (!c->prof_on) return;
+  (void)hipEventRecord(c->prof_pending.back().e1, c->stream);
+}
+// call after the stream has been synchronised
+void prof_flush(Ctx* c) {
+  for (auto& p : c->prof_pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+      c->prof_ms[p.kid] += ms;
+      c->prof_cnt[p.kid]++;
+    } else {
+      (void)hipGetLastError();
+    }
+    c->prof_pool.push_back(p.e0);
+    c->prof_pool.push_back(p.e1);
+  }
+  c->prof_pending.clear();
+}
+#define KL(kid, kern, grid, block, ...)                                         \
+  do {                                                                          \
+    prof_pre(c, kid);                                                           \
+    hipLaunchKernelGGL(kern, grid, block, 0, c->stream, __VA_ARGS__);           \
+    prof_post(c);                                                               \
+  } while (0)
+#define SYNC_FLUSH(c)                          \
+  do {                                         \
+    HIPCK(hipStreamSynchronize((c)->stream));  \
+    prof_flush(c);                             \
+  } while (0)
+
 unsigned blocks_for(size_t n) { return (unsigned)((n + BLS_BLOCK - 1) / BLS_BLOCK); }
 
 // ---- shared device pipelines (stream-ordered; caller holds the context mutex) ------------------------
@@ -137,11 +198,11 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
   if (n == 0) return 0;
   unsigned nb = blocks_for(n);
   if (sg == 1)
-    hipLaunchKernelGGL(k_prepare<1>, dim3(nb), dim3(BLS_BLOCK), 0, c->stream, n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status);
+    KL(KID_PREPARE, k_prepare<1>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status);
   else
-    hipLaunchKernelGGL(k_prepare<2>, dim3(nb), dim3(BLS_BLOCK), 0, c->stream, n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status);
-  hipLaunchKernelGGL(k_miller2, dim3(nb), dim3(BLS_BLOCK), 0, c->stream, n, d_pairs, d_status, d_f);
-  hipLaunchKernelGGL(k_finalexp, dim3(nb), dim3(BLS_BLOCK), 0, c->stream, n, d_f, d_status);
+    KL(KID_PREPARE, k_prepare<2>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status);
+  KL(KID_MILLER2, k_miller2, dim3(nb), dim3(BLS_BLOCK), n, d_pairs, d_status, d_f);
+  KL(KID_FINALEXP, k_finalexp, dim3(nb), dim3(BLS_BLOCK), n, d_f, d_status);
   HIPCK(hipGetLastError());
   return 0;
 }
@@ -151,10 +212,10 @@ int run_f12_product_verdict(Ctx* c, uint32_t* d_f, size_t m, size_t stride, int3
   size_t cur = m;
   while (cur > 1) {
     size_t half = (cur + 1) / 2;
-    hipLaunchKernelGGL(k_f12_fold, dim3(blocks_for(half)), dim3(BLS_BLOCK), 0, c->stream, cur, half, d_f, stride);
+    KL(KID_F12_FOLD, k_f12_fold, dim3(blocks_for(half)), dim3(BLS_BLOCK), cur, half, d_f, stride);
     cur = half;
   }
-  hipLaunchKernelGGL(k_finalexp_one, dim3(1), dim3(64), 0, c->stream, d_f, stride, d_verdict);
+  KL(KID_FINALEXP_ONE, k_finalexp_one, dim3(1), dim3(64), d_f, stride, d_verdict);
   HIPCK(hipGetLastError());
   return 0;
 }
@@ -172,13 +233,13 @@ int run_point_sum(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_scalar
                   uint8_t* d_partials, size_t T) {
   unsigned nb = blocks_for(T);
   if (d_scalars)
-    hipLaunchKernelGGL((k_accumulate<G, 1>), dim3(nb), dim3(BLS_BLOCK), 0, c->stream, n, d_pts, fmt, d_scalars, d_perm, d_partials, T);
+    KL(KID_ACCUM, (k_accumulate<G, 1>), dim3(nb), dim3(BLS_BLOCK), n, d_pts, fmt, d_scalars, d_perm, d_partials, T);
   else
-    hipLaunchKernelGGL((k_accumulate<G, 0>), dim3(nb), dim3(BLS_BLOCK), 0, c->stream, n, d_pts, fmt, d_scalars, d_perm, d_partials, T);
+    KL(KID_ACCUM, (k_accumulate<G, 0>), dim3(nb), dim3(BLS_BLOCK), n, d_pts, fmt, d_scalars, d_perm, d_partials, T);
   size_t cur = T;
   while (cur > 1) {
     size_t half = (cur + 1) / 2;
-    hipLaunchKernelGGL(k_point_fold<G>, dim3(blocks_for(half)), dim3(BLS_BLOCK), 0, c->stream, cur, half, d_partials);
+    KL(KID_POINT_FOLD, k_point_fold<G>, dim3(blocks_for(half)), dim3(BLS_BLOCK), cur, half, d_partials);
     cur = half;
   }
   HIPCK(hipGetLastError());
@@ -280,6 +341,30 @@ void blsgpu_shutdown(void) {
   g_ctx = nullptr;
 }
 
+int blsgpu_profile_enable(int on) {
+  if (!g_ctx) return fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)");
+  std::lock_guard<std::mutex> lk(g_ctx->mu);
+  g_ctx->prof_on = on != 0;
+  for (int k = 0; k < KID_COUNT; k++) {
+    g_ctx->prof_ms[k] = 0;
+    g_ctx->prof_cnt[k] = 0;
+  }
+  return 0;
+}
+int blsgpu_profile_count(void) { return KID_COUNT; }
+int blsgpu_profile_get(int kernel_id, char* name, size_t name_cap, double* total_ms, uint64_t* launches) {
+  if (!g_ctx) return fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)");
+  if (kernel_id < 0 || kernel_id >= KID_COUNT) return fail(BLSGPU_E_ARG, "kernel id out of range");
+  std::lock_guard<std::mutex> lk(g_ctx->mu);
+  if (name && name_cap) {
+    strncpy(name, KID_NAMES[kernel_id], name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (total_ms) *total_ms = g_ctx->prof_ms[kernel_id];
+  if (launches) *launches = g_ctx->prof_cnt[kernel_id];
+  return 0;
+}
+
 size_t blsgpu_last_error(char* buf, size_t cap) {
   if (buf && cap) {
     size_t k = std::min(cap - 1, t_err.size());
@@ -320,7 +405,7 @@ int blsgpu_verify_batch(int sig_group, int scheme, const void* pks, const void* 
                         (const uint8_t*)d_msgs, (const uint64_t*)d_offs, 0, scheme_dst(sig_group, scheme), n, d_pairs, d_f, d_status);
   if (rc) return rc;
   if ((rc = copy_out(c, status, d_status, 4 * n))) return rc;
-  HIPCK(hipStreamSynchronize(c->stream));
+  SYNC_FLUSH(c);
   return 0;
 }
 
@@ -349,7 +434,7 @@ static int verify_one_tail(Ctx* c, int sig_group, int scheme, const uint8_t* d_p
                         scheme_dst(sig_group, scheme), 1, d_pairs, d_f, d_status);
   if (rc) return rc;
   if ((rc = copy_out(c, status, d_status, 4))) return rc;
-  HIPCK(hipStreamSynchronize(c->stream));
+  SYNC_FLUSH(c);
   return 0;
 }
 
@@ -433,15 +518,15 @@ int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const ui
     dst_arg dst = scheme_dst(sig_group, scheme);
     int aug = scheme == BLSGPU_SCHEME_AUG;
     if (sig_group == 1)
-      hipLaunchKernelGGL(k_prepare_agg<1>, dim3(blocks_for(m)), dim3(BLS_BLOCK), 0, c->stream, n, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, aug,
+      KL(KID_PREPARE_AGG, k_prepare_agg<1>, dim3(blocks_for(m)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, aug,
                          (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad);
     else
-      hipLaunchKernelGGL(k_prepare_agg<2>, dim3(blocks_for(m)), dim3(BLS_BLOCK), 0, c->stream, n, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, aug,
+      KL(KID_PREPARE_AGG, k_prepare_agg<2>, dim3(blocks_for(m)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, aug,
                          (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad);
     HIPCK(hipGetLastError());
     std::vector<int32_t> bad(m);
     HIPCK(hipMemcpyAsync(bad.data(), d_bad, 4 * m, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(hipStreamSynchronize(c->stream));
+    SYNC_FLUSH(c);
     // reference src/traits/sig_core.rs:155-167: signature identity first, then the first identity key (1-based)
     if (bad[n]) {
       st = BLSGPU_SIG_IDENTITY;
@@ -454,10 +539,10 @@ int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const ui
         }
     }
     if (st == BLSGPU_OK) {
-      hipLaunchKernelGGL(k_miller1, dim3(blocks_for(m)), dim3(BLS_BLOCK), 0, c->stream, m, d_pairs, d_bad, d_f);
+      KL(KID_MILLER1, k_miller1, dim3(blocks_for(m)), dim3(BLS_BLOCK), m, d_pairs, d_bad, d_f);
       if ((rc = run_f12_product_verdict(c, d_f, m, m, d_verdict))) return rc;
       HIPCK(hipMemcpyAsync(&st, d_verdict, 4, hipMemcpyDeviceToHost, c->stream));
-      HIPCK(hipStreamSynchronize(c->stream));
+      SYNC_FLUSH(c);
     }
   }
   if (is_device_ptr(status)) HIPCK(hipMemcpy(status, &st, 4, hipMemcpyHostToDevice));
@@ -495,7 +580,7 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
     else rc = run_point_sum<2>(c, (const uint8_t*)d_sig, fmt, nullptr, nullptr, 1, d_proj, 1);
     if (rc) return rc;
     HIPCK(hipMemcpyAsync(h.data(), d_proj, 288, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(hipStreamSynchronize(c->stream));
+    SYNC_FLUSH(c);
     const size_t zoff = sig_group == 1 ? 96 : 192, zlen = sig_group == 1 ? 48 : 96;
     bool inf = true;
     for (size_t k = 0; k < zlen; k++) inf = inf && h[zoff + k] == 0;
@@ -510,13 +595,13 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
     if (!d_bytes || !d_perm || !d_scal || !d_part) return fail(BLSGPU_E_HIP, "internal: arena too small");
     // PublicKey::to_bytes / to_bytes_with_mode of every key (reference src/secure_aggregation.rs:42,47; public_key.rs:146-151)
     if (sig_group == 1)
-      hipLaunchKernelGGL(k_compress<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), 0, c->stream, n, (const uint8_t*)d_pks, fmt, ser_format, d_bytes);
+      KL(KID_COMPRESS, k_compress<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, fmt, ser_format, d_bytes);
     else
-      hipLaunchKernelGGL(k_compress<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), 0, c->stream, n, (const uint8_t*)d_pks, fmt, ser_format, d_bytes);
+      KL(KID_COMPRESS, k_compress<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, fmt, ser_format, d_bytes);
     HIPCK(hipGetLastError());
     std::vector<uint8_t> kb(width * n);
     HIPCK(hipMemcpyAsync(kb.data(), d_bytes, width * n, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(hipStreamSynchronize(c->stream));
+    SYNC_FLUSH(c);
     std::vector<uint32_t> perm;
     std::vector<uint8_t> scal;
     st = secure_coefficients_host(kb.data(), n, width, perm, scal);
@@ -580,11 +665,11 @@ static int hash_to_group(int group, const uint8_t* msgs, const uint64_t* msg_off
   uint8_t* d_out = is_device_ptr(out) ? (uint8_t*)out : (uint8_t*)arena_take(c, osz * n);
   if (!d_out) return fail(BLSGPU_E_HIP, "internal: arena too small");
   dst_arg d = make_dst(dst, dst_len);
-  if (group == 1) hipLaunchKernelGGL(k_hash_to_g1, dim3(blocks_for(n)), dim3(BLS_BLOCK), 0, c->stream, n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out);
-  else hipLaunchKernelGGL(k_hash_to_g2, dim3(blocks_for(n)), dim3(BLS_BLOCK), 0, c->stream, n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out);
+  if (group == 1) KL(KID_HASH, k_hash_to_g1, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out);
+  else KL(KID_HASH, k_hash_to_g2, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out);
   HIPCK(hipGetLastError());
   if (d_out != out && (rc = copy_out(c, out, d_out, osz * n))) return rc;
-  HIPCK(hipStreamSynchronize(c->stream));
+  SYNC_FLUSH(c);
   return 0;
 }
 int blsgpu_hash_to_g1(const uint8_t* msgs, const uint64_t* msg_offsets, size_t n, const uint8_t* dst, size_t dst_len, void* out) {
@@ -614,7 +699,7 @@ static int point_sum_entry(int group, const void* pts, const uint8_t* scalars, s
   else rc = run_point_sum<2>(c, (const uint8_t*)d_pts, fmt, (const uint8_t*)d_scal, nullptr, n, d_part, T);
   if (rc) return rc;
   if ((rc = copy_out(c, out, d_part, osz))) return rc;
-  HIPCK(hipStreamSynchronize(c->stream));
+  SYNC_FLUSH(c);
   return 0;
 }
 int blsgpu_sum_g1(const void* pts, size_t n, int fmt, void* out) { return point_sum_entry(1, pts, nullptr, n, fmt, out); }
@@ -647,11 +732,11 @@ int blsgpu_pairing_product_is_one(const void* g1s, const void* g2s, size_t n, in
     uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)72 * 4 * n);
     uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * n);
     if (!d_skip || !d_pairs || !d_f) return fail(BLSGPU_E_HIP, "internal: arena too small");
-    hipLaunchKernelGGL(k_pairs_to_affine, dim3(blocks_for(n)), dim3(BLS_BLOCK), 0, c->stream, n, (const uint8_t*)d1, (const uint8_t*)d2, fmt, d_pairs, d_skip);
-    hipLaunchKernelGGL(k_miller1, dim3(blocks_for(n)), dim3(BLS_BLOCK), 0, c->stream, n, d_pairs, d_skip, d_f);
+    KL(KID_PAIRS_AFF, k_pairs_to_affine, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d1, (const uint8_t*)d2, fmt, d_pairs, d_skip);
+    KL(KID_MILLER1, k_miller1, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_pairs, d_skip, d_f);
     if ((rc = run_f12_product_verdict(c, d_f, n, n, d_skip + n))) return rc;
     HIPCK(hipMemcpyAsync(&verdict, d_skip + n, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(hipStreamSynchronize(c->stream));
+    SYNC_FLUSH(c);
   }
   int32_t one = verdict == BLSGPU_OK ? 1 : 0;
   if (is_device_ptr(is_one)) HIPCK(hipMemcpy(is_one, &one, 4, hipMemcpyHostToDevice));
@@ -678,15 +763,50 @@ int blsgpu_serialize(int group, const void* pts, size_t n, int fmt_in, int fmt_o
   uint8_t* d_out = is_device_ptr(out) ? (uint8_t*)out : (uint8_t*)arena_take(c, osz * n);
   if (!d_out) return fail(BLSGPU_E_HIP, "internal: arena too small");
   int legacy = fmt_out == BLSGPU_FMT_LEGACY;
-  if (group == 1) hipLaunchKernelGGL(k_compress<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), 0, c->stream, n, (const uint8_t*)d_pts, fmt_in, legacy, d_out);
-  else hipLaunchKernelGGL(k_compress<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), 0, c->stream, n, (const uint8_t*)d_pts, fmt_in, legacy, d_out);
+  if (group == 1) KL(KID_COMPRESS, k_compress<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pts, fmt_in, legacy, d_out);
+  else KL(KID_COMPRESS, k_compress<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pts, fmt_in, legacy, d_out);
   HIPCK(hipGetLastError());
   if (d_out != out && (rc = copy_out(c, out, d_out, osz * n))) return rc;
-  HIPCK(hipStreamSynchronize(c->stream));
+  SYNC_FLUSH(c);
   if (status) {
     std::vector<int32_t> z(n, 0);
     HIPCK(hipMemcpy(status, z.data(), 4 * n, is_device_ptr(status) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
   }
+  return 0;
+}
+
+int blsgpu_sign_batch(int sig_group, int scheme, const uint8_t* sks, const uint8_t* msgs, const uint64_t* msg_offsets, size_t n,
+                      void* out_pks, void* out_sigs) {
+  int rc = check_common(sig_group, scheme, BLSGPU_FMT_RAW_PROJ);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  if (!sks || !msg_offsets || !out_pks || !out_sigs) return fail(BLSGPU_E_ARG, "null argument");
+  Ctx* c = g_ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCK(hipSetDevice(c->dev));
+  uint64_t total = 0;
+  if (is_device_ptr(msg_offsets)) HIPCK(hipMemcpy(&total, msg_offsets + n, 8, hipMemcpyDeviceToHost));
+  else total = msg_offsets[n];
+  const size_t pkb = pk_size(sig_group, 0) * n, sgb = sig_size(sig_group, 0) * n;
+  if ((rc = arena_reserve(c, pad256(32 * n) + pad256(total) + pad256(8 * (n + 1)) + pad256(pkb) + pad256(sgb) + 4096))) return rc;
+  c->arena_off = 0;
+  const void *d_sks, *d_msgs, *d_offs;
+  if ((rc = stage_in(c, sks, 32 * n, &d_sks))) return rc;
+  if ((rc = stage_in(c, msgs, total, &d_msgs))) return rc;
+  if ((rc = stage_in(c, msg_offsets, 8 * (n + 1), &d_offs))) return rc;
+  uint8_t* d_pks = is_device_ptr(out_pks) ? (uint8_t*)out_pks : (uint8_t*)arena_take(c, pkb);
+  uint8_t* d_sigs = is_device_ptr(out_sigs) ? (uint8_t*)out_sigs : (uint8_t*)arena_take(c, sgb);
+  if (!d_pks || !d_sigs) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  dst_arg dst = scheme_dst(sig_group, scheme);
+  int aug = scheme == BLSGPU_SCHEME_AUG;
+  if (sig_group == 1)
+    KL(KID_SIGN, k_sign<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_sks, aug, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pks, d_sigs);
+  else
+    KL(KID_SIGN, k_sign<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_sks, aug, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pks, d_sigs);
+  HIPCK(hipGetLastError());
+  if (d_pks != out_pks && (rc = copy_out(c, out_pks, d_pks, pkb))) return rc;
+  if (d_sigs != out_sigs && (rc = copy_out(c, out_sigs, d_sigs, sgb))) return rc;
+  SYNC_FLUSH(c);
   return 0;
 }
 

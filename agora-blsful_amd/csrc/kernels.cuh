@@ -115,6 +115,34 @@ __device__ __forceinline__ void store_g2_pt(uint8_t* base, size_t i, const g2_ja
   fp2_store(w + 48, p.z);
 }
 
+
+// ---- kernel prototypes (each kernel is defined in exactly one translation unit, see the BLS_TU_* sections)
+template <int SG>
+__global__ void k_prepare(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int aug, const uint8_t* msgs,
+                          const uint64_t* offs, int single_msg, dst_arg dst, uint32_t* pairs, int32_t* status);
+__global__ void k_miller2(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws);
+__global__ void k_finalexp(size_t n, const uint32_t* fws, int32_t* status);
+template <int SG>
+__global__ void k_prepare_agg(size_t n, const uint8_t* pks, const uint8_t* sig, int fmt, int aug, const uint8_t* msgs,
+                              const uint64_t* offs, dst_arg dst, uint32_t* pairs, int32_t* bad);
+__global__ void k_pairs_to_affine(size_t n, const uint8_t* g1s, const uint8_t* g2s, int fmt, uint32_t* pairs, int32_t* skip);
+__global__ void k_miller1(size_t n, const uint32_t* pairs, const int32_t* skip, uint32_t* fws);
+__global__ void k_f12_fold(size_t m, size_t half, uint32_t* fws, size_t stride);
+__global__ void k_finalexp_one(const uint32_t* fws, size_t stride, int32_t* verdict);
+__global__ void k_hash_to_g1(size_t n, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint8_t* out);
+__global__ void k_hash_to_g2(size_t n, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint8_t* out);
+template <int G, int WITH_SCALARS>
+__global__ void k_accumulate(size_t n, const uint8_t* pts, int fmt, const uint8_t* scalars, const uint32_t* perm,
+                             uint8_t* partials, size_t T);
+template <int G>
+__global__ void k_point_fold(size_t m, size_t half, uint8_t* partials);
+template <int G>
+__global__ void k_compress(size_t n, const uint8_t* pts, int fmt, int legacy, uint8_t* out);
+template <int SG>
+__global__ void k_sign(size_t n, const uint8_t* sks, int aug, const uint8_t* msgs, const uint64_t* offs, dst_arg dst,
+                       uint8_t* out_pks, uint8_t* out_sigs);
+
+#if defined(BLS_TU_PREPARE1) || defined(BLS_TU_PREPARE2)
 // =====================================================================================================
 // verify_batch stage 1: identity checks, to-affine, Aug prefix, hash-to-curve  ->  two affine pairs per item.
 // single_msg != 0: every item uses message [offs[0], offs[1]) (multi_verify / verify_secure tail).
@@ -149,6 +177,14 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_prepare(size_t n, const uint8_t* 
   ws_st_pair(pairs, n, i, 1, P[1], Q[1]);
 }
 
+#if defined(BLS_TU_PREPARE1)
+template __global__ void k_prepare<1>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, int, dst_arg, uint32_t*, int32_t*);
+#else
+template __global__ void k_prepare<2>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, int, dst_arg, uint32_t*, int32_t*);
+#endif
+#endif  // BLS_TU_PREPARE*
+
+#if defined(BLS_TU_MILLER)
 // stage 2: two-pair Miller loop per item
 __global__ void __launch_bounds__(BLS_BLOCK) k_miller2(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -163,6 +199,9 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_miller2(size_t n, const uint32_t*
   ws_st_fp12(fws, n, i, f);
 }
 
+#endif  // BLS_TU_MILLER (first part)
+
+#if defined(BLS_TU_FINALEXP)
 // stage 3: final exponentiation and verdict per item
 __global__ void __launch_bounds__(BLS_BLOCK) k_finalexp(size_t n, const uint32_t* fws, int32_t* status) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -173,6 +212,9 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_finalexp(size_t n, const uint32_t
   status[i] = pairing_verdict(f);
 }
 
+#endif  // BLS_TU_FINALEXP (first part)
+
+#if defined(BLS_TU_AGG1) || defined(BLS_TU_AGG2)
 // =====================================================================================================
 // aggregate verify / pairing product: one pair per item, then a product tree over the Fp12 values.
 // mode 0: (g1s[i], g2s[i]) given by the caller (pairing_product_is_one)
@@ -242,6 +284,14 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_prepare_agg(size_t n, const uint8
   ws_st_pair(pairs, stride, i, 0, P, Q);
 }
 
+#if defined(BLS_TU_AGG1)
+template __global__ void k_prepare_agg<1>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, dst_arg, uint32_t*, int32_t*);
+#else
+template __global__ void k_prepare_agg<2>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, dst_arg, uint32_t*, int32_t*);
+#endif
+#endif  // BLS_TU_AGG*
+
+#if defined(BLS_TU_POINTS)
 // caller-supplied pairs -> affine workspace; pairs with an identity member are flagged and contribute 1
 __global__ void __launch_bounds__(BLS_BLOCK) k_pairs_to_affine(size_t n, const uint8_t* g1s, const uint8_t* g2s, int fmt,
                                                              uint32_t* pairs, int32_t* skip) {
@@ -259,6 +309,9 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_pairs_to_affine(size_t n, const u
   ws_st_pair(pairs, n, i, 0, P, Q);
 }
 
+#endif  // BLS_TU_POINTS (pairs_to_affine)
+
+#if defined(BLS_TU_MILLER)
 // one-pair Miller loop per item; skipped items write 1
 __global__ void __launch_bounds__(BLS_BLOCK) k_miller1(size_t n, const uint32_t* pairs, const int32_t* skip, uint32_t* fws) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -275,6 +328,9 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_miller1(size_t n, const uint32_t*
   ws_st_fp12(fws, n, i, f);
 }
 
+#endif  // BLS_TU_MILLER
+
+#if defined(BLS_TU_FINALEXP)
 // product tree step: f[i] *= f[i + half] for i + half < m   (stride = workspace stride)
 __global__ void __launch_bounds__(BLS_BLOCK) k_f12_fold(size_t m, size_t half, uint32_t* fws, size_t stride) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -294,6 +350,9 @@ __global__ void k_finalexp_one(const uint32_t* fws, size_t stride, int32_t* verd
   *verdict = pairing_verdict(f);
 }
 
+#endif  // BLS_TU_FINALEXP
+
+#if defined(BLS_TU_POINTS)
 // =====================================================================================================
 // hash_to_point batches
 __global__ void __launch_bounds__(BLS_BLOCK) k_hash_to_g1(size_t n, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint8_t* out) {
@@ -385,3 +444,76 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_compress(size_t n, const uint8_t*
     for (int k = 0; k < 96; k++) out[i * 96 + k] = b[k];
   }
 }
+
+template __global__ void k_accumulate<1, 0>(size_t, const uint8_t*, int, const uint8_t*, const uint32_t*, uint8_t*, size_t);
+template __global__ void k_accumulate<1, 1>(size_t, const uint8_t*, int, const uint8_t*, const uint32_t*, uint8_t*, size_t);
+template __global__ void k_accumulate<2, 0>(size_t, const uint8_t*, int, const uint8_t*, const uint32_t*, uint8_t*, size_t);
+template __global__ void k_accumulate<2, 1>(size_t, const uint8_t*, int, const uint8_t*, const uint32_t*, uint8_t*, size_t);
+template __global__ void k_point_fold<1>(size_t, size_t, uint8_t*);
+template __global__ void k_point_fold<2>(size_t, size_t, uint8_t*);
+template __global__ void k_compress<1>(size_t, const uint8_t*, int, int, uint8_t*);
+template __global__ void k_compress<2>(size_t, const uint8_t*, int, int, uint8_t*);
+#endif  // BLS_TU_POINTS
+
+#if defined(BLS_TU_SIGN1) || defined(BLS_TU_SIGN2)
+// =====================================================================================================
+// sign side, used to build synthetic inputs (bench.py, tests): pk = sk * g, sig = sk * H(msg)
+// (reference src/traits/sig_core.rs:108-117 core_sign, src/secret_key.rs:342-344 public_key).  sks: 32 B LE each.
+template <int SG>
+__global__ void __launch_bounds__(BLS_BLOCK) k_sign(size_t n, const uint8_t* sks, int aug, const uint8_t* msgs, const uint64_t* offs,
+                                                  dst_arg dst, uint8_t* out_pks, uint8_t* out_sigs) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* sk = (const uint32_t*)(sks + 32 * i);
+  const uint8_t* m = msgs + offs[i];
+  uint32_t mlen = (uint32_t)(offs[i + 1] - offs[i]);
+  if (SG == 1) {
+    g2_aff g;
+    fp2_load(g.x, G2_GEN_X);
+    fp2_load(g.y, G2_GEN_Y);
+    g.inf = false;
+    g2_jac gj, pk;
+    jac_from_aff(gj, g);
+    jac_mul_scalar(pk, gj, sk);
+    store_g2_pt(out_pks, i, pk);
+    uint8_t pre[96];
+    uint32_t pre_len = 0;
+    if (aug) {
+      g2_aff a;
+      jac_to_aff(a, pk);
+      g2_compress(pre, a, false);
+      pre_len = 96;
+    }
+    g1_jac h;
+    hash_to_g1(h, pre, pre_len, m, mlen, dst.b, dst.len);
+    jac_mul_scalar(h, h, sk);
+    store_g1_pt(out_sigs, i, h);
+  } else {
+    g1_aff g;
+    fp_load(g.x, G1_GEN_X);
+    fp_load(g.y, G1_GEN_Y);
+    g.inf = false;
+    g1_jac gj, pk;
+    jac_from_aff(gj, g);
+    jac_mul_scalar(pk, gj, sk);
+    store_g1_pt(out_pks, i, pk);
+    uint8_t pre[48];
+    uint32_t pre_len = 0;
+    if (aug) {
+      g1_aff a;
+      jac_to_aff(a, pk);
+      g1_compress(pre, a, false);
+      pre_len = 48;
+    }
+    g2_jac h;
+    hash_to_g2(h, pre, pre_len, m, mlen, dst.b, dst.len);
+    jac_mul_scalar(h, h, sk);
+    store_g2_pt(out_sigs, i, h);
+  }
+}
+#if defined(BLS_TU_SIGN1)
+template __global__ void k_sign<1>(size_t, const uint8_t*, int, const uint8_t*, const uint64_t*, dst_arg, uint8_t*, uint8_t*);
+#else
+template __global__ void k_sign<2>(size_t, const uint8_t*, int, const uint8_t*, const uint64_t*, dst_arg, uint8_t*, uint8_t*);
+#endif
+#endif  // BLS_TU_SIGN*

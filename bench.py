@@ -1,0 +1,168 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: batch BLS12-381 signature verification on MI355X.
+
+Workload (BASELINE.json configs[1]): N independent (pk, msg, sig) Signature<Bls12381G1Impl>::verify items per GPU
+(default 65,536, 32-byte messages, ProofOfPossession scheme = the reference default), inputs already resident in HBM
+in RAW_PROJ form, 1 % of the items tampered as negative controls.  A "step" = one pass over the batch through the
+C ABI (blsgpu_verify_batch).  One process per GPU; N > 1 ranks shard independent batches (weak scaling, no
+collective on the data path); timing = barrier + synchronize on both sides, max over ranks.
+
+Prints ONE JSON line on rank 0 (contract in the task description), including
+  roofline      the dominant kernel's algorithmic HBM bytes / its HIP-event-measured duration vs 8 TB/s
+  cpu_baseline  the oracle timed on a bounded sample of the same workload on this box's host cores
+"""
+import argparse
+import ctypes
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+R_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+SEED = hashlib.sha256(b'blsgpu-bench-v1').digest()
+S0 = int.from_bytes(SEED, 'big') % R_ORDER
+ALG_BYTES_PER_VERIFY = 468          # pk 288 + sig 144 + msg 32 + status 4
+HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FPMUL_PEAK_G = 58.0                 # profiles/ubench_r01.txt: fp_mul/s chip-wide at 4 waves/SIMD (integer-VALU roofline)
+
+
+def gen_inputs(n, base):
+    sks = [(S0 + base + i) % R_ORDER or 1 for i in range(n)]
+    msgs = [hashlib.sha256(SEED + (base + i).to_bytes(8, 'little')).digest() for i in range(n)]
+    return sks, msgs
+
+
+def cpu_baseline(sample, n_total):
+    """Oracle (CPU restatement) on `sample` items of the same workload, single thread."""
+    from oracle.py import blsful_ref as ref
+    C = ref.G1Impl
+    sks, msgs = gen_inputs(sample, 0)
+    items = []
+    for sk, m in zip(sks, msgs):
+        items.append((ref.public_key(C, sk), ref.sign(C, ref.POP, sk, m), m))
+    t0 = time.perf_counter()
+    ok = 0
+    for pk, sig, m in items:
+        try:
+            ref.verify(C, ref.POP, pk, sig, m)
+            ok += 1
+        except ref.BlsError:
+            pass
+    dt = time.perf_counter() - t0
+    assert ok == sample
+    return {'value': sample / dt, 'unit': 'verifications/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d of the %d items (first ones, untampered), oracle/py pure-Python big-int restatement, %.1f s' % (sample, n_total, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--n', type=int, default=65536, help='items per GPU')
+    ap.add_argument('--cpu-sample', type=int, default=100)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node == --gpus'
+    assert torch.cuda.is_available(), 'bench.py needs a GPU: the product has no CPU path'
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    import __graft_entry__ as ge
+    pkg = ge.import_pkg()
+    api = pkg.api
+    lib = api.init(local_rank)
+    n = args.n
+    dev = torch.device('cuda', local_rank)
+
+    # ---- synthetic inputs, signed on the device, left resident in HBM
+    sks, msgs = gen_inputs(n, rank * n)
+    skb = b''.join(s.to_bytes(32, 'little') for s in sks)
+    d_msgs = torch.frombuffer(bytearray(b''.join(msgs)), dtype=torch.uint8).to(dev)
+    d_offs = (torch.arange(n + 1, dtype=torch.int64) * 32).to(dev)
+    d_pks = torch.empty(n * 288, dtype=torch.uint8, device=dev)
+    d_sigs = torch.empty(n * 144, dtype=torch.uint8, device=dev)
+    d_status = torch.full((n,), -7, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    api._check(lib.blsgpu_sign_batch(1, api.POP, api._ptr(skb), P(d_msgs), P(d_offs), n, P(d_pks), P(d_sigs)))
+    # negative controls: flip one bit of the message of 1 % of the items after signing
+    bad = torch.arange(37, n, 100, device=dev)
+    d_msgs[bad * 32] ^= 1
+    expect = torch.zeros(n, dtype=torch.int32, device=dev)
+    expect[bad] = api.INVALID_SIGNATURE
+    torch.cuda.synchronize()
+
+    def step():
+        api._check(lib.blsgpu_verify_batch(1, api.POP, P(d_pks), P(d_sigs), P(d_msgs), P(d_offs), n, api.FMT_RAW_PROJ, P(d_status)))
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    assert torch.equal(d_status, expect), 'verdict vector differs from the expected one'
+    api.profile_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = api.profile_read()
+    api.profile_enable(False)
+    assert torch.equal(d_status, expect), 'verdict vector differs from the expected one'
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        dom = max(prof.items(), key=lambda kv: kv[1][0])
+        dom_ms = dom[1][0] / dom[1][1]
+        achieved = ALG_BYTES_PER_VERIFY * n / (dom_ms * 1e-3) / 1e9
+        kernels = {k: round(v[0] / v[1], 3) for k, v in prof.items()}
+        out = {
+            'metric': 'BLS12-381 sig verifications/sec (batch)', 'value': world * n * args.steps / dt, 'unit': 'verifications/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u32', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: %d independent Signature<Bls12381G1Impl>::verify items per GPU, 32-byte messages, '
+                                   'PoP scheme, RAW_PROJ inputs resident in HBM, 1%% tampered' % n,
+                       'items_per_gpu': n, 'sharding': 'independent batches per rank, no collective'},
+            'roofline': {'bound': 'hbm', 'kernel': dom[0], 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_ms': dom_ms,
+                         'algorithmic_bytes_per_launch': ALG_BYTES_PER_VERIFY * n,
+                         'note': 'integer-VALU bound path: see valu_roofline'},
+            'kernel_ms': kernels,
+        }
+        fpm = os.path.join(ROOT, 'profiles', 'fpmul_counts.json')
+        if os.path.exists(fpm):
+            cnt = json.load(open(fpm))['verify_g1impl_fp_mul_equiv']
+            rate = cnt * n * args.steps / dt / 1e9
+            out['valu_roofline'] = {'fp_mul_per_verify': cnt, 'achieved': rate, 'peak': FPMUL_PEAK_G, 'unit': 'G fp_mul/s',
+                                    'frac': rate / FPMUL_PEAK_G}
+        if world == 1:
+            out['cpu_baseline'] = cpu_baseline(args.cpu_sample, n)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

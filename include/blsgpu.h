@@ -131,6 +131,20 @@ int blsgpu_pairing_product_is_one(const void* g1s, const void* g2s, size_t n, in
  * src/impls/legacy.rs:85-170.  group = 1 (G1, 48 B) or 2 (G2, 96 B).  status[i]: 0 or BAD_ENCODING/LEGACY_FORMAT. */
 int blsgpu_serialize(int group, const void* pts, size_t n, int fmt_in, int fmt_out, void* out, int32_t* status);
 
+/* Measurement hooks (not part of the reference interface): when enabled, every kernel launch of the library is
+ * bracketed by HIP events on the library's own stream; blsgpu_profile_get returns the accumulated device time and
+ * launch count per kernel since the last enable.  bench.py derives the roofline figures from these. */
+int blsgpu_profile_enable(int on);
+int blsgpu_profile_count(void);
+int blsgpu_profile_get(int kernel_id, char* name, size_t name_cap, double* total_ms, uint64_t* launches);
+
+/* Sign side, provided so that benchmarks and tests can build inputs on the device:
+ * pk[i] = sk[i] * g (SecretKey::public_key, src/secret_key.rs:342-344) and
+ * sig[i] = sk[i] * H(msg[i]) (BlsSignatureCore::core_sign, src/traits/sig_core.rs:108-117; the Aug scheme prefixes
+ * the public-key bytes, src/traits/sig_aug.rs:12-17).  sks: 32 B little-endian each; outputs RAW_PROJ. */
+int blsgpu_sign_batch(int sig_group, int scheme, const uint8_t* sks, const uint8_t* msgs, const uint64_t* msg_offsets,
+                      size_t n, void* out_pks, void* out_sigs);
+
 #ifdef __cplusplus
 }
 #endif
