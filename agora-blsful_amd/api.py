@@ -86,6 +86,13 @@ def load_library(path=None):
     global _lib
     if _lib is None:
         p = path or LIB_PATH
+        # PyTorch wheels bundle their own libamdhip64; two HIP runtimes in one process cannot both own the device.
+        # Importing torch first makes libblsgpu's DT_NEEDED libamdhip64.so.7 resolve to the copy torch already loaded.
+        # (C/C++/Rust callers without torch simply get /opt/rocm's runtime.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(p):
             raise BlsGpuRuntimeError(f'{p} not found: build it with __graft_entry__.build(); there is no CPU fallback')
         lib = ctypes.CDLL(p)

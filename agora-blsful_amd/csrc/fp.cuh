@@ -166,7 +166,12 @@ BLS_FN void fp_mul_c(fp& r, const fp& a, const fp& b) {
 #include "fp_mul_gfx950.inc"
 BLS_FN void fp_mul(fp& r, const fp& a, const fp& b) { fp_mul_asm(r, a, b); }
 #else
+#if defined(BLS_COUNT_FPMUL)
+extern "C" { uint64_t g_fpmul_count = 0; }   // tools/count_fpmul.py: host-side instruction-mix census
+BLS_FN void fp_mul(fp& r, const fp& a, const fp& b) { g_fpmul_count++; fp_mul_c(r, a, b); }
+#else
 BLS_FN void fp_mul(fp& r, const fp& a, const fp& b) { fp_mul_c(r, a, b); }
+#endif
 #endif
 
 BLS_FN void fp_sqr(fp& r, const fp& a) { fp_mul(r, a, a); }
