@@ -164,7 +164,31 @@ BLS_FN void fp_mul_c(fp& r, const fp& a, const fp& b) {
 // gfx950: product-scanning form, one v_mad_u64_u32 + one v_addc_co_u32 per partial product.  Measured on
 // MI355X (profiles/ubench_r01.txt): 58 G fp_mul/s chip-wide at 4 waves/SIMD vs 40 G for the C form.
 #include "fp_mul_gfx950.inc"
-BLS_FN void fp_mul(fp& r, const fp& a, const fp& b) { fp_mul_asm(r, a, b); }
+// The multiplication body (about 720 instructions) is ONE non-inlined leaf per translation unit whose 24 operand
+// limbs and 12 result limbs travel in VGPRs (scalar arguments: clang passes aggregates above 16 dwords through
+// memory, which put every operand of every product into scratch: 80 GB of fabric traffic per 65,536-item Miller
+// launch and waves parked in s_waitcnt 47 % of the time, profiles/r01_pmc_before_leafcall.txt).  Everything above
+// fp_mul is inlined so that values stay in registers between calls.
+struct fp_ret {
+  uint32_t l[12];
+};
+__device__ __noinline__ fp_ret fp_mul_leaf(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6,
+                                           uint32_t a7, uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t b0, uint32_t b1,
+                                           uint32_t b2, uint32_t b3, uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7, uint32_t b8,
+                                           uint32_t b9, uint32_t b10, uint32_t b11) {
+  fp a = {{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11}}, b = {{b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11}}, r;
+  fp_mul_asm(r, a, b);
+  fp_ret o;
+#pragma unroll
+  for (int i = 0; i < 12; i++) o.l[i] = r.l[i];
+  return o;
+}
+BLS_FN void fp_mul(fp& r, const fp& a, const fp& b) {
+  fp_ret t = fp_mul_leaf(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], b.l[0], b.l[1],
+                         b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9], b.l[10], b.l[11]);
+#pragma unroll
+  for (int i = 0; i < 12; i++) r.l[i] = t.l[i];
+}
 #else
 #if defined(BLS_COUNT_FPMUL)
 extern "C" { uint64_t g_fpmul_count = 0; }   // tools/count_fpmul.py: host-side instruction-mix census

@@ -54,7 +54,7 @@ BLS_FN void fp2_conj(fp2& r, const fp2& a) {
   fp_neg(r.c1, a.c1);
 }
 // Karatsuba: 3 Fp multiplications
-BLS_NOINLINE void fp2_mul(fp2& r, const fp2& a, const fp2& b) {
+BLS_FN void fp2_mul(fp2& r, const fp2& a, const fp2& b) {
   fp t0, t1, s0, s1, m;
   fp_mul(t0, a.c0, b.c0);
   fp_mul(t1, a.c1, b.c1);
@@ -66,7 +66,7 @@ BLS_NOINLINE void fp2_mul(fp2& r, const fp2& a, const fp2& b) {
   fp_sub(r.c0, t0, t1);
 }
 // complex squaring: 2 Fp multiplications
-BLS_NOINLINE void fp2_sqr(fp2& r, const fp2& a) {
+BLS_FN void fp2_sqr(fp2& r, const fp2& a) {
   fp s, d, m;
   fp_add(s, a.c0, a.c1);
   fp_sub(d, a.c0, a.c1);
