@@ -23,7 +23,7 @@ BLS_FN void fp2_mul_3b(fp2& r, const fp2& a) {  // a * 3b' = a * 12 (1 + u)
 
 // T <- 2T and the tangent line at T evaluated at P = (xp, yp):
 //   l0 = Y^2 - 3b'Z^2,  l2 = -3X^2 xp,  l3 = 2YZ yp     (coefficients of w^0, w^2, w^3)
-BLS_FN void miller_dbl_step(g2_hom& t, fp2& l0, fp2& l2, fp2& l3, const fp& xp, const fp& yp) {
+BLS_NOINLINE void miller_dbl_step(g2_hom& t, fp2& l0, fp2& l2, fp2& l3, const fp& xp, const fp& yp) {
   fp2 a, b, c, e, f, h, g, s;
   fp2_mul(a, t.x, t.y);  // XY
   fp2_sqr(b, t.y);       // B = Y^2
@@ -62,7 +62,7 @@ BLS_FN void miller_dbl_step(g2_hom& t, fp2& l0, fp2& l2, fp2& l3, const fp& xp, 
 
 // T <- T + Q and the chord line through T and Q evaluated at P:
 //   l0 = theta xq - lambda yq,  l2 = -theta xp,  l3 = lambda yp
-BLS_FN void miller_add_step(g2_hom& t, fp2& l0, fp2& l2, fp2& l3, const fp2& xq, const fp2& yq, const fp& xp,
+BLS_NOINLINE void miller_add_step(g2_hom& t, fp2& l0, fp2& l2, fp2& l3, const fp2& xq, const fp2& yq, const fp& xp,
                             const fp& yp) {
   fp2 th, la, c, d, e, f, g, h, s;
   fp2_mul(th, yq, t.z);
@@ -128,7 +128,7 @@ BLS_FN void miller_loop(fp12& f, const g1_aff* P, const g2_aff* Q) {
 }
 
 // a^x for a in the cyclotomic subgroup (x < 0: conjugate of a^|x|)
-BLS_FN void fp12_pow_x(fp12& r, const fp12& a) {
+BLS_NOINLINE void fp12_pow_x(fp12& r, const fp12& a) {
   fp12 acc = a;
   for (int i = 62; i >= 0; i--) {
     fp12_cyclotomic_sqr(acc, acc);

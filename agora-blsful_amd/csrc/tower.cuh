@@ -268,7 +268,7 @@ BLS_FN void fp12_conj(fp12& r, const fp12& a) {
   fp6_neg(r.c1, a.c1);
 }
 // Karatsuba over Fp6: 18 Fp2 multiplications
-BLS_FN void fp12_mul(fp12& r, const fp12& a, const fp12& b) {
+BLS_NOINLINE void fp12_mul(fp12& r, const fp12& a, const fp12& b) {
   fp6 t0, t1, s, t, m;
   fp6_mul(t0, a.c0, b.c0);
   fp6_mul(t1, a.c1, b.c1);
@@ -281,7 +281,7 @@ BLS_FN void fp12_mul(fp12& r, const fp12& a, const fp12& b) {
   fp6_add(r.c0, t0, t1);
 }
 // complex squaring: 12 Fp2 multiplications
-BLS_FN void fp12_sqr(fp12& r, const fp12& a) {
+BLS_NOINLINE void fp12_sqr(fp12& r, const fp12& a) {
   fp6 t, s0, s1, m;
   fp6_mul(t, a.c0, a.c1);
   fp6_add(s0, a.c0, a.c1);
@@ -293,7 +293,7 @@ BLS_FN void fp12_sqr(fp12& r, const fp12& a) {
   fp6_sub(r.c0, m, s0);
   fp6_add(r.c1, t, t);
 }
-BLS_FN void fp12_inv(fp12& r, const fp12& a) {
+BLS_NOINLINE void fp12_inv(fp12& r, const fp12& a) {
   fp6 t0, t1;
   fp6_mul(t0, a.c0, a.c0);
   fp6_mul(t1, a.c1, a.c1);
@@ -338,7 +338,7 @@ BLS_FN void fp4_sqr(fp2& c0, fp2& c1, const fp2& a, const fp2& b) {
   fp2_sub(t2, t2, t0);
   fp2_sub(c1, t2, t1);
 }
-BLS_FN void fp12_cyclotomic_sqr(fp12& r, const fp12& f) {
+BLS_NOINLINE void fp12_cyclotomic_sqr(fp12& r, const fp12& f) {
   fp2 z0 = f.c0.a0, z4 = f.c0.a1, z3 = f.c0.a2, z2 = f.c1.a0, z1 = f.c1.a1, z5 = f.c1.a2;
   fp2 t0, t1, t2, t3;
   fp4_sqr(t0, t1, z0, z1);
@@ -372,7 +372,7 @@ BLS_FN void fp12_cyclotomic_sqr(fp12& r, const fp12& f) {
 }
 
 // f * (l0 + l2 w^2 + l3 w^3): the sparse line value of the Miller loop.  13 Fp2 multiplications.
-BLS_FN void fp12_mul_by_line(fp12& f, const fp2& l0, const fp2& l2, const fp2& l3) {
+BLS_NOINLINE void fp12_mul_by_line(fp12& f, const fp2& l0, const fp2& l2, const fp2& l3) {
   // L0 = (l0, l2, 0), L1 = (0, l3, 0) in Fp6
   fp6 t0, t1, s, m;
   fp2 x, y, z;

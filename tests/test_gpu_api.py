@@ -1,0 +1,353 @@
+"""GPU parity for the rest of the C ABI: MultiSignature::verify, AggregateSignature::verify, verify_secure[_with_mode],
+hash_to_point, point sums / MSM, pairing products, serialisation.  Each test cites the reference test it mirrors."""
+import hashlib
+import json
+import os
+import random
+
+import pytest
+
+import util
+from util import c, ref
+
+pytestmark = pytest.mark.gpu
+
+IMPLS = [(ref.G1Impl, 1), (ref.G2Impl, 2)]
+KATS = json.load(open(os.path.join(util.ROOT, 'tests', 'golden', 'ref_kats.json')))
+
+
+def raw_fns(sg):
+    return (util.g2_raw, util.g1_raw) if sg == 1 else (util.g1_raw, util.g2_raw)
+
+
+def keys(C, n, tag=0):
+    sks = [ref.keygen_from_hash(bytes([tag]) + i.to_bytes(4, 'big') + bytes(27)) for i in range(n)]
+    return sks, [ref.public_key(C, s) for s in sks]
+
+
+# ------------------------------------------------------------------ hash_to_point / group ops
+@pytest.mark.parametrize('group', [1, 2])
+def test_hash_to_point(api, group):
+    """HashToPoint::hash_to_point (reference src/impls/g1.rs:17-19, g2.rs:15-17) incl. RFC 9380 J.9.1/J.10.1 inputs."""
+    msgs = [b'', b'abc', b'abcdef0123456789', b'q128_' + b'q' * 128, b'a512_' + b'a' * 512, bytes(range(256))]
+    dst = (b'QUUX-V01-CS02-with-BLS12381G%d_XMD:SHA-256_SSWU_RO_' % group)
+    got = api.hash_to_point(group, msgs, dst)
+    comp = api.serialize(group, got)
+    for m, b in zip(msgs, comp):
+        want = c.g1_compress(c.hash_to_g1(m, dst)) if group == 1 else c.g2_compress(c.hash_to_g2(m, dst))
+        assert b == want
+    assert api.hash_to_point(group, [], dst) == []
+
+
+@pytest.mark.parametrize('group', [1, 2])
+def test_sum_and_msm(api, group):
+    """aggregate_public_keys (reference src/traits/sig_core.rs:50-59) and sum t_i pk_i (src/secure_aggregation.rs:201-204)."""
+    rng = random.Random(group)
+    E, gen, raw, comp = (c.E1, c.G1_GEN, util.g1_raw, c.g1_compress) if group == 1 else (c.E2, c.G2_GEN, util.g2_raw, c.g2_compress)
+    for n in (1, 2, 3, 63, 64, 65, 300):
+        ks = [rng.randrange(1, c.R) for _ in range(n)]
+        pts = [E.mul(gen, k) for k in ks]
+        if n >= 3:
+            pts[1] = None                       # an identity among the inputs
+            pts[2] = pts[0]                     # a duplicate (forces the doubling branch of the adder)
+        want = None
+        for p in pts:
+            want = E.add(want, p)
+        got = api.serialize(group, [api.point_sum(group, [raw(p, rng) for p in pts])])[0]
+        assert got == comp(want), n
+        if n <= 65:
+            scal = [rng.randrange(c.R) for _ in range(n)]
+            if n >= 2:
+                scal[0] = 0
+            want = None
+            for p, s in zip(pts, scal):
+                want = E.add(want, E.mul(p, s))
+            got = api.serialize(group, [api.point_sum(group, [raw(p, rng) for p in pts], scal)])[0]
+            assert got == comp(want), n
+    assert api.serialize(group, [api.point_sum(group, [])])[0] == comp(None)
+
+
+def test_sum_closed_form_large(api):
+    """Size-independent property at a large size: sum_i (s0 + i) g2 == (n s0 + n(n-1)/2) g2 for n = 20,000 device-made keys."""
+    n, s0 = 20000, 0x1234567
+    pks, _ = api.sign_batch(1, api.POP, [s0 + i for i in range(n)], [b'x'] * n)
+    got = api.serialize(2, [api.point_sum(2, pks)])[0]
+    assert got == c.g2_compress(c.E2.mul(c.G2_GEN, (n * s0 + n * (n - 1) // 2) % c.R))
+
+
+@pytest.mark.parametrize('group', [1, 2])
+def test_serialize_modes(api, group):
+    """to_bytes / to_bytes_with_mode incl. infinity (reference src/impls/legacy.rs:19-35,85-98,129-143; :204)."""
+    rng = random.Random(9)
+    E, gen, raw, comp = (c.E1, c.G1_GEN, util.g1_raw, c.g1_compress) if group == 1 else (c.E2, c.G2_GEN, util.g2_raw, c.g2_compress)
+    pts = [E.mul(gen, rng.randrange(1, c.R)) for _ in range(20)] + [None]
+    raws = [raw(p, rng) for p in pts]
+    assert api.serialize(group, raws) == [comp(p) for p in pts]
+    assert api.serialize(group, raws, legacy=True) == [ref.modern_to_legacy(comp(p)) for p in pts]
+    aff = [(util.g1_aff_raw(p) if group == 1 else util.g2_aff_raw(p)) if p else bytes(96 * group) for p in pts]
+    assert api.serialize(group, aff, fmt_in=api.FMT_RAW_AFFINE) == [comp(p) for p in pts]
+
+
+def test_pairing_product(api):
+    """Pairing::pairing(..).is_identity() (reference src/traits/pairings.rs:50, src/helpers.rs:41-63): bilinearity."""
+    rng = random.Random(4)
+    a, b = rng.randrange(1, c.R), rng.randrange(1, c.R)
+    P, Q = c.E1.mul(c.G1_GEN, a), c.E2.mul(c.G2_GEN, b)
+    nP = c.E1.neg(c.E1.mul(c.G1_GEN, a * b % c.R))
+    assert api.pairing_product_is_one([util.g1_raw(P, rng), util.g1_raw(nP, rng)], [util.g2_raw(Q, rng), util.g2_raw(c.G2_GEN, rng)])
+    assert not api.pairing_product_is_one([util.g1_raw(P, rng), util.g1_raw(nP, rng)], [util.g2_raw(Q, rng), util.g2_raw(Q, rng)])
+    assert api.pairing_product_is_one([util.g1_raw(None), util.g1_raw(P, rng)], [util.g2_raw(Q, rng), util.g2_raw(None)])
+    assert api.pairing_product_is_one([], [])
+    # 5 pairs: e(k_i G1, G2) for sum k_i = 0
+    ks = [rng.randrange(c.R) for _ in range(4)]
+    ks.append(-sum(ks) % c.R)
+    assert api.pairing_product_is_one([util.g1_raw(c.E1.mul(c.G1_GEN, k), rng) for k in ks], [util.g2_raw(c.G2_GEN, rng)] * 5)
+
+
+@pytest.mark.parametrize('C,sg', IMPLS, ids=['g1', 'g2'])
+def test_sign_batch_matches_oracle(api, C, sg):
+    """Sign side used for synthetic inputs: core_sign (reference src/traits/sig_core.rs:108-117) incl. Aug prefix."""
+    sks, pks = keys(C, 5, 3)
+    for scheme in (ref.BASIC, ref.AUG, ref.POP):
+        msgs = [b'm%d' % i for i in range(5)]
+        dpks, dsigs = api.sign_batch(sg, scheme, sks, msgs)
+        assert api.serialize(3 - sg, dpks) == [C.pk_to_bytes(p) for p in pks]
+        assert api.serialize(sg, dsigs) == [C.sig_to_bytes(ref.sign(C, scheme, s, m)) for s, m in zip(sks, msgs)]
+
+
+# ------------------------------------------------------------------ MultiSignature::verify
+@pytest.mark.parametrize('C,sg', IMPLS, ids=['g1', 'g2'])
+def test_multisig(api, pkg, C, sg):
+    """reference tests/signatures.rs:91-128: all signers ok, a missing key fails; plus identity aggregate key."""
+    rng = random.Random(sg)
+    pkraw, sigraw = raw_fns(sg)
+    impl = pkg.Bls12381G1Impl if sg == 1 else pkg.Bls12381G2Impl
+    sks, pks = keys(C, 6, 5)
+    msg = b'signatures_work'
+    for scheme in (ref.BASIC, ref.POP, ref.AUG):
+        if scheme == ref.AUG:   # the aggregate key is the augmentation prefix (reference src/traits/sig_aug.rs:20-24)
+            apk = ref.aggregate_public_keys(C, pks)
+            sig = None
+            for s in sks:
+                sig = C.sig_curve.add(sig, C.sig_curve.mul(C.hash_to_point(C.pk_to_bytes(apk) + msg, C.DST[scheme]), s))
+        else:
+            sig = ref.aggregate_signatures(C, [ref.sign(C, scheme, s, msg) for s in sks])
+        msig = pkg.MultiSignature(impl, scheme, sigraw(sig, rng))
+        mpk = pkg.MultiPublicKey.from_public_keys([pkg.PublicKey(impl, pkraw(p, rng)) for p in pks])
+        msig.verify(mpk, msg)
+        with pytest.raises(pkg.BlsError) as e:
+            msig.verify(pkg.MultiPublicKey.from_public_keys([pkg.PublicKey(impl, pkraw(p, rng)) for p in pks[1:]]), msg)
+        assert e.value == pkg.BlsError('InvalidSignature')
+        for bad in ([pks[0], C.pk_curve.neg(pks[0])], []):
+            try:
+                ref.multi_sig_verify(C, scheme, bad, sig, msg)
+                want = None
+            except ref.BlsError as ex:
+                want = (ex.kind, ex.msg)
+            with pytest.raises(pkg.BlsError) as e:
+                pkg.MultiSignature(impl, scheme, sigraw(sig, rng)).verify(pkg.MultiPublicKey(impl, [pkg.PublicKey(impl, pkraw(p, rng)) for p in bad]), msg)
+            assert (e.value.kind, e.value.msg) == want
+
+
+# ------------------------------------------------------------------ AggregateSignature::verify
+@pytest.mark.parametrize('C,sg', IMPLS, ids=['g1', 'g2'])
+def test_aggregate_verify(api, pkg, C, sg):
+    """reference tests/signatures.rs:133-173 (same message under Basic must fail, distinct ok, same message under Aug ok)
+    and the error order of src/traits/sig_basic.rs:41-64 / src/traits/sig_core.rs:149-178."""
+    rng = random.Random(20 + sg)
+    pkraw, sigraw = raw_fns(sg)
+    impl = pkg.Bls12381G1Impl if sg == 1 else pkg.Bls12381G2Impl
+    n = 9
+    sks, pks = keys(C, n, 9)
+
+    def both(scheme, items, sig):
+        try:
+            ref.aggregate_verify(C, scheme, items, sig)
+            want = None
+        except ref.BlsError as ex:
+            want = (ex.kind, ex.msg)
+        agg = pkg.AggregateSignature(impl, scheme, sigraw(sig, rng))
+        data = [(pkg.PublicKey(impl, pkraw(p, rng)), m) for p, m in items]
+        try:
+            agg.verify(data)
+            got = None
+        except pkg.BlsError as ex:
+            got = (ex.kind, ex.msg)
+        assert got == want, (scheme, got, want)
+        return got
+
+    for scheme in (ref.BASIC, ref.AUG, ref.POP):
+        msgs = [b'message %d' % i + bytes(i) for i in range(n)]
+        sig = ref.aggregate_signatures(C, [ref.sign(C, scheme, s, m) for s, m in zip(sks, msgs)])
+        assert both(scheme, list(zip(pks, msgs)), sig) is None
+        assert both(scheme, list(zip(pks, msgs))[:-1], sig) == ('InvalidSignature', '')
+        same = [b'same'] * n
+        sig2 = ref.aggregate_signatures(C, [ref.sign(C, scheme, s, m) for s, m in zip(sks, same)])
+        r = both(scheme, list(zip(pks, same)), sig2)
+        assert (r is not None) == (scheme == ref.BASIC)
+        # error precedence: duplicates (Basic) > signature identity > first identity key (1-based) > pairing
+        pk_id = list(pks)
+        pk_id[4] = None
+        pk_id[6] = None
+        both(scheme, list(zip(pk_id, msgs)), sig)
+        both(scheme, list(zip(pk_id, msgs)), None)
+        dup = list(msgs)
+        dup[7] = dup[2]
+        both(scheme, list(zip(pk_id, dup)), None)
+        both(scheme, [], sig)
+        both(scheme, [], None)
+
+
+def test_aggregate_verify_many(api):
+    """A larger aggregate (n = 600, product tree over several folds) built on the device; one tampered message flips it."""
+    n = 600
+    sks = [0x1000 + 7 * i for i in range(n)]
+    msgs = [hashlib.sha256(b'agg%d' % i).digest() for i in range(n)]
+    pks, sigs = api.sign_batch(1, api.BASIC, sks, msgs)
+    agg = api.point_sum(1, sigs)
+    assert api.aggregate_verify(1, api.BASIC, pks, msgs, agg) == (api.OK, (0, 0))
+    msgs2 = list(msgs)
+    msgs2[417] = b'tampered'
+    assert api.aggregate_verify(1, api.BASIC, pks, msgs2, agg)[0] == api.INVALID_SIGNATURE
+    msgs2[599] = msgs2[3]
+    assert api.aggregate_verify(1, api.BASIC, pks, msgs2, agg) == (api.DUPLICATE_MESSAGE, (3, 599))
+    assert api.aggregate_verify(1, api.POP, pks, msgs2, agg)[0] == api.INVALID_SIGNATURE
+
+
+# ------------------------------------------------------------------ verify_secure
+def test_secure_coefficients_golden(api):
+    """SHA-256-only golden values (inputs = reference tests/cpp_integration_test.rs:35-51)."""
+    pk = [bytes.fromhex(h) for h in KATS['cpp']['pk']]
+    st, perm, ts = api.secure_coefficients(pk[:2])
+    assert (st, perm) == (0, [1, 0])
+    assert ts == [0x584ccd89aaf51f8b06067b165b36a9096ae4abc23189c97ca1d34accb015244a,
+                  0x350f133013a3e8f028ab28c14c710b88cc15bfaa853497887728fe591c20a17d]
+    st, perm, ts = api.secure_coefficients(pk)
+    assert (st, perm) == (0, [2, 1, 0])
+    assert ts == [0x06affd8cb2dc37f9c3c4b15a8e7dc6c9b12a845877d24eaa2e2be6628dda7755,
+                  0x5bcd568774ca9fbe351d45b43e504a2f17d6d169142a4286414e90a9de5b01a8,
+                  0x07a4139aa0177dbc814d996431d547dca201ca30ff948d57c7d40bfed02f3c9e]
+    leg = [ref.modern_to_legacy(b) for b in pk]
+    st, perm, ts = api.secure_coefficients(leg)
+    assert (st, perm) == (0, [2, 1, 0])
+    assert ts[0] == 0x43cc66d4a23309b3e0d7c75dc3d2d04df70e6f9f6d826b025ecaf81371906b00
+    # against the oracle on random keys, with duplicates (stable order)
+    rng = random.Random(1)
+    kb = [bytes(rng.randrange(256) for _ in range(96)) for _ in range(40)]
+    kb[7] = kb[30]
+    perm_o, _, ts_o = ref.secure_coefficients(kb)
+    assert api.secure_coefficients(kb) == (0, perm_o, ts_o)
+
+
+def test_verify_secure_reference_kats(api, pkg):
+    """K2-K4 through the C ABI: reference tests/cpp_integration_test.rs:87-192 and
+    tests/secure_aggregation_test.rs:143-235 (57-signer production vector)."""
+    C, impl = ref.G2Impl, pkg.Bls12381G2Impl
+    cpp = KATS['cpp']
+    msg = bytes.fromhex(cpp['message'])
+    pks = [C.pk_from_bytes(bytes.fromhex(h)) for h in cpp['pk']]
+    sigs = [C.sig_from_bytes(bytes.fromhex(h)) for h in cpp['sig']]
+    P = [pkg.PublicKey(impl, util.g1_raw(p)) for p in pks]
+    for n in (2, 3):
+        agg = ref.aggregate_secure(C, pks[:n], sigs[:n])
+        pkg.Signature(impl, pkg.BASIC, util.g2_raw(agg)).verify_secure(P[:n], msg)
+        pkg.Signature(impl, pkg.BASIC, util.g2_raw(agg)).verify_secure(P[:n][::-1], msg)     # order independent
+    naive = C.sig_from_bytes(bytes.fromhex(cpp['naive_agg_sig_pk12']))
+    with pytest.raises(pkg.BlsError) as e:
+        pkg.Signature(impl, pkg.BASIC, util.g2_raw(naive)).verify_secure(P[:2], msg)
+    assert e.value == pkg.BlsError('InvalidSignature')
+    p57 = KATS['prod57']
+    P57 = [pkg.PublicKey(impl, util.g1_raw(C.pk_from_bytes(bytes.fromhex(h)))) for h in p57['pks']]
+    sig57 = pkg.Signature(impl, pkg.BASIC, util.g2_raw(C.sig_from_bytes(bytes.fromhex(p57['sig']))))
+    sig57.verify_secure(P57, bytes.fromhex(p57['message']))
+    sig57.verify_secure_with_mode(P57, bytes.fromhex(p57['message']), pkg.MODERN)
+    with pytest.raises(pkg.BlsError):
+        sig57.verify_secure_with_mode(P57, bytes.fromhex(p57['message']), pkg.LEGACY)       # cross-mode must fail
+    with pytest.raises(pkg.BlsError):
+        sig57.verify_secure(P57[:-1], bytes.fromhex(p57['message']))
+
+
+@pytest.mark.parametrize('C,sg', IMPLS, ids=['g1', 'g2'])
+def test_verify_secure_selfconsistency(api, pkg, C, sg):
+    """reference src/secure_aggregation.rs:433-602 (3 signers ok / wrong subset / reorder; rogue key; empty keys) and
+    tests/legacy_test.rs:110-171 (cross-mode verification fails)."""
+    rng = random.Random(sg)
+    pkraw, sigraw = raw_fns(sg)
+    impl = pkg.Bls12381G1Impl if sg == 1 else pkg.Bls12381G2Impl
+    sks, pks = keys(C, 5, 11)
+    msg = b'test message'
+    modes = [None] if sg == 1 else [None, ref.MODERN, ref.LEGACY]
+    for scheme in (ref.BASIC, ref.AUG, ref.POP):
+        sigs = [C.sig_curve.mul(C.hash_to_point(msg, C.DST[scheme]), s) for s in sks]   # Aug does not prefix here (:236-246)
+        for mode in modes:
+            agg = ref.aggregate_secure(C, pks, sigs, mode)
+            S = pkg.Signature(impl, scheme, sigraw(agg, rng))
+            P = [pkg.PublicKey(impl, pkraw(p, rng)) for p in pks]
+
+            def run(keys_, m=msg, sig=S):
+                try:
+                    if mode is None:
+                        sig.verify_secure(keys_, m)
+                    else:
+                        sig.verify_secure_with_mode(keys_, m, mode)
+                    return None
+                except pkg.BlsError as ex:
+                    return (ex.kind, ex.msg)
+            assert run(P) is None
+            assert run(P[::-1]) is None
+            assert run(P[:4]) == ('InvalidSignature', '')
+            assert run(P, b'wrong') == ('InvalidSignature', '')
+            if mode is not None:
+                other = ref.LEGACY if mode == ref.MODERN else ref.MODERN
+                try:
+                    S.verify_secure_with_mode(P, msg, other)
+                    crossed = None
+                except pkg.BlsError as ex:
+                    crossed = ex.kind
+                assert crossed == 'InvalidSignature'
+            assert run([]) == ('InvalidSignature', '')
+            ident = pkg.Signature(impl, scheme, sigraw(None))
+            assert run([], sig=ident) is None
+            assert run(P, sig=ident) == ('InvalidInputs', 'signature is the identity point')
+        # rogue key: pk_r = x g - pk_0 and naive aggregate must fail (reference :501-540)
+        x = 0x5151
+        rogue = C.pk_curve.add(C.pk_curve.mul(C.pk_gen, x), C.pk_curve.neg(pks[0]))
+        forged = C.sig_curve.mul(C.hash_to_point(msg, C.DST[scheme]), x)
+        S = pkg.Signature(impl, scheme, sigraw(forged, rng))
+        with pytest.raises(pkg.BlsError):
+            S.verify_secure([pkg.PublicKey(impl, pkraw(pks[0], rng)), pkg.PublicKey(impl, pkraw(rogue, rng))], msg)
+
+
+def test_verify_secure_large(api):
+    """verify_secure at n = 3,000 keys made on the device; the aggregate is built from the library's own coefficient
+    step, so this is a round trip (sort -> H -> t_i -> MSM -> verify) at a size the oracle would need minutes for."""
+    n = 3000
+    sks = [0x777 + 13 * i for i in range(n)]
+    msg = b'large secure aggregate'
+    pks, sigs = api.sign_batch(2, api.BASIC, sks, [msg] * n)        # G2Impl: 48-byte keys, both modes exist
+    for mode in (api.MODERN, api.LEGACY):
+        kb = api.serialize(1, pks, legacy=(mode == api.LEGACY))
+        st, perm, ts = api.secure_coefficients(kb)
+        assert st == 0 and sorted(perm) == list(range(n))
+        agg = api.point_sum(2, [sigs[i] for i in perm], ts)
+        assert api.verify_secure(2, api.BASIC, pks, agg, msg, mode) == api.OK
+        assert api.verify_secure(2, api.BASIC, pks[:-1], agg, msg, mode) == api.INVALID_SIGNATURE
+        assert api.verify_secure(2, api.BASIC, pks, agg, msg, 1 - mode) == api.INVALID_SIGNATURE
+
+
+def test_verify_batch_large_property(api):
+    """BASELINE-size style property at n = 8,192: device-signed batch, every 97th message tampered, every 101st
+    signature replaced by its neighbour's: the verdict vector must be exactly the tamper pattern."""
+    n = 8192
+    sks = [0xabcdef + i for i in range(n)]
+    msgs = [hashlib.sha256(i.to_bytes(8, 'little')).digest() for i in range(n)]
+    pks, sigs = api.sign_batch(1, api.POP, sks, msgs)
+    expect = [0] * n
+    msgs2, sigs2 = list(msgs), list(sigs)
+    for i in range(0, n, 97):
+        msgs2[i] = msgs2[i][:-1] + bytes([msgs2[i][-1] ^ 1])
+        expect[i] = 1
+    for i in range(5, n, 101):
+        sigs2[i] = sigs[(i + 1) % n]
+        expect[i] = 1
+    assert api.verify_batch(1, api.POP, pks, sigs2, msgs2) == expect
