@@ -410,8 +410,11 @@ int blsgpu_verify_batch(int sig_group, int scheme, const void* pks, const void* 
 }
 
 // shared tail of multi_verify / verify_secure: one core_verify of (d_pk RAW_PROJ on device, caller's sig, msg)
-static int verify_one_tail(Ctx* c, int sig_group, int scheme, const uint8_t* d_pk_proj, const void* sig, int fmt, const uint8_t* msg,
-                           size_t msg_len, int32_t* status) {
+// aug_prefix: MultiSignature::verify under MessageAugmentation prefixes the (aggregated) key bytes
+// (reference src/traits/sig_aug.rs:20-24); verify_secure_message_augmentation does NOT, it only switches the DST
+// (reference src/secure_aggregation.rs:236-246).
+static int verify_one_tail(Ctx* c, int sig_group, int scheme, int aug_prefix, const uint8_t* d_pk_proj, const void* sig, int fmt,
+                           const uint8_t* msg, size_t msg_len, int32_t* status) {
   int rc;
   // bring the signature to RAW_PROJ next to the key so one k_prepare call (single fmt) serves both
   const void* d_sig_in;
@@ -430,7 +433,7 @@ static int verify_one_tail(Ctx* c, int sig_group, int scheme, const uint8_t* d_p
   if (sig_group == 1) rc = run_point_sum<1>(c, (const uint8_t*)d_sig_in, fmt, nullptr, nullptr, 1, d_sig_proj, 1);
   else rc = run_point_sum<2>(c, (const uint8_t*)d_sig_in, fmt, nullptr, nullptr, 1, d_sig_proj, 1);
   if (rc) return rc;
-  rc = run_verify_items(c, sig_group, scheme == BLSGPU_SCHEME_AUG, d_pk_proj, d_sig_proj, BLSGPU_FMT_RAW_PROJ, (const uint8_t*)d_msg, d_offs, 1,
+  rc = run_verify_items(c, sig_group, aug_prefix, d_pk_proj, d_sig_proj, BLSGPU_FMT_RAW_PROJ, (const uint8_t*)d_msg, d_offs, 1,
                         scheme_dst(sig_group, scheme), 1, d_pairs, d_f, d_status);
   if (rc) return rc;
   if ((rc = copy_out(c, status, d_status, 4))) return rc;
@@ -458,7 +461,7 @@ int blsgpu_multi_verify(int sig_group, int scheme, const void* pks, size_t n, co
   if (sig_group == 1) rc = run_point_sum<2>(c, (const uint8_t*)d_pks, fmt, nullptr, nullptr, n, d_part, T);
   else rc = run_point_sum<1>(c, (const uint8_t*)d_pks, fmt, nullptr, nullptr, n, d_part, T);
   if (rc) return rc;
-  return verify_one_tail(c, sig_group, scheme, d_part, sig, fmt, msg, msg_len, status);
+  return verify_one_tail(c, sig_group, scheme, scheme == BLSGPU_SCHEME_AUG, d_part, sig, fmt, msg, msg_len, status);
 }
 
 int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const uint8_t* msgs, const uint64_t* msg_offsets,
@@ -612,7 +615,7 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
       if (sig_group == 1) rc = run_point_sum<2>(c, (const uint8_t*)d_pks, fmt, d_scal, d_perm, n, d_part, T);
       else rc = run_point_sum<1>(c, (const uint8_t*)d_pks, fmt, d_scal, d_perm, n, d_part, T);
       if (rc) return rc;
-      return verify_one_tail(c, sig_group, scheme, d_part, sig, fmt, msg, msg_len, status);
+      return verify_one_tail(c, sig_group, scheme, 0, d_part, sig, fmt, msg, msg_len, status);
     }
   }
   if (is_device_ptr(status)) HIPCK(hipMemcpy(status, &st, 4, hipMemcpyHostToDevice));
