@@ -79,3 +79,24 @@ def build_hostsim():
         import subprocess
         subprocess.check_call(['g++', '-O2', '-shared', '-fPIC', '-o', so, src])
     return ctypes.CDLL(so)
+
+
+def load_c_oracle():
+    """Build (if needed) and load oracle/c/liboracle.so with argument types declared."""
+    import subprocess
+    d = os.path.join(ROOT, 'oracle', 'c')
+    subprocess.check_call(['make', '-s', '-C', d])
+    lib = ctypes.CDLL(os.path.join(d, 'liboracle.so'))
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    cp = ctypes.c_char_p
+    lib.bo_init.restype = None
+    lib.bo_verify.argtypes = [ci, ci, cp, cp, cp, sz]
+    lib.bo_verify_batch.argtypes = [ci, ci, vp, vp, vp, vp, sz, vp, ci]
+    lib.bo_verify_batch.restype = None
+    lib.bo_hash_to_point.argtypes = [ci, cp, sz, cp, sz, vp]
+    lib.bo_hash_to_point.restype = None
+    lib.bo_compress.argtypes = [ci, cp, vp]
+    lib.bo_compress.restype = None
+    lib.bo_verify_secure.argtypes = [ci, ci, cp, sz, cp, cp, sz, ci]
+    lib.bo_init()
+    return lib
