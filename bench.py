@@ -37,12 +37,24 @@ def gen_inputs(n, base):
     return sks, msgs
 
 
+def host_cores():
+    """Cores this process may actually use: min(affinity mask, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(d_pks, d_sigs, msgs_host, sample, n_total):
     """The C oracle (oracle/c, kind "port") on the first `sample` items of the very batch the GPU verified (tampered
     ones included), on all host cores of this box: contiguous item ranges, one pthread per core."""
     import util
     bo = util.load_c_oracle()
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     pks = d_pks[:sample * 288].cpu().numpy().tobytes()
     sigs = d_sigs[:sample * 144].cpu().numpy().tobytes()
     blob = b''.join(msgs_host[:sample])
