@@ -31,6 +31,7 @@ EXPORTS = [
     'blsgpu_hash_to_g2', 'blsgpu_sum_g1', 'blsgpu_sum_g2', 'blsgpu_msm_g1', 'blsgpu_msm_g2',
     'blsgpu_pairing_product_is_one', 'blsgpu_serialize', 'blsgpu_sign_batch',
     'blsgpu_profile_enable', 'blsgpu_profile_count', 'blsgpu_profile_get',
+    'blsgpu_aggregate_partial', 'blsgpu_fp12_product_is_one', 'blsgpu_core_verify',
 ]
 
 
@@ -117,6 +118,9 @@ def load_library(path=None):
         lib.blsgpu_serialize.argtypes = [ci, vp, sz, ci, ci, vp, i32p]
         lib.blsgpu_sign_batch.argtypes = [ci, ci, u8p, u8p, u64p, sz, vp, vp]
         lib.blsgpu_profile_enable.argtypes = [ci]
+        lib.blsgpu_aggregate_partial.argtypes = [ci, ci, vp, u8p, u64p, sz, vp, ci, vp, ctypes.POINTER(ctypes.c_int64)]
+        lib.blsgpu_fp12_product_is_one.argtypes = [vp, sz, i32p]
+        lib.blsgpu_core_verify.argtypes = [ci, u8p, sz, vp, vp, u8p, u64p, sz, ci, i32p]
         lib.blsgpu_profile_get.argtypes = [ci, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
         _lib = lib
     return _lib
@@ -163,6 +167,26 @@ def verify_batch(sig_group, scheme, pks, sigs, msgs, fmt=FMT_RAW_PROJ):
     _check(lib.blsgpu_verify_batch(sig_group, scheme, _ptr(pkb), _ptr(sgb), _ptr(blob), ctypes.cast(offs, ctypes.c_void_p), n, fmt,
                                    ctypes.cast(st, ctypes.c_void_p)))
     return list(st)
+
+
+DST = {  # reference src/impls/g1.rs:110-119, src/impls/g2.rs:108-117
+    (1, BASIC): b'BLS_SIG_BLS12381G1_XMD:SHA-256_SSWU_RO_NUL_', (1, AUG): b'BLS_SIG_BLS12381G1_XMD:SHA-256_SSWU_RO_AUG_',
+    (1, POP): b'BLS_SIG_BLS12381G1_XMD:SHA-256_SSWU_RO_POP_', (2, BASIC): b'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_',
+    (2, AUG): b'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_AUG_', (2, POP): b'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_',
+}
+POP_DST = {1: b'BLS_POP_BLS12381G1_XMD:SHA-256_SSWU_RO_POP_', 2: b'BLS_POP_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_'}
+
+
+def core_verify(sig_group, dst, pks, sigs, msgs, fmt=FMT_RAW_PROJ):
+    """status list of BlsSignatureCore::core_verify with an explicit DST (no augmentation)."""
+    lib = init()
+    n = len(msgs)
+    offs, blob = _offsets(msgs)
+    st = (ctypes.c_int32 * max(n, 1))()
+    pkb, sgb = b''.join(pks), b''.join(sigs)
+    _check(lib.blsgpu_core_verify(sig_group, _ptr(dst), len(dst), _ptr(pkb), _ptr(sgb), _ptr(blob), ctypes.cast(offs, ctypes.c_void_p), n, fmt,
+                                  ctypes.cast(st, ctypes.c_void_p)))
+    return list(st)[:n]
 
 
 def multi_verify(sig_group, scheme, pks, sig, msg, fmt=FMT_RAW_PROJ):
@@ -261,6 +285,26 @@ def sign_batch(sig_group, scheme, sks, msgs):
     _check(lib.blsgpu_sign_batch(sig_group, scheme, _ptr(skb), _ptr(blob), ctypes.cast(offs, ctypes.c_void_p), n,
                                  ctypes.cast(opk, ctypes.c_void_p), ctypes.cast(osg, ctypes.c_void_p)))
     return ([opk.raw[pksz * i:pksz * (i + 1)] for i in range(n)], [osg.raw[sgsz * i:sgsz * (i + 1)] for i in range(n)])
+
+
+def aggregate_partial(sig_group, scheme, pks, msgs, sig=None, fmt=FMT_RAW_PROJ):
+    """(576-byte Fp12 record, first_bad) for a shard of (pk, msg) pairs; sig is folded in when given."""
+    lib = init()
+    offs, blob = _offsets(msgs)
+    out = ctypes.create_string_buffer(576)
+    fb = ctypes.c_int64(-2)
+    pkb = b''.join(pks)
+    _check(lib.blsgpu_aggregate_partial(sig_group, scheme, _ptr(pkb), _ptr(blob), ctypes.cast(offs, ctypes.c_void_p), len(pks),
+                                        _ptr(sig) if sig is not None else None, fmt, ctypes.cast(out, ctypes.c_void_p), ctypes.byref(fb)))
+    return out.raw, fb.value
+
+
+def fp12_product_is_one(records):
+    lib = init()
+    r = ctypes.c_int32(-99)
+    blob = b''.join(records)
+    _check(lib.blsgpu_fp12_product_is_one(_ptr(blob), len(records), ctypes.byref(r)))
+    return bool(r.value)
 
 
 def profile_enable(on=True):

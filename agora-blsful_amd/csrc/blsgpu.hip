@@ -16,14 +16,15 @@
 
 namespace {
 
+const uint32_t FP_ONE_HOST[12] = FP_ONE_WORDS;
 thread_local std::string t_err;
 
 enum {
   KID_PREPARE, KID_MILLER2, KID_FINALEXP, KID_PREPARE_AGG, KID_PAIRS_AFF, KID_MILLER1, KID_F12_FOLD, KID_FINALEXP_ONE,
-  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_COUNT
+  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_F12_IO, KID_COUNT
 };
 const char* KID_NAMES[KID_COUNT] = {"k_prepare", "k_miller2", "k_finalexp", "k_prepare_agg", "k_pairs_to_affine", "k_miller1", "k_f12_fold",
-                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign"};
+                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign", "k_f12_io"};
 
 struct Ctx {
   int dev = -1;
@@ -207,14 +208,21 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
   return 0;
 }
 
-// product of m Fp12 values in a workspace (stride given) folded into item 0, then verdict
-int run_f12_product_verdict(Ctx* c, uint32_t* d_f, size_t m, size_t stride, int32_t* d_verdict) {
+// product of m Fp12 values in a workspace (stride given) folded into item 0
+int run_f12_fold(Ctx* c, uint32_t* d_f, size_t m, size_t stride) {
   size_t cur = m;
   while (cur > 1) {
     size_t half = (cur + 1) / 2;
     KL(KID_F12_FOLD, k_f12_fold, dim3(blocks_for(half)), dim3(BLS_BLOCK), cur, half, d_f, stride);
     cur = half;
   }
+  HIPCK(hipGetLastError());
+  return 0;
+}
+// ... then the verdict of item 0
+int run_f12_product_verdict(Ctx* c, uint32_t* d_f, size_t m, size_t stride, int32_t* d_verdict) {
+  int rc = run_f12_fold(c, d_f, m, stride);
+  if (rc) return rc;
   KL(KID_FINALEXP_ONE, k_finalexp_one, dim3(1), dim3(64), d_f, stride, d_verdict);
   HIPCK(hipGetLastError());
   return 0;
@@ -542,7 +550,7 @@ int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const ui
         }
     }
     if (st == BLSGPU_OK) {
-      KL(KID_MILLER1, k_miller1, dim3(blocks_for(m)), dim3(BLS_BLOCK), m, d_pairs, d_bad, d_f);
+      KL(KID_MILLER1, k_miller1, dim3(blocks_for(m)), dim3(BLS_BLOCK), m, m, d_pairs, d_bad, d_f);
       if ((rc = run_f12_product_verdict(c, d_f, m, m, d_verdict))) return rc;
       HIPCK(hipMemcpyAsync(&st, d_verdict, 4, hipMemcpyDeviceToHost, c->stream));
       SYNC_FLUSH(c);
@@ -736,7 +744,7 @@ int blsgpu_pairing_product_is_one(const void* g1s, const void* g2s, size_t n, in
     uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * n);
     if (!d_skip || !d_pairs || !d_f) return fail(BLSGPU_E_HIP, "internal: arena too small");
     KL(KID_PAIRS_AFF, k_pairs_to_affine, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d1, (const uint8_t*)d2, fmt, d_pairs, d_skip);
-    KL(KID_MILLER1, k_miller1, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_pairs, d_skip, d_f);
+    KL(KID_MILLER1, k_miller1, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, n, d_pairs, d_skip, d_f);
     if ((rc = run_f12_product_verdict(c, d_f, n, n, d_skip + n))) return rc;
     HIPCK(hipMemcpyAsync(&verdict, d_skip + n, 4, hipMemcpyDeviceToHost, c->stream));
     SYNC_FLUSH(c);
@@ -810,6 +818,144 @@ int blsgpu_sign_batch(int sig_group, int scheme, const uint8_t* sks, const uint8
   if (d_pks != out_pks && (rc = copy_out(c, out_pks, d_pks, pkb))) return rc;
   if (d_sigs != out_sigs && (rc = copy_out(c, out_sigs, d_sigs, sgb))) return rc;
   SYNC_FLUSH(c);
+  return 0;
+}
+
+/* ---- sharded aggregate verify: the local part of core_aggregate_verify (reference
+ * src/traits/sig_core.rs:149-178) for a contiguous shard of the (pk, msg) pairs.  out_f12 = product of the Miller
+ * values of the shard's pairs [times the (sig, -g) pair when sig != NULL] BEFORE the final exponentiation, as a
+ * 576-byte record; *first_bad = local index of the first identity public key, n when the signature is the identity,
+ * or -1.  Duplicate-message detection is global and stays with the caller. */
+int blsgpu_aggregate_partial(int sig_group, int scheme, const void* pks, const uint8_t* msgs, const uint64_t* msg_offsets, size_t n,
+                             const void* sig, int fmt, void* out_f12, int64_t* first_bad) {
+  int rc = check_common(sig_group, scheme, fmt);
+  if (rc) return rc;
+  if (!out_f12 || !first_bad || !msg_offsets || (n && !pks)) return fail(BLSGPU_E_ARG, "null argument");
+  Ctx* c = g_ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCK(hipSetDevice(c->dev));
+  uint64_t total = 0;
+  if (is_device_ptr(msg_offsets)) HIPCK(hipMemcpy(&total, msg_offsets + n, 8, hipMemcpyDeviceToHost));
+  else total = msg_offsets[n];
+  const size_t m = n + 1, psz = pk_size(sig_group, fmt);
+  size_t need = pad256(psz * n) + pad256(sig_size(sig_group, fmt)) + pad256(total) + pad256(8 * m) + pad256(4 * m) +
+                2 * pad256((size_t)WS_PAIRS_WORDS * 4 * m) + 8192;
+  if ((rc = arena_reserve(c, need))) return rc;
+  c->arena_off = 0;
+  const void *d_pks, *d_sig = nullptr, *d_msgs, *d_offs;
+  if ((rc = stage_in(c, pks, psz * n, &d_pks))) return rc;
+  if (sig && (rc = stage_in(c, sig, sig_size(sig_group, fmt), &d_sig))) return rc;
+  if ((rc = stage_in(c, msgs, total, &d_msgs))) return rc;
+  if ((rc = stage_in(c, msg_offsets, 8 * m, &d_offs))) return rc;
+  int32_t* d_bad = (int32_t*)arena_take(c, 4 * m);
+  uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)72 * 4 * m);
+  uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * m);
+  uint8_t* d_out = (uint8_t*)arena_take(c, 576);
+  if (!d_bad || !d_pairs || !d_f || !d_out) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  dst_arg dst = scheme_dst(sig_group, scheme);
+  int aug = scheme == BLSGPU_SCHEME_AUG;
+  // without a signature the extra lane n is simply not launched (mm = n): k_prepare_agg treats i == n as the sig lane
+  const size_t mm = sig ? m : n;
+  std::vector<int32_t> bad(m, 0);
+  int64_t fb = -1;
+  if (mm > 0) {
+    // the workspace stride is always n + 1 (k_prepare_agg's layout); lanes >= mm are never read
+    if (sig_group == 1) {
+      if (sig) KL(KID_PREPARE_AGG, k_prepare_agg<1>, dim3(blocks_for(m)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, aug, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad);
+      else KL(KID_PREPARE_AGG, k_prepare_agg<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_pks, fmt, aug, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad);
+    } else {
+      if (sig) KL(KID_PREPARE_AGG, k_prepare_agg<2>, dim3(blocks_for(m)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, aug, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad);
+      else KL(KID_PREPARE_AGG, k_prepare_agg<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_pks, fmt, aug, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad);
+    }
+    HIPCK(hipGetLastError());
+    HIPCK(hipMemcpyAsync(bad.data(), d_bad, 4 * mm, hipMemcpyDeviceToHost, c->stream));
+    SYNC_FLUSH(c);
+    if (sig && bad[n]) fb = (int64_t)n;
+    else
+      for (size_t i = 0; i < n; i++)
+        if (bad[i]) { fb = (int64_t)i; break; }
+  }
+  std::vector<uint8_t> one(576, 0);
+  if (fb < 0 && mm > 0) {
+    KL(KID_MILLER1, k_miller1, dim3(blocks_for(mm)), dim3(BLS_BLOCK), mm, m, d_pairs, d_bad, d_f);   // stride n + 1 as k_prepare_agg wrote
+  }
+  *first_bad = fb;
+  if (fb >= 0 || mm == 0) {
+    // neutral element (Montgomery one in c0.a0) so that callers can always fold
+    memcpy(one.data(), FP_ONE_HOST, 48);
+    HIPCK(hipMemcpy(out_f12, one.data(), 576, is_device_ptr(out_f12) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+    return 0;
+  }
+  if ((rc = run_f12_fold(c, d_f, mm, m))) return rc;
+  KL(KID_F12_IO, k_f12_export, dim3(1), dim3(192), d_f, m, d_out);
+  HIPCK(hipGetLastError());
+  if ((rc = copy_out(c, out_f12, d_out, 576))) return rc;
+  SYNC_FLUSH(c);
+  return 0;
+}
+
+/* BlsSignatureCore::core_verify(pk, sig, msg, dst) with an explicit DST (reference src/traits/sig_core.rs:120-146):
+ * n items share one DST; no message augmentation.  Used by the sharded verify_secure tail and by PoP checks
+ * (pop_verify = core_verify(pk, sig, pk_bytes, POP_DST), src/traits/sig_pop.rs:67-70). */
+int blsgpu_core_verify(int sig_group, const uint8_t* dst, size_t dst_len, const void* pks, const void* sigs, const uint8_t* msgs,
+                       const uint64_t* msg_offsets, size_t n, int fmt, int32_t* status) {
+  int rc = check_common(sig_group, 0, fmt);
+  if (rc) return rc;
+  if (dst_len > 255 || (!dst && dst_len)) return fail(BLSGPU_E_ARG, "dst must be at most 255 bytes");
+  if (n == 0) return 0;
+  if (!pks || !sigs || !msg_offsets || !status) return fail(BLSGPU_E_ARG, "null argument");
+  Ctx* c = g_ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCK(hipSetDevice(c->dev));
+  uint64_t total = 0;
+  if (is_device_ptr(msg_offsets)) HIPCK(hipMemcpy(&total, msg_offsets + n, 8, hipMemcpyDeviceToHost));
+  else total = msg_offsets[n];
+  const size_t pkb = pk_size(sig_group, fmt) * n, sgb = sig_size(sig_group, fmt) * n;
+  size_t need = pad256(pkb) + pad256(sgb) + pad256(total) + pad256(8 * (n + 1)) + pad256(4 * n) + 2 * pad256((size_t)WS_PAIRS_WORDS * 4 * n) + 4096;
+  if ((rc = arena_reserve(c, need))) return rc;
+  c->arena_off = 0;
+  const void *d_pks, *d_sigs, *d_msgs, *d_offs;
+  if ((rc = stage_in(c, pks, pkb, &d_pks))) return rc;
+  if ((rc = stage_in(c, sigs, sgb, &d_sigs))) return rc;
+  if ((rc = stage_in(c, msgs, total, &d_msgs))) return rc;
+  if ((rc = stage_in(c, msg_offsets, 8 * (n + 1), &d_offs))) return rc;
+  int32_t* d_status = (int32_t*)arena_take(c, 4 * n);
+  uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)WS_PAIRS_WORDS * 4 * n);
+  uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * n);
+  if (!d_status || !d_pairs || !d_f) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  rc = run_verify_items(c, sig_group, 0, (const uint8_t*)d_pks, (const uint8_t*)d_sigs, fmt, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, 0,
+                        make_dst(dst, dst_len), n, d_pairs, d_f, d_status);
+  if (rc) return rc;
+  if ((rc = copy_out(c, status, d_status, 4 * n))) return rc;
+  SYNC_FLUSH(c);
+  return 0;
+}
+
+/* product of k Fp12 records (the partials of blsgpu_aggregate_partial) -> final exponentiation -> *is_one */
+int blsgpu_fp12_product_is_one(const void* f12s, size_t k, int32_t* is_one) {
+  if (!g_ctx) return fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)");
+  if (!is_one || (k && !f12s)) return fail(BLSGPU_E_ARG, "null argument");
+  int32_t verdict = BLSGPU_OK;
+  if (k > 0) {
+    Ctx* c = g_ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCK(hipSetDevice(c->dev));
+    int rc = arena_reserve(c, pad256(576 * k) + pad256((size_t)WS_F_WORDS * 4 * k) + 4096);
+    if (rc) return rc;
+    c->arena_off = 0;
+    const void* d_in;
+    if ((rc = stage_in(c, f12s, 576 * k, &d_in))) return rc;
+    uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * k);
+    int32_t* d_v = (int32_t*)arena_take(c, 4);
+    if (!d_f || !d_v) return fail(BLSGPU_E_HIP, "internal: arena too small");
+    KL(KID_F12_IO, k_f12_import, dim3(blocks_for(k)), dim3(BLS_BLOCK), k, (const uint8_t*)d_in, d_f, k);
+    if ((rc = run_f12_product_verdict(c, d_f, k, k, d_v))) return rc;
+    HIPCK(hipMemcpyAsync(&verdict, d_v, 4, hipMemcpyDeviceToHost, c->stream));
+    SYNC_FLUSH(c);
+  }
+  int32_t one = verdict == BLSGPU_OK ? 1 : 0;
+  if (is_device_ptr(is_one)) HIPCK(hipMemcpy(is_one, &one, 4, hipMemcpyHostToDevice));
+  else *is_one = one;
   return 0;
 }
 

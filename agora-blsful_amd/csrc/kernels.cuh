@@ -126,9 +126,11 @@ template <int SG>
 __global__ void k_prepare_agg(size_t n, const uint8_t* pks, const uint8_t* sig, int fmt, int aug, const uint8_t* msgs,
                               const uint64_t* offs, dst_arg dst, uint32_t* pairs, int32_t* bad);
 __global__ void k_pairs_to_affine(size_t n, const uint8_t* g1s, const uint8_t* g2s, int fmt, uint32_t* pairs, int32_t* skip);
-__global__ void k_miller1(size_t n, const uint32_t* pairs, const int32_t* skip, uint32_t* fws);
+__global__ void k_miller1(size_t n, size_t stride, const uint32_t* pairs, const int32_t* skip, uint32_t* fws);
 __global__ void k_f12_fold(size_t m, size_t half, uint32_t* fws, size_t stride);
 __global__ void k_finalexp_one(const uint32_t* fws, size_t stride, int32_t* verdict);
+__global__ void k_f12_import(size_t n, const uint8_t* src, uint32_t* fws, size_t stride);
+__global__ void k_f12_export(const uint32_t* fws, size_t stride, uint8_t* dst);
 __global__ void k_hash_to_g1(size_t n, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint8_t* out);
 __global__ void k_hash_to_g2(size_t n, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint8_t* out);
 template <int G, int WITH_SCALARS>
@@ -313,7 +315,7 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_pairs_to_affine(size_t n, const u
 
 #if defined(BLS_TU_MILLER)
 // one-pair Miller loop per item; skipped items write 1
-__global__ void __launch_bounds__(BLS_BLOCK) k_miller1(size_t n, const uint32_t* pairs, const int32_t* skip, uint32_t* fws) {
+__global__ void __launch_bounds__(BLS_BLOCK) k_miller1(size_t n, size_t stride, const uint32_t* pairs, const int32_t* skip, uint32_t* fws) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   fp12 f;
@@ -322,10 +324,10 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_miller1(size_t n, const uint32_t*
   } else {
     g1_aff P[1];
     g2_aff Q[1];
-    ws_ld_pair(P[0], Q[0], pairs, n, i, 0);
+    ws_ld_pair(P[0], Q[0], pairs, stride, i, 0);
     miller_loop<1>(f, P, Q);
   }
-  ws_st_fp12(fws, n, i, f);
+  ws_st_fp12(fws, stride, i, f);
 }
 
 #endif  // BLS_TU_MILLER
@@ -350,6 +352,18 @@ __global__ void k_finalexp_one(const uint32_t* fws, size_t stride, int32_t* verd
   *verdict = pairing_verdict(f);
 }
 
+// Fp12 partial products cross the C ABI as 576-byte records (c0.a0, c0.a1, c0.a2, c1.a0, c1.a1, c1.a2; each Fp2 =
+// c0 then c1; Montgomery limbs): array-of-records <-> word-major workspace
+__global__ void __launch_bounds__(BLS_BLOCK) k_f12_import(size_t n, const uint8_t* src, uint32_t* fws, size_t stride) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* w = (const uint32_t*)(src + i * 576);
+  for (int k = 0; k < 144; k++) fws[(size_t)k * stride + i] = w[k];
+}
+__global__ void k_f12_export(const uint32_t* fws, size_t stride, uint8_t* dst) {
+  if (blockIdx.x != 0 || threadIdx.x >= 144) return;
+  ((uint32_t*)dst)[threadIdx.x] = fws[(size_t)threadIdx.x * stride];
+}
 #endif  // BLS_TU_FINALEXP
 
 #if defined(BLS_TU_POINTS)

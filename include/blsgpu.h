@@ -77,6 +77,12 @@ size_t blsgpu_last_error(char* buf, size_t cap);
 int blsgpu_verify_batch(int sig_group, int scheme, const void* pks, const void* sigs, const uint8_t* msgs,
                         const uint64_t* msg_offsets, size_t n, int fmt, int32_t* status);
 
+/* BlsSignatureCore::core_verify(pk, sig, msg, dst) for n items that share an explicit DST, no message augmentation
+ * (reference src/traits/sig_core.rs:120-146).  pop_verify is core_verify(pk, sig, pk_bytes, POP_DST)
+ * (src/traits/sig_pop.rs:67-70); the sharded verify_secure tail uses it with the scheme's DST. */
+int blsgpu_core_verify(int sig_group, const uint8_t* dst, size_t dst_len, const void* pks, const void* sigs,
+                       const uint8_t* msgs, const uint64_t* msg_offsets, size_t n, int fmt, int32_t* status);
+
 /* MultiSignature::<C>::verify(MultiPublicKey::from_public_keys(pks), msg)     src/multi_signature.rs:127-135,
  * src/multi_public_key.rs:79-83 -> BlsMultiKey::from_public_keys (serial sum) src/traits/pk_multi.rs:7-13;
  * fused form BlsSignaturePop::multi_sig_verify                                src/traits/sig_pop.rs:42-49. */
@@ -130,6 +136,16 @@ int blsgpu_pairing_product_is_one(const void* g1s, const void* g2s, size_t n, in
 /* point codec: to_bytes / from_bytes [_with_mode]                             src/public_key.rs:58-74,146-171,
  * src/impls/legacy.rs:85-170.  group = 1 (G1, 48 B) or 2 (G2, 96 B).  status[i]: 0 or BAD_ENCODING/LEGACY_FORMAT. */
 int blsgpu_serialize(int group, const void* pts, size_t n, int fmt_in, int fmt_out, void* out, int32_t* status);
+
+/* Sharded aggregate verify (one process per GPU): the shard-local part of core_aggregate_verify
+ * (src/traits/sig_core.rs:149-178).  out_f12 (576 B) = product of the Miller values of the shard's (H(m_i), pk_i) pairs
+ * [times (sig, -g) when sig != NULL], before the final exponentiation; *first_bad = local index of the first identity
+ * key, n when the signature is the identity, -1 otherwise.  Ranks exchange the records (all-gather) and finish with
+ * blsgpu_fp12_product_is_one.  Duplicate-message detection (Basic, src/traits/sig_basic.rs:46-58) is global and stays
+ * with the caller. */
+int blsgpu_aggregate_partial(int sig_group, int scheme, const void* pks, const uint8_t* msgs, const uint64_t* msg_offsets,
+                             size_t n, const void* sig, int fmt, void* out_f12, int64_t* first_bad);
+int blsgpu_fp12_product_is_one(const void* f12s, size_t k, int32_t* is_one);
 
 /* Measurement hooks (not part of the reference interface): when enabled, every kernel launch of the library is
  * bracketed by HIP events on the library's own stream; blsgpu_profile_get returns the accumulated device time and

@@ -1,0 +1,76 @@
+"""Worker for the world_size-2 tests of agora-blsful_amd/dist.py (spawned by tests/test_dist.py).
+argv: rank world port backend('fake'|'hip') outfile"""
+import json
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def main():
+    rank, world, port, backend, outfile = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import util
+    from util import c, ref
+    import __graft_entry__ as ge
+    pkg = ge.import_pkg()
+    from agora_blsful_amd import dist as bd
+    if backend == 'fake':
+        import fake_backend as be
+    else:
+        be = pkg.api
+        be.init()
+    sh = bd.Sharded(be, dist)
+    res = {}
+    rng = random.Random(77)                      # same data on every rank; each rank uses its shard
+    for C, sg in ((ref.G1Impl, 1), (ref.G2Impl, 2)):
+        pkraw, sigraw = (util.g2_raw, util.g1_raw) if sg == 1 else (util.g1_raw, util.g2_raw)
+        n = 7
+        sks = [ref.keygen_from_hash(bytes([i, sg]) * 16) for i in range(n)]
+        pks = [ref.public_key(C, s) for s in sks]
+        lo, hi = bd.shard_range(n, rank, world)
+        # config 2
+        msgs = [b'item %d' % i for i in range(n)]
+        sigs = [ref.sign(C, ref.POP, s, m) for s, m in zip(sks, msgs)]
+        msgs_t = list(msgs)
+        msgs_t[5] = b'tampered'
+        praw, sraw = [pkraw(p, rng) for p in pks], [sigraw(s, rng) for s in sigs]
+        res['verify_batch_%d' % sg] = sh.verify_batch(sg, ref.POP, praw[lo:hi], sraw[lo:hi], msgs_t[lo:hi])
+        # config 3
+        m1 = b'one message'
+        msig = ref.aggregate_signatures(C, [ref.sign(C, ref.POP, s, m1) for s in sks])
+        res['multi_ok_%d' % sg] = sh.multi_verify(sg, ref.POP, praw[lo:hi], sigraw(msig, rng), m1)
+        res['multi_bad_%d' % sg] = sh.multi_verify(sg, ref.POP, praw[lo:hi], sigraw(msig, rng), b'other')
+        # config 4
+        for scheme in (ref.BASIC, ref.AUG):
+            asig = ref.aggregate_signatures(C, [ref.sign(C, scheme, s, m) for s, m in zip(sks, msgs)])
+            res['agg_ok_%d_%d' % (sg, scheme)] = sh.aggregate_verify(sg, scheme, praw[lo:hi], msgs[lo:hi], sigraw(asig, rng), lo)
+            res['agg_bad_%d_%d' % (sg, scheme)] = sh.aggregate_verify(sg, scheme, praw[lo:hi], msgs_t[lo:hi], sigraw(asig, rng), lo)
+            dup = list(msgs)
+            dup[6] = dup[1]                        # duplicate across the shard boundary
+            res['agg_dup_%d_%d' % (sg, scheme)] = sh.aggregate_verify(sg, scheme, praw[lo:hi], dup[lo:hi], sigraw(asig, rng), lo)
+            pid = list(praw)
+            pid[4] = pkraw(None)
+            pid[5] = pkraw(None)
+            res['agg_pkid_%d_%d' % (sg, scheme)] = sh.aggregate_verify(sg, scheme, pid[lo:hi], msgs[lo:hi], sigraw(asig, rng), lo)
+            res['agg_sigid_%d_%d' % (sg, scheme)] = sh.aggregate_verify(sg, scheme, pid[lo:hi], msgs[lo:hi], sigraw(None), lo)
+        # config 5
+        modes = [0] if sg == 1 else [0, 1]
+        for mode in modes:
+            ssigs = [C.sig_curve.mul(C.hash_to_point(m1, C.DST[ref.AUG]), s) for s in sks]
+            agg = ref.aggregate_secure(C, pks, ssigs, None if sg == 1 else mode)
+            res['secure_ok_%d_%d' % (sg, mode)] = sh.verify_secure(sg, ref.AUG, praw[lo:hi], sigraw(agg, rng), m1, lo, mode)
+            res['secure_sub_%d_%d' % (sg, mode)] = sh.verify_secure(sg, ref.AUG, praw[lo:hi][:-1] if rank == world - 1 else praw[lo:hi],
+                                                                    sigraw(agg, rng), m1, lo, mode)
+        res['secure_empty_%d' % sg] = [sh.verify_secure(sg, ref.BASIC, [], sigraw(None), m1, 0), sh.verify_secure(sg, ref.BASIC, [], sigraw(msig, rng), m1, 0)]
+    json.dump(res, open(outfile, 'w'))
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

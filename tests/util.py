@@ -100,3 +100,18 @@ def load_c_oracle():
     lib.bo_verify_secure.argtypes = [ci, ci, cp, sz, cp, cp, sz, ci]
     lib.bo_init()
     return lib
+
+
+_TOWER_TO_W = [0, 2, 4, 1, 3, 5]      # record slot (c0.a0, c0.a1, c0.a2, c1.a0, c1.a1, c1.a2) -> power of w
+
+
+def f12_record(f):
+    """oracle Fp12 (w-power order) -> the 576-byte record of the C ABI (tower order, Montgomery limbs)."""
+    return b''.join(fp2_raw(f[_TOWER_TO_W[k]]) for k in range(6))
+
+
+def f12_from_record(b):
+    out = [None] * 6
+    for k in range(6):
+        out[_TOWER_TO_W[k]] = (fp_from_raw(b[96 * k:96 * k + 48]), fp_from_raw(b[96 * k + 48:96 * k + 96]))
+    return tuple(out)
