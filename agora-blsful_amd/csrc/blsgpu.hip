@@ -887,7 +887,7 @@ int blsgpu_aggregate_partial(int sig_group, int scheme, const void* pks, const u
     return 0;
   }
   if ((rc = run_f12_fold(c, d_f, mm, m))) return rc;
-  KL(KID_F12_IO, k_f12_export, dim3(1), dim3(192), d_f, m, d_out);
+  KL(KID_F12_IO, k_f12_export, dim3(1), dim3(BLS_BLOCK), d_f, m, d_out);
   HIPCK(hipGetLastError());
   if ((rc = copy_out(c, out_f12, d_out, 576))) return rc;
   SYNC_FLUSH(c);

@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_f12_fold(size_t m, size_t half, u
 }
 
 // final exponentiation of item 0 of a workspace -> *verdict (BLS_OK / BLS_ERR_INVALID_SIGNATURE)
-__global__ void k_finalexp_one(const uint32_t* fws, size_t stride, int32_t* verdict) {
+__global__ void __launch_bounds__(BLS_BLOCK) k_finalexp_one(const uint32_t* fws, size_t stride, int32_t* verdict) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   fp12 f;
   ws_ld_fp12(f, fws, stride, 0);
@@ -360,9 +360,9 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_f12_import(size_t n, const uint8_
   const uint32_t* w = (const uint32_t*)(src + i * 576);
   for (int k = 0; k < 144; k++) fws[(size_t)k * stride + i] = w[k];
 }
-__global__ void k_f12_export(const uint32_t* fws, size_t stride, uint8_t* dst) {
-  if (blockIdx.x != 0 || threadIdx.x >= 144) return;
-  ((uint32_t*)dst)[threadIdx.x] = fws[(size_t)threadIdx.x * stride];
+__global__ void __launch_bounds__(BLS_BLOCK) k_f12_export(const uint32_t* fws, size_t stride, uint8_t* dst) {
+  if (blockIdx.x != 0) return;
+  for (int k = threadIdx.x; k < 144; k += BLS_BLOCK) ((uint32_t*)dst)[k] = fws[(size_t)k * stride];
 }
 #endif  // BLS_TU_FINALEXP
 
