@@ -2,6 +2,7 @@
 // There is no CPU compute path in this library: without a gfx950 device every entry point fails loudly.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <mutex>
@@ -188,6 +189,16 @@ void prof_flush(Ctx* c) {
     prof_flush(c);                             \
   } while (0)
 
+// BLSGPU_SPLIT=0 selects the one-lane-per-item Miller / final-exponentiation kernels (A/B switch); default: lane-split
+bool split_mode() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("BLSGPU_SPLIT");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v != 0;
+}
+
 unsigned blocks_for(size_t n) { return (unsigned)((n + BLS_BLOCK - 1) / BLS_BLOCK); }
 
 // ---- shared device pipelines (stream-ordered; caller holds the context mutex) ------------------------
@@ -202,8 +213,13 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
     KL(KID_PREPARE, k_prepare<1>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status);
   else
     KL(KID_PREPARE, k_prepare<2>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status);
-  KL(KID_MILLER2, k_miller2, dim3(nb), dim3(BLS_BLOCK), n, d_pairs, d_status, d_f);
-  KL(KID_FINALEXP, k_finalexp, dim3(nb), dim3(BLS_BLOCK), n, d_f, d_status);
+  if (split_mode()) {  // two lanes per item
+    KL(KID_MILLER2, k_miller2s, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_pairs, d_status, d_f);
+    KL(KID_FINALEXP, k_finalexps, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_f, d_status);
+  } else {
+    KL(KID_MILLER2, k_miller2, dim3(nb), dim3(BLS_BLOCK), n, d_pairs, d_status, d_f);
+    KL(KID_FINALEXP, k_finalexp, dim3(nb), dim3(BLS_BLOCK), n, d_f, d_status);
+  }
   HIPCK(hipGetLastError());
   return 0;
 }

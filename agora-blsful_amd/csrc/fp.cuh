@@ -189,6 +189,37 @@ BLS_FN void fp_mul(fp& r, const fp& a, const fp& b) {
 #pragma unroll
   for (int i = 0; i < 12; i++) r.l[i] = t.l[i];
 }
+// REDC(a*b + c*d) in one pass (lazy reduction for the lane-split Fp2 product).  48 operand dwords: the first 32
+// travel in VGPRs, the last 16 through the stack (AMDGPU calling convention).
+typedef uint32_t u32x12 __attribute__((ext_vector_type(12)));
+__device__ __noinline__ u32x12 fp_dotp2_leaf(u32x12 a, u32x12 b, u32x12 c, u32x12 d) {
+  fp x, y, z, w, r;
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    x.l[i] = a[i];
+    y.l[i] = b[i];
+    z.l[i] = c[i];
+    w.l[i] = d[i];
+  }
+  fp_dotp2_asm(r, x, y, z, w);
+  u32x12 o;
+#pragma unroll
+  for (int i = 0; i < 12; i++) o[i] = r.l[i];
+  return o;
+}
+BLS_FN void fp_dotp2(fp& r, const fp& a, const fp& b, const fp& c, const fp& d) {
+  u32x12 x, y, z, w;
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    x[i] = a.l[i];
+    y[i] = b.l[i];
+    z[i] = c.l[i];
+    w[i] = d.l[i];
+  }
+  u32x12 o = fp_dotp2_leaf(x, y, z, w);
+#pragma unroll
+  for (int i = 0; i < 12; i++) r.l[i] = o[i];
+}
 #else
 #if defined(BLS_COUNT_FPMUL)
 extern "C" { uint64_t g_fpmul_count = 0; }   // tools/count_fpmul.py: host-side instruction-mix census

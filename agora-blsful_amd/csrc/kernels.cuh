@@ -122,6 +122,8 @@ __global__ void k_prepare(size_t n, const uint8_t* pks, const uint8_t* sigs, int
                           const uint64_t* offs, int single_msg, dst_arg dst, uint32_t* pairs, int32_t* status);
 __global__ void k_miller2(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws);
 __global__ void k_finalexp(size_t n, const uint32_t* fws, int32_t* status);
+__global__ void k_miller2s(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws);
+__global__ void k_finalexps(size_t n, const uint32_t* fws, int32_t* status);
 template <int SG>
 __global__ void k_prepare_agg(size_t n, const uint8_t* pks, const uint8_t* sig, int fmt, int aug, const uint8_t* msgs,
                               const uint64_t* offs, dst_arg dst, uint32_t* pairs, int32_t* bad);
@@ -531,3 +533,66 @@ template __global__ void k_sign<1>(size_t, const uint8_t*, int, const uint8_t*, 
 template __global__ void k_sign<2>(size_t, const uint8_t*, int, const uint8_t*, const uint64_t*, dst_arg, uint8_t*, uint8_t*);
 #endif
 #endif  // BLS_TU_SIGN*
+
+#if defined(BLS_TU_MILLERS) || defined(BLS_TU_FINALEXPS)
+// =====================================================================================================
+// lane-split variants (tower_split.cuh): two adjacent lanes per item, 64-thread workgroups = 32 items
+#include "tower_split.cuh"
+__device__ __forceinline__ void ws_ld_hfp2(hfp2& r, const uint32_t* ws, size_t stride, size_t i, int w0) {
+  ws_ld_fp(r.v, ws, stride, i, w0 + (lane_hi() ? 12 : 0));
+}
+__device__ __forceinline__ void ws_st_hfp2(uint32_t* ws, size_t stride, size_t i, int w0, const hfp2& a) {
+  ws_st_fp(ws, stride, i, w0 + (lane_hi() ? 12 : 0), a.v);
+}
+__device__ __forceinline__ void ws_ld_hfp12(fp12_t<hfp2>& f, const uint32_t* ws, size_t stride, size_t i) {
+  ws_ld_hfp2(f.c0.a0, ws, stride, i, 0);
+  ws_ld_hfp2(f.c0.a1, ws, stride, i, 24);
+  ws_ld_hfp2(f.c0.a2, ws, stride, i, 48);
+  ws_ld_hfp2(f.c1.a0, ws, stride, i, 72);
+  ws_ld_hfp2(f.c1.a1, ws, stride, i, 96);
+  ws_ld_hfp2(f.c1.a2, ws, stride, i, 120);
+}
+__device__ __forceinline__ void ws_st_hfp12(uint32_t* ws, size_t stride, size_t i, const fp12_t<hfp2>& f) {
+  ws_st_hfp2(ws, stride, i, 0, f.c0.a0);
+  ws_st_hfp2(ws, stride, i, 24, f.c0.a1);
+  ws_st_hfp2(ws, stride, i, 48, f.c0.a2);
+  ws_st_hfp2(ws, stride, i, 72, f.c1.a0);
+  ws_st_hfp2(ws, stride, i, 96, f.c1.a1);
+  ws_st_hfp2(ws, stride, i, 120, f.c1.a2);
+}
+#endif
+
+#if defined(BLS_TU_MILLERS)
+__global__ void __launch_bounds__(BLS_BLOCK, 2) k_miller2s(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  if (i >= n) return;
+  if (status[i] != BLS_OK) return;
+  g1_aff P[2];
+  aff<hfp2> Q[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int w0 = k * 72;
+    ws_ld_fp(P[k].x, pairs, n, i, w0);
+    ws_ld_fp(P[k].y, pairs, n, i, w0 + 12);
+    ws_ld_hfp2(Q[k].x, pairs, n, i, w0 + 24);
+    ws_ld_hfp2(Q[k].y, pairs, n, i, w0 + 48);
+    P[k].inf = false;
+    Q[k].inf = false;
+  }
+  fp12_t<hfp2> f;
+  miller_loop<2>(f, P, Q);
+  ws_st_hfp12(fws, n, i, f);
+}
+#endif
+
+#if defined(BLS_TU_FINALEXPS)
+__global__ void __launch_bounds__(BLS_BLOCK, 2) k_finalexps(size_t n, const uint32_t* fws, int32_t* status) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  if (i >= n) return;
+  if (status[i] != BLS_OK) return;
+  fp12_t<hfp2> f;
+  ws_ld_hfp12(f, fws, n, i);
+  int st = pairing_verdict(f);
+  if (!lane_hi()) status[i] = st;
+}
+#endif

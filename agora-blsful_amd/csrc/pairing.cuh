@@ -8,12 +8,15 @@
 #include "curve.cuh"
 
 // homogeneous projective point on the twist, used only inside the Miller loop
-struct g2_hom {
-  fp2 x, y, z;
+template <class F2>
+struct g2_hom_t {
+  F2 x, y, z;
 };
+typedef g2_hom_t<fp2> g2_hom;
 
-BLS_FN void fp2_mul_3b(fp2& r, const fp2& a) {  // a * 3b' = a * 12 (1 + u)
-  fp2 t, t2;
+template <class F2>
+BLS_FN void fp2_mul_3b(F2& r, const F2& a) {  // a * 3b' = a * 12 (1 + u)
+  F2 t, t2;
   fp2_mul_xi(t, a);
   fp2_dbl(t2, t);   // 2
   fp2_add(t, t2, t);  // 3
@@ -23,8 +26,9 @@ BLS_FN void fp2_mul_3b(fp2& r, const fp2& a) {  // a * 3b' = a * 12 (1 + u)
 
 // T <- 2T and the tangent line at T evaluated at P = (xp, yp):
 //   l0 = Y^2 - 3b'Z^2,  l2 = -3X^2 xp,  l3 = 2YZ yp     (coefficients of w^0, w^2, w^3)
-BLS_NOINLINE void miller_dbl_step(g2_hom& t, fp2& l0, fp2& l2, fp2& l3, const fp& xp, const fp& yp) {
-  fp2 a, b, c, e, f, h, g, s;
+template <class F2>
+BLS_NOINLINE void miller_dbl_step(g2_hom_t<F2>& t, F2& l0, F2& l2, F2& l3, const fp& xp, const fp& yp) {
+  F2 a, b, c, e, f, h, g, s;
   fp2_mul(a, t.x, t.y);  // XY
   fp2_sqr(b, t.y);       // B = Y^2
   fp2_sqr(c, t.z);       // C = Z^2
@@ -62,9 +66,10 @@ BLS_NOINLINE void miller_dbl_step(g2_hom& t, fp2& l0, fp2& l2, fp2& l3, const fp
 
 // T <- T + Q and the chord line through T and Q evaluated at P:
 //   l0 = theta xq - lambda yq,  l2 = -theta xp,  l3 = lambda yp
-BLS_NOINLINE void miller_add_step(g2_hom& t, fp2& l0, fp2& l2, fp2& l3, const fp2& xq, const fp2& yq, const fp& xp,
-                            const fp& yp) {
-  fp2 th, la, c, d, e, f, g, h, s;
+template <class F2>
+BLS_NOINLINE void miller_add_step(g2_hom_t<F2>& t, F2& l0, F2& l2, F2& l3, const F2& xq, const F2& yq, const fp& xp,
+                                  const fp& yp) {
+  F2 th, la, c, d, e, f, g, h, s;
   fp2_mul(th, yq, t.z);
   fp2_sub(th, t.y, th);  // theta = Y - yq Z
   fp2_mul(la, xq, t.z);
@@ -92,9 +97,9 @@ BLS_NOINLINE void miller_add_step(g2_hom& t, fp2& l0, fp2& l2, fp2& l3, const fp
 }
 
 // f <- conj( prod_i f_{|x|,Q_i}(P_i) ).  Pairs with a point at infinity contribute 1.
-template <int N>
-BLS_FN void miller_loop(fp12& f, const g1_aff* P, const g2_aff* Q) {
-  g2_hom T[N];
+template <int N, class F2>
+BLS_FN void miller_loop(fp12_t<F2>& f, const g1_aff* P, const aff<F2>* Q) {
+  g2_hom_t<F2> T[N];
   bool skip[N];
 #pragma unroll
   for (int k = 0; k < N; k++) {
@@ -104,7 +109,7 @@ BLS_FN void miller_loop(fp12& f, const g1_aff* P, const g2_aff* Q) {
     fp2_one(T[k].z);
   }
   fp12_one(f);
-  fp2 l0, l2, l3;
+  F2 l0, l2, l3;
   for (int i = 62; i >= 0; i--) {
     if (i != 62) fp12_sqr(f, f);
 #pragma unroll
@@ -128,8 +133,9 @@ BLS_FN void miller_loop(fp12& f, const g1_aff* P, const g2_aff* Q) {
 }
 
 // a^x for a in the cyclotomic subgroup (x < 0: conjugate of a^|x|)
-BLS_NOINLINE void fp12_pow_x(fp12& r, const fp12& a) {
-  fp12 acc = a;
+template <class F2>
+BLS_NOINLINE void fp12_pow_x(fp12_t<F2>& r, const fp12_t<F2>& a) {
+  fp12_t<F2> acc = a;
   for (int i = 62; i >= 0; i--) {
     fp12_cyclotomic_sqr(acc, acc);
     if ((BLS_X_ABS >> i) & 1) fp12_mul(acc, acc, a);
@@ -138,8 +144,9 @@ BLS_NOINLINE void fp12_pow_x(fp12& r, const fp12& a) {
 }
 
 // f^(3 (p^12 - 1)/r), using 3 (p^4 - p^2 + 1)/r = (x-1)^2 (x+p) (x^2+p^2-1) + 3
-BLS_FN void final_exponentiation(fp12& r, const fp12& fin) {
-  fp12 f, t, u, v;
+template <class F2>
+BLS_FN void final_exponentiation(fp12_t<F2>& r, const fp12_t<F2>& fin) {
+  fp12_t<F2> f, t, u, v;
   // easy part: f^((p^6 - 1)(p^2 + 1))
   fp12_inv(t, fin);
   fp12_conj(f, fin);

@@ -74,6 +74,12 @@ BLS_FN void fp2_sqr(fp2& r, const fp2& a) {
   fp_mul(r.c0, s, d);
   fp_dbl(r.c1, m);
 }
+// a * k for a constant k stored as 24 Montgomery words
+BLS_FN void fp2_mul_const(fp2& r, const fp2& a, const uint32_t* k) {
+  fp2 g;
+  fp2_load(g, k);
+  fp2_mul(r, a, g);
+}
 BLS_FN void fp2_mul_fp(fp2& r, const fp2& a, const fp& k) {
   fp_mul(r.c0, a.c0, k);
   fp_mul(r.c1, a.c1, k);
@@ -157,45 +163,53 @@ BLS_FN bool fp2_lex_largest(const fp2& a) {
 }
 
 // ------------------------------------------------------------------ Fp6
-struct fp6 {
-  fp2 a0, a1, a2;
+template <class F2>
+struct fp6_t {
+  F2 a0, a1, a2;
 };
+typedef fp6_t<fp2> fp6;
 
-BLS_FN void fp6_zero(fp6& r) {
+template <class F2>
+BLS_FN void fp6_zero(fp6_t<F2>& r) {
   fp2_zero(r.a0);
   fp2_zero(r.a1);
   fp2_zero(r.a2);
 }
-BLS_FN void fp6_add(fp6& r, const fp6& a, const fp6& b) {
+template <class F2>
+BLS_FN void fp6_add(fp6_t<F2>& r, const fp6_t<F2>& a, const fp6_t<F2>& b) {
   fp2_add(r.a0, a.a0, b.a0);
   fp2_add(r.a1, a.a1, b.a1);
   fp2_add(r.a2, a.a2, b.a2);
 }
-BLS_FN void fp6_sub(fp6& r, const fp6& a, const fp6& b) {
+template <class F2>
+BLS_FN void fp6_sub(fp6_t<F2>& r, const fp6_t<F2>& a, const fp6_t<F2>& b) {
   fp2_sub(r.a0, a.a0, b.a0);
   fp2_sub(r.a1, a.a1, b.a1);
   fp2_sub(r.a2, a.a2, b.a2);
 }
-BLS_FN void fp6_neg(fp6& r, const fp6& a) {
+template <class F2>
+BLS_FN void fp6_neg(fp6_t<F2>& r, const fp6_t<F2>& a) {
   fp2_neg(r.a0, a.a0);
   fp2_neg(r.a1, a.a1);
   fp2_neg(r.a2, a.a2);
 }
 // multiply by v: (a0, a1, a2) -> (xi a2, a0, a1)
-BLS_FN void fp6_mul_v(fp6& r, const fp6& a) {
-  fp2 t;
+template <class F2>
+BLS_FN void fp6_mul_v(fp6_t<F2>& r, const fp6_t<F2>& a) {
+  F2 t;
   fp2_mul_xi(t, a.a2);
   r.a2 = a.a1;
   r.a1 = a.a0;
   r.a0 = t;
 }
 // Karatsuba: 6 Fp2 multiplications
-BLS_FN void fp6_mul(fp6& r, const fp6& a, const fp6& b) {
-  fp2 v0, v1, v2, s, t, m;
+template <class F2>
+BLS_FN void fp6_mul(fp6_t<F2>& r, const fp6_t<F2>& a, const fp6_t<F2>& b) {
+  F2 v0, v1, v2, s, t, m;
   fp2_mul(v0, a.a0, b.a0);
   fp2_mul(v1, a.a1, b.a1);
   fp2_mul(v2, a.a2, b.a2);
-  fp6 o;
+  fp6_t<F2> o;
   // c0 = v0 + xi((a1+a2)(b1+b2) - v1 - v2)
   fp2_add(s, a.a1, a.a2);
   fp2_add(t, b.a1, b.a2);
@@ -221,8 +235,9 @@ BLS_FN void fp6_mul(fp6& r, const fp6& a, const fp6& b) {
   fp2_add(o.a2, m, v1);
   r = o;
 }
-BLS_FN void fp6_inv(fp6& r, const fp6& a) {
-  fp2 t0, t1, t2, m, d;
+template <class F2>
+BLS_FN void fp6_inv(fp6_t<F2>& r, const fp6_t<F2>& a) {
+  F2 t0, t1, t2, m, d;
   fp2_sqr(t0, a.a0);
   fp2_mul(m, a.a1, a.a2);
   fp2_mul_xi(m, m);
@@ -235,7 +250,7 @@ BLS_FN void fp6_inv(fp6& r, const fp6& a) {
   fp2_mul(m, a.a0, a.a2);
   fp2_sub(t2, t2, m);  // a1^2 - a0 a2
   fp2_mul(d, a.a0, t0);
-  fp2 e;
+  F2 e;
   fp2_mul(m, a.a2, t1);
   fp2_mul(e, a.a1, t2);
   fp2_add(m, m, e);
@@ -248,28 +263,34 @@ BLS_FN void fp6_inv(fp6& r, const fp6& a) {
 }
 
 // ------------------------------------------------------------------ Fp12
-struct fp12 {
-  fp6 c0, c1;
+template <class F2>
+struct fp12_t {
+  fp6_t<F2> c0, c1;
 };
+typedef fp12_t<fp2> fp12;
 
-BLS_FN void fp12_one(fp12& r) {
+template <class F2>
+BLS_FN void fp12_one(fp12_t<F2>& r) {
   fp6_zero(r.c0);
   fp6_zero(r.c1);
   fp2_one(r.c0.a0);
 }
-BLS_FN bool fp12_is_one(const fp12& a) {
-  fp2 one;
+template <class F2>
+BLS_FN bool fp12_is_one(const fp12_t<F2>& a) {
+  F2 one;
   fp2_one(one);
   return fp2_eq(a.c0.a0, one) && fp2_is_zero(a.c0.a1) && fp2_is_zero(a.c0.a2) && fp2_is_zero(a.c1.a0) &&
          fp2_is_zero(a.c1.a1) && fp2_is_zero(a.c1.a2);
 }
-BLS_FN void fp12_conj(fp12& r, const fp12& a) {
+template <class F2>
+BLS_FN void fp12_conj(fp12_t<F2>& r, const fp12_t<F2>& a) {
   r.c0 = a.c0;
   fp6_neg(r.c1, a.c1);
 }
 // Karatsuba over Fp6: 18 Fp2 multiplications
-BLS_NOINLINE void fp12_mul(fp12& r, const fp12& a, const fp12& b) {
-  fp6 t0, t1, s, t, m;
+template <class F2>
+BLS_NOINLINE void fp12_mul(fp12_t<F2>& r, const fp12_t<F2>& a, const fp12_t<F2>& b) {
+  fp6_t<F2> t0, t1, s, t, m;
   fp6_mul(t0, a.c0, b.c0);
   fp6_mul(t1, a.c1, b.c1);
   fp6_add(s, a.c0, a.c1);
@@ -281,8 +302,9 @@ BLS_NOINLINE void fp12_mul(fp12& r, const fp12& a, const fp12& b) {
   fp6_add(r.c0, t0, t1);
 }
 // complex squaring: 12 Fp2 multiplications
-BLS_NOINLINE void fp12_sqr(fp12& r, const fp12& a) {
-  fp6 t, s0, s1, m;
+template <class F2>
+BLS_NOINLINE void fp12_sqr(fp12_t<F2>& r, const fp12_t<F2>& a) {
+  fp6_t<F2> t, s0, s1, m;
   fp6_mul(t, a.c0, a.c1);
   fp6_add(s0, a.c0, a.c1);
   fp6_mul_v(s1, a.c1);
@@ -293,8 +315,9 @@ BLS_NOINLINE void fp12_sqr(fp12& r, const fp12& a) {
   fp6_sub(r.c0, m, s0);
   fp6_add(r.c1, t, t);
 }
-BLS_NOINLINE void fp12_inv(fp12& r, const fp12& a) {
-  fp6 t0, t1;
+template <class F2>
+BLS_NOINLINE void fp12_inv(fp12_t<F2>& r, const fp12_t<F2>& a) {
+  fp6_t<F2> t0, t1;
   fp6_mul(t0, a.c0, a.c0);
   fp6_mul(t1, a.c1, a.c1);
   fp6_mul_v(t1, t1);
@@ -305,17 +328,16 @@ BLS_NOINLINE void fp12_inv(fp12& r, const fp12& a) {
   fp6_neg(r.c1, t1);
 }
 // a^(p^J), J = 1 or 2:  coefficient of w^k -> conj^J(c_k) * FROBJ[k]
-template <int J>
-BLS_FN void fp12_frob(fp12& r, const fp12& a) {
+template <int J, class F2>
+BLS_FN void fp12_frob(fp12_t<F2>& r, const fp12_t<F2>& a) {
   const uint32_t(*tab)[24] = (J == 1) ? FROB1 : FROB2;
-  fp2 g, c;
+  F2 c;
 #define FROB_ONE(dst, src, k)        \
   if (J == 1) fp2_conj(c, src);      \
   else c = src;                      \
   if (k == 0) dst = c;               \
   else {                             \
-    fp2_load(g, tab[k]);             \
-    fp2_mul(dst, c, g);              \
+    fp2_mul_const(dst, c, tab[k]);   \
   }
   FROB_ONE(r.c0.a0, a.c0.a0, 0)
   FROB_ONE(r.c1.a0, a.c1.a0, 1)
@@ -327,8 +349,9 @@ BLS_FN void fp12_frob(fp12& r, const fp12& a) {
 }
 
 // Granger-Scott squaring, valid in the cyclotomic subgroup (after the easy part of the final exponentiation)
-BLS_FN void fp4_sqr(fp2& c0, fp2& c1, const fp2& a, const fp2& b) {
-  fp2 t0, t1, t2;
+template <class F2>
+BLS_FN void fp4_sqr(F2& c0, F2& c1, const F2& a, const F2& b) {
+  F2 t0, t1, t2;
   fp2_sqr(t0, a);
   fp2_sqr(t1, b);
   fp2_mul_xi(t2, t1);
@@ -338,9 +361,10 @@ BLS_FN void fp4_sqr(fp2& c0, fp2& c1, const fp2& a, const fp2& b) {
   fp2_sub(t2, t2, t0);
   fp2_sub(c1, t2, t1);
 }
-BLS_NOINLINE void fp12_cyclotomic_sqr(fp12& r, const fp12& f) {
-  fp2 z0 = f.c0.a0, z4 = f.c0.a1, z3 = f.c0.a2, z2 = f.c1.a0, z1 = f.c1.a1, z5 = f.c1.a2;
-  fp2 t0, t1, t2, t3;
+template <class F2>
+BLS_NOINLINE void fp12_cyclotomic_sqr(fp12_t<F2>& r, const fp12_t<F2>& f) {
+  F2 z0 = f.c0.a0, z4 = f.c0.a1, z3 = f.c0.a2, z2 = f.c1.a0, z1 = f.c1.a1, z5 = f.c1.a2;
+  F2 t0, t1, t2, t3;
   fp4_sqr(t0, t1, z0, z1);
   fp2_sub(z0, t0, z0);
   fp2_dbl(z0, z0);
@@ -372,14 +396,15 @@ BLS_NOINLINE void fp12_cyclotomic_sqr(fp12& r, const fp12& f) {
 }
 
 // f * (l0 + l2 w^2 + l3 w^3): the sparse line value of the Miller loop.  13 Fp2 multiplications.
-BLS_NOINLINE void fp12_mul_by_line(fp12& f, const fp2& l0, const fp2& l2, const fp2& l3) {
+template <class F2>
+BLS_NOINLINE void fp12_mul_by_line(fp12_t<F2>& f, const F2& l0, const F2& l2, const F2& l3) {
   // L0 = (l0, l2, 0), L1 = (0, l3, 0) in Fp6
-  fp6 t0, t1, s, m;
-  fp2 x, y, z;
+  fp6_t<F2> t0, t1, s, m;
+  F2 x, y, z;
   // t0 = f.c0 * (l0 + l2 v): Karatsuba on the two non-zero coefficients, 5 mul
   {
-    const fp6& a = f.c0;
-    fp2 v0, v1;
+    const fp6_t<F2>& a = f.c0;
+    F2 v0, v1;
     fp2_mul(v0, a.a0, l0);
     fp2_mul(v1, a.a1, l2);
     fp2_mul(x, a.a2, l2);  // a2 l2 v^3 = xi a2 l2
@@ -395,7 +420,7 @@ BLS_NOINLINE void fp12_mul_by_line(fp12& f, const fp2& l0, const fp2& l2, const 
   }
   // t1 = f.c1 * (l3 v) = (xi a2 l3, a0 l3, a1 l3), 3 mul
   {
-    const fp6& a = f.c1;
+    const fp6_t<F2>& a = f.c1;
     fp2_mul(x, a.a2, l3);
     fp2_mul_xi(t1.a0, x);
     fp2_mul(t1.a1, a.a0, l3);
@@ -404,7 +429,7 @@ BLS_NOINLINE void fp12_mul_by_line(fp12& f, const fp2& l0, const fp2& l2, const 
   // m = (f.c0 + f.c1) * (l0 + (l2 + l3) v), 5 mul
   fp6_add(s, f.c0, f.c1);
   {
-    fp2 l23, v0, v1;
+    F2 l23, v0, v1;
     fp2_add(l23, l2, l3);
     fp2_mul(v0, s.a0, l0);
     fp2_mul(v1, s.a1, l23);

@@ -1,0 +1,105 @@
+// Lane-split Fp2: one Fp2 element per PAIR of adjacent lanes -- the even lane holds c0, the odd lane c1 -- so that one
+// item occupies two lanes.  Why: 65,536 items are exactly one wave per SIMD, and a lone wave issues one VALU instruction
+// per ~5 cycles while two waves per SIMD reach ~3.5 (profiles/ubench_r01.txt).  Splitting at Fp2 doubles the wave count,
+// halves the per-lane register state (an Fp12 is 72 dwords per lane) and balances perfectly:
+//     c0 = REDC(a0 b0 + (p - a1) b1)   on the even lane,      c1 = REDC(a0 b1 + a1 b0)   on the odd lane
+// i.e. ONE fused two-product Montgomery pass per lane (lazy reduction for free) instead of three full multiplications
+// in one lane.  Partner components travel by DPP quad_perm [1,0,3,2] (full-rate VALU moves, no LDS).
+// Everything above Fp2 (Fp6, Fp12, Miller steps, final exponentiation) is the same template code as the one-lane path.
+// Device only.
+#pragma once
+#include "pairing.cuh"
+
+struct hfp2 {
+  fp v;  // this lane's component
+};
+
+__device__ __forceinline__ bool lane_hi() { return (threadIdx.x & 1u) != 0; }
+__device__ __forceinline__ uint32_t dpp_swap(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ void fp_partner(fp& r, const fp& a) {
+#pragma unroll
+  for (int i = 0; i < 12; i++) r.l[i] = dpp_swap(a.l[i]);
+}
+__device__ __forceinline__ void fp_sel(fp& r, bool c, const fp& a, const fp& b) {  // r = c ? a : b
+#pragma unroll
+  for (int i = 0; i < 12; i++) r.l[i] = c ? a.l[i] : b.l[i];
+}
+
+__device__ __forceinline__ void fp2_zero(hfp2& r) { fp_zero(r.v); }
+__device__ __forceinline__ void fp2_one(hfp2& r) {
+  fp one, z;
+  fp_one(one);
+  fp_zero(z);
+  fp_sel(r.v, lane_hi(), z, one);
+}
+__device__ __forceinline__ void fp2_load(hfp2& r, const uint32_t* c) { fp_load(r.v, c + (lane_hi() ? 12 : 0)); }
+__device__ __forceinline__ bool fp2_is_zero(const hfp2& a) {
+  uint32_t z = fp_is_zero(a.v) ? 1u : 0u;
+  return (z & dpp_swap(z)) != 0;
+}
+__device__ __forceinline__ bool fp2_eq(const hfp2& a, const hfp2& b) {
+  uint32_t e = fp_eq(a.v, b.v) ? 1u : 0u;
+  return (e & dpp_swap(e)) != 0;
+}
+__device__ __forceinline__ void fp2_cmov(hfp2& r, const hfp2& a, bool c) { fp_cmov(r.v, a.v, c); }
+__device__ __forceinline__ void fp2_add(hfp2& r, const hfp2& a, const hfp2& b) { fp_add(r.v, a.v, b.v); }
+__device__ __forceinline__ void fp2_sub(hfp2& r, const hfp2& a, const hfp2& b) { fp_sub(r.v, a.v, b.v); }
+__device__ __forceinline__ void fp2_neg(hfp2& r, const hfp2& a) { fp_neg(r.v, a.v); }
+__device__ __forceinline__ void fp2_dbl(hfp2& r, const hfp2& a) { fp_dbl(r.v, a.v); }
+__device__ __forceinline__ void fp2_conj(hfp2& r, const hfp2& a) {
+  fp n;
+  fp_neg(n, a.v);
+  fp_sel(r.v, lane_hi(), n, a.v);
+}
+__device__ __forceinline__ void fp2_mul(hfp2& r, const hfp2& a, const hfp2& b) {
+  const bool hi = lane_hi();
+  fp pa, pb, npa, x0, x1;
+  fp_partner(pa, a.v);
+  fp_partner(pb, b.v);
+  fp_neg(npa, pa);
+  fp_sel(x0, hi, pa, a.v);    // a0 on both lanes
+  fp_sel(x1, hi, a.v, npa);   // even: -a1, odd: a1
+  fp_dotp2(r.v, x0, b.v, x1, pb);
+}
+__device__ __forceinline__ void fp2_sqr(hfp2& r, const hfp2& a) {
+  const bool hi = lane_hi();
+  fp pa, t, z, x, y;
+  fp_partner(pa, a.v);
+  fp_sel(t, hi, pa, a.v);
+  fp_add(x, t, pa);           // even: a0 + a1, odd: 2 a0
+  fp_zero(z);
+  fp_sel(t, hi, z, pa);
+  fp_sub(y, a.v, t);          // even: a0 - a1, odd: a1
+  fp_mul(r.v, x, y);
+}
+__device__ __forceinline__ void fp2_mul_fp(hfp2& r, const hfp2& a, const fp& k) { fp_mul(r.v, a.v, k); }
+__device__ __forceinline__ void fp2_mul_xi(hfp2& r, const hfp2& a) {
+  fp pa, d, s;
+  fp_partner(pa, a.v);
+  fp_sub(d, a.v, pa);         // even: a0 - a1
+  fp_add(s, a.v, pa);         // odd:  a1 + a0
+  fp_sel(r.v, lane_hi(), s, d);
+}
+__device__ __forceinline__ void fp2_mul_const(hfp2& r, const hfp2& a, const uint32_t* k) {
+  const bool hi = lane_hi();
+  fp k0, k1, pa, npa, x0, x1, y0, y1;
+  fp_load(k0, k);
+  fp_load(k1, k + 12);
+  fp_partner(pa, a.v);
+  fp_neg(npa, pa);
+  fp_sel(x0, hi, pa, a.v);
+  fp_sel(x1, hi, a.v, npa);
+  fp_sel(y0, hi, k1, k0);
+  fp_sel(y1, hi, k0, k1);
+  fp_dotp2(r.v, x0, y0, x1, y1);  // even: a0 k0 - a1 k1, odd: a0 k1 + a1 k0
+}
+__device__ __forceinline__ void fp2_inv(hfp2& r, const hfp2& a) {
+  fp sq, ps, n, t;
+  fp_sqr(sq, a.v);
+  fp_partner(ps, sq);
+  fp_add(n, sq, ps);
+  fp_inv(n, n);               // both lanes compute the same inverse of the norm
+  fp_mul(t, a.v, n);
+  fp_neg(n, t);
+  fp_sel(r.v, lane_hi(), n, t);
+}
