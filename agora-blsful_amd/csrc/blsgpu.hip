@@ -214,10 +214,10 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
   else
     KL(KID_PREPARE, k_prepare<2>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status);
   if (split_mode()) {  // two lanes per item
-    KL(KID_MILLER2, k_miller2s, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_pairs, d_status, d_f);
+    KL(KID_MILLER2, k_miller2s, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_pairs, d_status, d_f, sg == 1 ? 1 : 0);
     KL(KID_FINALEXP, k_finalexps, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_f, d_status);
   } else {
-    KL(KID_MILLER2, k_miller2, dim3(nb), dim3(BLS_BLOCK), n, d_pairs, d_status, d_f);
+    KL(KID_MILLER2, k_miller2, dim3(nb), dim3(BLS_BLOCK), n, d_pairs, d_status, d_f, sg == 1 ? 1 : 0);
     KL(KID_FINALEXP, k_finalexp, dim3(nb), dim3(BLS_BLOCK), n, d_f, d_status);
   }
   HIPCK(hipGetLastError());

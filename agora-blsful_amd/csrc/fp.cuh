@@ -189,34 +189,42 @@ BLS_FN void fp_mul(fp& r, const fp& a, const fp& b) {
 #pragma unroll
   for (int i = 0; i < 12; i++) r.l[i] = t.l[i];
 }
-// REDC(a*b + c*d) in one pass (lazy reduction for the lane-split Fp2 product).  48 operand dwords: the first 32
-// travel in VGPRs, the last 16 through the stack (AMDGPU calling convention).
+// ---- lane-split Fp2 product leaf (tower_split.cuh): each lane of an adjacent pair passes ITS component of a and b
+// (24 dwords in VGPRs, nothing on the stack); the leaf fetches the partner's components by DPP quad_perm [1,0,3,2] and
+// computes, in one fused two-product Montgomery pass (lazy reduction):
+//     even lane: REDC(a0 b0 + (p - a1) b1) = c0          odd lane: REDC(a0 b1 + a1 b0) = c1
 typedef uint32_t u32x12 __attribute__((ext_vector_type(12)));
-__device__ __noinline__ u32x12 fp_dotp2_leaf(u32x12 a, u32x12 b, u32x12 c, u32x12 d) {
-  fp x, y, z, w, r;
+__device__ __forceinline__ uint32_t dpp_swap(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true); }
+__device__ __noinline__ u32x12 fp2_mul_split_leaf(u32x12 av, u32x12 bv) {
+  const bool hi = (threadIdx.x & 1u) != 0;
+  fp a, b, pa, pb, npa, x0, x1, r;
 #pragma unroll
   for (int i = 0; i < 12; i++) {
-    x.l[i] = a[i];
-    y.l[i] = b[i];
-    z.l[i] = c[i];
-    w.l[i] = d[i];
+    a.l[i] = av[i];
+    b.l[i] = bv[i];
+    pa.l[i] = dpp_swap(av[i]);
+    pb.l[i] = dpp_swap(bv[i]);
   }
-  fp_dotp2_asm(r, x, y, z, w);
+  fp_neg(npa, pa);
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    x0.l[i] = hi ? pa.l[i] : a.l[i];    // a0 on both lanes
+    x1.l[i] = hi ? a.l[i] : npa.l[i];   // even: -a1, odd: a1
+  }
+  fp_dotp2_asm(r, x0, b, x1, pb);
   u32x12 o;
 #pragma unroll
   for (int i = 0; i < 12; i++) o[i] = r.l[i];
   return o;
 }
-BLS_FN void fp_dotp2(fp& r, const fp& a, const fp& b, const fp& c, const fp& d) {
-  u32x12 x, y, z, w;
+BLS_FN void fp2_mul_split(fp& r, const fp& a, const fp& b) {
+  u32x12 x, y;
 #pragma unroll
   for (int i = 0; i < 12; i++) {
     x[i] = a.l[i];
     y[i] = b.l[i];
-    z[i] = c.l[i];
-    w[i] = d.l[i];
   }
-  u32x12 o = fp_dotp2_leaf(x, y, z, w);
+  u32x12 o = fp2_mul_split_leaf(x, y);
 #pragma unroll
   for (int i = 0; i < 12; i++) r.l[i] = o[i];
 }

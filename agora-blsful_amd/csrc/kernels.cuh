@@ -120,9 +120,9 @@ __device__ __forceinline__ void store_g2_pt(uint8_t* base, size_t i, const g2_ja
 template <int SG>
 __global__ void k_prepare(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int aug, const uint8_t* msgs,
                           const uint64_t* offs, int single_msg, dst_arg dst, uint32_t* pairs, int32_t* status);
-__global__ void k_miller2(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws);
+__global__ void k_miller2(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws, int fixed_g2);
 __global__ void k_finalexp(size_t n, const uint32_t* fws, int32_t* status);
-__global__ void k_miller2s(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws);
+__global__ void k_miller2s(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws, int fixed_g2);
 __global__ void k_finalexps(size_t n, const uint32_t* fws, int32_t* status);
 template <int SG>
 __global__ void k_prepare_agg(size_t n, const uint8_t* pks, const uint8_t* sig, int fmt, int aug, const uint8_t* msgs,
@@ -190,7 +190,8 @@ template __global__ void k_prepare<2>(size_t, const uint8_t*, const uint8_t*, in
 
 #if defined(BLS_TU_MILLER)
 // stage 2: two-pair Miller loop per item
-__global__ void __launch_bounds__(BLS_BLOCK) k_miller2(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws) {
+// fixed_g2 != 0: the second pair's G2 member is -g2 (Bls12381G1Impl) and its lines come from the precomputed table
+__global__ void __launch_bounds__(BLS_BLOCK) k_miller2(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws, int fixed_g2) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (status[i] != BLS_OK) return;
@@ -199,7 +200,8 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_miller2(size_t n, const uint32_t*
   ws_ld_pair(P[0], Q[0], pairs, n, i, 0);
   ws_ld_pair(P[1], Q[1], pairs, n, i, 1);
   fp12 f;
-  miller_loop<2>(f, P, Q);
+  if (fixed_g2) miller_loop_fixed_g2(f, P[0], Q[0], P[1]);
+  else miller_loop<2>(f, P, Q);
   ws_st_fp12(fws, n, i, f);
 }
 
@@ -563,7 +565,7 @@ __device__ __forceinline__ void ws_st_hfp12(uint32_t* ws, size_t stride, size_t 
 #endif
 
 #if defined(BLS_TU_MILLERS)
-__global__ void __launch_bounds__(BLS_BLOCK, 2) k_miller2s(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws) {
+__global__ void __launch_bounds__(BLS_BLOCK, 2) k_miller2s(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws, int fixed_g2) {
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
   if (i >= n) return;
   if (status[i] != BLS_OK) return;
@@ -580,7 +582,8 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_miller2s(size_t n, const uint3
     Q[k].inf = false;
   }
   fp12_t<hfp2> f;
-  miller_loop<2>(f, P, Q);
+  if (fixed_g2) miller_loop_fixed_g2(f, P[0], Q[0], P[1]);
+  else miller_loop<2>(f, P, Q);
   ws_st_hfp12(fws, n, i, f);
 }
 #endif

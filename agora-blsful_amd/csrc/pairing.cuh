@@ -6,6 +6,7 @@
 // cube of the canonical value (gcd(3, r) = 1: same verdict).
 #pragma once
 #include "curve.cuh"
+#include "g2neg_lines.cuh"
 
 // homogeneous projective point on the twist, used only inside the Miller loop
 template <class F2>
@@ -127,6 +128,44 @@ BLS_FN void miller_loop(fp12_t<F2>& f, const g1_aff* P, const aff<F2>* Q) {
           fp12_mul_by_line(f, l0, l2, l3);
         }
       }
+    }
+  }
+  fp12_conj(f, f);
+}
+
+// The same product for exactly two pairs whose SECOND G2 argument is the constant -g2 (core_verify of Bls12381G1Impl:
+// e(H(m), pk) e(sig, -g2), reference src/traits/sig_core.rs:136-138): that pair's point arithmetic is replaced by the
+// precomputed table G2NEG_LINES (tools/gen_g2_lines.py); only the two Fp2-by-Fp scalings by (xP, yP) remain.
+template <class F2>
+BLS_FN void miller_loop_fixed_g2(fp12_t<F2>& f, const g1_aff& P0, const aff<F2>& Q0, const g1_aff& P1) {
+  g2_hom_t<F2> T;
+  T.x = Q0.x;
+  T.y = Q0.y;
+  fp2_one(T.z);
+  fp12_one(f);
+  F2 l0, l2, l3, t;
+  int row = 0;
+  for (int i = 62; i >= 0; i--) {
+    if (i != 62) fp12_sqr(f, f);
+    miller_dbl_step(T, l0, l2, l3, P0.x, P0.y);
+    fp12_mul_by_line(f, l0, l2, l3);
+    fp2_load(l0, &G2NEG_LINES[row][0]);
+    fp2_load(t, &G2NEG_LINES[row][24]);
+    fp2_mul_fp(l2, t, P1.x);
+    fp2_load(t, &G2NEG_LINES[row][48]);
+    fp2_mul_fp(l3, t, P1.y);
+    fp12_mul_by_line(f, l0, l2, l3);
+    row++;
+    if ((BLS_X_ABS >> i) & 1) {
+      miller_add_step(T, l0, l2, l3, Q0.x, Q0.y, P0.x, P0.y);
+      fp12_mul_by_line(f, l0, l2, l3);
+      fp2_load(l0, &G2NEG_LINES[row][0]);
+      fp2_load(t, &G2NEG_LINES[row][24]);
+      fp2_mul_fp(l2, t, P1.x);
+      fp2_load(t, &G2NEG_LINES[row][48]);
+      fp2_mul_fp(l3, t, P1.y);
+      fp12_mul_by_line(f, l0, l2, l3);
+      row++;
     }
   }
   fp12_conj(f, f);

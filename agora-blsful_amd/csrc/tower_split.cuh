@@ -15,7 +15,6 @@ struct hfp2 {
 };
 
 __device__ __forceinline__ bool lane_hi() { return (threadIdx.x & 1u) != 0; }
-__device__ __forceinline__ uint32_t dpp_swap(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true); }
 __device__ __forceinline__ void fp_partner(fp& r, const fp& a) {
 #pragma unroll
   for (int i = 0; i < 12; i++) r.l[i] = dpp_swap(a.l[i]);
@@ -51,16 +50,7 @@ __device__ __forceinline__ void fp2_conj(hfp2& r, const hfp2& a) {
   fp_neg(n, a.v);
   fp_sel(r.v, lane_hi(), n, a.v);
 }
-__device__ __forceinline__ void fp2_mul(hfp2& r, const hfp2& a, const hfp2& b) {
-  const bool hi = lane_hi();
-  fp pa, pb, npa, x0, x1;
-  fp_partner(pa, a.v);
-  fp_partner(pb, b.v);
-  fp_neg(npa, pa);
-  fp_sel(x0, hi, pa, a.v);    // a0 on both lanes
-  fp_sel(x1, hi, a.v, npa);   // even: -a1, odd: a1
-  fp_dotp2(r.v, x0, b.v, x1, pb);
-}
+__device__ __forceinline__ void fp2_mul(hfp2& r, const hfp2& a, const hfp2& b) { fp2_mul_split(r.v, a.v, b.v); }
 __device__ __forceinline__ void fp2_sqr(hfp2& r, const hfp2& a) {
   const bool hi = lane_hi();
   fp pa, t, z, x, y;
@@ -81,17 +71,9 @@ __device__ __forceinline__ void fp2_mul_xi(hfp2& r, const hfp2& a) {
   fp_sel(r.v, lane_hi(), s, d);
 }
 __device__ __forceinline__ void fp2_mul_const(hfp2& r, const hfp2& a, const uint32_t* k) {
-  const bool hi = lane_hi();
-  fp k0, k1, pa, npa, x0, x1, y0, y1;
-  fp_load(k0, k);
-  fp_load(k1, k + 12);
-  fp_partner(pa, a.v);
-  fp_neg(npa, pa);
-  fp_sel(x0, hi, pa, a.v);
-  fp_sel(x1, hi, a.v, npa);
-  fp_sel(y0, hi, k1, k0);
-  fp_sel(y1, hi, k0, k1);
-  fp_dotp2(r.v, x0, y0, x1, y1);  // even: a0 k0 - a1 k1, odd: a0 k1 + a1 k0
+  hfp2 kk;
+  fp2_load(kk, k);              // this lane's component of the constant
+  fp2_mul_split(r.v, a.v, kk.v);
 }
 __device__ __forceinline__ void fp2_inv(hfp2& r, const hfp2& a) {
   fp sq, ps, n, t;

@@ -83,6 +83,20 @@ void hs_pairing(int n, const uint32_t* g1s, const uint32_t* g2s, uint32_t* out_p
   final_exponentiation(e, f);
   store_fp12_plain(out_plain, e);
 }
+// Miller loop with the precomputed -g2 line table vs the generic two-pair loop with Q1 = -g2: raw Miller values
+int hs_miller_fixed_g2_matches(const uint32_t* p0, const uint32_t* q0, const uint32_t* p1) {
+  g1_aff P[2]; g2_aff Q[2];
+  fp_load(P[0].x, p0); fp_load(P[0].y, p0 + 12); P[0].inf = false;
+  fp_load(P[1].x, p1); fp_load(P[1].y, p1 + 12); P[1].inf = false;
+  fp2_load(Q[0].x, q0); fp2_load(Q[0].y, q0 + 24); Q[0].inf = false;
+  g2_neg_gen(Q[1]);
+  fp12 a, b;
+  miller_loop<2>(a, P, Q);
+  miller_loop_fixed_g2(b, P[0], Q[0], P[1]);
+  uint32_t wa[144], wb[144];
+  store_fp12_plain(wa, a); store_fp12_plain(wb, b);
+  return memcmp(wa, wb, sizeof wa) == 0;
+}
 // cyclotomic squaring vs generic squaring on an element of the cyclotomic subgroup
 int hs_cyclotomic_check(int n, const uint32_t* g1s, const uint32_t* g2s) {
   g1_aff P[1]; g2_aff Q[1];
