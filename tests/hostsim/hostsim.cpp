@@ -125,7 +125,8 @@ int hs_verify(int sig_group, const uint32_t* pk, const uint32_t* sig, int aug, c
   }
   if (st != BLS_OK) return st;
   fp12 f;
-  miller_loop<2>(f, P, Q);
+  if (sig_group == 1) miller_loop_fixed_g2(f, P[0], Q[0], P[1]);   // as k_miller2 does for Bls12381G1Impl
+  else miller_loop<2>(f, P, Q);
   return pairing_verdict(f);
 }
 }
