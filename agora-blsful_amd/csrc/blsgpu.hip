@@ -183,6 +183,11 @@ void prof_flush(Ctx* c) {
     hipLaunchKernelGGL(kern, grid, block, 0, c->stream, __VA_ARGS__);           \
     prof_post(c);                                                               \
   } while (0)
+#define MILLER1_LAUNCH(cnt, ...)                                                                             \
+  do {                                                                                                     \
+    if (split_mode()) KL(KID_MILLER1, k_miller1s, dim3(blocks_for(2 * (cnt))), dim3(BLS_BLOCK), cnt, __VA_ARGS__); \
+    else KL(KID_MILLER1, k_miller1, dim3(blocks_for(cnt)), dim3(BLS_BLOCK), cnt, __VA_ARGS__);            \
+  } while (0)
 #define SYNC_FLUSH(c)                          \
   do {                                         \
     HIPCK(hipStreamSynchronize((c)->stream));  \
@@ -239,7 +244,8 @@ int run_f12_fold(Ctx* c, uint32_t* d_f, size_t m, size_t stride) {
 int run_f12_product_verdict(Ctx* c, uint32_t* d_f, size_t m, size_t stride, int32_t* d_verdict) {
   int rc = run_f12_fold(c, d_f, m, stride);
   if (rc) return rc;
-  KL(KID_FINALEXP_ONE, k_finalexp_one, dim3(1), dim3(64), d_f, stride, d_verdict);
+  if (split_mode()) KL(KID_FINALEXP_ONE, k_finalexp_ones, dim3(1), dim3(BLS_BLOCK), d_f, stride, d_verdict);
+  else KL(KID_FINALEXP_ONE, k_finalexp_one, dim3(1), dim3(BLS_BLOCK), d_f, stride, d_verdict);
   HIPCK(hipGetLastError());
   return 0;
 }
@@ -306,7 +312,17 @@ bool hash_to_scalar_le(const uint8_t hash[32], uint8_t out[32]) {
 int secure_coefficients_host(const uint8_t* kb, size_t n, size_t width, std::vector<uint32_t>& perm, std::vector<uint8_t>& scalars) {
   perm.resize(n);
   std::iota(perm.begin(), perm.end(), 0u);
-  std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return memcmp(kb + (size_t)a * width, kb + (size_t)b * width, width) < 0; });
+  // byte-lexicographic, stable (Rust's sort_by is stable): compare the first 8 bytes as a big-endian word first
+  std::vector<uint64_t> pre(n);
+  for (size_t i = 0; i < n; i++) {
+    uint64_t v = 0;
+    for (int k = 0; k < 8; k++) v = (v << 8) | kb[i * width + k];
+    pre[i] = v;
+  }
+  std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) {
+    if (pre[a] != pre[b]) return pre[a] < pre[b];
+    return memcmp(kb + (size_t)a * width + 8, kb + (size_t)b * width + 8, width - 8) < 0;
+  });
   host_sha256 h;
   for (size_t i = 0; i < n; i++) h.update(kb + (size_t)perm[i] * width, width);
   uint8_t H[32];
@@ -566,7 +582,7 @@ int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const ui
         }
     }
     if (st == BLSGPU_OK) {
-      KL(KID_MILLER1, k_miller1, dim3(blocks_for(m)), dim3(BLS_BLOCK), m, m, d_pairs, d_bad, d_f);
+      MILLER1_LAUNCH(m, m, d_pairs, d_bad, d_f);
       if ((rc = run_f12_product_verdict(c, d_f, m, m, d_verdict))) return rc;
       HIPCK(hipMemcpyAsync(&st, d_verdict, 4, hipMemcpyDeviceToHost, c->stream));
       SYNC_FLUSH(c);
@@ -760,7 +776,7 @@ int blsgpu_pairing_product_is_one(const void* g1s, const void* g2s, size_t n, in
     uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * n);
     if (!d_skip || !d_pairs || !d_f) return fail(BLSGPU_E_HIP, "internal: arena too small");
     KL(KID_PAIRS_AFF, k_pairs_to_affine, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d1, (const uint8_t*)d2, fmt, d_pairs, d_skip);
-    KL(KID_MILLER1, k_miller1, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, n, d_pairs, d_skip, d_f);
+    MILLER1_LAUNCH(n, n, d_pairs, d_skip, d_f);
     if ((rc = run_f12_product_verdict(c, d_f, n, n, d_skip + n))) return rc;
     HIPCK(hipMemcpyAsync(&verdict, d_skip + n, 4, hipMemcpyDeviceToHost, c->stream));
     SYNC_FLUSH(c);
@@ -893,7 +909,7 @@ int blsgpu_aggregate_partial(int sig_group, int scheme, const void* pks, const u
   }
   std::vector<uint8_t> one(576, 0);
   if (fb < 0 && mm > 0) {
-    KL(KID_MILLER1, k_miller1, dim3(blocks_for(mm)), dim3(BLS_BLOCK), mm, m, d_pairs, d_bad, d_f);   // stride n + 1 as k_prepare_agg wrote
+    MILLER1_LAUNCH(mm, m, d_pairs, d_bad, d_f);   // stride n + 1 as k_prepare_agg wrote
   }
   *first_bad = fb;
   if (fb >= 0 || mm == 0) {

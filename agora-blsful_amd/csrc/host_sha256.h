@@ -5,6 +5,62 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#define HOST_SHA_X86 1
+#endif
+
+#if defined(HOST_SHA_X86)
+// SHA-NI path (runtime-dispatched): W_g = msg2(msg1(W_{g-4}, W_{g-3}) + alignr(W_{g-1}, W_{g-2}, 4), W_{g-1})
+__attribute__((target("sha,sse4.1,ssse3"))) static inline void host_sha256_blocks_shani(uint32_t h[8], const uint8_t* p, size_t nblk) {
+  alignas(16) static const uint32_t K[64] = {
+      0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+      0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+      0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+      0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+      0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+      0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+      0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+  const __m128i bswap = _mm_set_epi64x(0x0c0d0e0f08090a0bULL, 0x0405060700010203ULL);
+  __m128i tmp = _mm_loadu_si128((const __m128i*)&h[0]);      // DCBA
+  __m128i st1 = _mm_loadu_si128((const __m128i*)&h[4]);      // HGFE
+  tmp = _mm_shuffle_epi32(tmp, 0xB1);                        // CDAB
+  st1 = _mm_shuffle_epi32(st1, 0x1B);                        // EFGH
+  __m128i st0 = _mm_alignr_epi8(tmp, st1, 8);                // ABEF
+  st1 = _mm_blend_epi16(st1, tmp, 0xF0);                     // CDGH
+  for (size_t b = 0; b < nblk; b++, p += 64) {
+    const __m128i save0 = st0, save1 = st1;
+    __m128i w[4];
+    for (int g = 0; g < 16; g++) {
+      __m128i m;
+      if (g < 4) {
+        m = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 16 * g)), bswap);
+      } else {
+        m = _mm_sha256msg1_epu32(w[g & 3], w[(g + 1) & 3]);
+        m = _mm_add_epi32(m, _mm_alignr_epi8(w[(g + 3) & 3], w[(g + 2) & 3], 4));
+        m = _mm_sha256msg2_epu32(m, w[(g + 3) & 3]);
+      }
+      w[g & 3] = m;
+      __m128i x = _mm_add_epi32(m, _mm_load_si128((const __m128i*)&K[4 * g]));
+      st1 = _mm_sha256rnds2_epu32(st1, st0, x);
+      x = _mm_shuffle_epi32(x, 0x0E);
+      st0 = _mm_sha256rnds2_epu32(st0, st1, x);
+    }
+    st0 = _mm_add_epi32(st0, save0);
+    st1 = _mm_add_epi32(st1, save1);
+  }
+  tmp = _mm_shuffle_epi32(st0, 0x1B);                        // FEBA
+  st1 = _mm_shuffle_epi32(st1, 0xB1);                        // DCHG
+  st0 = _mm_blend_epi16(tmp, st1, 0xF0);                     // DCBA
+  st1 = _mm_alignr_epi8(st1, tmp, 8);                        // HGFE
+  _mm_storeu_si128((__m128i*)&h[0], st0);
+  _mm_storeu_si128((__m128i*)&h[4], st1);
+}
+static inline bool host_sha256_have_shani() {
+  static const int v = __builtin_cpu_supports("sha") ? 1 : 0;
+  return v != 0;
+}
+#endif
 
 struct host_sha256 {
   uint32_t h[8];
@@ -41,13 +97,23 @@ struct host_sha256 {
     }
     h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
   }
+  void blocks(const uint8_t* p, size_t nblk) {
+#if defined(HOST_SHA_X86)
+    if (host_sha256_have_shani()) {
+      host_sha256_blocks_shani(h, p, nblk);
+      return;
+    }
+#endif
+    for (size_t i = 0; i < nblk; i++) block(p + 64 * i);
+  }
   void update(const uint8_t* p, size_t n) {
     total += n;
     while (n) {
       if (fill == 0 && n >= 64) {
-        block(p);
-        p += 64;
-        n -= 64;
+        size_t nb = n / 64;
+        blocks(p, nb);
+        p += 64 * nb;
+        n -= 64 * nb;
         continue;
       }
       size_t k = 64 - fill < n ? 64 - fill : n;
@@ -56,7 +122,7 @@ struct host_sha256 {
       p += k;
       n -= k;
       if (fill == 64) {
-        block(buf);
+        blocks(buf, 1);
         fill = 0;
       }
     }

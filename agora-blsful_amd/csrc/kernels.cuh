@@ -124,6 +124,8 @@ __global__ void k_miller2(size_t n, const uint32_t* pairs, const int32_t* status
 __global__ void k_finalexp(size_t n, const uint32_t* fws, int32_t* status);
 __global__ void k_miller2s(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws, int fixed_g2);
 __global__ void k_finalexps(size_t n, const uint32_t* fws, int32_t* status);
+__global__ void k_miller1s(size_t n, size_t stride, const uint32_t* pairs, const int32_t* skip, uint32_t* fws);
+__global__ void k_finalexp_ones(const uint32_t* fws, size_t stride, int32_t* verdict);
 template <int SG>
 __global__ void k_prepare_agg(size_t n, const uint8_t* pks, const uint8_t* sig, int fmt, int aug, const uint8_t* msgs,
                               const uint64_t* offs, dst_arg dst, uint32_t* pairs, int32_t* bad);
@@ -588,7 +590,38 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_miller2s(size_t n, const uint3
 }
 #endif
 
+#if defined(BLS_TU_MILLERS)
+// one pair per item (aggregate verify / pairing product), two lanes per item; skipped items write 1
+__global__ void __launch_bounds__(BLS_BLOCK, 2) k_miller1s(size_t n, size_t stride, const uint32_t* pairs, const int32_t* skip, uint32_t* fws) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  if (i >= n) return;
+  fp12_t<hfp2> f;
+  if (skip[i]) {
+    fp12_one(f);
+  } else {
+    g1_aff P[1];
+    aff<hfp2> Q[1];
+    ws_ld_fp(P[0].x, pairs, stride, i, 0);
+    ws_ld_fp(P[0].y, pairs, stride, i, 12);
+    ws_ld_hfp2(Q[0].x, pairs, stride, i, 24);
+    ws_ld_hfp2(Q[0].y, pairs, stride, i, 48);
+    P[0].inf = false;
+    Q[0].inf = false;
+    miller_loop<1>(f, P, Q);
+  }
+  ws_st_hfp12(fws, stride, i, f);
+}
+#endif
+
 #if defined(BLS_TU_FINALEXPS)
+// final exponentiation of item 0 of a workspace on one lane pair
+__global__ void __launch_bounds__(BLS_BLOCK, 2) k_finalexp_ones(const uint32_t* fws, size_t stride, int32_t* verdict) {
+  if (blockIdx.x != 0 || threadIdx.x >= 2) return;
+  fp12_t<hfp2> f;
+  ws_ld_hfp12(f, fws, stride, 0);
+  int st = pairing_verdict(f);
+  if (!lane_hi()) *verdict = st;
+}
 __global__ void __launch_bounds__(BLS_BLOCK, 2) k_finalexps(size_t n, const uint32_t* fws, int32_t* status) {
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
   if (i >= n) return;
