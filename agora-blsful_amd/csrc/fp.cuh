@@ -253,13 +253,25 @@ BLS_FN void fp_from_mont(fp& r, const fp& a) {
   fp_mul(r, a, one);
 }
 
-// a^e for a public exponent given as little-endian 32-bit words (same for every lane: no divergence)
+// a^e for a public exponent given as little-endian 32-bit words (same for every lane: no divergence).
+// Fixed 4-bit windows: bits/4 * 4 squarings + one multiplication per non-zero digit + 14 for the table.
 BLS_NOINLINE void fp_pow(fp& r, const fp& a, const uint32_t* e, int nbits) {
+  fp tbl[16];
+  fp_one(tbl[0]);
+  tbl[1] = a;
+  for (int i = 2; i < 16; i++) fp_mul(tbl[i], tbl[i - 1], a);
   fp acc;
   fp_one(acc);
-  for (int i = nbits - 1; i >= 0; i--) {
-    fp_sqr(acc, acc);
-    if ((e[i >> 5] >> (i & 31)) & 1) fp_mul(acc, acc, a);
+  const int ndig = (nbits + 3) / 4;
+  for (int d = ndig - 1; d >= 0; d--) {
+    if (d != ndig - 1) {
+      fp_sqr(acc, acc);
+      fp_sqr(acc, acc);
+      fp_sqr(acc, acc);
+      fp_sqr(acc, acc);
+    }
+    const uint32_t dig = (e[d >> 3] >> ((d & 7) * 4)) & 15u;
+    if (dig) fp_mul(acc, acc, tbl[dig]);
   }
   r = acc;
 }

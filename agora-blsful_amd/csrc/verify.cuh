@@ -89,21 +89,34 @@ BLS_FN void g2_neg_gen(g2_aff& r) {
   r.inf = false;
 }
 
-// Bls12381G1Impl: builds P[0] = H(m), Q[0] = pk, P[1] = sig, Q[1] = -g2
+// Bls12381G1Impl: builds P[0] = H(m), Q[0] = pk, P[1] = sig, Q[1] = -g2.
+// Without message augmentation the three Jacobian -> affine conversions (sig, pk, H(m)) share ONE field inversion;
+// with augmentation the key must be affine (compressed) before hashing, so that path keeps two.
 BLS_FN int prepare_g1impl(g1_aff* P, g2_aff* Q, const g2_jac& pk, const g1_jac& sig, bool aug, const uint8_t* msg,
                           uint32_t msg_len, const uint8_t* dst, uint32_t dst_len) {
   if (jac_is_inf(sig)) return BLS_ERR_SIG_IDENTITY;
   if (jac_is_inf(pk)) return BLS_ERR_PK_IDENTITY;
-  g1g2_to_aff(P[1], Q[0], sig, pk);
-  uint8_t pre[96];
-  uint32_t pre_len = 0;
-  if (aug) {
-    g2_compress(pre, Q[0], false);
-    pre_len = 96;
-  }
   g1_jac h;
-  hash_to_g1(h, pre, pre_len, msg, msg_len, dst, dst_len);
-  jac_to_aff(P[0], h);
+  if (aug) {
+    g1g2_to_aff(P[1], Q[0], sig, pk);
+    uint8_t pre[96];
+    g2_compress(pre, Q[0], false);
+    hash_to_g1(h, pre, 96, msg, msg_len, dst, dst_len);
+    jac_to_aff(P[0], h);
+  } else {
+    hash_to_g1(h, nullptr, 0, msg, msg_len, dst, dst_len);
+    if (jac_is_inf(h)) {            // cannot happen for a hash output in practice; keep the generic path correct
+      g1g2_to_aff(P[1], Q[0], sig, pk);
+      jac_to_aff(P[0], h);
+    } else {
+      fp zs = sig.z, zh = h.z, n;
+      fp2_norm(n, pk.z);
+      fp_inv3(zs, zh, n);
+      g1_apply_zinv(P[1], sig, zs);
+      g1_apply_zinv(P[0], h, zh);
+      g2_apply_ninv(Q[0], pk, n);
+    }
+  }
   g2_neg_gen(Q[1]);
   return BLS_OK;
 }
@@ -113,16 +126,28 @@ BLS_FN int prepare_g2impl(g1_aff* P, g2_aff* Q, const g1_jac& pk, const g2_jac& 
                           uint32_t msg_len, const uint8_t* dst, uint32_t dst_len) {
   if (jac_is_inf(sig)) return BLS_ERR_SIG_IDENTITY;
   if (jac_is_inf(pk)) return BLS_ERR_PK_IDENTITY;
-  g1g2_to_aff(P[0], Q[1], pk, sig);
-  uint8_t pre[48];
-  uint32_t pre_len = 0;
-  if (aug) {
-    g1_compress(pre, P[0], false);
-    pre_len = 48;
-  }
   g2_jac h;
-  hash_to_g2(h, pre, pre_len, msg, msg_len, dst, dst_len);
-  jac_to_aff(Q[0], h);
+  if (aug) {
+    g1g2_to_aff(P[0], Q[1], pk, sig);
+    uint8_t pre[48];
+    g1_compress(pre, P[0], false);
+    hash_to_g2(h, pre, 48, msg, msg_len, dst, dst_len);
+    jac_to_aff(Q[0], h);
+  } else {
+    hash_to_g2(h, nullptr, 0, msg, msg_len, dst, dst_len);
+    if (jac_is_inf(h)) {
+      g1g2_to_aff(P[0], Q[1], pk, sig);
+      jac_to_aff(Q[0], h);
+    } else {
+      fp zp = pk.z, ns, nh;
+      fp2_norm(ns, sig.z);
+      fp2_norm(nh, h.z);
+      fp_inv3(zp, ns, nh);
+      g1_apply_zinv(P[0], pk, zp);
+      g2_apply_ninv(Q[1], sig, ns);
+      g2_apply_ninv(Q[0], h, nh);
+    }
+  }
   g1_neg_gen(P[1]);
   return BLS_OK;
 }

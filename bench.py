@@ -86,7 +86,7 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs a GPU: the product has no CPU path'
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:      # under torch.distributed.run: exercise RCCL init / barrier / all-reduce
         import torch.distributed as dist_mod
         dist = dist_mod
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
