@@ -22,10 +22,10 @@ thread_local std::string t_err;
 
 enum {
   KID_PREPARE, KID_MILLER2, KID_FINALEXP, KID_PREPARE_AGG, KID_PAIRS_AFF, KID_MILLER1, KID_F12_FOLD, KID_FINALEXP_ONE,
-  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_F12_IO, KID_COUNT
+  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_F12_IO, KID_MSM_SORT, KID_MSM_BUCKET, KID_MSM_CHUNK, KID_COUNT
 };
 const char* KID_NAMES[KID_COUNT] = {"k_prepare", "k_miller2", "k_finalexp", "k_prepare_agg", "k_pairs_to_affine", "k_miller1", "k_f12_fold",
-                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign", "k_f12_io"};
+                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign", "k_f12_io", "k_msm_sort", "k_msm_bucket", "k_msm_chunk"};
 
 struct Ctx {
   int dev = -1;
@@ -257,10 +257,15 @@ size_t accumulate_lanes(size_t n) {
   return (t + 63) & ~(size_t)63;
 }
 
+bool msm_use_pippenger(size_t n);
+template <int G>
+int run_msm_pippenger(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_scalars, const uint32_t* d_perm, size_t n, uint8_t* d_out);
+
 // sum (or sum of scalar multiples) of n points of group G into partials[0] (RAW_PROJ, device)
 template <int G>
 int run_point_sum(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_scalars, const uint32_t* d_perm, size_t n,
                   uint8_t* d_partials, size_t T) {
+  if (d_scalars && msm_use_pippenger(n)) return run_msm_pippenger<G>(c, d_pts, fmt, d_scalars, d_perm, n, d_partials);
   unsigned nb = blocks_for(T);
   if (d_scalars)
     KL(KID_ACCUM, (k_accumulate<G, 1>), dim3(nb), dim3(BLS_BLOCK), n, d_pts, fmt, d_scalars, d_perm, d_partials, T);
@@ -273,6 +278,61 @@ int run_point_sum(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_scalar
     cur = half;
   }
   HIPCK(hipGetLastError());
+  return 0;
+}
+
+// Pippenger MSM into out[0] (RAW_PROJ, device, Z = 1).  Workspace comes from the arena (caller reserved msm_ws_bytes).
+struct msm_plan {
+  int c, W, CH;
+  size_t nb, nchunks;
+};
+msm_plan msm_make_plan(size_t n) {
+  msm_plan p;
+  p.c = n >= 16384 ? 11 : 8;
+  p.W = (255 + p.c - 1) / p.c;
+  p.CH = 32;
+  p.nb = (size_t)p.W << p.c;
+  p.nchunks = p.nb / p.CH;
+  return p;
+}
+size_t msm_ws_bytes(size_t n) {
+  msm_plan p = msm_make_plan(n);
+  return 3 * pad256(4 * p.nb) + pad256(4 * n * p.W) + pad256(288 * p.nb) + pad256(288 * p.nchunks) + 4096;
+}
+bool msm_use_pippenger(size_t n) {
+  static int force_naive = -1;
+  if (force_naive < 0) {
+    const char* e = getenv("BLSGPU_MSM_NAIVE");
+    force_naive = (e && e[0] == '1') ? 1 : 0;
+  }
+  return !force_naive && n >= 1024;
+}
+template <int G>
+int run_msm_pippenger(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_scalars, const uint32_t* d_perm, size_t n, uint8_t* d_out) {
+  msm_plan p = msm_make_plan(n);
+  uint32_t* d_cnt = (uint32_t*)arena_take(c, 4 * p.nb);
+  uint32_t* d_off = (uint32_t*)arena_take(c, 4 * p.nb);
+  uint32_t* d_cur = (uint32_t*)arena_take(c, 4 * p.nb);
+  uint32_t* d_idx = (uint32_t*)arena_take(c, 4 * n * p.W);
+  uint8_t* d_sums = (uint8_t*)arena_take(c, 288 * p.nb);
+  uint8_t* d_part = (uint8_t*)arena_take(c, 288 * p.nchunks);
+  if (!d_cnt || !d_off || !d_cur || !d_idx || !d_sums || !d_part) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  HIPCK(hipMemsetAsync(d_cnt, 0, 4 * p.nb, c->stream));
+  HIPCK(hipMemsetAsync(d_cur, 0, 4 * p.nb, c->stream));
+  KL(KID_MSM_SORT, k_msm_count, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_scalars, p.c, p.W, d_cnt);
+  KL(KID_MSM_SORT, k_msm_scan, dim3(1), dim3(BLS_BLOCK), p.nb, d_cnt, d_off);
+  KL(KID_MSM_SORT, k_msm_fill, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_scalars, p.c, p.W, d_off, d_cur, d_idx);
+  KL(KID_MSM_BUCKET, k_msm_bucket<G>, dim3(blocks_for(p.nb)), dim3(BLS_BLOCK), p.nb, d_pts, fmt, d_perm, d_cnt, d_off, d_idx, d_sums);
+  KL(KID_MSM_CHUNK, k_msm_chunk<G>, dim3(blocks_for(p.nchunks)), dim3(BLS_BLOCK), p.c, p.W, p.CH, d_sums, d_part);
+  size_t cur = p.nchunks;
+  while (cur > 1) {
+    size_t half = (cur + 1) / 2;
+    KL(KID_POINT_FOLD, k_point_fold<G>, dim3(blocks_for(half)), dim3(BLS_BLOCK), cur, half, d_part);
+    cur = half;
+  }
+  KL(KID_MSM_CHUNK, k_normalize<G>, dim3(1), dim3(BLS_BLOCK), d_part);
+  HIPCK(hipGetLastError());
+  HIPCK(hipMemcpyAsync(d_out, d_part, G == 1 ? 144 : 288, hipMemcpyDeviceToDevice, c->stream));
   return 0;
 }
 
@@ -609,7 +669,7 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCK(hipSetDevice(c->dev));
   const size_t psz = pk_size(sig_group, fmt), width = sig_group == 1 ? 96 : 48, T = accumulate_lanes(n);
-  size_t need = pad256(psz * n) + pad256(width * n) + pad256(4 * n) + pad256(32 * n) + pad256(288 * T) + pad256(msg_len) + 16384;
+  size_t need = pad256(psz * n) + pad256(width * n) + pad256(4 * n) + pad256(32 * n) + pad256(288 * T) + pad256(msg_len) + 16384 + msm_ws_bytes(n);
   if ((rc = arena_reserve(c, need))) return rc;
   c->arena_off = 0;
   int32_t st = BLSGPU_OK;
@@ -730,7 +790,7 @@ static int point_sum_entry(int group, const void* pts, const uint8_t* scalars, s
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCK(hipSetDevice(c->dev));
   const size_t psz = group == 1 ? g1_size(fmt) : g2_size(fmt), osz = group == 1 ? 144 : 288, T = accumulate_lanes(n);
-  int rc = arena_reserve(c, pad256(psz * n) + pad256(32 * n) + pad256(288 * T) + 4096);
+  int rc = arena_reserve(c, pad256(psz * n) + pad256(32 * n) + pad256(288 * T) + 4096 + (scalars ? msm_ws_bytes(n) : 0));
   if (rc) return rc;
   c->arena_off = 0;
   const void *d_pts, *d_scal = nullptr;

@@ -147,6 +147,17 @@ __global__ void k_compress(size_t n, const uint8_t* pts, int fmt, int legacy, ui
 template <int SG>
 __global__ void k_sign(size_t n, const uint8_t* sks, int aug, const uint8_t* msgs, const uint64_t* offs, dst_arg dst,
                        uint8_t* out_pks, uint8_t* out_sigs);
+// Pippenger multi-scalar multiplication (bucket method), see the BLS_TU_MSM section
+__global__ void k_msm_count(size_t n, const uint8_t* scalars, int c, int W, uint32_t* cnt);
+__global__ void k_msm_scan(size_t m, const uint32_t* cnt, uint32_t* off);
+__global__ void k_msm_fill(size_t n, const uint8_t* scalars, int c, int W, const uint32_t* off, uint32_t* cursor, uint32_t* idx);
+template <int G>
+__global__ void k_msm_bucket(size_t nb, const uint8_t* pts, int fmt, const uint32_t* perm, const uint32_t* cnt, const uint32_t* off,
+                             const uint32_t* idx, uint8_t* sums);
+template <int G>
+__global__ void k_msm_chunk(int c, int W, int CH, const uint8_t* sums, uint8_t* partials);
+template <int G>
+__global__ void k_normalize(uint8_t* pt);
 
 #if defined(BLS_TU_PREPARE1) || defined(BLS_TU_PREPARE2)
 // =====================================================================================================
@@ -632,3 +643,149 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_finalexps(size_t n, const uint
   if (!lane_hi()) status[i] = st;
 }
 #endif
+
+#if defined(BLS_TU_MSM1) || defined(BLS_TU_MSM2)
+// =====================================================================================================
+// Pippenger MSM: sum_i k_i P_i with c-bit windows, W = ceil(255 / c) windows, B = 2^c buckets per window.
+//   k_msm_count / k_msm_scan / k_msm_fill : counting sort of (window, digit) -> per-bucket index lists
+//   k_msm_bucket   : one lane per bucket sums its points                     (n W / (1 - 2^-c) additions in total)
+//   k_msm_chunk    : one lane per CH consecutive buckets of a window: running sums give sum_d (d - lo + 1) S_d, plus
+//                    (lo - 1) * (chunk total) by a c-bit double-and-add, then c*w doublings weigh the window
+//   k_point_fold   : tree sum of all chunk partials;  k_normalize: Z = 1 so the output bytes do not depend on the
+//                    (atomic) fill order.
+// Replaces the serial loop `aggregated_pk += pk.0 * *coeff` of reference src/secure_aggregation.rs:201-204.
+__device__ __forceinline__ uint32_t msm_digit(const uint32_t* k, int w, int c) {
+  const int bit = w * c;
+  const int wi = bit >> 5, sh = bit & 31;
+  uint64_t v = k[wi];
+  if (wi + 1 < 8) v |= (uint64_t)k[wi + 1] << 32;
+  return (uint32_t)(v >> sh) & ((1u << c) - 1u);
+}
+#if defined(BLS_TU_MSM1)
+__global__ void __launch_bounds__(BLS_BLOCK) k_msm_count(size_t n, const uint8_t* scalars, int c, int W, uint32_t* cnt) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* k = (const uint32_t*)(scalars + 32 * i);
+  for (int w = 0; w < W; w++) {
+    uint32_t d = msm_digit(k, w, c);
+    if (d) atomicAdd(&cnt[((size_t)w << c) + d], 1u);
+  }
+}
+// exclusive prefix sum over m counters, one workgroup
+__global__ void __launch_bounds__(BLS_BLOCK) k_msm_scan(size_t m, const uint32_t* cnt, uint32_t* off) {
+  __shared__ uint32_t part[BLS_BLOCK];
+  const size_t per = (m + BLS_BLOCK - 1) / BLS_BLOCK, lo = per * threadIdx.x, hi = lo + per < m ? lo + per : m;
+  uint32_t s = 0;
+  for (size_t j = lo; j < hi; j++) s += cnt[j];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  uint32_t base = 0;
+  for (unsigned t = 0; t < threadIdx.x; t++) base += part[t];
+  for (size_t j = lo; j < hi; j++) {
+    off[j] = base;
+    base += cnt[j];
+  }
+}
+__global__ void __launch_bounds__(BLS_BLOCK) k_msm_fill(size_t n, const uint8_t* scalars, int c, int W, const uint32_t* off, uint32_t* cursor,
+                                                      uint32_t* idx) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* k = (const uint32_t*)(scalars + 32 * i);
+  for (int w = 0; w < W; w++) {
+    uint32_t d = msm_digit(k, w, c);
+    if (d) {
+      size_t b = ((size_t)w << c) + d;
+      uint32_t slot = atomicAdd(&cursor[b], 1u);
+      idx[off[b] + slot] = (uint32_t)i;
+    }
+  }
+}
+#endif
+template <int G>
+struct msm_pt;
+template <>
+struct msm_pt<1> {
+  typedef g1_jac jac_t;
+  __device__ static void load(g1_jac& p, const uint8_t* b, size_t i, int fmt) { load_g1_pt(p, b, i, fmt); }
+  __device__ static void store(uint8_t* b, size_t i, const g1_jac& p) { store_g1_pt(b, i, p); }
+};
+template <>
+struct msm_pt<2> {
+  typedef g2_jac jac_t;
+  __device__ static void load(g2_jac& p, const uint8_t* b, size_t i, int fmt) { load_g2_pt(p, b, i, fmt); }
+  __device__ static void store(uint8_t* b, size_t i, const g2_jac& p) { store_g2_pt(b, i, p); }
+};
+template <int G>
+__global__ void __launch_bounds__(BLS_BLOCK) k_msm_bucket(size_t nb, const uint8_t* pts, int fmt, const uint32_t* perm, const uint32_t* cnt,
+                                                        const uint32_t* off, const uint32_t* idx, uint8_t* sums) {
+  size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  typename msm_pt<G>::jac_t acc, p;
+  jac_set_inf(acc);
+  const uint32_t n = cnt[b], o = off[b];
+  for (uint32_t j = 0; j < n; j++) {
+    uint32_t i = idx[o + j];
+    msm_pt<G>::load(p, pts, perm ? perm[i] : i, fmt);
+    jac_add(acc, acc, p);
+  }
+  msm_pt<G>::store(sums, b, acc);
+}
+template <int G>
+__global__ void __launch_bounds__(BLS_BLOCK) k_msm_chunk(int c, int W, int CH, const uint8_t* sums, uint8_t* partials) {
+  const size_t chunks_per_w = ((size_t)1 << c) / CH;
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= chunks_per_w * W) return;
+  const int w = (int)(t / chunks_per_w);
+  const size_t lo = (t % chunks_per_w) * CH;
+  typename msm_pt<G>::jac_t run, acc, s;
+  jac_set_inf(run);
+  jac_set_inf(acc);
+  for (int d = CH - 1; d >= 0; d--) {
+    msm_pt<G>::load(s, sums, ((size_t)w << c) + lo + d, 0);
+    jac_add(run, run, s);
+    jac_add(acc, acc, run);   // acc = sum_d (d + 1) S_{lo + d}
+  }
+  // sum_d (lo + d) S = acc + (lo - 1) run
+  if (lo == 0) {
+    jac_neg(s, run);
+  } else {
+    jac_set_inf(s);
+    const uint32_t mlt = (uint32_t)(lo - 1);
+    for (int bit = c; bit >= 0; bit--) {
+      jac_dbl(s, s);
+      if ((mlt >> bit) & 1u) jac_add(s, s, run);
+    }
+  }
+  jac_add(acc, acc, s);
+  for (int k = 0; k < c * w; k++) jac_dbl(acc, acc);   // weight 2^(c w)
+  msm_pt<G>::store(partials, t, acc);
+}
+// Z = 1 (or the canonical identity) in place
+template <int G>
+__global__ void __launch_bounds__(BLS_BLOCK) k_normalize(uint8_t* pt) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  typename msm_pt<G>::jac_t p;
+  msm_pt<G>::load(p, pt, 0, 0);
+  if (jac_is_inf(p)) {
+    jac_set_inf(p);
+  } else {
+    decltype(p.x) zi, zi2;
+    fe_inv(zi, p.z);
+    fe_sqr(zi2, zi);
+    fe_mul(p.x, p.x, zi2);
+    fe_mul(zi2, zi2, zi);
+    fe_mul(p.y, p.y, zi2);
+    fe_one(p.z);
+  }
+  msm_pt<G>::store(pt, 0, p);
+}
+#if defined(BLS_TU_MSM1)
+template __global__ void k_msm_bucket<1>(size_t, const uint8_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*);
+template __global__ void k_msm_chunk<1>(int, int, int, const uint8_t*, uint8_t*);
+template __global__ void k_normalize<1>(uint8_t*);
+#else
+template __global__ void k_msm_bucket<2>(size_t, const uint8_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*);
+template __global__ void k_msm_chunk<2>(int, int, int, const uint8_t*, uint8_t*);
+template __global__ void k_normalize<2>(uint8_t*);
+#endif
+#endif  // BLS_TU_MSM*

@@ -351,3 +351,22 @@ def test_verify_batch_large_property(api):
         sigs2[i] = sigs[(i + 1) % n]
         expect[i] = 1
     assert api.verify_batch(1, api.POP, pks, sigs2, msgs2) == expect
+
+
+@pytest.mark.parametrize('group', [1, 2])
+def test_msm_pippenger_closed_form(api, group):
+    """Bucket-method MSM at n = 1,500 (8-bit windows) and 20,000 (11-bit windows): points sk_i * g made on the device,
+    random 255-bit scalars incl. 0, 1, r-1; expected (sum t_i sk_i) * g from one oracle scalar multiplication."""
+    rng = random.Random(50 + group)
+    sg = 2 if group == 1 else 1                 # public keys of Bls12381G2Impl live in G1 and vice versa
+    E, gen, comp = (c.E1, c.G1_GEN, c.g1_compress) if group == 1 else (c.E2, c.G2_GEN, c.g2_compress)
+    for n in (1500, 20000):
+        sks = [rng.randrange(1, c.R) for _ in range(n)]
+        pks, _ = api.sign_batch(sg, api.BASIC, sks, [b''] * n)
+        ts = [rng.randrange(c.R) for _ in range(n)]
+        ts[0], ts[1], ts[2] = 0, 1, c.R - 1
+        pks[7] = pks[3]                          # duplicate point
+        sks[7] = sks[3]
+        want = E.mul(gen, sum(t * s for t, s in zip(ts, sks)) % c.R)
+        got = api.serialize(group, [api.point_sum(group, pks, ts)])[0]
+        assert got == comp(want), n
