@@ -283,15 +283,16 @@ int run_point_sum(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_scalar
 
 // Pippenger MSM into out[0] (RAW_PROJ, device, Z = 1).  Workspace comes from the arena (caller reserved msm_ws_bytes).
 struct msm_plan {
-  int c, W, CH;
+  int c, W, clast, CH;
   size_t nb, nchunks;
 };
 msm_plan msm_make_plan(size_t n) {
   msm_plan p;
   p.c = n >= 16384 ? 11 : 8;
-  p.W = (255 + p.c - 1) / p.c;
+  p.W = 255 / p.c;                      // scalars are < r < 2^255
+  p.clast = 255 - p.c * (p.W - 1);      // the last window takes the remainder: c <= clast < 2c
   p.CH = 32;
-  p.nb = (size_t)p.W << p.c;
+  p.nb = ((size_t)(p.W - 1) << p.c) + ((size_t)1 << p.clast);
   p.nchunks = p.nb / p.CH;
   return p;
 }
@@ -319,11 +320,11 @@ int run_msm_pippenger(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_sc
   if (!d_cnt || !d_off || !d_cur || !d_idx || !d_sums || !d_part) return fail(BLSGPU_E_HIP, "internal: arena too small");
   HIPCK(hipMemsetAsync(d_cnt, 0, 4 * p.nb, c->stream));
   HIPCK(hipMemsetAsync(d_cur, 0, 4 * p.nb, c->stream));
-  KL(KID_MSM_SORT, k_msm_count, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_scalars, p.c, p.W, d_cnt);
+  KL(KID_MSM_SORT, k_msm_count, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_scalars, p.c, p.W, p.clast, d_cnt);
   KL(KID_MSM_SORT, k_msm_scan, dim3(1), dim3(BLS_BLOCK), p.nb, d_cnt, d_off);
-  KL(KID_MSM_SORT, k_msm_fill, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_scalars, p.c, p.W, d_off, d_cur, d_idx);
+  KL(KID_MSM_SORT, k_msm_fill, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_scalars, p.c, p.W, p.clast, d_off, d_cur, d_idx);
   KL(KID_MSM_BUCKET, k_msm_bucket<G>, dim3(blocks_for(p.nb)), dim3(BLS_BLOCK), p.nb, d_pts, fmt, d_perm, d_cnt, d_off, d_idx, d_sums);
-  KL(KID_MSM_CHUNK, k_msm_chunk<G>, dim3(blocks_for(p.nchunks)), dim3(BLS_BLOCK), p.c, p.W, p.CH, d_sums, d_part);
+  KL(KID_MSM_CHUNK, k_msm_chunk<G>, dim3(blocks_for(p.nchunks)), dim3(BLS_BLOCK), p.c, p.W, p.clast, p.CH, d_sums, d_part);
   size_t cur = p.nchunks;
   while (cur > 1) {
     size_t half = (cur + 1) / 2;

@@ -148,14 +148,14 @@ template <int SG>
 __global__ void k_sign(size_t n, const uint8_t* sks, int aug, const uint8_t* msgs, const uint64_t* offs, dst_arg dst,
                        uint8_t* out_pks, uint8_t* out_sigs);
 // Pippenger multi-scalar multiplication (bucket method), see the BLS_TU_MSM section
-__global__ void k_msm_count(size_t n, const uint8_t* scalars, int c, int W, uint32_t* cnt);
+__global__ void k_msm_count(size_t n, const uint8_t* scalars, int c, int W, int clast, uint32_t* cnt);
 __global__ void k_msm_scan(size_t m, const uint32_t* cnt, uint32_t* off);
-__global__ void k_msm_fill(size_t n, const uint8_t* scalars, int c, int W, const uint32_t* off, uint32_t* cursor, uint32_t* idx);
+__global__ void k_msm_fill(size_t n, const uint8_t* scalars, int c, int W, int clast, const uint32_t* off, uint32_t* cursor, uint32_t* idx);
 template <int G>
 __global__ void k_msm_bucket(size_t nb, const uint8_t* pts, int fmt, const uint32_t* perm, const uint32_t* cnt, const uint32_t* off,
                              const uint32_t* idx, uint8_t* sums);
 template <int G>
-__global__ void k_msm_chunk(int c, int W, int CH, const uint8_t* sums, uint8_t* partials);
+__global__ void k_msm_chunk(int c, int W, int clast, int CH, const uint8_t* sums, uint8_t* partials);
 template <int G>
 __global__ void k_normalize(uint8_t* pt);
 
@@ -646,7 +646,9 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_finalexps(size_t n, const uint
 
 #if defined(BLS_TU_MSM1) || defined(BLS_TU_MSM2)
 // =====================================================================================================
-// Pippenger MSM: sum_i k_i P_i with c-bit windows, W = ceil(255 / c) windows, B = 2^c buckets per window.
+// Pippenger MSM: sum_i k_i P_i.  Scalars are < r < 2^255: W = floor(255 / c) windows, the first W - 1 are c bits wide
+// (2^c buckets each) and the LAST takes the remaining clast = 255 - c (W - 1) bits (2^clast buckets), so no window is a
+// narrow remainder whose few buckets would each receive n / 4 points.  Bucket b of window w sits at (w << c) + b.
 //   k_msm_count / k_msm_scan / k_msm_fill : counting sort of (window, digit) -> per-bucket index lists
 //   k_msm_bucket   : one lane per bucket sums its points                     (n W / (1 - 2^-c) additions in total)
 //   k_msm_chunk    : one lane per CH consecutive buckets of a window: running sums give sum_d (d - lo + 1) S_d, plus
@@ -654,20 +656,19 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_finalexps(size_t n, const uint
 //   k_point_fold   : tree sum of all chunk partials;  k_normalize: Z = 1 so the output bytes do not depend on the
 //                    (atomic) fill order.
 // Replaces the serial loop `aggregated_pk += pk.0 * *coeff` of reference src/secure_aggregation.rs:201-204.
-__device__ __forceinline__ uint32_t msm_digit(const uint32_t* k, int w, int c) {
-  const int bit = w * c;
+__device__ __forceinline__ uint32_t msm_digit(const uint32_t* k, int bit, int c) {
   const int wi = bit >> 5, sh = bit & 31;
   uint64_t v = k[wi];
   if (wi + 1 < 8) v |= (uint64_t)k[wi + 1] << 32;
   return (uint32_t)(v >> sh) & ((1u << c) - 1u);
 }
 #if defined(BLS_TU_MSM1)
-__global__ void __launch_bounds__(BLS_BLOCK) k_msm_count(size_t n, const uint8_t* scalars, int c, int W, uint32_t* cnt) {
+__global__ void __launch_bounds__(BLS_BLOCK) k_msm_count(size_t n, const uint8_t* scalars, int c, int W, int clast, uint32_t* cnt) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t* k = (const uint32_t*)(scalars + 32 * i);
   for (int w = 0; w < W; w++) {
-    uint32_t d = msm_digit(k, w, c);
+    uint32_t d = msm_digit(k, w * c, w == W - 1 ? clast : c);
     if (d) atomicAdd(&cnt[((size_t)w << c) + d], 1u);
   }
 }
@@ -686,13 +687,13 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_msm_scan(size_t m, const uint32_t
     base += cnt[j];
   }
 }
-__global__ void __launch_bounds__(BLS_BLOCK) k_msm_fill(size_t n, const uint8_t* scalars, int c, int W, const uint32_t* off, uint32_t* cursor,
-                                                      uint32_t* idx) {
+__global__ void __launch_bounds__(BLS_BLOCK) k_msm_fill(size_t n, const uint8_t* scalars, int c, int W, int clast, const uint32_t* off,
+                                                      uint32_t* cursor, uint32_t* idx) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t* k = (const uint32_t*)(scalars + 32 * i);
   for (int w = 0; w < W; w++) {
-    uint32_t d = msm_digit(k, w, c);
+    uint32_t d = msm_digit(k, w * c, w == W - 1 ? clast : c);
     if (d) {
       size_t b = ((size_t)w << c) + d;
       uint32_t slot = atomicAdd(&cursor[b], 1u);
@@ -731,12 +732,14 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_msm_bucket(size_t nb, const uint8
   msm_pt<G>::store(sums, b, acc);
 }
 template <int G>
-__global__ void __launch_bounds__(BLS_BLOCK) k_msm_chunk(int c, int W, int CH, const uint8_t* sums, uint8_t* partials) {
-  const size_t chunks_per_w = ((size_t)1 << c) / CH;
+__global__ void __launch_bounds__(BLS_BLOCK) k_msm_chunk(int c, int W, int clast, int CH, const uint8_t* sums, uint8_t* partials) {
+  const size_t cpw = ((size_t)1 << c) / CH, cpl = ((size_t)1 << clast) / CH;   // chunks per regular / last window
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= chunks_per_w * W) return;
-  const int w = (int)(t / chunks_per_w);
-  const size_t lo = (t % chunks_per_w) * CH;
+  if (t >= cpw * (W - 1) + cpl) return;
+  const bool last = t >= cpw * (W - 1);
+  const int w = last ? W - 1 : (int)(t / cpw);
+  const size_t lo = (last ? t - cpw * (W - 1) : t % cpw) * CH;
+  const int wbits = last ? clast : c;
   typename msm_pt<G>::jac_t run, acc, s;
   jac_set_inf(run);
   jac_set_inf(acc);
@@ -751,7 +754,7 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_msm_chunk(int c, int W, int CH, c
   } else {
     jac_set_inf(s);
     const uint32_t mlt = (uint32_t)(lo - 1);
-    for (int bit = c; bit >= 0; bit--) {
+    for (int bit = wbits; bit >= 0; bit--) {
       jac_dbl(s, s);
       if ((mlt >> bit) & 1u) jac_add(s, s, run);
     }
@@ -781,11 +784,11 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_normalize(uint8_t* pt) {
 }
 #if defined(BLS_TU_MSM1)
 template __global__ void k_msm_bucket<1>(size_t, const uint8_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*);
-template __global__ void k_msm_chunk<1>(int, int, int, const uint8_t*, uint8_t*);
+template __global__ void k_msm_chunk<1>(int, int, int, int, const uint8_t*, uint8_t*);
 template __global__ void k_normalize<1>(uint8_t*);
 #else
 template __global__ void k_msm_bucket<2>(size_t, const uint8_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*);
-template __global__ void k_msm_chunk<2>(int, int, int, const uint8_t*, uint8_t*);
+template __global__ void k_msm_chunk<2>(int, int, int, int, const uint8_t*, uint8_t*);
 template __global__ void k_normalize<2>(uint8_t*);
 #endif
 #endif  // BLS_TU_MSM*
