@@ -31,7 +31,7 @@ EXPORTS = [
     'blsgpu_hash_to_g2', 'blsgpu_sum_g1', 'blsgpu_sum_g2', 'blsgpu_msm_g1', 'blsgpu_msm_g2',
     'blsgpu_pairing_product_is_one', 'blsgpu_serialize', 'blsgpu_sign_batch',
     'blsgpu_profile_enable', 'blsgpu_profile_count', 'blsgpu_profile_get',
-    'blsgpu_aggregate_partial', 'blsgpu_fp12_product_is_one', 'blsgpu_core_verify',
+    'blsgpu_aggregate_partial', 'blsgpu_fp12_product_is_one', 'blsgpu_core_verify', 'blsgpu_deserialize',
 ]
 
 
@@ -121,6 +121,7 @@ def load_library(path=None):
         lib.blsgpu_aggregate_partial.argtypes = [ci, ci, vp, u8p, u64p, sz, vp, ci, vp, ctypes.POINTER(ctypes.c_int64)]
         lib.blsgpu_fp12_product_is_one.argtypes = [vp, sz, i32p]
         lib.blsgpu_core_verify.argtypes = [ci, u8p, sz, vp, vp, u8p, u64p, sz, ci, i32p]
+        lib.blsgpu_deserialize.argtypes = [ci, u8p, sz, ci, vp, i32p]
         lib.blsgpu_profile_get.argtypes = [ci, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
         _lib = lib
     return _lib
@@ -261,6 +262,19 @@ def pairing_product_is_one(g1s, g2s, fmt=FMT_RAW_PROJ):
     a, b = b''.join(g1s), b''.join(g2s)
     _check(lib.blsgpu_pairing_product_is_one(_ptr(a), _ptr(b), len(g1s), fmt, ctypes.byref(r)))
     return bool(r.value)
+
+
+def deserialize(group, blobs, legacy=False):
+    """(RAW_PROJ points, statuses) from 48/96-byte encodings: checked decompression on the GPU."""
+    lib = init()
+    n = len(blobs)
+    osz = 144 if group == 1 else 288
+    out = ctypes.create_string_buffer(osz * max(n, 1))
+    st = (ctypes.c_int32 * max(n, 1))()
+    blob = b''.join(blobs)
+    _check(lib.blsgpu_deserialize(group, _ptr(blob), n, FMT_LEGACY if legacy else FMT_COMPRESSED, ctypes.cast(out, ctypes.c_void_p),
+                                  ctypes.cast(st, ctypes.c_void_p)))
+    return [out.raw[osz * i:osz * (i + 1)] for i in range(n)], list(st)[:n]
 
 
 def serialize(group, pts, fmt_in=FMT_RAW_PROJ, legacy=False):

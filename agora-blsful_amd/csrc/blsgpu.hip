@@ -22,10 +22,10 @@ thread_local std::string t_err;
 
 enum {
   KID_PREPARE, KID_MILLER2, KID_FINALEXP, KID_PREPARE_AGG, KID_PAIRS_AFF, KID_MILLER1, KID_F12_FOLD, KID_FINALEXP_ONE,
-  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_F12_IO, KID_MSM_SORT, KID_MSM_BUCKET, KID_MSM_CHUNK, KID_COUNT
+  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_F12_IO, KID_MSM_SORT, KID_MSM_BUCKET, KID_MSM_CHUNK, KID_DECOMPRESS, KID_COUNT
 };
 const char* KID_NAMES[KID_COUNT] = {"k_prepare", "k_miller2", "k_finalexp", "k_prepare_agg", "k_pairs_to_affine", "k_miller1", "k_f12_fold",
-                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign", "k_f12_io", "k_msm_sort", "k_msm_bucket", "k_msm_chunk"};
+                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign", "k_f12_io", "k_msm_sort", "k_msm_bucket", "k_msm_chunk", "k_decompress"};
 
 struct Ctx {
   int dev = -1;
@@ -211,13 +211,13 @@ unsigned blocks_for(size_t n) { return (unsigned)((n + BLS_BLOCK - 1) / BLS_BLOC
 // one core_verify per item: statuses end up in d_status (device)
 int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_t* d_sigs, int fmt, const uint8_t* d_msgs,
                      const uint64_t* d_offs, int single_msg, const dst_arg& dst, size_t n, uint32_t* d_pairs, uint32_t* d_f,
-                     int32_t* d_status) {
+                     int32_t* d_status, int pre_status = 0) {
   if (n == 0) return 0;
   unsigned nb = blocks_for(n);
   if (sg == 1)
-    KL(KID_PREPARE, k_prepare<1>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status);
+    KL(KID_PREPARE, k_prepare<1>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status, pre_status);
   else
-    KL(KID_PREPARE, k_prepare<2>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status);
+    KL(KID_PREPARE, k_prepare<2>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status, pre_status);
   if (split_mode()) {  // two lanes per item
     KL(KID_MILLER2, k_miller2s, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_pairs, d_status, d_f, sg == 1 ? 1 : 0);
     KL(KID_FINALEXP, k_finalexps, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_f, d_status);
@@ -477,7 +477,8 @@ size_t blsgpu_last_error(char* buf, size_t cap) {
 
 int blsgpu_verify_batch(int sig_group, int scheme, const void* pks, const void* sigs, const uint8_t* msgs,
                         const uint64_t* msg_offsets, size_t n, int fmt, int32_t* status) {
-  int rc = check_common(sig_group, scheme, fmt);
+  const bool wire = fmt == BLSGPU_FMT_COMPRESSED || fmt == BLSGPU_FMT_LEGACY;
+  int rc = check_common(sig_group, scheme, wire ? BLSGPU_FMT_RAW_PROJ : fmt);
   if (rc) return rc;
   if (n == 0) return 0;
   if (!pks || !sigs || !msg_offsets || !status) return fail(BLSGPU_E_ARG, "null argument");
@@ -489,7 +490,8 @@ int blsgpu_verify_batch(int sig_group, int scheme, const void* pks, const void* 
   if (is_device_ptr(msg_offsets)) HIPCK(hipMemcpy(&total, msg_offsets + n, 8, hipMemcpyDeviceToHost));
   else total = msg_offsets[n];
   const size_t pkb = pk_size(sig_group, fmt) * n, sgb = sig_size(sig_group, fmt) * n;
-  size_t need = pad256(pkb) + pad256(sgb) + pad256(total) + pad256(8 * (n + 1)) + pad256(4 * n) + 2 * pad256((size_t)WS_PAIRS_WORDS * 4 * n) + 4096;
+  size_t need = pad256(pkb) + pad256(sgb) + pad256(total) + pad256(8 * (n + 1)) + pad256(4 * n) + 2 * pad256((size_t)WS_PAIRS_WORDS * 4 * n) + 4096 +
+                (wire ? pad256(288 * n) + pad256(144 * n) : 0);
   rc = arena_reserve(c, need);
   if (rc) return rc;
   c->arena_off = 0;
@@ -502,15 +504,36 @@ int blsgpu_verify_batch(int sig_group, int scheme, const void* pks, const void* 
   uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)WS_PAIRS_WORDS * 4 * n);
   uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * n);
   if (!d_status || !d_pairs || !d_f) return fail(BLSGPU_E_HIP, "internal: arena too small");
-  rc = run_verify_items(c, sig_group, scheme == BLSGPU_SCHEME_AUG, (const uint8_t*)d_pks, (const uint8_t*)d_sigs, fmt,
-                        (const uint8_t*)d_msgs, (const uint64_t*)d_offs, 0, scheme_dst(sig_group, scheme), n, d_pairs, d_f, d_status);
+  int pre = 0, kfmt = fmt;
+  if (wire) {
+    // wire ingest: PublicKey / Signature from_bytes[_with_mode] -- checked decompression incl. subgroup
+    // test, reference src/public_key.rs:58-74,158-171, src/signature.rs:231-253, src/impls/legacy.rs:100-170.
+    // A decode failure is the item's status (key first, then signature), exactly what a caller that deserialises
+    // before verifying would have seen.
+    uint8_t* d_pk_raw = (uint8_t*)arena_take(c, (sig_group == 1 ? 288 : 144) * n);
+    uint8_t* d_sig_raw = (uint8_t*)arena_take(c, (sig_group == 1 ? 144 : 288) * n);
+    if (!d_pk_raw || !d_sig_raw) return fail(BLSGPU_E_HIP, "internal: arena too small");
+    const int legacy = fmt == BLSGPU_FMT_LEGACY;
+    if (sig_group == 1) {
+      KL(KID_DECOMPRESS, k_decompress<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, legacy, d_pk_raw, d_status, 0);
+      KL(KID_DECOMPRESS, k_decompress<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_sigs, legacy, d_sig_raw, d_status, 1);
+    } else {
+      KL(KID_DECOMPRESS, k_decompress<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, legacy, d_pk_raw, d_status, 0);
+      KL(KID_DECOMPRESS, k_decompress<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_sigs, legacy, d_sig_raw, d_status, 1);
+    }
+    d_pks = d_pk_raw;
+    d_sigs = d_sig_raw;
+    pre = 1;
+    kfmt = BLSGPU_FMT_RAW_PROJ;
+  }
+  rc = run_verify_items(c, sig_group, scheme == BLSGPU_SCHEME_AUG, (const uint8_t*)d_pks, (const uint8_t*)d_sigs, kfmt,
+                        (const uint8_t*)d_msgs, (const uint64_t*)d_offs, 0, scheme_dst(sig_group, scheme), n, d_pairs, d_f, d_status, pre);
   if (rc) return rc;
   if ((rc = copy_out(c, status, d_status, 4 * n))) return rc;
   SYNC_FLUSH(c);
   return 0;
 }
 
-// shared tail of multi_verify / verify_secure: one core_verify of (d_pk RAW_PROJ on device, caller's sig, msg)
 // aug_prefix: MultiSignature::verify under MessageAugmentation prefixes the (aggregated) key bytes
 // (reference src/traits/sig_aug.rs:20-24); verify_secure_message_augmentation does NOT, it only switches the DST
 // (reference src/secure_aggregation.rs:236-246).
@@ -876,6 +899,34 @@ int blsgpu_serialize(int group, const void* pts, size_t n, int fmt_in, int fmt_o
     std::vector<int32_t> z(n, 0);
     HIPCK(hipMemcpy(status, z.data(), 4 * n, is_device_ptr(status) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
   }
+  return 0;
+}
+
+int blsgpu_deserialize(int group, const uint8_t* bytes, size_t n, int fmt_in, void* out, int32_t* status) {
+  if (!g_ctx) return fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)");
+  if (group != 1 && group != 2) return fail(BLSGPU_E_ARG, "group must be 1 or 2");
+  if (fmt_in != BLSGPU_FMT_COMPRESSED && fmt_in != BLSGPU_FMT_LEGACY) return fail(BLSGPU_E_ARG, "fmt_in must be COMPRESSED or LEGACY");
+  if (n == 0) return 0;
+  if (!bytes || !out || !status) return fail(BLSGPU_E_ARG, "null argument");
+  Ctx* c = g_ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCK(hipSetDevice(c->dev));
+  const size_t isz = group == 1 ? 48 : 96, osz = group == 1 ? 144 : 288;
+  int rc = arena_reserve(c, pad256(isz * n) + pad256(osz * n) + pad256(4 * n) + 4096);
+  if (rc) return rc;
+  c->arena_off = 0;
+  const void* d_in;
+  if ((rc = stage_in(c, bytes, isz * n, &d_in))) return rc;
+  uint8_t* d_out = is_device_ptr(out) ? (uint8_t*)out : (uint8_t*)arena_take(c, osz * n);
+  int32_t* d_st = is_device_ptr(status) ? status : (int32_t*)arena_take(c, 4 * n);
+  if (!d_out || !d_st) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  const int legacy = fmt_in == BLSGPU_FMT_LEGACY;
+  if (group == 1) KL(KID_DECOMPRESS, k_decompress<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_in, legacy, d_out, d_st, 0);
+  else KL(KID_DECOMPRESS, k_decompress<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_in, legacy, d_out, d_st, 0);
+  HIPCK(hipGetLastError());
+  if (d_out != out && (rc = copy_out(c, out, d_out, osz * n))) return rc;
+  if (d_st != status && (rc = copy_out(c, status, d_st, 4 * n))) return rc;
+  SYNC_FLUSH(c);
   return 0;
 }
 

@@ -290,3 +290,127 @@ BLS_FN void g2_compress(uint8_t* out, const g2_aff& a, bool legacy) {
   out[0] |= 0x80 | (fp2_lex_largest(a.y) ? 0x20 : 0);
   if (legacy) header_to_legacy(out);
 }
+
+// ---- subgroup membership (endomorphism tests, Scott 2021): needed when points arrive as wire bytes
+// G1: phi(P) = (beta x, y) == [-x^2] P          G2: psi(P) == [x] P          (x = -|x|)
+BLS_FN bool g1_in_subgroup(const g1_aff& p) {
+  if (p.inf) return true;
+  g1_jac j, q;
+  jac_from_aff(j, p);
+  jac_mul_u64(q, j, BLS_X_ABS);
+  jac_mul_u64(q, q, BLS_X_ABS);              // [x^2] P
+  if (jac_is_inf(q)) return false;
+  fp beta, bx, z2, z3, t;
+  fp_load(beta, G1_BETA);
+  fp_mul(bx, beta, p.x);
+  fp_sqr(z2, q.z);
+  fp_mul(z3, z2, q.z);
+  fp_mul(t, bx, z2);
+  if (!fp_eq(t, q.x)) return false;          // x(phi P) == x(-[x^2]P)
+  fp_mul(t, p.y, z3);
+  fp_neg(t, t);
+  return fp_eq(t, q.y);                      // y(phi P) == -y([x^2]P)
+}
+BLS_FN bool g2_in_subgroup(const g2_aff& p) {
+  if (p.inf) return true;
+  g2_jac j, q, ps;
+  jac_from_aff(j, p);
+  jac_mul_u64(q, j, BLS_X_ABS);              // [|x|] P = -[x] P
+  if (jac_is_inf(q)) return false;
+  g2_psi(ps, j);                             // Z = 1
+  fp2 z2, z3, t;
+  fp2_sqr(z2, q.z);
+  fp2_mul(z3, z2, q.z);
+  fp2_mul(t, ps.x, z2);
+  if (!fp2_eq(t, q.x)) return false;
+  fp2_mul(t, ps.y, z3);
+  fp2_neg(t, t);
+  return fp2_eq(t, q.y);
+}
+
+// ---- checked decompression (ZCash encoding; `legacy` = Dash header, reference src/impls/legacy.rs:39-67,100-126,144-170)
+// returns 0 ok, 7 bad encoding (DeserializationError), 8 legacy header violation (LegacyFormatError)
+BLS_FN bool fp_from_be48_checked(fp& r, const uint8_t* b, uint8_t b0) {   // b0 = first byte with the flag bits cleared
+  fp t;
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    const uint8_t* q = b + 4 * (11 - i);
+    uint32_t hi = (i == 11) ? b0 : q[0];
+    t.l[i] = (hi << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+  }
+  uint32_t bw = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) (void)subb32(t.l[i], FP_P[i], bw);
+  if (!bw) return false;                     // value >= p
+  fp_to_mont(r, t);
+  return true;
+}
+BLS_FN int wire_header(uint8_t& b0, bool legacy) {
+  if (legacy) {
+    if (b0 != 0xc0) {
+      const bool ys = (b0 & 0x80) != 0;
+      b0 &= 0x7f;
+      if (b0 & 0xe0) return 8;
+      b0 |= 0x80;
+      if (ys) b0 |= 0x20;
+    }
+  } else if (b0 != 0xc0 && (b0 & 0xc0) != 0x80) {
+    return 7;                                // validate_modern_format, legacy.rs:71-82
+  }
+  return 0;
+}
+BLS_FN int g1_decompress(g1_jac& out, const uint8_t* b, bool legacy) {
+  uint8_t b0 = b[0];
+  int rc = wire_header(b0, legacy);
+  if (rc) return rc;
+  if (!(b0 & 0x80)) return 7;
+  const bool inf = (b0 & 0x40) != 0, sign = (b0 & 0x20) != 0;
+  if (inf) {
+    uint32_t o = (b0 & 0x3f);
+    for (int i = 1; i < 48; i++) o |= b[i];
+    if (o) return 7;
+    jac_set_inf(out);
+    return 0;
+  }
+  g1_aff a;
+  if (!fp_from_be48_checked(a.x, b, b0 & 0x1f)) return 7;
+  fp y2, t, four;
+  fp_sqr(t, a.x);
+  fp_mul(t, t, a.x);
+  fp_load(four, G1_B);
+  fp_add(y2, t, four);
+  if (!fp_sqrt(a.y, y2)) return 7;
+  if (fp_lex_largest(a.y) != sign) fp_neg(a.y, a.y);
+  a.inf = false;
+  if (!g1_in_subgroup(a)) return 7;
+  jac_from_aff(out, a);
+  return 0;
+}
+BLS_FN int g2_decompress(g2_jac& out, const uint8_t* b, bool legacy) {
+  uint8_t b0 = b[0];
+  int rc = wire_header(b0, legacy);
+  if (rc) return rc;
+  if (!(b0 & 0x80)) return 7;
+  const bool inf = (b0 & 0x40) != 0, sign = (b0 & 0x20) != 0;
+  if (inf) {
+    uint32_t o = (b0 & 0x3f);
+    for (int i = 1; i < 96; i++) o |= b[i];
+    if (o) return 7;
+    jac_set_inf(out);
+    return 0;
+  }
+  g2_aff a;
+  if (!fp_from_be48_checked(a.x.c1, b, b0 & 0x1f)) return 7;
+  if (!fp_from_be48_checked(a.x.c0, b + 48, b[48])) return 7;
+  fp2 y2, t, bb;
+  fp2_sqr(t, a.x);
+  fp2_mul(t, t, a.x);
+  fp2_load(bb, G2_B);
+  fp2_add(y2, t, bb);
+  if (!fp2_sqrt(a.y, y2)) return 7;
+  if (fp2_lex_largest(a.y) != sign) fp2_neg(a.y, a.y);
+  a.inf = false;
+  if (!g2_in_subgroup(a)) return 7;
+  jac_from_aff(out, a);
+  return 0;
+}

@@ -119,7 +119,7 @@ __device__ __forceinline__ void store_g2_pt(uint8_t* base, size_t i, const g2_ja
 // ---- kernel prototypes (each kernel is defined in exactly one translation unit, see the BLS_TU_* sections)
 template <int SG>
 __global__ void k_prepare(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int aug, const uint8_t* msgs,
-                          const uint64_t* offs, int single_msg, dst_arg dst, uint32_t* pairs, int32_t* status);
+                          const uint64_t* offs, int single_msg, dst_arg dst, uint32_t* pairs, int32_t* status, int pre_status);
 __global__ void k_miller2(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws, int fixed_g2);
 __global__ void k_finalexp(size_t n, const uint32_t* fws, int32_t* status);
 __global__ void k_miller2s(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws, int fixed_g2);
@@ -158,6 +158,10 @@ template <int G>
 __global__ void k_msm_chunk(int c, int W, int clast, int CH, const uint8_t* sums, uint8_t* partials);
 template <int G>
 __global__ void k_normalize(uint8_t* pt);
+// wire bytes (48/96 B, modern or legacy header) -> RAW_PROJ with the checks of from_compressed; status[i] = 0 / 7 / 8.
+// keep != 0: leave a non-zero status[i] that is already there (first error wins when keys and signatures are decoded)
+template <int G>
+__global__ void k_decompress(size_t n, const uint8_t* bytes, int legacy, uint8_t* out, int32_t* status, int keep);
 
 #if defined(BLS_TU_PREPARE1) || defined(BLS_TU_PREPARE2)
 // =====================================================================================================
@@ -166,9 +170,10 @@ __global__ void k_normalize(uint8_t* pt);
 template <int SG>
 __global__ void __launch_bounds__(BLS_BLOCK) k_prepare(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int aug,
                                                      const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst,
-                                                     uint32_t* pairs, int32_t* status) {
+                                                     uint32_t* pairs, int32_t* status, int pre_status) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (pre_status && status[i] != BLS_OK) return;   // the item already failed to decode
   size_t mi = single_msg ? 0 : i;
   const uint8_t* m = msgs + offs[mi];
   uint32_t mlen = (uint32_t)(offs[mi + 1] - offs[mi]);
@@ -195,9 +200,9 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_prepare(size_t n, const uint8_t* 
 }
 
 #if defined(BLS_TU_PREPARE1)
-template __global__ void k_prepare<1>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, int, dst_arg, uint32_t*, int32_t*);
+template __global__ void k_prepare<1>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, int, dst_arg, uint32_t*, int32_t*, int);
 #else
-template __global__ void k_prepare<2>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, int, dst_arg, uint32_t*, int32_t*);
+template __global__ void k_prepare<2>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, int, dst_arg, uint32_t*, int32_t*, int);
 #endif
 #endif  // BLS_TU_PREPARE*
 
@@ -782,11 +787,26 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_normalize(uint8_t* pt) {
   }
   msm_pt<G>::store(pt, 0, p);
 }
+template <int G>
+__global__ void __launch_bounds__(BLS_BLOCK) k_decompress(size_t n, const uint8_t* bytes, int legacy, uint8_t* out, int32_t* status, int keep) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (keep && status[i] != BLS_OK) return;
+  typename msm_pt<G>::jac_t p;
+  int rc;
+  if (G == 1) rc = g1_decompress(*(g1_jac*)&p, bytes + 48 * i, legacy != 0);
+  else rc = g2_decompress(*(g2_jac*)&p, bytes + 96 * i, legacy != 0);
+  if (rc) jac_set_inf(p);
+  msm_pt<G>::store(out, i, p);
+  status[i] = rc;
+}
 #if defined(BLS_TU_MSM1)
+template __global__ void k_decompress<1>(size_t, const uint8_t*, int, uint8_t*, int32_t*, int);
 template __global__ void k_msm_bucket<1>(size_t, const uint8_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*);
 template __global__ void k_msm_chunk<1>(int, int, int, int, const uint8_t*, uint8_t*);
 template __global__ void k_normalize<1>(uint8_t*);
 #else
+template __global__ void k_decompress<2>(size_t, const uint8_t*, int, uint8_t*, int32_t*, int);
 template __global__ void k_msm_bucket<2>(size_t, const uint8_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*);
 template __global__ void k_msm_chunk<2>(int, int, int, int, const uint8_t*, uint8_t*);
 template __global__ void k_normalize<2>(uint8_t*);

@@ -137,6 +137,14 @@ int blsgpu_pairing_product_is_one(const void* g1s, const void* g2s, size_t n, in
  * src/impls/legacy.rs:85-170.  group = 1 (G1, 48 B) or 2 (G2, 96 B).  status[i]: 0 or BAD_ENCODING/LEGACY_FORMAT. */
 int blsgpu_serialize(int group, const void* pts, size_t n, int fmt_in, int fmt_out, void* out, int32_t* status);
 
+/* Wire ingest: PublicKey::try_from / from_bytes_with_mode and Signature::from_bytes_with_mode -- checked decompression
+ * (on curve, subgroup) of 48-byte (group 1) or 96-byte (group 2) encodings, modern or legacy header
+ * (src/public_key.rs:58-74,158-171, src/signature.rs:231-253, src/impls/legacy.rs:39-82,100-126,144-170).
+ * out: RAW_PROJ; status[i]: 0, BLSGPU_BAD_ENCODING or BLSGPU_LEGACY_FORMAT.  blsgpu_verify_batch also accepts
+ * fmt = BLSGPU_FMT_COMPRESSED / BLSGPU_FMT_LEGACY directly (keys and signatures in the same format); a decode failure
+ * becomes that item's status. */
+int blsgpu_deserialize(int group, const uint8_t* bytes, size_t n, int fmt_in, void* out, int32_t* status);
+
 /* Sharded aggregate verify (one process per GPU): the shard-local part of core_aggregate_verify
  * (src/traits/sig_core.rs:149-178).  out_f12 (576 B) = product of the Miller values of the shard's (H(m_i), pk_i) pairs
  * [times (sig, -g) when sig != NULL], before the final exponentiation; *first_bad = local index of the first identity

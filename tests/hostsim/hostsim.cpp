@@ -112,6 +112,15 @@ int hs_cyclotomic_check(int n, const uint32_t* g1s, const uint32_t* g2s) {
   (void)n;
   return memcmp(wa, wb, sizeof wa) == 0;
 }
+// checked decompression: returns the status code; on success writes the re-compressed (modern) bytes
+int hs_decompress(int group, const uint8_t* in, int legacy, uint8_t* out) {
+  if (group == 1) {
+    g1_jac p; int rc = g1_decompress(p, in, legacy != 0); if (rc) return rc;
+    g1_aff a; jac_to_aff(a, p); g1_compress(out, a, false); return 0;
+  }
+  g2_jac p; int rc = g2_decompress(p, in, legacy != 0); if (rc) return rc;
+  g2_aff a; jac_to_aff(a, p); g2_compress(out, a, false); return 0;
+}
 int hs_verify(int sig_group, const uint32_t* pk, const uint32_t* sig, int aug, const uint8_t* msg, uint32_t len,
               const uint8_t* dst, uint32_t dlen) {
   g1_aff P[2]; g2_aff Q[2];

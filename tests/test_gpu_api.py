@@ -370,3 +370,63 @@ def test_msm_pippenger_closed_form(api, group):
         want = E.mul(gen, sum(t * s for t, s in zip(ts, sks)) % c.R)
         got = api.serialize(group, [api.point_sum(group, pks, ts)])[0]
         assert got == comp(want), n
+
+
+@pytest.mark.parametrize('group', [1, 2])
+def test_deserialize_wire_formats(api, group):
+    """Checked decompression on the GPU vs the oracle: valid points, both sign bits, infinity, legacy headers, malformed
+    headers, x >= p, off-curve x, on-curve points outside the subgroup (reference src/impls/legacy.rs:172-253,
+    tests/legacy_comprehensive_test.rs:212-240)."""
+    rng = random.Random(70 + group)
+    E, gen, comp, dec = (c.E1, c.G1_GEN, c.g1_compress, c.g1_decompress) if group == 1 else (c.E2, c.G2_GEN, c.g2_compress, c.g2_decompress)
+    w = 48 * group
+    good = [comp(E.mul(gen, rng.randrange(1, c.R))) for _ in range(8)] + [comp(None)]
+    flipped = [bytes([b[0] ^ 0x20]) + b[1:] for b in good[:8]]
+    bad = [bytes(w), bytes([0x40]) + bytes(w - 1), bytes([0xc0]) + bytes(w - 2) + b'\x01', bytes([0xe0]) + bytes(w - 1),
+           bytes([0x9f]) + b'\xff' * (w - 1)]
+    scan = []
+    x0 = rng.randrange(c.P)
+    for k in range(24):
+        x = (x0 + k) % c.P
+        enc = x.to_bytes(48, 'big') if group == 1 else (5).to_bytes(48, 'big') + x.to_bytes(48, 'big')
+        scan.append(bytes([enc[0] | 0x80]) + enc[1:])
+    blobs = good + flipped + bad + scan
+
+    def want(b):
+        try:
+            return comp(dec(b)), 0
+        except c.DecodeError:
+            return None, 7
+    pts, st = api.deserialize(group, blobs)
+    expect = [want(b) for b in blobs]
+    assert st == [e[1] for e in expect]
+    back = api.serialize(group, [p for p, s in zip(pts, st) if s == 0])
+    assert back == [e[0] for e in expect if e[1] == 0]
+    assert sum(1 for e in expect[-24:] if e[1] == 7) >= 5 and any(e[1] == 0 for e in expect[:9])
+    # legacy headers
+    leg = [ref.modern_to_legacy(b) for b in good]
+    pts, st = api.deserialize(group, leg + [bytes([0xff]) * w, bytes([0x20]) + bytes(w - 1)], legacy=True)
+    assert st == [0] * 9 + [8, 8]
+    assert api.serialize(group, pts[:9]) == good
+
+
+def test_verify_batch_wire_formats(api):
+    """verify_batch straight from wire bytes (keys 48 B / signatures 96 B of Bls12381G2Impl, modern and legacy), incl. the
+    reference's C++ vectors as raw bytes (tests/cpp_integration_test.rs:35-82) and undecodable items."""
+    k = KATS['cpp']
+    msg = bytes.fromhex(k['message'])
+    pks = [bytes.fromhex(h) for h in k['pk']]
+    sigs = [bytes.fromhex(h) for h in k['sig']]
+    assert api.verify_batch(2, api.BASIC, pks, sigs, [msg] * 3, fmt=api.FMT_COMPRESSED) == [0, 0, 0]
+    leg_p, leg_s = [ref.modern_to_legacy(b) for b in pks], [ref.modern_to_legacy(b) for b in sigs]
+    assert api.verify_batch(2, api.BASIC, leg_p, leg_s, [msg] * 3, fmt=api.FMT_LEGACY) == [0, 0, 0]
+    bad_pk = [pks[0], bytes(48), pks[2]]
+    bad_sig = [sigs[1], sigs[1], bytes([0x40]) + bytes(95)]
+    assert api.verify_batch(2, api.BASIC, bad_pk, bad_sig, [msg] * 3, fmt=api.FMT_COMPRESSED) == [1, 7, 7]
+    assert api.verify_batch(2, api.BASIC, [bytes([0xff]) * 48], [leg_s[0]], [msg], fmt=api.FMT_LEGACY) == [8]
+    # G1Impl orientation from wire bytes
+    C = ref.G1Impl
+    sk = ref.keygen_from_hash(b'\x21' * 32)
+    pk, sig = C.pk_to_bytes(ref.public_key(C, sk)), C.sig_to_bytes(ref.sign(C, ref.AUG, sk, b'wire'))
+    assert api.verify_batch(1, api.AUG, [pk], [sig], [b'wire'], fmt=api.FMT_COMPRESSED) == [0]
+    assert api.verify_batch(1, api.AUG, [pk], [sig], [b'wirf'], fmt=api.FMT_COMPRESSED) == [1]

@@ -134,3 +134,41 @@ def test_verify_items(hs):
             assert hs.hs_verify(sg, pkraw(pk, rng), sigraw(None), aug, m, len(m), d, len(d)) == 2
             assert hs.hs_verify(sg, pkraw(None), sigraw(sig, rng), aug, m, len(m), d, len(d)) == 3
             assert hs.hs_verify(sg, pkraw(None), sigraw(None), aug, m, len(m), d, len(d)) == 2
+
+
+def test_decompress(hs):
+    """Checked decompression (device code on the host) vs the oracle: sign bits, infinity, legacy, malformed, off-curve and
+    on-curve-but-not-in-subgroup encodings (fast endomorphism subgroup tests vs the oracle's [r]P)."""
+    rng = random.Random(12)
+
+    def dec(group, b, legacy=0):
+        out = ctypes.create_string_buffer(48 * group)
+        rc = hs.hs_decompress(group, b, legacy, out)
+        return rc, out.raw
+    for group, E, gen, comp in ((1, c.E1, c.G1_GEN, c.g1_compress), (2, c.E2, c.G2_GEN, c.g2_compress)):
+        w = 48 * group
+        for _ in range(4):
+            pt = E.mul(gen, rng.randrange(1, c.R))
+            b = comp(pt)
+            assert dec(group, b) == (0, b) and dec(group, ref.modern_to_legacy(b), 1) == (0, b)
+            assert dec(group, bytes([b[0] ^ 0x20]) + b[1:]) == (0, comp(E.neg(pt)))
+        assert dec(group, comp(None)) == (0, comp(None)) and dec(group, comp(None), 1) == (0, comp(None))
+        for bb in (bytes(w), bytes([0x40]) + bytes(w - 1), bytes([0xc0]) + bytes(w - 2) + b'\x01', bytes([0xe0]) + bytes(w - 1),
+                   bytes([0x9f]) + b'\xff' * (w - 1)):
+            assert dec(group, bb)[0] == 7
+        assert dec(group, bytes([0xff]) * w, 1)[0] == 8 and dec(group, bytes([0x20]) + bytes(w - 1), 1)[0] == 8
+        x0 = rng.randrange(c.P)
+        seen = set()
+        for k in range(30):
+            x = (x0 + k) % c.P if group == 1 else ((x0 + k) % c.P, 5)
+            y = c.fp_sqrt(E.rhs(x)) if group == 1 else c.f2_sqrt(E.rhs(x))
+            enc = x.to_bytes(48, 'big') if group == 1 else x[1].to_bytes(48, 'big') + x[0].to_bytes(48, 'big')
+            rc, _ = dec(group, bytes([enc[0] | 0x80]) + enc[1:])
+            if y is None:
+                assert rc == 7
+                seen.add('off')
+            else:
+                insub = c.g1_in_subgroup((x, y)) if group == 1 else c.g2_in_subgroup((x, y))
+                assert (rc == 0) == insub
+                seen.add('sub' if insub else 'nosub')
+        assert {'off', 'nosub'} <= seen
