@@ -31,7 +31,7 @@ EXPORTS = [
     'blsgpu_hash_to_g2', 'blsgpu_sum_g1', 'blsgpu_sum_g2', 'blsgpu_msm_g1', 'blsgpu_msm_g2',
     'blsgpu_pairing_product_is_one', 'blsgpu_serialize', 'blsgpu_sign_batch',
     'blsgpu_profile_enable', 'blsgpu_profile_count', 'blsgpu_profile_get',
-    'blsgpu_aggregate_partial', 'blsgpu_fp12_product_is_one', 'blsgpu_core_verify', 'blsgpu_deserialize',
+    'blsgpu_aggregate_partial', 'blsgpu_fp12_product_is_one', 'blsgpu_core_verify', 'blsgpu_deserialize', 'blsgpu_pop_verify_batch', 'blsgpu_aggregate_secure',
 ]
 
 
@@ -122,6 +122,8 @@ def load_library(path=None):
         lib.blsgpu_fp12_product_is_one.argtypes = [vp, sz, i32p]
         lib.blsgpu_core_verify.argtypes = [ci, u8p, sz, vp, vp, u8p, u64p, sz, ci, i32p]
         lib.blsgpu_deserialize.argtypes = [ci, u8p, sz, ci, vp, i32p]
+        lib.blsgpu_pop_verify_batch.argtypes = [ci, vp, vp, sz, ci, i32p]
+        lib.blsgpu_aggregate_secure.argtypes = [ci, vp, vp, sz, ci, ci, vp, i32p]
         lib.blsgpu_profile_get.argtypes = [ci, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
         _lib = lib
     return _lib
@@ -262,6 +264,27 @@ def pairing_product_is_one(g1s, g2s, fmt=FMT_RAW_PROJ):
     a, b = b''.join(g1s), b''.join(g2s)
     _check(lib.blsgpu_pairing_product_is_one(_ptr(a), _ptr(b), len(g1s), fmt, ctypes.byref(r)))
     return bool(r.value)
+
+
+def pop_verify_batch(sig_group, pks, proofs, fmt=FMT_RAW_PROJ):
+    """status list of ProofOfPossession::verify for n (pk, proof) pairs."""
+    lib = init()
+    n = len(pks)
+    st = (ctypes.c_int32 * max(n, 1))()
+    a, b = b''.join(pks), b''.join(proofs)
+    _check(lib.blsgpu_pop_verify_batch(sig_group, _ptr(a), _ptr(b), n, fmt, ctypes.cast(st, ctypes.c_void_p)))
+    return list(st)[:n]
+
+
+def aggregate_secure(sig_group, pks, sigs, ser_format=MODERN, fmt=FMT_RAW_PROJ):
+    """(status, RAW_PROJ aggregate signature) of aggregate_secure[_with_mode]."""
+    lib = init()
+    osz = 144 if sig_group == 1 else 288
+    out = ctypes.create_string_buffer(osz)
+    st = ctypes.c_int32(-99)
+    a, b = b''.join(pks), b''.join(sigs)
+    _check(lib.blsgpu_aggregate_secure(sig_group, _ptr(a), _ptr(b), len(pks), ser_format, fmt, ctypes.cast(out, ctypes.c_void_p), ctypes.byref(st)))
+    return st.value, out.raw
 
 
 def deserialize(group, blobs, legacy=False):

@@ -902,6 +902,101 @@ int blsgpu_serialize(int group, const void* pts, size_t n, int fmt_in, int fmt_o
   return 0;
 }
 
+/* ProofOfPossession::verify for n (pk, proof) pairs: pop_verify(pk, sig) = core_verify(pk, sig, pk.to_bytes(), POP_DST)
+ * (reference src/proof_of_possession.rs:79-81, src/traits/sig_pop.rs:67-70; POP_DST src/impls/g1.rs:119, g2.rs:117). */
+int blsgpu_pop_verify_batch(int sig_group, const void* pks, const void* proofs, size_t n, int fmt, int32_t* status) {
+  int rc = check_common(sig_group, 0, fmt);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  if (!pks || !proofs || !status) return fail(BLSGPU_E_ARG, "null argument");
+  Ctx* c = g_ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCK(hipSetDevice(c->dev));
+  const size_t pkb = pk_size(sig_group, fmt) * n, sgb = sig_size(sig_group, fmt) * n;
+  size_t need = pad256(pkb) + pad256(sgb) + pad256(4 * n) + 2 * pad256((size_t)WS_PAIRS_WORDS * 4 * n) + 4096;
+  if ((rc = arena_reserve(c, need))) return rc;
+  c->arena_off = 0;
+  const void *d_pks, *d_sigs;
+  if ((rc = stage_in(c, pks, pkb, &d_pks))) return rc;
+  if ((rc = stage_in(c, proofs, sgb, &d_sigs))) return rc;
+  uint64_t* d_offs = (uint64_t*)arena_take(c, 16);
+  int32_t* d_status = (int32_t*)arena_take(c, 4 * n);
+  uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)WS_PAIRS_WORDS * 4 * n);
+  uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * n);
+  if (!d_offs || !d_status || !d_pairs || !d_f) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  HIPCK(hipMemsetAsync(d_offs, 0, 16, c->stream));
+  const char* pd = sig_group == 1 ? "BLS_POP_BLS12381G1_XMD:SHA-256_SSWU_RO_POP_" : "BLS_POP_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_";
+  // mode 2: the message is the compressed key (single_msg = 1 keeps the unused message indexing in bounds)
+  rc = run_verify_items(c, sig_group, 2, (const uint8_t*)d_pks, (const uint8_t*)d_sigs, fmt, (const uint8_t*)d_offs, d_offs, 1,
+                        make_dst((const uint8_t*)pd, strlen(pd)), n, d_pairs, d_f, d_status);
+  if (rc) return rc;
+  if ((rc = copy_out(c, status, d_status, 4 * n))) return rc;
+  SYNC_FLUSH(c);
+  return 0;
+}
+
+/* Sign-side secure aggregation: aggregate_secure[_with_mode] / AggregateSignature::from_signatures_secure
+ * (reference src/secure_aggregation.rs:110-169,338-352, src/aggregate_signature.rs:191-227): sig_agg = sum t_i * sig[idx_i]
+ * over the keys in sorted order, where idx_i is the FIRST input position whose serialised key equals the i-th sorted key
+ * (the reference's `position` search, so duplicate keys pick the first matching signature).  n == 0: the identity. */
+int blsgpu_aggregate_secure(int sig_group, const void* pks, const void* sigs, size_t n, int ser_format, int fmt, void* out_sig,
+                            int32_t* status) {
+  int rc = check_common(sig_group, 0, fmt);
+  if (rc) return rc;
+  if (!out_sig || !status || (n && (!pks || !sigs))) return fail(BLSGPU_E_ARG, "null argument");
+  if (ser_format != 0 && ser_format != 1) return fail(BLSGPU_E_ARG, "ser_format must be 0 (Modern) or 1 (Legacy)");
+  if (ser_format == 1 && sig_group != 2) return fail(BLSGPU_E_ARG, "Legacy serialization exists only for Bls12381G2Impl");
+  Ctx* c = g_ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCK(hipSetDevice(c->dev));
+  const size_t psz = pk_size(sig_group, fmt), ssz = sig_size(sig_group, fmt), width = sig_group == 1 ? 96 : 48, T = accumulate_lanes(n);
+  const size_t osz = sig_group == 1 ? 144 : 288;
+  size_t need = pad256(psz * n) + pad256(ssz * n) + pad256(width * n) + pad256(4 * n) + pad256(32 * n) + pad256(288 * T) + 8192 + msm_ws_bytes(n);
+  if ((rc = arena_reserve(c, need))) return rc;
+  c->arena_off = 0;
+  int32_t st = BLSGPU_OK;
+  uint8_t* d_part = (uint8_t*)arena_take(c, 288 * T);
+  if (!d_part) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  if (n == 0) {
+    if (sig_group == 1) rc = run_point_sum<1>(c, nullptr, fmt, nullptr, nullptr, 0, d_part, T);
+    else rc = run_point_sum<2>(c, nullptr, fmt, nullptr, nullptr, 0, d_part, T);
+    if (rc) return rc;
+  } else {
+    const void *d_pks, *d_sigs;
+    if ((rc = stage_in(c, pks, psz * n, &d_pks))) return rc;
+    if ((rc = stage_in(c, sigs, ssz * n, &d_sigs))) return rc;
+    uint8_t* d_bytes = (uint8_t*)arena_take(c, width * n);
+    uint32_t* d_idx = (uint32_t*)arena_take(c, 4 * n);
+    uint8_t* d_scal = (uint8_t*)arena_take(c, 32 * n);
+    if (!d_bytes || !d_idx || !d_scal) return fail(BLSGPU_E_HIP, "internal: arena too small");
+    if (sig_group == 1) KL(KID_COMPRESS, k_compress<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, fmt, ser_format, d_bytes);
+    else KL(KID_COMPRESS, k_compress<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, fmt, ser_format, d_bytes);
+    HIPCK(hipGetLastError());
+    std::vector<uint8_t> kb(width * n);
+    HIPCK(hipMemcpyAsync(kb.data(), d_bytes, width * n, hipMemcpyDeviceToHost, c->stream));
+    SYNC_FLUSH(c);
+    std::vector<uint32_t> perm;
+    std::vector<uint8_t> scal;
+    st = secure_coefficients_host(kb.data(), n, width, perm, scal);
+    if (st == BLSGPU_OK) {
+      std::vector<uint32_t> idx(n);
+      for (size_t i = 0; i < n; i++)   // stable sort: equal keys keep input order, the first of a run has the smallest index
+        idx[i] = (i > 0 && memcmp(&kb[(size_t)perm[i] * width], &kb[(size_t)perm[i - 1] * width], width) == 0) ? idx[i - 1] : perm[i];
+      HIPCK(hipMemcpyAsync(d_idx, idx.data(), 4 * n, hipMemcpyHostToDevice, c->stream));
+      HIPCK(hipMemcpyAsync(d_scal, scal.data(), 32 * n, hipMemcpyHostToDevice, c->stream));
+      if (sig_group == 1) rc = run_point_sum<1>(c, (const uint8_t*)d_sigs, fmt, d_scal, d_idx, n, d_part, T);
+      else rc = run_point_sum<2>(c, (const uint8_t*)d_sigs, fmt, d_scal, d_idx, n, d_part, T);
+      if (rc) return rc;
+      SYNC_FLUSH(c);                   // idx / scal are host vectors: finish the copies before they go out of scope
+    }
+  }
+  if (st == BLSGPU_OK && (rc = copy_out(c, out_sig, d_part, osz))) return rc;
+  SYNC_FLUSH(c);
+  if (is_device_ptr(status)) HIPCK(hipMemcpy(status, &st, 4, hipMemcpyHostToDevice));
+  else *status = st;
+  return 0;
+}
+
 int blsgpu_deserialize(int group, const uint8_t* bytes, size_t n, int fmt_in, void* out, int32_t* status) {
   if (!g_ctx) return fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)");
   if (group != 1 && group != 2) return fail(BLSGPU_E_ARG, "group must be 1 or 2");

@@ -185,13 +185,13 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_prepare(size_t n, const uint8_t* 
     g1_jac sig;
     load_g2_pt(pk, pks, i, fmt);
     load_g1_pt(sig, sigs, i, fmt);
-    st = prepare_g1impl(P, Q, pk, sig, aug != 0, m, mlen, dst.b, dst.len);
+    st = prepare_g1impl(P, Q, pk, sig, aug, m, mlen, dst.b, dst.len);
   } else {
     g1_jac pk;
     g2_jac sig;
     load_g1_pt(pk, pks, i, fmt);
     load_g2_pt(sig, sigs, i, fmt);
-    st = prepare_g2impl(P, Q, pk, sig, aug != 0, m, mlen, dst.b, dst.len);
+    st = prepare_g2impl(P, Q, pk, sig, aug, m, mlen, dst.b, dst.len);
   }
   status[i] = st;
   if (st != BLS_OK) return;

@@ -137,6 +137,17 @@ int blsgpu_pairing_product_is_one(const void* g1s, const void* g2s, size_t n, in
  * src/impls/legacy.rs:85-170.  group = 1 (G1, 48 B) or 2 (G2, 96 B).  status[i]: 0 or BAD_ENCODING/LEGACY_FORMAT. */
 int blsgpu_serialize(int group, const void* pts, size_t n, int fmt_in, int fmt_out, void* out, int32_t* status);
 
+/* ProofOfPossession::<C>::verify(pk) for n pairs: pop_verify = core_verify(pk, proof, pk.to_bytes(), POP_DST)
+ * (src/proof_of_possession.rs:79-81, src/traits/sig_pop.rs:67-70). */
+int blsgpu_pop_verify_batch(int sig_group, const void* pks, const void* proofs, size_t n, int fmt, int32_t* status);
+
+/* aggregate_secure / aggregate_secure_with_mode / AggregateSignature::from_signatures_secure: the signature that
+ * verify_secure accepts, sum t_i * sig[idx_i] over the sorted keys (src/secure_aggregation.rs:110-169,338-352,
+ * src/aggregate_signature.rs:191-227; duplicate keys pick the first matching signature, as the reference's position
+ * search does).  out_sig: one RAW_PROJ point; *status: BLSGPU_OK or BLSGPU_INVALID_COEFFICIENT. */
+int blsgpu_aggregate_secure(int sig_group, const void* pks, const void* sigs, size_t n, int ser_format, int fmt,
+                            void* out_sig, int32_t* status);
+
 /* Wire ingest: PublicKey::try_from / from_bytes_with_mode and Signature::from_bytes_with_mode -- checked decompression
  * (on curve, subgroup) of 48-byte (group 1) or 96-byte (group 2) encodings, modern or legacy header
  * (src/public_key.rs:58-74,158-171, src/signature.rs:231-253, src/impls/legacy.rs:39-82,100-126,144-170).

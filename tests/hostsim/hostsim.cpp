@@ -127,10 +127,10 @@ int hs_verify(int sig_group, const uint32_t* pk, const uint32_t* sig, int aug, c
   int st;
   if (sig_group == 1) {
     g2_jac k; g1_jac s; load_g2_jac(k, pk); load_g1_jac(s, sig);
-    st = prepare_g1impl(P, Q, k, s, aug != 0, msg, len, dst, dlen);
+    st = prepare_g1impl(P, Q, k, s, aug, msg, len, dst, dlen);
   } else {
     g1_jac k; g2_jac s; load_g1_jac(k, pk); load_g2_jac(s, sig);
-    st = prepare_g2impl(P, Q, k, s, aug != 0, msg, len, dst, dlen);
+    st = prepare_g2impl(P, Q, k, s, aug, msg, len, dst, dlen);
   }
   if (st != BLS_OK) return st;
   fp12 f;

@@ -430,3 +430,54 @@ def test_verify_batch_wire_formats(api):
     pk, sig = C.pk_to_bytes(ref.public_key(C, sk)), C.sig_to_bytes(ref.sign(C, ref.AUG, sk, b'wire'))
     assert api.verify_batch(1, api.AUG, [pk], [sig], [b'wire'], fmt=api.FMT_COMPRESSED) == [0]
     assert api.verify_batch(1, api.AUG, [pk], [sig], [b'wirf'], fmt=api.FMT_COMPRESSED) == [1]
+
+
+@pytest.mark.parametrize('C,sg', IMPLS, ids=['g1', 'g2'])
+def test_pop_verify_batch(api, C, sg):
+    """ProofOfPossession::verify (reference src/proof_of_possession.rs:79-81, src/traits/sig_pop.rs:61-70)."""
+    rng = random.Random(80 + sg)
+    pkraw, sigraw = raw_fns(sg)
+    sks, pks = keys(C, 6, 21)
+    proofs = [ref.pop_prove(C, s) for s in sks]
+    expect = [0] * 6
+    proofs[2] = proofs[3]                      # someone else's proof
+    expect[2] = 1
+    pk_in = list(pks)
+    pk_in[4] = None
+    expect[4] = 3
+    pr_in = list(proofs)
+    pr_in[5] = None
+    expect[5] = 2
+    for i in range(6):
+        try:
+            ref.pop_verify(C, pk_in[i], pr_in[i])
+            assert expect[i] == 0
+        except ref.BlsError:
+            assert expect[i] != 0
+    assert api.pop_verify_batch(sg, [pkraw(p, rng) for p in pk_in], [sigraw(s, rng) for s in pr_in]) == expect
+    # a signature under the signing DST is not a proof of possession
+    sig = ref.sign(C, ref.POP, sks[0], C.pk_to_bytes(pks[0]))
+    assert api.pop_verify_batch(sg, [pkraw(pks[0], rng)], [sigraw(sig, rng)]) == [1]
+
+
+@pytest.mark.parametrize('C,sg', IMPLS, ids=['g1', 'g2'])
+def test_aggregate_secure(api, C, sg):
+    """aggregate_secure[_with_mode] (reference src/secure_aggregation.rs:110-169,338-352): equals the oracle's aggregate,
+    incl. duplicate keys (first matching signature), and round-trips through verify_secure; n = 2,000 uses the bucket MSM."""
+    rng = random.Random(90 + sg)
+    pkraw, sigraw = raw_fns(sg)
+    sks, pks = keys(C, 7, 31)
+    msg = b'aggregate me'
+    sigs = [ref.sign(C, ref.BASIC, s, msg) for s in sks]
+    pks[5], sigs[5] = pks[1], ref.sign(C, ref.BASIC, sks[1], b'another message')      # duplicate key, different signature
+    for mode in ([0] if sg == 1 else [0, 1]):
+        st, agg = api.aggregate_secure(sg, [pkraw(p, rng) for p in pks], [sigraw(s, rng) for s in sigs], mode)
+        want = ref.aggregate_secure(C, pks, sigs, None if sg == 1 else mode)
+        assert st == 0 and api.serialize(sg, [agg])[0] == C.sig_to_bytes(want)
+    assert api.serialize(sg, [api.aggregate_secure(sg, [], [])[1]])[0] == C.sig_to_bytes(None)
+    n = 2000
+    dsks = [0x4242 + 3 * i for i in range(n)]
+    dpks, dsigs = api.sign_batch(sg, api.BASIC, dsks, [msg] * n)
+    st, agg = api.aggregate_secure(sg, dpks, dsigs)
+    assert st == 0 and api.verify_secure(sg, api.BASIC, dpks, agg, msg) == 0
+    assert api.verify_secure(sg, api.BASIC, dpks[1:], agg, msg) == 1
