@@ -22,10 +22,10 @@ thread_local std::string t_err;
 
 enum {
   KID_PREPARE, KID_MILLER2, KID_FINALEXP, KID_PREPARE_AGG, KID_PAIRS_AFF, KID_MILLER1, KID_F12_FOLD, KID_FINALEXP_ONE,
-  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_F12_IO, KID_MSM_SORT, KID_MSM_BUCKET, KID_MSM_CHUNK, KID_DECOMPRESS, KID_COUNT
+  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_F12_IO, KID_MSM_SORT, KID_MSM_BUCKET, KID_MSM_CHUNK, KID_DECOMPRESS, KID_PAIRING_COOP, KID_COUNT
 };
 const char* KID_NAMES[KID_COUNT] = {"k_prepare", "k_miller2", "k_finalexp", "k_prepare_agg", "k_pairs_to_affine", "k_miller1", "k_f12_fold",
-                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign", "k_f12_io", "k_msm_sort", "k_msm_bucket", "k_msm_chunk", "k_decompress"};
+                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign", "k_f12_io", "k_msm_sort", "k_msm_bucket", "k_msm_chunk", "k_decompress", "k_pairing_coop"};
 
 struct Ctx {
   int dev = -1;
@@ -204,6 +204,17 @@ bool split_mode() {
   return v != 0;
 }
 
+// batches up to this size use the wave-cooperative pairing (one wave per item); BLSGPU_COOP_MAX overrides (0 = never)
+size_t coop_max_items() {
+  static long v = -1;
+  if (v < 0) {
+    const char* e = getenv("BLSGPU_COOP_MAX");
+    v = e ? atol(e) : 4096;
+    if (v < 0) v = 0;
+  }
+  return (size_t)v;
+}
+
 unsigned blocks_for(size_t n) { return (unsigned)((n + BLS_BLOCK - 1) / BLS_BLOCK); }
 
 // ---- shared device pipelines (stream-ordered; caller holds the context mutex) ------------------------
@@ -218,7 +229,9 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
     KL(KID_PREPARE, k_prepare<1>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status, pre_status);
   else
     KL(KID_PREPARE, k_prepare<2>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status, pre_status);
-  if (split_mode()) {  // two lanes per item
+  if (split_mode() && n <= coop_max_items()) {  // small batches and single-item tails: one wave per item
+    KL(KID_PAIRING_COOP, k_pairing_coop, dim3((unsigned)n), dim3(BLS_BLOCK), n, d_pairs, d_status, sg == 1 ? 1 : 0);
+  } else if (split_mode()) {  // two lanes per item
     KL(KID_MILLER2, k_miller2s, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_pairs, d_status, d_f, sg == 1 ? 1 : 0);
     KL(KID_FINALEXP, k_finalexps, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_f, d_status);
   } else {
@@ -244,7 +257,8 @@ int run_f12_fold(Ctx* c, uint32_t* d_f, size_t m, size_t stride) {
 int run_f12_product_verdict(Ctx* c, uint32_t* d_f, size_t m, size_t stride, int32_t* d_verdict) {
   int rc = run_f12_fold(c, d_f, m, stride);
   if (rc) return rc;
-  if (split_mode()) KL(KID_FINALEXP_ONE, k_finalexp_ones, dim3(1), dim3(BLS_BLOCK), d_f, stride, d_verdict);
+  if (split_mode() && coop_max_items() > 0) KL(KID_FINALEXP_ONE, k_finalexp_coop, dim3(1), dim3(BLS_BLOCK), d_f, stride, d_verdict);
+  else if (split_mode()) KL(KID_FINALEXP_ONE, k_finalexp_ones, dim3(1), dim3(BLS_BLOCK), d_f, stride, d_verdict);
   else KL(KID_FINALEXP_ONE, k_finalexp_one, dim3(1), dim3(BLS_BLOCK), d_f, stride, d_verdict);
   HIPCK(hipGetLastError());
   return 0;

@@ -1,0 +1,286 @@
+// Wave-cooperative pairing: ONE 64-lane wave per item, for the single-item tails of MultiSignature::verify and
+// verify_secure (one core_verify after the big parallel part) and for small batches, where the per-item kernels leave
+// the chip idle and one lane pair needs ~25 ms.
+//
+// An Fp12 value is held in LDS as its six Fp2 coefficients over the basis w^0..w^5 (w^6 = xi) -- the 2-3-2 tower's
+// coefficients in the order c0.a0, c1.a0, c0.a1, c1.a1, c0.a2, c1.a2.  The 32 lane pairs of the wave each own one
+// (or two) of the 36 coefficient products a_i b_j; a product is the fused two-product Montgomery pass of
+// tower_split.cuh (even lane: real part, odd lane: imaginary part).  Six lane pairs then reduce the products along the
+// anti-diagonals i + j = k (mod 6), multiplying the wrapped half by xi.  Squaring uses the 21 products i <= j, the
+// sparse line multiplication 18.  Point arithmetic of the Miller loop (9 dependent Fp2 products per doubling) stays on
+// lane pair 0, which runs the ordinary lane-split template code.
+// Device only.
+#pragma once
+#include "tower_split.cuh"
+#include "verify.cuh"
+
+#define COOP_FP2_WORDS 24
+struct coop_f12 {
+  uint32_t c[6][COOP_FP2_WORDS];  // coefficient k: words 0..11 real part, 12..23 imaginary part
+};
+struct coop_shared {
+  coop_f12 f, t, u, v, acc;
+  uint32_t prod[36][COOP_FP2_WORDS];
+  uint32_t line[3][COOP_FP2_WORDS];
+  int flag;
+};
+
+__device__ __forceinline__ int coop_pair() { return (int)(threadIdx.x >> 1); }
+__device__ __forceinline__ void coop_ld(hfp2& r, const uint32_t* slot) {
+  const uint32_t* p = slot + (lane_hi() ? 12 : 0);
+#pragma unroll
+  for (int i = 0; i < 12; i++) r.v.l[i] = p[i];
+}
+__device__ __forceinline__ void coop_st(uint32_t* slot, const hfp2& a) {
+  uint32_t* p = slot + (lane_hi() ? 12 : 0);
+#pragma unroll
+  for (int i = 0; i < 12; i++) p[i] = a.v.l[i];
+}
+// reduce the products prod[idx] along anti-diagonals into dst; npair products described by (i, j, weight)
+// every lane pair k < 6 builds  sum_{i+j = k} w P  +  xi * sum_{i+j = k+6} w P
+template <class IDX>
+__device__ __forceinline__ void coop_reduce(coop_shared& S, coop_f12& dst, int nprod, IDX idx_of) {
+  const int k = coop_pair();
+  if (k < 6) {
+    hfp2 lo, hiacc, p;
+    fp2_zero(lo);
+    fp2_zero(hiacc);
+    for (int q = 0; q < nprod; q++) {
+      int i, j, w;
+      idx_of(q, i, j, w);
+      const int s = i + j;
+      if (s != k && s != k + 6) continue;
+      coop_ld(p, S.prod[q]);
+      if (w == 2) fp2_dbl(p, p);
+      if (s == k) fp2_add(lo, lo, p);
+      else fp2_add(hiacc, hiacc, p);
+    }
+    fp2_mul_xi(hiacc, hiacc);
+    fp2_add(lo, lo, hiacc);
+    coop_st(dst.c[k], lo);
+  }
+  __syncthreads();
+}
+
+// dst = a * b   (dst may alias a or b: products are staged in S.prod first)
+__device__ __noinline__ void coop_mul(coop_shared& S, coop_f12& dst, const coop_f12& a, const coop_f12& b) {
+  const int pr = coop_pair();
+  for (int r = 0; r < 2; r++) {
+    const int q = pr + 32 * r;
+    if (q < 36) {
+      hfp2 x, y, p;
+      coop_ld(x, a.c[q / 6]);
+      coop_ld(y, b.c[q % 6]);
+      fp2_mul(p, x, y);
+      coop_st(S.prod[q], p);
+    }
+  }
+  __syncthreads();
+  coop_reduce(S, dst, 36, [](int q, int& i, int& j, int& w) { i = q / 6; j = q % 6; w = 1; });
+}
+// the 21 index pairs i <= j in row-major order
+__device__ __forceinline__ void coop_sqr_idx(int q, int& i, int& j, int& w) {
+  int ii = 0, base = 0;
+  while (q >= base + (6 - ii)) {
+    base += 6 - ii;
+    ii++;
+  }
+  i = ii;
+  j = ii + (q - base);
+  w = (i == j) ? 1 : 2;
+}
+__device__ __noinline__ void coop_sqr(coop_shared& S, coop_f12& dst, const coop_f12& a) {
+  const int q = coop_pair();
+  if (q < 21) {
+    int i, j, w;
+    coop_sqr_idx(q, i, j, w);
+    hfp2 x, y, p;
+    coop_ld(x, a.c[i]);
+    coop_ld(y, a.c[j]);
+    fp2_mul(p, x, y);
+    coop_st(S.prod[q], p);
+  }
+  __syncthreads();
+  coop_reduce(S, dst, 21, [](int q2, int& i, int& j, int& w) { coop_sqr_idx(q2, i, j, w); });
+}
+// f *= (l0 + l2 w^2 + l3 w^3), the line in S.line[0..2]
+__device__ __noinline__ void coop_mul_line(coop_shared& S, coop_f12& f) {
+  const int q = coop_pair();
+  if (q < 18) {
+    hfp2 x, y, p;
+    coop_ld(x, f.c[q / 3]);
+    coop_ld(y, S.line[q % 3]);
+    fp2_mul(p, x, y);
+    coop_st(S.prod[q], p);
+  }
+  __syncthreads();
+  coop_reduce(S, f, 18, [](int q2, int& i, int& j, int& w) { i = q2 / 3; j = (q2 % 3 == 0) ? 0 : (q2 % 3 + 1); w = 1; });
+}
+__device__ __forceinline__ void coop_copy(coop_f12& dst, const coop_f12& a) {
+  for (int w = threadIdx.x; w < 6 * COOP_FP2_WORDS; w += BLS_BLOCK) (&dst.c[0][0])[w] = (&a.c[0][0])[w];
+  __syncthreads();
+}
+// a^(p^6): negate the odd coefficients
+__device__ __forceinline__ void coop_conj(coop_f12& dst, const coop_f12& a) {
+  const int k = coop_pair();
+  if (k < 6) {
+    hfp2 x;
+    coop_ld(x, a.c[k]);
+    if (k & 1) fp2_neg(x, x);
+    coop_st(dst.c[k], x);
+  }
+  __syncthreads();
+}
+// a^(p^J): coefficient k -> conj^J(c_k) * FROBJ[k]
+template <int J>
+__device__ __forceinline__ void coop_frob(coop_f12& dst, const coop_f12& a) {
+  const int k = coop_pair();
+  if (k < 6) {
+    hfp2 x, c;
+    coop_ld(x, a.c[k]);
+    if (J == 1) fp2_conj(c, x);
+    else c = x;
+    if (k) fp2_mul_const(x, c, (J == 1) ? FROB1[k] : FROB2[k]);
+    else x = c;
+    coop_st(dst.c[k], x);
+  }
+  __syncthreads();
+}
+// tower <-> coefficient order on lane pair 0 (for the one inversion of the easy part)
+__device__ __forceinline__ void coop_to_tower(fp12_t<hfp2>& r, const coop_f12& a) {
+  coop_ld(r.c0.a0, a.c[0]);
+  coop_ld(r.c1.a0, a.c[1]);
+  coop_ld(r.c0.a1, a.c[2]);
+  coop_ld(r.c1.a1, a.c[3]);
+  coop_ld(r.c0.a2, a.c[4]);
+  coop_ld(r.c1.a2, a.c[5]);
+}
+__device__ __forceinline__ void coop_from_tower(coop_f12& d, const fp12_t<hfp2>& r) {
+  coop_st(d.c[0], r.c0.a0);
+  coop_st(d.c[1], r.c1.a0);
+  coop_st(d.c[2], r.c0.a1);
+  coop_st(d.c[3], r.c1.a1);
+  coop_st(d.c[4], r.c0.a2);
+  coop_st(d.c[5], r.c1.a2);
+}
+// dst = a^x (x < 0) for a in the cyclotomic subgroup: generic squarings are one round each here
+__device__ __noinline__ void coop_pow_x(coop_shared& S, coop_f12& dst, const coop_f12& a) {
+  coop_copy(S.acc, a);
+  for (int i = 62; i >= 0; i--) {
+    coop_sqr(S, S.acc, S.acc);
+    if ((BLS_X_ABS >> i) & 1) coop_mul(S, S.acc, S.acc, a);
+  }
+  coop_conj(dst, S.acc);
+}
+
+// Miller loop of two pairs into S.f.  fixed_g2: pair 1's G2 member is -g2 (line table), else both pairs are general.
+__device__ __noinline__ void coop_miller2(coop_shared& S, const g1_aff* P, const aff<hfp2>* Q, int fixed_g2) {
+  const bool lead = coop_pair() == 0;
+  g2_hom_t<hfp2> T0, T1;
+  T0.x = Q[0].x;
+  T0.y = Q[0].y;
+  fp2_one(T0.z);
+  T1.x = Q[1].x;
+  T1.y = Q[1].y;
+  fp2_one(T1.z);
+  {  // f = 1
+    const int k = coop_pair();
+    if (k < 6) {
+      hfp2 x;
+      if (k == 0) fp2_one(x);
+      else fp2_zero(x);
+      coop_st(S.f.c[k], x);
+    }
+    __syncthreads();
+  }
+  hfp2 l0, l2, l3, t;
+  int row = 0;
+  for (int i = 62; i >= 0; i--) {
+    if (i != 62) coop_sqr(S, S.f, S.f);
+    for (int step = 0; step < 2; step++) {          // 0: doubling, 1: addition (only at set bits of |x|)
+      if (step == 1 && !((BLS_X_ABS >> i) & 1)) break;
+      if (lead) {
+        if (step == 0) miller_dbl_step(T0, l0, l2, l3, P[0].x, P[0].y);
+        else miller_add_step(T0, l0, l2, l3, Q[0].x, Q[0].y, P[0].x, P[0].y);
+        coop_st(S.line[0], l0);
+        coop_st(S.line[1], l2);
+        coop_st(S.line[2], l3);
+      }
+      __syncthreads();
+      coop_mul_line(S, S.f);
+      if (lead) {
+        if (fixed_g2) {
+          fp2_load(l0, &G2NEG_LINES[row][0]);
+          fp2_load(t, &G2NEG_LINES[row][24]);
+          fp2_mul_fp(l2, t, P[1].x);
+          fp2_load(t, &G2NEG_LINES[row][48]);
+          fp2_mul_fp(l3, t, P[1].y);
+        } else if (step == 0) {
+          miller_dbl_step(T1, l0, l2, l3, P[1].x, P[1].y);
+        } else {
+          miller_add_step(T1, l0, l2, l3, Q[1].x, Q[1].y, P[1].x, P[1].y);
+        }
+        coop_st(S.line[0], l0);
+        coop_st(S.line[1], l2);
+        coop_st(S.line[2], l3);
+      }
+      __syncthreads();
+      coop_mul_line(S, S.f);
+      row++;
+    }
+  }
+  coop_conj(S.f, S.f);
+}
+
+// final exponentiation of S.f (as pairing.cuh final_exponentiation) and comparison with 1; returns the status code
+__device__ __noinline__ int coop_final_verdict(coop_shared& S) {
+  // easy part: f^((p^6 - 1)(p^2 + 1))
+  if (coop_pair() == 0) {
+    fp12_t<hfp2> a, b;
+    coop_to_tower(a, S.f);
+    fp12_inv(b, a);
+    coop_from_tower(S.t, b);
+  }
+  __syncthreads();
+  coop_conj(S.u, S.f);
+  coop_mul(S, S.f, S.u, S.t);
+  coop_frob<2>(S.t, S.f);
+  coop_mul(S, S.f, S.t, S.f);
+  // hard part: t = f^((x-1)^2 (x+p) (x^2+p^2-1)) * f^3
+  coop_pow_x(S, S.t, S.f);
+  coop_conj(S.u, S.f);
+  coop_mul(S, S.t, S.t, S.u);      // f^(x-1)
+  coop_pow_x(S, S.u, S.t);
+  coop_conj(S.v, S.t);
+  coop_mul(S, S.t, S.u, S.v);      // f^((x-1)^2)
+  coop_pow_x(S, S.u, S.t);
+  coop_frob<1>(S.v, S.t);
+  coop_mul(S, S.t, S.u, S.v);      // ^(x+p)
+  coop_pow_x(S, S.u, S.t);
+  coop_pow_x(S, S.u, S.u);         // t^(x^2)
+  coop_frob<2>(S.v, S.t);
+  coop_mul(S, S.u, S.u, S.v);
+  coop_conj(S.v, S.t);
+  coop_mul(S, S.t, S.u, S.v);      // ^(x^2+p^2-1)
+  coop_sqr(S, S.u, S.f);
+  coop_mul(S, S.u, S.u, S.f);      // f^3
+  coop_mul(S, S.t, S.t, S.u);
+  // == 1 ?
+  if (threadIdx.x == 0) S.flag = 1;
+  __syncthreads();
+  const int k = coop_pair();
+  if (k < 6) {
+    hfp2 x, one;
+    coop_ld(x, S.t.c[k]);
+    bool ok;
+    if (k == 0) {
+      fp2_one(one);
+      ok = fp2_eq(x, one);
+    } else {
+      ok = fp2_is_zero(x);
+    }
+    if (!ok) S.flag = 0;
+  }
+  __syncthreads();
+  return S.flag ? BLS_OK : BLS_ERR_INVALID_SIGNATURE;
+}

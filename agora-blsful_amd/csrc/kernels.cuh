@@ -126,6 +126,9 @@ __global__ void k_miller2s(size_t n, const uint32_t* pairs, const int32_t* statu
 __global__ void k_finalexps(size_t n, const uint32_t* fws, int32_t* status);
 __global__ void k_miller1s(size_t n, size_t stride, const uint32_t* pairs, const int32_t* skip, uint32_t* fws);
 __global__ void k_finalexp_ones(const uint32_t* fws, size_t stride, int32_t* verdict);
+// wave-cooperative variants (coop.cuh): one 64-lane wave per item
+__global__ void k_pairing_coop(size_t n, const uint32_t* pairs, int32_t* status, int fixed_g2);
+__global__ void k_finalexp_coop(const uint32_t* fws, size_t stride, int32_t* verdict);
 template <int SG>
 __global__ void k_prepare_agg(size_t n, const uint8_t* pks, const uint8_t* sig, int fmt, int aug, const uint8_t* msgs,
                               const uint64_t* offs, dst_arg dst, uint32_t* pairs, int32_t* bad);
@@ -812,3 +815,46 @@ template __global__ void k_msm_chunk<2>(int, int, int, int, const uint8_t*, uint
 template __global__ void k_normalize<2>(uint8_t*);
 #endif
 #endif  // BLS_TU_MSM*
+
+#if defined(BLS_TU_COOP)
+// =====================================================================================================
+#include "coop.cuh"
+// Miller loop of the item's two pairs + final exponentiation + verdict, one workgroup (= one wave) per item
+__global__ void __launch_bounds__(BLS_BLOCK) k_pairing_coop(size_t n, const uint32_t* pairs, int32_t* status, int fixed_g2) {
+  __shared__ coop_shared S;
+  const size_t i = blockIdx.x;
+  if (i >= n) return;
+  if (status[i] != BLS_OK) return;
+  g1_aff P[2];
+  aff<hfp2> Q[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int w0 = k * 72;
+    ws_ld_fp(P[k].x, pairs, n, i, w0);
+    ws_ld_fp(P[k].y, pairs, n, i, w0 + 12);
+    ws_ld_fp(Q[k].x.v, pairs, n, i, w0 + 24 + (lane_hi() ? 12 : 0));
+    ws_ld_fp(Q[k].y.v, pairs, n, i, w0 + 48 + (lane_hi() ? 12 : 0));
+    P[k].inf = false;
+    Q[k].inf = false;
+  }
+  coop_miller2(S, P, Q, fixed_g2);
+  int st = coop_final_verdict(S);
+  if (threadIdx.x == 0) status[i] = st;
+}
+// final exponentiation + verdict of workspace item 0
+__global__ void __launch_bounds__(BLS_BLOCK) k_finalexp_coop(const uint32_t* fws, size_t stride, int32_t* verdict) {
+  __shared__ coop_shared S;
+  if (blockIdx.x != 0) return;
+  // workspace order is the tower order c0.a0, c0.a1, c0.a2, c1.a0, c1.a1, c1.a2 -> powers 0, 2, 4, 1, 3, 5
+  const int k = coop_pair();
+  if (k < 6) {
+    const int pw = (k < 3) ? 2 * k : 2 * (k - 3) + 1;
+    hfp2 x;
+    ws_ld_fp(x.v, fws, stride, 0, 24 * k + (lane_hi() ? 12 : 0));
+    coop_st(S.f.c[pw], x);
+  }
+  __syncthreads();
+  int st = coop_final_verdict(S);
+  if (threadIdx.x == 0) *verdict = st;
+}
+#endif
