@@ -86,7 +86,7 @@ def load_library(path=None):
     """dlopen libblsgpu.so (no device needed for this).  Raises if the HIP extension has not been built."""
     global _lib
     if _lib is None:
-        p = path or LIB_PATH
+        p = path or os.environ.get('BLSGPU_LIB') or LIB_PATH
         # PyTorch wheels bundle their own libamdhip64; two HIP runtimes in one process cannot both own the device.
         # Importing torch first makes libblsgpu's DT_NEEDED libamdhip64.so.7 resolve to the copy torch already loaded.
         # (C/C++/Rust callers without torch simply get /opt/rocm's runtime.)

@@ -36,24 +36,39 @@ __device__ __forceinline__ void coop_st(uint32_t* slot, const hfp2& a) {
 #pragma unroll
   for (int i = 0; i < 12; i++) p[i] = a.v.l[i];
 }
-// reduce the products prod[idx] along anti-diagonals into dst; npair products described by (i, j, weight)
-// every lane pair k < 6 builds  sum_{i+j = k} w P  +  xi * sum_{i+j = k+6} w P
-template <class IDX>
-__device__ __forceinline__ void coop_reduce(coop_shared& S, coop_f12& dst, int nprod, IDX idx_of) {
+// Anti-diagonal reduction: lane pair k < 6 builds  sum_{i+j = k} w P_ij  +  xi * sum_{i+j = k+6} w P_ij  from the staged
+// products.  MODE 0: full product (P_ij at prod[6 i + j]);  1: squaring (prod index of i <= j, off-diagonal weight 2);
+// 2: sparse line (prod[3 i + c], c = 0, 1, 2 for the line coefficients at w^0, w^2, w^3).
+__device__ __forceinline__ int coop_sqr_slot(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }   // i <= j
+template <int MODE>
+__device__ __forceinline__ void coop_reduce(coop_shared& S, coop_f12& dst) {
   const int k = coop_pair();
   if (k < 6) {
     hfp2 lo, hiacc, p;
     fp2_zero(lo);
     fp2_zero(hiacc);
-    for (int q = 0; q < nprod; q++) {
-      int i, j, w;
-      idx_of(q, i, j, w);
-      const int s = i + j;
-      if (s != k && s != k + 6) continue;
-      coop_ld(p, S.prod[q]);
-      if (w == 2) fp2_dbl(p, p);
-      if (s == k) fp2_add(lo, lo, p);
-      else fp2_add(hiacc, hiacc, p);
+    if (MODE == 2) {
+      const int jw[3] = {0, 2, 3};
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const int i = (k - jw[c] + 6) % 6;             // i + jw[c] = k or k + 6
+        coop_ld(p, S.prod[3 * i + c]);
+        if (i + jw[c] == k) fp2_add(lo, lo, p);
+        else fp2_add(hiacc, hiacc, p);
+      }
+    } else {
+      for (int i = 0; i < 6; i++) {
+        const int j = (k - i + 6) % 6;
+        if (MODE == 1) {
+          if (i > j) continue;                          // the pair (j, i) is visited as (i', j') with i' < j'
+          coop_ld(p, S.prod[coop_sqr_slot(i, j)]);
+          if (i != j) fp2_dbl(p, p);
+        } else {
+          coop_ld(p, S.prod[6 * i + j]);
+        }
+        if (i + j == k) fp2_add(lo, lo, p);
+        else fp2_add(hiacc, hiacc, p);
+      }
     }
     fp2_mul_xi(hiacc, hiacc);
     fp2_add(lo, lo, hiacc);
@@ -76,7 +91,7 @@ __device__ __noinline__ void coop_mul(coop_shared& S, coop_f12& dst, const coop_
     }
   }
   __syncthreads();
-  coop_reduce(S, dst, 36, [](int q, int& i, int& j, int& w) { i = q / 6; j = q % 6; w = 1; });
+  coop_reduce<0>(S, dst);
 }
 // the 21 index pairs i <= j in row-major order
 __device__ __forceinline__ void coop_sqr_idx(int q, int& i, int& j, int& w) {
@@ -101,7 +116,7 @@ __device__ __noinline__ void coop_sqr(coop_shared& S, coop_f12& dst, const coop_
     coop_st(S.prod[q], p);
   }
   __syncthreads();
-  coop_reduce(S, dst, 21, [](int q2, int& i, int& j, int& w) { coop_sqr_idx(q2, i, j, w); });
+  coop_reduce<1>(S, dst);
 }
 // f *= (l0 + l2 w^2 + l3 w^3), the line in S.line[0..2]
 __device__ __noinline__ void coop_mul_line(coop_shared& S, coop_f12& f) {
@@ -114,7 +129,7 @@ __device__ __noinline__ void coop_mul_line(coop_shared& S, coop_f12& f) {
     coop_st(S.prod[q], p);
   }
   __syncthreads();
-  coop_reduce(S, f, 18, [](int q2, int& i, int& j, int& w) { i = q2 / 3; j = (q2 % 3 == 0) ? 0 : (q2 % 3 + 1); w = 1; });
+  coop_reduce<2>(S, f);
 }
 __device__ __forceinline__ void coop_copy(coop_f12& dst, const coop_f12& a) {
   for (int w = threadIdx.x; w < 6 * COOP_FP2_WORDS; w += BLS_BLOCK) (&dst.c[0][0])[w] = (&a.c[0][0])[w];

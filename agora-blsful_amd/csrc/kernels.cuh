@@ -1,6 +1,9 @@
 // __global__ kernels of the verify path.  One lane = one item; intermediates live in HBM workspaces laid out
 // word-major (word k of item i at ws[k * stride + i]) so that every workspace access is a coalesced dword stream.
 #pragma once
+#ifndef BLS_SPLIT_WAVES
+#define BLS_SPLIT_WAVES 2   // waves per SIMD the lane-split kernels are compiled for (register budget 512 / waves)
+#endif
 #include "verify.cuh"
 
 #define BLS_BLOCK 64           // one wave per workgroup: 65,536 items = 1,024 waves = one per SIMD
@@ -586,7 +589,7 @@ __device__ __forceinline__ void ws_st_hfp12(uint32_t* ws, size_t stride, size_t 
 #endif
 
 #if defined(BLS_TU_MILLERS)
-__global__ void __launch_bounds__(BLS_BLOCK, 2) k_miller2s(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws, int fixed_g2) {
+__global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_miller2s(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws, int fixed_g2) {
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
   if (i >= n) return;
   if (status[i] != BLS_OK) return;
@@ -611,7 +614,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_miller2s(size_t n, const uint3
 
 #if defined(BLS_TU_MILLERS)
 // one pair per item (aggregate verify / pairing product), two lanes per item; skipped items write 1
-__global__ void __launch_bounds__(BLS_BLOCK, 2) k_miller1s(size_t n, size_t stride, const uint32_t* pairs, const int32_t* skip, uint32_t* fws) {
+__global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_miller1s(size_t n, size_t stride, const uint32_t* pairs, const int32_t* skip, uint32_t* fws) {
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
   if (i >= n) return;
   fp12_t<hfp2> f;
@@ -634,14 +637,14 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_miller1s(size_t n, size_t stri
 
 #if defined(BLS_TU_FINALEXPS)
 // final exponentiation of item 0 of a workspace on one lane pair
-__global__ void __launch_bounds__(BLS_BLOCK, 2) k_finalexp_ones(const uint32_t* fws, size_t stride, int32_t* verdict) {
+__global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_finalexp_ones(const uint32_t* fws, size_t stride, int32_t* verdict) {
   if (blockIdx.x != 0 || threadIdx.x >= 2) return;
   fp12_t<hfp2> f;
   ws_ld_hfp12(f, fws, stride, 0);
   int st = pairing_verdict(f);
   if (!lane_hi()) *verdict = st;
 }
-__global__ void __launch_bounds__(BLS_BLOCK, 2) k_finalexps(size_t n, const uint32_t* fws, int32_t* status) {
+__global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_finalexps(size_t n, const uint32_t* fws, int32_t* status) {
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
   if (i >= n) return;
   if (status[i] != BLS_OK) return;

@@ -14,9 +14,9 @@
 #define REP8(X) X X X X X X X X
 #define ITERS 512
 
-enum { I_ADD32, I_MAD64, I_MULLO, I_MULHI, I_MAD24, I_LSHLADD64, I_FMA64, I_FMA32, I_ADDC, I_MADCARRY, I_N };
+enum { I_ADD32, I_MAD64, I_MULLO, I_MULHI, I_MAD24, I_LSHLADD64, I_FMA64, I_FMA32, I_ADDC, I_MADCARRY, I_CHAIN_NOP, I_CHAIN2_NOP0, I_N };
 static const char* NAMES[] = {"v_add_u32", "v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_lshl_add_u64",
-                              "v_fma_f64", "v_fma_f32", "v_addc_co_u32(3 chains)", "mad_u64+addc(grp3)"};
+                              "v_fma_f64", "v_fma_f32", "v_addc_co_u32(3 chains)", "mad_u64+addc(grp3)", "addc 1 chain + s_nop 1", "addc 2 chains + s_nop 0"};
 
 template <int KIND>
 __global__ void __launch_bounds__(256) k_rate(uint64_t* cycles, uint32_t* sink, uint32_t seed) {
@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256) k_rate(uint64_t* cycles, uint32_t* sink, 
   double d0 = x0, d1 = x1, d2 = x2, d3 = x3, d4 = 1.5, d5 = 2.5, d6 = 3.5, d7 = 4.5;
   float f0 = x0, f1 = x1, f2 = x2, f3 = x3, f4 = 1.5f, f5 = 2.5f, f6 = 3.5f, f7 = 4.5f;
   uint32_t w0 = x0, w1 = x1, w2 = x2, w3 = x3, w4 = x0 ^ 5, w5 = x1 ^ 5, w6 = x2 ^ 5, w7 = x3 ^ 5;
-  uint64_t s0, s1, s2;
+  uint64_t s0 = 0, s1 = 0, s2 = 0;
   uint64_t t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < ITERS; it++) {
     if (KIND == I_ADD32) {
@@ -67,6 +67,19 @@ __global__ void __launch_bounds__(256) k_rate(uint64_t* cycles, uint32_t* sink, 
                         "v_addc_co_u32 %0, %3, %0, %6, %3\n v_addc_co_u32 %1, %4, %1, %6, %4\n v_addc_co_u32 %2, %5, %2, %6, %5\n"
                         "v_addc_co_u32 %0, %3, %0, %6, %3\n v_addc_co_u32 %1, %4, %1, %6, %4"
                         : "+v"(w0), "+v"(w1), "+v"(w2), "+s"(s0), "+s"(s1), "+s"(s2) : "v"(x1));)
+    } else if (KIND == I_CHAIN_NOP) {
+      // what hipcc emits for a 12-limb add: every link followed by s_nop 1 (8 links counted per asm)
+      REP8(asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc\n s_nop 1\n v_addc_co_u32 %0, vcc, %0, %1, vcc\n s_nop 1\n"
+                        "v_addc_co_u32 %0, vcc, %0, %1, vcc\n s_nop 1\n v_addc_co_u32 %0, vcc, %0, %1, vcc\n s_nop 1\n"
+                        "v_addc_co_u32 %0, vcc, %0, %1, vcc\n s_nop 1\n v_addc_co_u32 %0, vcc, %0, %1, vcc\n s_nop 1\n"
+                        "v_addc_co_u32 %0, vcc, %0, %1, vcc\n s_nop 1\n v_addc_co_u32 %0, vcc, %0, %1, vcc\n s_nop 1"
+                        : "+v"(w0) : "v"(x1) : "vcc");)
+    } else if (KIND == I_CHAIN2_NOP0) {
+      REP8(asm volatile("v_addc_co_u32 %0, %2, %0, %4, %2\n v_addc_co_u32 %1, %3, %1, %4, %3\n s_nop 0\n"
+                        "v_addc_co_u32 %0, %2, %0, %4, %2\n v_addc_co_u32 %1, %3, %1, %4, %3\n s_nop 0\n"
+                        "v_addc_co_u32 %0, %2, %0, %4, %2\n v_addc_co_u32 %1, %3, %1, %4, %3\n s_nop 0\n"
+                        "v_addc_co_u32 %0, %2, %0, %4, %2\n v_addc_co_u32 %1, %3, %1, %4, %3\n s_nop 0"
+                        : "+v"(w0), "+v"(w1), "+s"(s0), "+s"(s1) : "v"(x1));)
     } else if (KIND == I_MADCARRY) {
       // the fp_mul inner pattern: 3 mads then 3 addc (6 instructions)
       REP8(asm volatile("v_mad_u64_u32 %0, %2, %5, %6, %0\n v_mad_u64_u32 %0, %3, %5, %7, %0\n v_mad_u64_u32 %0, %4, %6, %7, %0\n"
@@ -172,7 +185,7 @@ int main() {
     run_rate<I_ADD32>(wps, dcy, dsink); run_rate<I_MAD64>(wps, dcy, dsink); run_rate<I_MULLO>(wps, dcy, dsink);
     run_rate<I_MULHI>(wps, dcy, dsink); run_rate<I_MAD24>(wps, dcy, dsink); run_rate<I_LSHLADD64>(wps, dcy, dsink);
     run_rate<I_FMA64>(wps, dcy, dsink); run_rate<I_FMA32>(wps, dcy, dsink); run_rate<I_ADDC>(wps, dcy, dsink);
-    run_rate<I_MADCARRY>(wps, dcy, dsink);
+    run_rate<I_MADCARRY>(wps, dcy, dsink); run_rate<I_CHAIN_NOP>(wps, dcy, dsink); run_rate<I_CHAIN2_NOP0>(wps, dcy, dsink);
   }
   std::vector<uint32_t> ref1, ref2;
   for (int wps = 1; wps <= 4; wps *= 2) {
