@@ -17,7 +17,7 @@
 
 namespace {
 
-const uint32_t FP_ONE_HOST[12] = FP_ONE_WORDS;
+const uint32_t FP_ONE_HOST[12] = FP_RAW_ONE_WORDS;   // 1 as the C ABI's Fp12 records carry it
 thread_local std::string t_err;
 
 enum {
@@ -183,26 +183,12 @@ void prof_flush(Ctx* c) {
     hipLaunchKernelGGL(kern, grid, block, 0, c->stream, __VA_ARGS__);           \
     prof_post(c);                                                               \
   } while (0)
-#define MILLER1_LAUNCH(cnt, ...)                                                                             \
-  do {                                                                                                     \
-    if (split_mode()) KL(KID_MILLER1, k_miller1s, dim3(blocks_for(2 * (cnt))), dim3(BLS_BLOCK), cnt, __VA_ARGS__); \
-    else KL(KID_MILLER1, k_miller1, dim3(blocks_for(cnt)), dim3(BLS_BLOCK), cnt, __VA_ARGS__);            \
-  } while (0)
+#define MILLER1_LAUNCH(cnt, ...) KL(KID_MILLER1, k_miller1s, dim3(blocks_for(2 * (cnt))), dim3(BLS_BLOCK), cnt, __VA_ARGS__)
 #define SYNC_FLUSH(c)                          \
   do {                                         \
     HIPCK(hipStreamSynchronize((c)->stream));  \
     prof_flush(c);                             \
   } while (0)
-
-// BLSGPU_SPLIT=0 selects the one-lane-per-item Miller / final-exponentiation kernels (A/B switch); default: lane-split
-bool split_mode() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("BLSGPU_SPLIT");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v != 0;
-}
 
 // batches up to this size use the wave-cooperative pairing (one wave per item); BLSGPU_COOP_MAX overrides (0 = never)
 size_t coop_max_items() {
@@ -229,14 +215,11 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
     KL(KID_PREPARE, k_prepare<1>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status, pre_status);
   else
     KL(KID_PREPARE, k_prepare<2>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status, pre_status);
-  if (split_mode() && n <= coop_max_items()) {  // small batches and single-item tails: one wave per item
+  if (n <= coop_max_items()) {  // small batches and single-item tails: one wave per item
     KL(KID_PAIRING_COOP, k_pairing_coop, dim3((unsigned)n), dim3(BLS_BLOCK), n, d_pairs, d_status, sg == 1 ? 1 : 0);
-  } else if (split_mode()) {  // two lanes per item
+  } else {                      // two lanes per item (tower_split.cuh)
     KL(KID_MILLER2, k_miller2s, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_pairs, d_status, d_f, sg == 1 ? 1 : 0);
     KL(KID_FINALEXP, k_finalexps, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_f, d_status);
-  } else {
-    KL(KID_MILLER2, k_miller2, dim3(nb), dim3(BLS_BLOCK), n, d_pairs, d_status, d_f, sg == 1 ? 1 : 0);
-    KL(KID_FINALEXP, k_finalexp, dim3(nb), dim3(BLS_BLOCK), n, d_f, d_status);
   }
   HIPCK(hipGetLastError());
   return 0;
@@ -257,9 +240,8 @@ int run_f12_fold(Ctx* c, uint32_t* d_f, size_t m, size_t stride) {
 int run_f12_product_verdict(Ctx* c, uint32_t* d_f, size_t m, size_t stride, int32_t* d_verdict) {
   int rc = run_f12_fold(c, d_f, m, stride);
   if (rc) return rc;
-  if (split_mode() && coop_max_items() > 0) KL(KID_FINALEXP_ONE, k_finalexp_coop, dim3(1), dim3(BLS_BLOCK), d_f, stride, d_verdict);
-  else if (split_mode()) KL(KID_FINALEXP_ONE, k_finalexp_ones, dim3(1), dim3(BLS_BLOCK), d_f, stride, d_verdict);
-  else KL(KID_FINALEXP_ONE, k_finalexp_one, dim3(1), dim3(BLS_BLOCK), d_f, stride, d_verdict);
+  if (coop_max_items() > 0) KL(KID_FINALEXP_ONE, k_finalexp_coop, dim3(1), dim3(BLS_BLOCK), d_f, stride, d_verdict);
+  else KL(KID_FINALEXP_ONE, k_finalexp_ones, dim3(1), dim3(BLS_BLOCK), d_f, stride, d_verdict);
   HIPCK(hipGetLastError());
   return 0;
 }

@@ -14,9 +14,9 @@
 #include "tower_split.cuh"
 #include "verify.cuh"
 
-#define COOP_FP2_WORDS 24
+#define COOP_FP2_WORDS (2 * FP_NL)
 struct coop_f12 {
-  uint32_t c[6][COOP_FP2_WORDS];  // coefficient k: words 0..11 real part, 12..23 imaginary part
+  uint32_t c[6][COOP_FP2_WORDS];  // coefficient k: FP_NL words real part, then FP_NL words imaginary part
 };
 struct coop_shared {
   coop_f12 f, t, u, v, acc;
@@ -27,14 +27,14 @@ struct coop_shared {
 
 __device__ __forceinline__ int coop_pair() { return (int)(threadIdx.x >> 1); }
 __device__ __forceinline__ void coop_ld(hfp2& r, const uint32_t* slot) {
-  const uint32_t* p = slot + (lane_hi() ? 12 : 0);
+  const uint32_t* p = slot + (lane_hi() ? FP_NL : 0);
 #pragma unroll
-  for (int i = 0; i < 12; i++) r.v.l[i] = p[i];
+  for (int i = 0; i < FP_NL; i++) r.v.l[i] = (int32_t)p[i];
 }
 __device__ __forceinline__ void coop_st(uint32_t* slot, const hfp2& a) {
-  uint32_t* p = slot + (lane_hi() ? 12 : 0);
+  uint32_t* p = slot + (lane_hi() ? FP_NL : 0);
 #pragma unroll
-  for (int i = 0; i < 12; i++) p[i] = a.v.l[i];
+  for (int i = 0; i < FP_NL; i++) p[i] = (uint32_t)a.v.l[i];
 }
 // Anti-diagonal reduction: lane pair k < 6 builds  sum_{i+j = k} w P_ij  +  xi * sum_{i+j = k+6} w P_ij  from the staged
 // products.  MODE 0: full product (P_ij at prod[6 i + j]);  1: squaring (prod index of i <= j, off-diagonal weight 2);
@@ -70,8 +70,12 @@ __device__ __forceinline__ void coop_reduce(coop_shared& S, coop_f12& dst) {
         else fp2_add(hiacc, hiacc, p);
       }
     }
+    // up to six staged products per half (limbs below 6 * 2^28): bring both halves back before xi doubles one of them
+    fp2_reduce(hiacc, hiacc);
     fp2_mul_xi(hiacc, hiacc);
+    fp2_norm(lo, lo);
     fp2_add(lo, lo, hiacc);
+    fp2_reduce(lo, lo);
     coop_st(dst.c[k], lo);
   }
   __syncthreads();
@@ -226,9 +230,9 @@ __device__ __noinline__ void coop_miller2(coop_shared& S, const g1_aff* P, const
       if (lead) {
         if (fixed_g2) {
           fp2_load(l0, &G2NEG_LINES[row][0]);
-          fp2_load(t, &G2NEG_LINES[row][24]);
+          fp2_load(t, &G2NEG_LINES[row][2 * FP_NL]);
           fp2_mul_fp(l2, t, P[1].x);
-          fp2_load(t, &G2NEG_LINES[row][48]);
+          fp2_load(t, &G2NEG_LINES[row][4 * FP_NL]);
           fp2_mul_fp(l3, t, P[1].y);
         } else if (step == 0) {
           miller_dbl_step(T1, l0, l2, l3, P[1].x, P[1].y);

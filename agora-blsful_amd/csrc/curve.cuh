@@ -1,6 +1,8 @@
 // G1 (over Fp) and G2 (over Fp2, the M-twist y^2 = x^3 + 4(1+u)) group arithmetic in Jacobian coordinates
 // (x = X/Z^2, y = Y/Z^3, infinity = Z == 0) -- the coordinate system of blst's blst_p1/blst_p2, which is what the
-// reference's G1Projective/G2Projective hold in memory, so RAW_PROJ buffers are consumed as they are.
+// reference's G1Projective/G2Projective hold in memory: RAW_PROJ buffers need only the per-coordinate
+// radix change of fp_from_raw / fp_to_raw.
+// Bounds (fp.cuh): point coordinates enter and leave every function here reduced (exact limbs, |value| < 1.2 p).
 // Replaces: `+`, `-`, `* scalar`, `to_affine`, `is_identity`, `to_compressed` of the un-vendored backend
 // (reference call sites src/traits/pk_multi.rs:10, src/secure_aggregation.rs:42,203, src/helpers.rs:44,56).
 #pragma once
@@ -19,6 +21,8 @@ BLS_FN bool fe_eq(const fp& a, const fp& b) { return fp_eq(a, b); }
 BLS_FN void fe_zero(fp& r) { fp_zero(r); }
 BLS_FN void fe_one(fp& r) { fp_one(r); }
 BLS_FN void fe_cmov(fp& r, const fp& a, bool c) { fp_cmov(r, a, c); }
+BLS_FN void fe_norm(fp& r, const fp& a) { fp_norm(r, a); }
+BLS_FN void fe_reduce(fp& r, const fp& a) { fp_reduce(r, a); }
 
 BLS_FN void fe_add(fp2& r, const fp2& a, const fp2& b) { fp2_add(r, a, b); }
 BLS_FN void fe_sub(fp2& r, const fp2& a, const fp2& b) { fp2_sub(r, a, b); }
@@ -32,6 +36,8 @@ BLS_FN bool fe_eq(const fp2& a, const fp2& b) { return fp2_eq(a, b); }
 BLS_FN void fe_zero(fp2& r) { fp2_zero(r); }
 BLS_FN void fe_one(fp2& r) { fp2_one(r); }
 BLS_FN void fe_cmov(fp2& r, const fp2& a, bool c) { fp2_cmov(r, a, c); }
+BLS_FN void fe_norm(fp2& r, const fp2& a) { fp2_norm(r, a); }
+BLS_FN void fe_reduce(fp2& r, const fp2& a) { fp2_reduce(r, a); }
 
 template <class F>
 struct jac {
@@ -74,9 +80,11 @@ BLS_FN void jac_from_aff(jac<F>& r, const aff<F>& a) {
   fe_one(r.z);
 }
 
+// The point functions are not inlined: each is a few thousand instructions, and the prepare / MSM kernels call them
+// from dozens of sites (inlining all of them made single translation units compile for the better part of an hour).
 // doubling on y^2 = x^3 + b (a = 0), dbl-2009-l: 2M + 5S
 template <class F>
-BLS_FN void jac_dbl(jac<F>& r, const jac<F>& p) {
+BLS_NOINLINE void jac_dbl(jac<F>& r, const jac<F>& p) {
   F A, B, C, D, E, Fq, t;
   fe_sqr(A, p.x);
   fe_sqr(B, p.y);
@@ -86,27 +94,34 @@ BLS_FN void jac_dbl(jac<F>& r, const jac<F>& p) {
   fe_sub(t, t, A);
   fe_sub(t, t, C);
   fe_dbl(D, t);
+  fe_reduce(D, D);       // D = 2((X + B)^2 - A - C)
   fe_dbl(E, A);
   fe_add(E, E, A);
+  fe_reduce(E, E);       // E = 3A
   fe_sqr(Fq, E);
   F z3;
   fe_mul(z3, p.y, p.z);
   fe_dbl(z3, z3);
   fe_dbl(t, D);
-  fe_sub(r.x, Fq, t);
-  fe_sub(t, D, r.x);
+  fe_sub(t, Fq, t);
+  F x3;
+  fe_reduce(x3, t);      // X3 = F - 2D
+  fe_sub(t, D, x3);
   fe_mul(t, E, t);
   fe_dbl(C, C);
   fe_dbl(C, C);
-  fe_dbl(C, C);
-  fe_sub(r.y, t, C);
-  r.z = z3;
+  fe_reduce(C, C);
+  fe_dbl(C, C);          // 8C
+  fe_sub(t, t, C);
+  fe_reduce(r.y, t);
+  r.x = x3;
+  fe_reduce(r.z, z3);
 }
 
 // general addition, add-2007-bl with the exceptional cases handled (inputs are attacker-chosen: equal or opposite
 // points do occur, e.g. duplicated public keys in an aggregate)
 template <class F>
-BLS_FN void jac_add(jac<F>& r, const jac<F>& p, const jac<F>& q) {
+BLS_NOINLINE void jac_add(jac<F>& r, const jac<F>& p, const jac<F>& q) {
   if (jac_is_inf(p)) {
     r = q;
     return;
@@ -135,7 +150,9 @@ BLS_FN void jac_add(jac<F>& r, const jac<F>& p, const jac<F>& q) {
     return;
   }
   fe_dbl(rr, rr);
+  fe_reduce(rr, rr);
   fe_dbl(i, h);
+  fe_reduce(i, i);
   fe_sqr(i, i);
   fe_mul(j, h, i);
   fe_mul(v, u1, i);
@@ -144,6 +161,7 @@ BLS_FN void jac_add(jac<F>& r, const jac<F>& p, const jac<F>& q) {
   fe_sub(x3, x3, j);
   fe_dbl(t, v);
   fe_sub(x3, x3, t);
+  fe_reduce(x3, x3);
   fe_sub(t, v, x3);
   fe_mul(y3, rr, t);
   fe_mul(t, s1, j);
@@ -153,9 +171,11 @@ BLS_FN void jac_add(jac<F>& r, const jac<F>& p, const jac<F>& q) {
   fe_sqr(z3, z3);
   fe_sub(z3, z3, z1z1);
   fe_sub(z3, z3, z2z2);
+  fe_reduce(z3, z3);
+  fe_reduce(h, h);
   fe_mul(z3, z3, h);
   r.x = x3;
-  r.y = y3;
+  fe_reduce(r.y, y3);
   r.z = z3;
 }
 
@@ -168,7 +188,7 @@ BLS_FN void jac_add_aff(jac<F>& r, const jac<F>& p, const aff<F>& q) {
 }
 
 template <class F>
-BLS_FN void jac_to_aff(aff<F>& r, const jac<F>& p) {
+BLS_NOINLINE void jac_to_aff(aff<F>& r, const jac<F>& p) {
   if (jac_is_inf(p)) {
     r.inf = true;
     fe_zero(r.x);
@@ -186,7 +206,7 @@ BLS_FN void jac_to_aff(aff<F>& r, const jac<F>& p) {
 
 // [k] P for a 64-bit public scalar (left-to-right; k is the same in every lane: no divergence)
 template <class F>
-BLS_FN void jac_mul_u64(jac<F>& r, const jac<F>& p, uint64_t k) {
+BLS_NOINLINE void jac_mul_u64(jac<F>& r, const jac<F>& p, uint64_t k) {
   jac<F> acc;
   jac_set_inf(acc);
   for (int i = 63; i >= 0; i--) {
@@ -198,7 +218,7 @@ BLS_FN void jac_mul_u64(jac<F>& r, const jac<F>& p, uint64_t k) {
 
 // [k] P for a 256-bit scalar given as 8 little-endian 32-bit words (per-lane scalars: the branch diverges)
 template <class F>
-BLS_FN void jac_mul_scalar(jac<F>& r, const jac<F>& p, const uint32_t* k) {
+BLS_NOINLINE void jac_mul_scalar(jac<F>& r, const jac<F>& p, const uint32_t* k) {
   jac<F> acc;
   jac_set_inf(acc);
   for (int i = 255; i >= 0; i--) {
@@ -230,7 +250,7 @@ BLS_FN void g2_psi2(g2_jac& r, const g2_jac& p) {
 }
 
 // RFC 9380 Appendix G.3 clear_cofactor_bls12381_g2 (x is negative: [x]P = -[|x|]P)
-BLS_FN void g2_clear_cofactor(g2_jac& r, const g2_jac& p) {
+BLS_NOINLINE void g2_clear_cofactor(g2_jac& r, const g2_jac& p) {
   g2_jac t1, t2, t3, n;
   jac_mul_u64(t1, p, BLS_X_ABS);
   jac_neg(t1, t1);  // t1 = x P
@@ -253,10 +273,12 @@ BLS_FN void g2_clear_cofactor(g2_jac& r, const g2_jac& p) {
 // reference src/impls/legacy.rs:19-35
 BLS_FN void fp_to_be48(uint8_t* out, const fp& a_mont) {
   fp t;
+  uint32_t ww[12];
   fp_from_mont(t, a_mont);
+  fp_get_words(ww, t);
 #pragma unroll
   for (int i = 0; i < 12; i++) {
-    uint32_t w = t.l[11 - i];
+    uint32_t w = ww[11 - i];
     out[4 * i + 0] = (uint8_t)(w >> 24);
     out[4 * i + 1] = (uint8_t)(w >> 16);
     out[4 * i + 2] = (uint8_t)(w >> 8);
@@ -293,7 +315,7 @@ BLS_FN void g2_compress(uint8_t* out, const g2_aff& a, bool legacy) {
 
 // ---- subgroup membership (endomorphism tests, Scott 2021): needed when points arrive as wire bytes
 // G1: phi(P) = (beta x, y) == [-x^2] P          G2: psi(P) == [x] P          (x = -|x|)
-BLS_FN bool g1_in_subgroup(const g1_aff& p) {
+BLS_NOINLINE bool g1_in_subgroup(const g1_aff& p) {
   if (p.inf) return true;
   g1_jac j, q;
   jac_from_aff(j, p);
@@ -311,7 +333,7 @@ BLS_FN bool g1_in_subgroup(const g1_aff& p) {
   fp_neg(t, t);
   return fp_eq(t, q.y);                      // y(phi P) == -y([x^2]P)
 }
-BLS_FN bool g2_in_subgroup(const g2_aff& p) {
+BLS_NOINLINE bool g2_in_subgroup(const g2_aff& p) {
   if (p.inf) return true;
   g2_jac j, q, ps;
   jac_from_aff(j, p);
@@ -332,16 +354,18 @@ BLS_FN bool g2_in_subgroup(const g2_aff& p) {
 // returns 0 ok, 7 bad encoding (DeserializationError), 8 legacy header violation (LegacyFormatError)
 BLS_FN bool fp_from_be48_checked(fp& r, const uint8_t* b, uint8_t b0) {   // b0 = first byte with the flag bits cleared
   fp t;
+  uint32_t ww[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) {
     const uint8_t* q = b + 4 * (11 - i);
     uint32_t hi = (i == 11) ? b0 : q[0];
-    t.l[i] = (hi << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+    ww[i] = (hi << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
   }
-  uint32_t bw = 0;
+  fp_set_words(t, ww);
+  int32_t c = 0;
 #pragma unroll
-  for (int i = 0; i < 12; i++) (void)subb32(t.l[i], FP_P[i], bw);
-  if (!bw) return false;                     // value >= p
+  for (int i = 0; i < FP_NL; i++) c = (t.l[i] - (int32_t)FP_P[i] + c) >> FP_LB;
+  if (c >= 0) return false;                  // value >= p
   fp_to_mont(r, t);
   return true;
 }
@@ -359,7 +383,7 @@ BLS_FN int wire_header(uint8_t& b0, bool legacy) {
   }
   return 0;
 }
-BLS_FN int g1_decompress(g1_jac& out, const uint8_t* b, bool legacy) {
+BLS_NOINLINE int g1_decompress(g1_jac& out, const uint8_t* b, bool legacy) {
   uint8_t b0 = b[0];
   int rc = wire_header(b0, legacy);
   if (rc) return rc;
@@ -386,7 +410,7 @@ BLS_FN int g1_decompress(g1_jac& out, const uint8_t* b, bool legacy) {
   jac_from_aff(out, a);
   return 0;
 }
-BLS_FN int g2_decompress(g2_jac& out, const uint8_t* b, bool legacy) {
+BLS_NOINLINE int g2_decompress(g2_jac& out, const uint8_t* b, bool legacy) {
   uint8_t b0 = b[0];
   int rc = wire_header(b0, legacy);
   if (rc) return rc;

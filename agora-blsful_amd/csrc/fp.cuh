@@ -1,12 +1,38 @@
-// Fp arithmetic for BLS12-381 on gfx950: 12 x 32-bit limbs, Montgomery form, R = 2^384.
+// Fp arithmetic for BLS12-381 on gfx950: fourteen SIGNED 28-bit limbs (one per 32-bit register), Montgomery form with
+// R = 2^392, lazy (carry-free) additions.
 //
-// The in-memory form is byte-identical to blst's 6 x u64 little-endian Montgomery limbs, which is what
-// the reference's G1Projective/G2Projective hold, so RAW_PROJ buffers need no conversion.
-// 32-bit limbs because the CDNA4 integer multiplier is 32 x 32 (+64) -> 64 (v_mad_u64_u32).
+// Why this shape (measured on MI355X, profiles/ubench_r01.txt + tools/ubench): on gfx950 every VOP3-encoded integer
+// instruction -- v_mad_u64_u32, v_mul_lo_u32, and also v_addc_co_u32 with an SGPR carry -- costs the same issue slot
+// (~4.5 cycles per wave-instruction at two waves per SIMD), a carry chain needs two wait states between links (hipcc pads
+// every link of a 12-limb add with s_nop 1), and only VOP2 adds without carry run at ~2.4 cycles.  A saturated 12 x 32-bit
+// representation therefore pays one multiply-class slot per partial product for the carry fold and ~250 cycles per
+// modular addition.  With 28-bit limbs a column of 14 (or 28) products fits a 64-bit accumulator, so a product costs ONE
+// v_mad_i64_i32 and nothing else; additions, subtractions and negations are 14 plain v_add/v_sub_u32 with no carries, no
+// conditional subtraction and no hazards.  Signed limbs make subtraction as cheap as addition.
+//
+// Value discipline.  A limb vector (l_0..l_13) stands for the integer sum l_i 2^(28 i); an element is that integer mod p.
+//   * fp_mul / fp_dotp2 return limbs 0..12 in [0, 2^28) and a small signed top limb; the value lies in (-p/8, p + p/8)
+//     whenever the products of the operands' magnitudes sum to less than 256 p^2 (p / R = 2^-11.3).
+//   * fp_add / fp_sub / fp_neg / fp_dbl are limb-wise and exact on the integers: bounds add up.
+//   * A multiplication needs 14 * sum |a_i| |b_j| + 2^60 < 2^63 per column: operand limb bounds with
+//     A * B <= 2^59 (one product stream) or 2^58 (two streams).  fp_norm (one parallel carry pass, 3 VOP2 per limb)
+//     brings limbs back to 2^28 + a few units when a chain of additions gets too long (the value is unchanged).
+//   * Additions also let the VALUE grow (nothing is subtracted), and a squaring chain doubles it every step, so the
+//     tower functions (Fp6/Fp12 products, cyclotomic squaring, curve formulas) fp_reduce their results: one exact
+//     carry pass that subtracts the nearest multiple of p -> limbs in [0, 2^28), value in (-0.52 p, 0.52 p).
+//   * Predicates and serialisation (fp_is_zero, fp_eq, sgn0, compress, ...) go through fp_canon, the unique
+//     representative in [0, p) with exact limbs.
+// tests/hostsim compiles this header on the host with -DBLS_TRACK_BOUNDS: every fp then carries worst-case bounds
+// (limb magnitude, value in units of p) that are propagated through every operation and checked against the rules above,
+// so one pass over the verification paths proves the placement of the fp_norm calls for all inputs.
+//
+// The caller-facing RAW formats stay blst's 6 x u64 little-endian Montgomery words (R = 2^384):
+// fp_from_raw / fp_to_raw convert with one multiplication (by 2^400 resp. 2^384 mod p) at the boundary.
 //
 // This header also compiles as plain C++ (no HIP) for the host-side unit tests in tests/hostsim.
 #pragma once
 #include <stdint.h>
+#include <math.h>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -21,236 +47,331 @@
 
 #include "consts.cuh"
 
+#if defined(BLS_TRACK_BOUNDS) && !defined(__HIPCC__)
+#include <stdio.h>
+#include <stdlib.h>
+#define FP_TRK(...) __VA_ARGS__
+#define FP_LB_N 268435456.0   // 2^28: limb bound of a normalised element
+static void fp_trk_fail(const char* what, double x, double y) {
+  fprintf(stderr, "BLS_TRACK_BOUNDS: %s violated (%.4g, %.4g)\n", what, x, y);
+  abort();
+}
+#else
+#define FP_TRK(...)
+#endif
+
 struct fp {
-  uint32_t l[12];
+  int32_t l[FP_NL];
+  FP_TRK(double lb; double vb;)   // worst-case |limb| and |value| / p
 };
 
-// ---- carry helpers -------------------------------------------------------------------------------
-BLS_FN uint32_t addc32(uint32_t a, uint32_t b, uint32_t& carry) {
-#if defined(__clang__)
-  unsigned co;
-  uint32_t r = __builtin_addc(a, b, carry, &co);
-  carry = co;
-  return r;
-#else
-  uint64_t s = (uint64_t)a + b + carry;
-  carry = (uint32_t)(s >> 32);
-  return (uint32_t)s;
-#endif
-}
-
-BLS_FN uint32_t subb32(uint32_t a, uint32_t b, uint32_t& borrow) {
-#if defined(__clang__)
-  unsigned bo;
-  uint32_t r = __builtin_subc(a, b, borrow, &bo);
-  borrow = bo;
-  return r;
-#else
-  uint64_t s = (uint64_t)a - b - borrow;
-  borrow = (uint32_t)(s >> 63);
-  return (uint32_t)s;
-#endif
-}
-
 // ---- basic ops -----------------------------------------------------------------------------------
+// internal 14-word form (constants, device workspaces): limbs are normalised, value in (-p/8, p + p/8)
 BLS_FN void fp_load(fp& r, const uint32_t* c) {
 #pragma unroll
-  for (int i = 0; i < 12; i++) r.l[i] = c[i];
+  for (int i = 0; i < FP_NL; i++) r.l[i] = (int32_t)c[i];
+  FP_TRK(r.lb = FP_LB_N; r.vb = 1.125;)
 }
 
 BLS_FN void fp_store(uint32_t* c, const fp& a) {
+  FP_TRK(if (a.lb > FP_LB_N || a.vb > 1.125) fp_trk_fail("fp_store of a normalised product", a.lb, a.vb);)
 #pragma unroll
-  for (int i = 0; i < 12; i++) c[i] = a.l[i];
+  for (int i = 0; i < FP_NL; i++) c[i] = (uint32_t)a.l[i];
 }
 
 BLS_FN void fp_zero(fp& r) {
 #pragma unroll
-  for (int i = 0; i < 12; i++) r.l[i] = 0;
+  for (int i = 0; i < FP_NL; i++) r.l[i] = 0;
+  FP_TRK(r.lb = 0; r.vb = 0;)
 }
 
 BLS_FN void fp_one(fp& r) { fp_load(r, FP_ONE); }
 
-BLS_FN bool fp_is_zero(const fp& a) {
-  uint32_t o = 0;
-#pragma unroll
-  for (int i = 0; i < 12; i++) o |= a.l[i];
-  return o == 0;
-}
-
-BLS_FN bool fp_eq(const fp& a, const fp& b) {
-  uint32_t o = 0;
-#pragma unroll
-  for (int i = 0; i < 12; i++) o |= a.l[i] ^ b.l[i];
-  return o == 0;
-}
-
 BLS_FN void fp_cmov(fp& r, const fp& a, bool c) {  // r = c ? a : r
 #pragma unroll
-  for (int i = 0; i < 12; i++) r.l[i] = c ? a.l[i] : r.l[i];
-}
-
-// r = a - p if a >= p else a   (a < 2p)
-BLS_FN void fp_reduce_once(fp& r, const fp& a) {
-  uint32_t d[12], bw = 0;
-#pragma unroll
-  for (int i = 0; i < 12; i++) d[i] = subb32(a.l[i], FP_P[i], bw);
-#pragma unroll
-  for (int i = 0; i < 12; i++) r.l[i] = bw ? a.l[i] : d[i];
+  for (int i = 0; i < FP_NL; i++) r.l[i] = c ? a.l[i] : r.l[i];
+  FP_TRK(r.lb = fmax(r.lb, a.lb); r.vb = fmax(r.vb, a.vb);)
 }
 
 BLS_FN void fp_add(fp& r, const fp& a, const fp& b) {
-  fp t;
-  uint32_t c = 0;
+  FP_TRK(const double lb = a.lb + b.lb, vb = a.vb + b.vb; if (lb >= 2147483648.0) fp_trk_fail("fp_add limb < 2^31", a.lb, b.lb);)
 #pragma unroll
-  for (int i = 0; i < 12; i++) t.l[i] = addc32(a.l[i], b.l[i], c);
-  fp_reduce_once(r, t);  // a + b < 2p < 2^384: no carry out
+  for (int i = 0; i < FP_NL; i++) r.l[i] = a.l[i] + b.l[i];
+  FP_TRK(r.lb = lb; r.vb = vb;)
 }
 
 BLS_FN void fp_sub(fp& r, const fp& a, const fp& b) {
-  uint32_t d[12], bw = 0;
+  FP_TRK(const double lb = a.lb + b.lb, vb = a.vb + b.vb; if (lb >= 2147483648.0) fp_trk_fail("fp_sub limb < 2^31", a.lb, b.lb);)
 #pragma unroll
-  for (int i = 0; i < 12; i++) d[i] = subb32(a.l[i], b.l[i], bw);
-  uint32_t mask = 0u - bw, c = 0;
-#pragma unroll
-  for (int i = 0; i < 12; i++) r.l[i] = addc32(d[i], FP_P[i] & mask, c);
+  for (int i = 0; i < FP_NL; i++) r.l[i] = a.l[i] - b.l[i];
+  FP_TRK(r.lb = lb; r.vb = vb;)
 }
 
 BLS_FN void fp_neg(fp& r, const fp& a) {
-  uint32_t bw = 0, nz = 0;
-  uint32_t d[12];
+  FP_TRK(const double lb = a.lb, vb = a.vb;)
 #pragma unroll
-  for (int i = 0; i < 12; i++) {
-    nz |= a.l[i];
-    d[i] = subb32(FP_P[i], a.l[i], bw);
-  }
-#pragma unroll
-  for (int i = 0; i < 12; i++) r.l[i] = nz ? d[i] : 0u;
+  for (int i = 0; i < FP_NL; i++) r.l[i] = -a.l[i];
+  FP_TRK(r.lb = lb; r.vb = vb;)
 }
 
 BLS_FN void fp_dbl(fp& r, const fp& a) { fp_add(r, a, a); }
 
-// ---- Montgomery multiplication ---------------------------------------------------------------------
-// Portable CIOS (interleaved; top limb of p < 2^31 so no extra carry word).  Used by the host-side unit
-// tests and as the reference the asm form is checked against (tools/ubench).
-BLS_FN void fp_mul_c(fp& r, const fp& a, const fp& b) {
-  uint32_t t[12];
+// one parallel carry pass: limbs 0..12 -> [-2^(B-28), 2^28 + 2^(B-28)), the value is unchanged
+BLS_FN void fp_norm(fp& r, const fp& a) {
+  FP_TRK(const double lb = FP_LB_N + floor(a.lb / FP_LB_N) + 1, vb = a.vb;)
+  int32_t c[FP_NL - 1];
 #pragma unroll
-  for (int i = 0; i < 12; i++) t[i] = 0;
+  for (int i = 0; i < FP_NL - 1; i++) c[i] = a.l[i] >> FP_LB;
+  const int32_t top = a.l[FP_NL - 1] + c[FP_NL - 2];
 #pragma unroll
-  for (int i = 0; i < 12; i++) {
-    const uint32_t bi = b.l[i];
-    uint64_t A = (uint64_t)a.l[0] * bi + t[0];
-    const uint32_t m = (uint32_t)A * FP_N0INV;
-    uint64_t C = (uint64_t)m * FP_P[0] + (uint32_t)A;
-    A >>= 32;
-    C >>= 32;
-#pragma unroll
-    for (int j = 1; j < 12; j++) {
-      A += (uint64_t)a.l[j] * bi + t[j];
-      C += (uint64_t)m * FP_P[j] + (uint32_t)A;
-      t[j - 1] = (uint32_t)C;
-      A >>= 32;
-      C >>= 32;
-    }
-    t[11] = (uint32_t)(A + C);
-  }
-  fp tt;
-#pragma unroll
-  for (int i = 0; i < 12; i++) tt.l[i] = t[i];
-  fp_reduce_once(r, tt);
+  for (int i = FP_NL - 2; i >= 1; i--) r.l[i] = (a.l[i] & FP_MASK) + c[i - 1];
+  r.l[0] = a.l[0] & FP_MASK;
+  r.l[FP_NL - 1] = top;
+  FP_TRK(r.lb = lb; r.vb = vb;)
 }
 
-#if defined(__HIPCC__)
-// gfx950: product-scanning form, one v_mad_u64_u32 + one v_addc_co_u32 per partial product.  Measured on
-// MI355X (profiles/ubench_r01.txt): 58 G fp_mul/s chip-wide at 4 waves/SIMD vs 40 G for the C form.
-#include "fp_mul_gfx950.inc"
-// The multiplication body (about 720 instructions) is ONE non-inlined leaf per translation unit whose 24 operand
-// limbs and 12 result limbs travel in VGPRs (scalar arguments: clang passes aggregates above 16 dwords through
-// memory, which put every operand of every product into scratch: 80 GB of fabric traffic per 65,536-item Miller
-// launch and waves parked in s_waitcnt 47 % of the time, profiles/r01_pmc_before_leafcall.txt).  Everything above
-// fp_mul is inlined so that values stay in registers between calls.
-struct fp_ret {
-  uint32_t l[12];
-};
-__device__ __noinline__ fp_ret fp_mul_leaf(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6,
-                                           uint32_t a7, uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t b0, uint32_t b1,
-                                           uint32_t b2, uint32_t b3, uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7, uint32_t b8,
-                                           uint32_t b9, uint32_t b10, uint32_t b11) {
-  fp a = {{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11}}, b = {{b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11}}, r;
-  fp_mul_asm(r, a, b);
-  fp_ret o;
+// Value reduction: subtract the multiple of p nearest to the value (quotient estimated from the top limb, whose unit
+// 2^364 is p / 106,514, so the lazy lower limbs cannot disturb it) in one exact carry pass.
+// Result: limbs 0..12 in [0, 2^28), signed top limb, value in (-0.52 p, 0.52 p).  Any input with limbs below 2^31 - 2^8.
+BLS_FN void fp_reduce(fp& r, const fp& a) {
+  FP_TRK(if (a.lb >= 2147483392.0) fp_trk_fail("fp_reduce limb < 2^31 - 2^8", a.lb, 0); if (a.vb > 120.0) fp_trk_fail("fp_reduce |value| < 120 p", a.vb, 0);)
+  const int32_t k = (int32_t)rintf((float)a.l[FP_NL - 1] * FP_PTOP_INV);
+  int32_t c = 0;
 #pragma unroll
-  for (int i = 0; i < 12; i++) o.l[i] = r.l[i];
+  for (int i = 0; i < FP_NL; i++) {
+    const int64_t x = (int64_t)(a.l[i] + c) - (int64_t)k * (int32_t)FP_P[i];
+    if (i < FP_NL - 1) {
+      r.l[i] = (int32_t)((uint32_t)x & FP_MASK);
+      c = (int32_t)(x >> FP_LB);
+    } else {
+      r.l[i] = (int32_t)x;
+    }
+  }
+  FP_TRK(r.lb = FP_LB_N; r.vb = 0.52;)
+}
+
+// The representative in [0, p) with exact limbs.
+BLS_FN void fp_canon(fp& r, const fp& a) {
+  fp t;
+  fp_reduce(t, a);
+  const int32_t m = t.l[FP_NL - 1] < 0 ? -1 : 0;   // negative -> add p
+  int32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) {
+    const int32_t x = t.l[i] + ((int32_t)FP_P[i] & m) + c;
+    if (i < FP_NL - 1) {
+      r.l[i] = x & FP_MASK;
+      c = x >> FP_LB;
+    } else {
+      r.l[i] = x;
+    }
+  }
+  FP_TRK(r.lb = FP_LB_N; r.vb = 1.0;)
+}
+
+BLS_FN bool fp_is_zero(const fp& a) {
+  fp t;
+  fp_reduce(t, a);   // the only multiple of p in (-0.52 p, 0.52 p) is 0, and exact limbs represent it uniquely
+  int32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) o |= t.l[i];
+  return o == 0;
+}
+
+BLS_FN bool fp_eq(const fp& a, const fp& b) {
+  fp d;
+  fp_sub(d, a, b);
+  return fp_is_zero(d);
+}
+
+// ---- Montgomery multiplication ---------------------------------------------------------------------
+// Product scanning, R = 2^392:  r = REDC(a b)  or, with STREAMS == 2,  r = REDC(a b + c d)  in one pass (one reduction
+// for two products: the Fp2 product of tower_split.cuh).  Every partial product is one 32 x 32 + 64 multiply-add into a
+// signed 64-bit column accumulator; the column sum stays below 2^63 under the limb bounds stated at the top.
+template <int STREAMS>
+BLS_FN void fp_redc_products(fp& r, const fp& a, const fp& b, const fp& c, const fp& d) {
+#if defined(BLS_TRACK_BOUNDS) && !defined(__HIPCC__)
+  {
+    const double prod = a.lb * b.lb + (STREAMS == 2 ? c.lb * d.lb : 0.0);
+    if (14.0 * prod + 14.0 * 72057594037927936.0 + 68719476736.0 >= 9223372036854775808.0) fp_trk_fail("column sum < 2^63", a.lb * b.lb, STREAMS == 2 ? c.lb * d.lb : 0.0);
+    const double vprod = a.vb * b.vb + (STREAMS == 2 ? c.vb * d.vb : 0.0);
+    if (vprod > 256.0) fp_trk_fail("REDC input |a||b| + |c||d| <= 256 p^2", a.vb * b.vb, STREAMS == 2 ? c.vb * d.vb : 0.0);
+  }
+#endif
+  int64_t acc = 0, acc2 = 0;
+  int32_t m[FP_NL];
+  int32_t t[FP_NL];
+#pragma unroll
+  for (int k = 0; k < 2 * FP_NL - 1; k++) {
+    const int lo = k > FP_NL - 1 ? k - (FP_NL - 1) : 0, hi = k < FP_NL - 1 ? k : FP_NL - 1;
+#pragma unroll
+    for (int i = lo; i <= hi; i++) {
+      acc += (int64_t)a.l[i] * b.l[k - i];
+      if (STREAMS == 2) acc2 += (int64_t)c.l[i] * d.l[k - i];
+    }
+    if (STREAMS == 2) {
+      acc += acc2;
+      acc2 = 0;
+    }
+#pragma unroll
+    for (int i = lo; i <= hi; i++) {
+      if (k < FP_NL && i == k) continue;  // m[k] is not known yet
+      acc += (int64_t)m[i] * (int32_t)FP_P[k - i];
+    }
+    if (k < FP_NL) {
+      m[k] = (int32_t)(((uint32_t)acc * FP_N0INV) & FP_MASK);
+      acc += (int64_t)m[k] * (int32_t)FP_P[0];
+      acc >>= FP_LB;
+    } else {
+      t[k - FP_NL] = (int32_t)((uint32_t)acc & FP_MASK);
+      acc >>= FP_LB;
+    }
+  }
+  t[FP_NL - 1] = (int32_t)acc;
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) r.l[i] = t[i];
+  FP_TRK(r.lb = FP_LB_N; r.vb = 1.125;)
+}
+
+#if defined(BLS_COUNT_FPMUL)
+extern "C" { uint64_t g_fpmul_count = 0; }   // tools/count_fpmul.py: host-side instruction-mix census
+#define FP_COUNT(n) g_fpmul_count += (n)
+#else
+#define FP_COUNT(n)
+#endif
+
+#if defined(__HIPCC__)
+// The multiplication bodies (about 520 / 770 instructions) are ONE non-inlined leaf each per translation unit whose 28
+// operand limbs and 14 result limbs travel in VGPRs (ext_vector arguments: clang passes aggregates above 16 dwords
+// through memory, which put every operand of every product into scratch, profiles/r01_pmc_before_leafcall.txt).
+// Everything above is inlined so that values stay in registers between calls.
+typedef int32_t i32x14 __attribute__((ext_vector_type(14)));
+#define FP_OPAQUE(x) asm volatile("" : "+v"(x))   // keeps the sign extension next to the multiply: v_mad_i64_i32 selects
+__device__ __noinline__ i32x14 fp_mul_leaf(i32x14 av, i32x14 bv) {
+  fp a, b, r;
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) {
+    a.l[i] = av[i];
+    b.l[i] = bv[i];
+    FP_OPAQUE(a.l[i]);
+    FP_OPAQUE(b.l[i]);
+  }
+  fp_redc_products<1>(r, a, b, a, b);
+  i32x14 o;
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) o[i] = r.l[i];
   return o;
 }
 BLS_FN void fp_mul(fp& r, const fp& a, const fp& b) {
-  fp_ret t = fp_mul_leaf(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], b.l[0], b.l[1],
-                         b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9], b.l[10], b.l[11]);
+  i32x14 x, y;
 #pragma unroll
-  for (int i = 0; i < 12; i++) r.l[i] = t.l[i];
-}
-// ---- lane-split Fp2 product leaf (tower_split.cuh): each lane of an adjacent pair passes ITS component of a and b
-// (24 dwords in VGPRs, nothing on the stack); the leaf fetches the partner's components by DPP quad_perm [1,0,3,2] and
-// computes, in one fused two-product Montgomery pass (lazy reduction):
-//     even lane: REDC(a0 b0 + (p - a1) b1) = c0          odd lane: REDC(a0 b1 + a1 b0) = c1
-typedef uint32_t u32x12 __attribute__((ext_vector_type(12)));
-__device__ __forceinline__ uint32_t dpp_swap(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true); }
-__device__ __noinline__ u32x12 fp2_mul_split_leaf(u32x12 av, u32x12 bv) {
-  const bool hi = (threadIdx.x & 1u) != 0;
-  fp a, b, pa, pb, npa, x0, x1, r;
-#pragma unroll
-  for (int i = 0; i < 12; i++) {
-    a.l[i] = av[i];
-    b.l[i] = bv[i];
-    pa.l[i] = dpp_swap(av[i]);
-    pb.l[i] = dpp_swap(bv[i]);
-  }
-  fp_neg(npa, pa);
-#pragma unroll
-  for (int i = 0; i < 12; i++) {
-    x0.l[i] = hi ? pa.l[i] : a.l[i];    // a0 on both lanes
-    x1.l[i] = hi ? a.l[i] : npa.l[i];   // even: -a1, odd: a1
-  }
-  fp_dotp2_asm(r, x0, b, x1, pb);
-  u32x12 o;
-#pragma unroll
-  for (int i = 0; i < 12; i++) o[i] = r.l[i];
-  return o;
-}
-BLS_FN void fp2_mul_split(fp& r, const fp& a, const fp& b) {
-  u32x12 x, y;
-#pragma unroll
-  for (int i = 0; i < 12; i++) {
+  for (int i = 0; i < FP_NL; i++) {
     x[i] = a.l[i];
     y[i] = b.l[i];
   }
-  u32x12 o = fp2_mul_split_leaf(x, y);
+  i32x14 o = fp_mul_leaf(x, y);
 #pragma unroll
-  for (int i = 0; i < 12; i++) r.l[i] = o[i];
+  for (int i = 0; i < FP_NL; i++) r.l[i] = o[i];
+}
+// ---- lane-split Fp2 product leaf (tower_split.cuh): each lane of an adjacent pair passes ITS component of a and b
+// (28 dwords in VGPRs, nothing on the stack); the leaf fetches the partner's components by DPP quad_perm [1,0,3,2] and
+// computes, in one fused two-product Montgomery pass:
+//     even lane: REDC(a0 b0 + (-a1) b1) = c0          odd lane: REDC(a0 b1 + a1 b0) = c1
+__device__ __forceinline__ int32_t dpp_swap(int32_t x) { return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true); }
+__device__ __noinline__ i32x14 fp2_mul_split_leaf(i32x14 av, i32x14 bv) {
+  const bool hi = (threadIdx.x & 1u) != 0;
+  fp b, pb, x0, x1, r;
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) {
+    const int32_t pa = dpp_swap(av[i]);
+    b.l[i] = bv[i];
+    pb.l[i] = dpp_swap(bv[i]);
+    x0.l[i] = hi ? pa : av[i];     // a0 on both lanes
+    x1.l[i] = hi ? av[i] : -pa;    // even: -a1, odd: a1
+    FP_OPAQUE(b.l[i]);
+    FP_OPAQUE(pb.l[i]);
+    FP_OPAQUE(x0.l[i]);
+    FP_OPAQUE(x1.l[i]);
+  }
+  fp_redc_products<2>(r, x0, b, x1, pb);
+  i32x14 o;
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) o[i] = r.l[i];
+  return o;
+}
+BLS_FN void fp2_mul_split(fp& r, const fp& a, const fp& b) {
+  i32x14 x, y;
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) {
+    x[i] = a.l[i];
+    y[i] = b.l[i];
+  }
+  i32x14 o = fp2_mul_split_leaf(x, y);
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) r.l[i] = o[i];
 }
 #else
-#if defined(BLS_COUNT_FPMUL)
-extern "C" { uint64_t g_fpmul_count = 0; }   // tools/count_fpmul.py: host-side instruction-mix census
-BLS_FN void fp_mul(fp& r, const fp& a, const fp& b) { g_fpmul_count++; fp_mul_c(r, a, b); }
-#else
-BLS_FN void fp_mul(fp& r, const fp& a, const fp& b) { fp_mul_c(r, a, b); }
-#endif
+BLS_FN void fp_mul(fp& r, const fp& a, const fp& b) {
+  FP_COUNT(1);
+  fp_redc_products<1>(r, a, b, a, b);
+}
+// REDC(a b + c d): host twin of the lane-split product (tower_split.cuh's host emulation)
+BLS_FN void fp_dotp2(fp& r, const fp& a, const fp& b, const fp& c, const fp& d) {
+  FP_COUNT(1);  // 1.5 multiplication equivalents; two of these make one Fp2 product = 3 equivalents
+  fp_redc_products<2>(r, a, b, c, d);
+}
 #endif
 
 BLS_FN void fp_sqr(fp& r, const fp& a) { fp_mul(r, a, a); }
 
-// plain integer -> Montgomery, and back
+// ---- conversions ---------------------------------------------------------------------------------
+// 12 little-endian 32-bit words of a plain integer < 2^384  ->  limbs of the same integer
+BLS_FN void fp_set_words(fp& r, const uint32_t* w) {
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) {
+    const int bit = FP_LB * i, j = bit >> 5, s = bit & 31;
+    uint64_t x = w[j];
+    if (j + 1 < 12) x |= (uint64_t)w[j + 1] << 32;
+    r.l[i] = (int32_t)((uint32_t)(x >> s) & FP_MASK);
+  }
+  FP_TRK(r.lb = FP_LB_N; r.vb = 9.85;)   // 2^384 / p
+}
+// canonical limbs (fp_canon output) -> 12 little-endian 32-bit words
+BLS_FN void fp_get_words(uint32_t* w, const fp& a) {
+#pragma unroll
+  for (int j = 0; j < 12; j++) {
+    const int bit = 32 * j, i = bit / FP_LB, s = bit % FP_LB;
+    uint64_t x = (uint64_t)(uint32_t)a.l[i] >> s;
+    if (i + 1 < FP_NL) x |= (uint64_t)(uint32_t)a.l[i + 1] << (FP_LB - s);
+    if (i + 2 < FP_NL) x |= (uint64_t)(uint32_t)a.l[i + 2] << (2 * FP_LB - s);
+    w[j] = (uint32_t)x;
+  }
+}
+// plain integer -> Montgomery, and back (canonical integer limbs)
 BLS_FN void fp_to_mont(fp& r, const fp& a) {
   fp r2;
   fp_load(r2, FP_R2);
   fp_mul(r, a, r2);
 }
-
 BLS_FN void fp_from_mont(fp& r, const fp& a) {
-  fp one;
-  fp_zero(one);
-  one.l[0] = 1;
-  fp_mul(r, a, one);
+  fp one, t;
+  fp_load(one, FP_INT_ONE);
+  fp_mul(t, a, one);
+  fp_canon(r, t);
+}
+// caller format: blst's Montgomery words (R = 2^384)
+BLS_FN void fp_from_raw(fp& r, const uint32_t* w) {
+  fp t, k;
+  fp_set_words(t, w);
+  fp_load(k, FP_C400);
+  fp_mul(r, t, k);
+}
+BLS_FN void fp_to_raw(uint32_t* w, const fp& a) {
+  fp t, k;
+  fp_load(k, FP_C384);
+  fp_mul(t, a, k);
+  fp_canon(t, t);
+  fp_get_words(w, t);
 }
 
 // a^e for a public exponent given as little-endian 32-bit words (same for every lane: no divergence).
@@ -258,8 +379,8 @@ BLS_FN void fp_from_mont(fp& r, const fp& a) {
 BLS_NOINLINE void fp_pow(fp& r, const fp& a, const uint32_t* e, int nbits) {
   fp tbl[16];
   fp_one(tbl[0]);
-  tbl[1] = a;
-  for (int i = 2; i < 16; i++) fp_mul(tbl[i], tbl[i - 1], a);
+  fp_norm(tbl[1], a);
+  for (int i = 2; i < 16; i++) fp_mul(tbl[i], tbl[i - 1], tbl[1]);
   fp acc;
   fp_one(acc);
   const int ndig = (nbits + 3) / 4;
@@ -301,15 +422,15 @@ BLS_FN bool fp_sqrt(fp& r, const fp& a) {
 BLS_FN uint32_t fp_parity(const fp& a) {
   fp t;
   fp_from_mont(t, a);
-  return t.l[0] & 1;
+  return (uint32_t)t.l[0] & 1u;
 }
 
 // a (Montgomery) as integer > (p-1)/2 ?
 BLS_FN bool fp_lex_largest(const fp& a) {
   fp t;
   fp_from_mont(t, a);
-  uint32_t bw = 0;
+  int32_t c = 0;
 #pragma unroll
-  for (int i = 0; i < 12; i++) (void)subb32(FP_PM1D2[i], t.l[i], bw);
-  return bw != 0;  // (p-1)/2 - a < 0
+  for (int i = 0; i < FP_NL; i++) c = ((int32_t)FP_PM1D2[i] - t.l[i] + c) >> FP_LB;
+  return c < 0;  // (p-1)/2 - a < 0
 }

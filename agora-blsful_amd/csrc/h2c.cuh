@@ -113,29 +113,32 @@ BLS_FN void expand_message_xmd(uint8_t* out, const uint8_t* pre, uint32_t pre_le
   }
 }
 
-// 64 big-endian bytes -> Fp (Montgomery): (lo48 + hi16 * 2^384) mod p = lo48 * R2/R + hi16 * R3/R
+// 64 big-endian bytes -> Fp (Montgomery): (lo48 + hi16 * 2^384) mod p = REDC(lo48 R^2) + REDC(hi16 2^384 R^2)
 BLS_FN void fp_from_be64(fp& r, const uint8_t* b) {
-  fp lo, hi, t;
-  fp_zero(hi);
+  fp lo, hi, t, k;
+  uint32_t w[12];
+  for (int i = 0; i < 12; i++) w[i] = 0;
   for (int i = 0; i < 4; i++) {
     const uint8_t* q = b + 4 * (3 - i);
-    hi.l[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+    w[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
   }
+  fp_set_words(hi, w);
   for (int i = 0; i < 12; i++) {
     const uint8_t* q = b + 16 + 4 * (11 - i);
-    lo.l[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+    w[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
   }
-  fp k;
+  fp_set_words(lo, w);
   fp_load(k, FP_R2);
-  fp_mul(t, k, lo);   // unreduced operand second (see fp_mul_c bound)
-  fp_load(k, FP_R3);
+  fp_mul(t, k, lo);
+  fp_load(k, FP_R2_384);
   fp_mul(hi, k, hi);
-  fp_add(r, t, hi);
+  fp_add(t, t, hi);
+  fp_reduce(r, t);
 }
 
 // ------------------------------------------------------------------ G1: simplified SWU (RFC 9380 F.2, straight line)
 // returns x = xn/xd and y on E'1
-BLS_FN void sswu_g1(fp& xn, fp& xd, fp& y, const fp& u) {
+BLS_NOINLINE void sswu_g1(fp& xn, fp& xd, fp& y, const fp& u) {
   fp A, B, Z, tv1, tv2, tv3, tv4, tv5, tv6, x, y1, t;
   fp_load(A, SSWU1_A);
   fp_load(B, SSWU1_B);
@@ -184,7 +187,7 @@ BLS_FN void sswu_g1(fp& xn, fp& xd, fp& y, const fp& u) {
 }
 
 // homogenised Horner: sum_i k_i xn^i xd^(D-i), zp[j] = xd^j
-BLS_FN void iso1_poly(fp& r, const uint32_t (*k)[12], int deg, const fp& xn, const fp* zp) {
+BLS_FN void iso1_poly(fp& r, const uint32_t (*k)[FP_NL], int deg, const fp& xn, const fp* zp) {
   fp acc, c, t;
   fp_load(acc, k[deg]);
   for (int i = deg - 1; i >= 0; i--) {
@@ -197,7 +200,7 @@ BLS_FN void iso1_poly(fp& r, const uint32_t (*k)[12], int deg, const fp& xn, con
 }
 
 // 11-isogeny E'1 -> E1 applied to (xn/xd, y); Jacobian output
-BLS_FN void iso_map_g1(g1_jac& r, const fp& xn, const fp& xd, const fp& y) {
+BLS_NOINLINE void iso_map_g1(g1_jac& r, const fp& xn, const fp& xd, const fp& y) {
   fp zp[16];
   fp_one(zp[0]);
   zp[1] = xd;
@@ -219,7 +222,7 @@ BLS_FN void iso_map_g1(g1_jac& r, const fp& xn, const fp& xd, const fp& y) {
   fp_mul(r.y, t, y);      // Y = y YN zx^3 YD^2
 }
 
-BLS_FN void hash_to_g1(g1_jac& r, const uint8_t* pre, uint32_t pre_len, const uint8_t* m, uint32_t m_len,
+BLS_NOINLINE void hash_to_g1(g1_jac& r, const uint8_t* pre, uint32_t pre_len, const uint8_t* m, uint32_t m_len,
                        const uint8_t* dst, uint32_t dst_len) {
   uint8_t ub[128];
   expand_message_xmd<128>(ub, pre, pre_len, m, m_len, dst, dst_len);
@@ -247,7 +250,7 @@ BLS_FN void fp2_curve_rhs_iso(fp2& r, const fp2& x) {  // x^3 + A' x + B' on E'2
   fp2_mul(t, t, x);
   fp2_add(r, t, B);
 }
-BLS_FN void sswu_g2(fp2& x, fp2& y, const fp2& u) {
+BLS_NOINLINE void sswu_g2(fp2& x, fp2& y, const fp2& u) {
   fp2 Z, zu2, tv1, x1, gx, one, t;
   fp2_load(Z, SSWU2_Z);
   fp2_sqr(zu2, u);
@@ -274,7 +277,7 @@ BLS_FN void sswu_g2(fp2& x, fp2& y, const fp2& u) {
   }
   if (fp2_sgn0(u) != fp2_sgn0(y)) fp2_neg(y, y);
 }
-BLS_FN void iso2_poly(fp2& r, const uint32_t (*k)[24], int deg, const fp2& x) {
+BLS_FN void iso2_poly(fp2& r, const uint32_t (*k)[2 * FP_NL], int deg, const fp2& x) {
   fp2 acc, c;
   fp2_load(acc, k[deg]);
   for (int i = deg - 1; i >= 0; i--) {
@@ -284,7 +287,7 @@ BLS_FN void iso2_poly(fp2& r, const uint32_t (*k)[24], int deg, const fp2& x) {
   }
   r = acc;
 }
-BLS_FN void iso_map_g2(g2_jac& r, const fp2& x, const fp2& y) {
+BLS_NOINLINE void iso_map_g2(g2_jac& r, const fp2& x, const fp2& y) {
   fp2 XN, XD, YN, YD, t, yd2;
   iso2_poly(XN, ISO2_XNUM, 3, x);
   iso2_poly(XD, ISO2_XDEN, 2, x);
@@ -300,7 +303,7 @@ BLS_FN void iso_map_g2(g2_jac& r, const fp2& x, const fp2& y) {
   fp2_mul(t, t, YN);
   fp2_mul(r.y, t, y);
 }
-BLS_FN void hash_to_g2(g2_jac& r, const uint8_t* pre, uint32_t pre_len, const uint8_t* m, uint32_t m_len,
+BLS_NOINLINE void hash_to_g2(g2_jac& r, const uint8_t* pre, uint32_t pre_len, const uint8_t* m, uint32_t m_len,
                        const uint8_t* dst, uint32_t dst_len) {
   uint8_t ub[256];
   expand_message_xmd<256>(ub, pre, pre_len, m, m_len, dst, dst_len);

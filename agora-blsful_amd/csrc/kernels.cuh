@@ -7,8 +7,10 @@
 #include "verify.cuh"
 
 #define BLS_BLOCK 64           // one wave per workgroup: 65,536 items = 1,024 waves = one per SIMD
-#define WS_PAIRS_WORDS 144     // P0(24) Q0(48) P1(24) Q1(48), affine Montgomery
-#define WS_F_WORDS 144         // Fp12
+#define W1 FP_NL               // workspace words per Fp (internal 28-bit-limb form, fp.cuh)
+#define W2 (2 * FP_NL)         // per Fp2
+#define WS_PAIRS_WORDS (6 * W2)  // P0(2 Fp) Q0(2 Fp2) P1 Q1, affine, internal form
+#define WS_F_WORDS (6 * W2)      // Fp12
 
 struct dst_arg {
   uint8_t b[256];
@@ -18,54 +20,62 @@ struct dst_arg {
 // ---- word-major workspace accessors
 __device__ __forceinline__ void ws_ld_fp(fp& r, const uint32_t* ws, size_t stride, size_t i, int w0) {
 #pragma unroll
-  for (int k = 0; k < 12; k++) r.l[k] = ws[(size_t)(w0 + k) * stride + i];
+  for (int k = 0; k < FP_NL; k++) r.l[k] = (int32_t)ws[(size_t)(w0 + k) * stride + i];
 }
 __device__ __forceinline__ void ws_st_fp(uint32_t* ws, size_t stride, size_t i, int w0, const fp& a) {
 #pragma unroll
-  for (int k = 0; k < 12; k++) ws[(size_t)(w0 + k) * stride + i] = a.l[k];
+  for (int k = 0; k < FP_NL; k++) ws[(size_t)(w0 + k) * stride + i] = (uint32_t)a.l[k];
 }
 __device__ __forceinline__ void ws_ld_fp2(fp2& r, const uint32_t* ws, size_t stride, size_t i, int w0) {
   ws_ld_fp(r.c0, ws, stride, i, w0);
-  ws_ld_fp(r.c1, ws, stride, i, w0 + 12);
+  ws_ld_fp(r.c1, ws, stride, i, w0 + W1);
 }
 __device__ __forceinline__ void ws_st_fp2(uint32_t* ws, size_t stride, size_t i, int w0, const fp2& a) {
   ws_st_fp(ws, stride, i, w0, a.c0);
-  ws_st_fp(ws, stride, i, w0 + 12, a.c1);
+  ws_st_fp(ws, stride, i, w0 + W1, a.c1);
 }
 __device__ __forceinline__ void ws_ld_fp12(fp12& f, const uint32_t* ws, size_t stride, size_t i) {
   ws_ld_fp2(f.c0.a0, ws, stride, i, 0);
-  ws_ld_fp2(f.c0.a1, ws, stride, i, 24);
-  ws_ld_fp2(f.c0.a2, ws, stride, i, 48);
-  ws_ld_fp2(f.c1.a0, ws, stride, i, 72);
-  ws_ld_fp2(f.c1.a1, ws, stride, i, 96);
-  ws_ld_fp2(f.c1.a2, ws, stride, i, 120);
+  ws_ld_fp2(f.c0.a1, ws, stride, i, W2);
+  ws_ld_fp2(f.c0.a2, ws, stride, i, 2 * W2);
+  ws_ld_fp2(f.c1.a0, ws, stride, i, 3 * W2);
+  ws_ld_fp2(f.c1.a1, ws, stride, i, 4 * W2);
+  ws_ld_fp2(f.c1.a2, ws, stride, i, 5 * W2);
 }
 __device__ __forceinline__ void ws_st_fp12(uint32_t* ws, size_t stride, size_t i, const fp12& f) {
   ws_st_fp2(ws, stride, i, 0, f.c0.a0);
-  ws_st_fp2(ws, stride, i, 24, f.c0.a1);
-  ws_st_fp2(ws, stride, i, 48, f.c0.a2);
-  ws_st_fp2(ws, stride, i, 72, f.c1.a0);
-  ws_st_fp2(ws, stride, i, 96, f.c1.a1);
-  ws_st_fp2(ws, stride, i, 120, f.c1.a2);
+  ws_st_fp2(ws, stride, i, W2, f.c0.a1);
+  ws_st_fp2(ws, stride, i, 2 * W2, f.c0.a2);
+  ws_st_fp2(ws, stride, i, 3 * W2, f.c1.a0);
+  ws_st_fp2(ws, stride, i, 4 * W2, f.c1.a1);
+  ws_st_fp2(ws, stride, i, 5 * W2, f.c1.a2);
 }
 __device__ __forceinline__ void ws_st_pair(uint32_t* ws, size_t stride, size_t i, int slot, const g1_aff& p, const g2_aff& q) {
-  const int w0 = slot * 72;
+  const int w0 = slot * 3 * W2;
   ws_st_fp(ws, stride, i, w0, p.x);
-  ws_st_fp(ws, stride, i, w0 + 12, p.y);
-  ws_st_fp2(ws, stride, i, w0 + 24, q.x);
-  ws_st_fp2(ws, stride, i, w0 + 48, q.y);
+  ws_st_fp(ws, stride, i, w0 + W1, p.y);
+  ws_st_fp2(ws, stride, i, w0 + W2, q.x);
+  ws_st_fp2(ws, stride, i, w0 + 2 * W2, q.y);
 }
 __device__ __forceinline__ void ws_ld_pair(g1_aff& p, g2_aff& q, const uint32_t* ws, size_t stride, size_t i, int slot) {
-  const int w0 = slot * 72;
+  const int w0 = slot * 3 * W2;
   ws_ld_fp(p.x, ws, stride, i, w0);
-  ws_ld_fp(p.y, ws, stride, i, w0 + 12);
-  ws_ld_fp2(q.x, ws, stride, i, w0 + 24);
-  ws_ld_fp2(q.y, ws, stride, i, w0 + 48);
+  ws_ld_fp(p.y, ws, stride, i, w0 + W1);
+  ws_ld_fp2(q.x, ws, stride, i, w0 + W2);
+  ws_ld_fp2(q.y, ws, stride, i, w0 + 2 * W2);
   p.inf = false;
   q.inf = false;
 }
 
-// ---- caller-format point loads (array of structs, one struct per item)
+// ---- caller-format point loads (array of structs, one struct per item; blst Montgomery words, 12 per Fp)
+__device__ __forceinline__ void fp2_from_raw(fp2& r, const uint32_t* w) {
+  fp_from_raw(r.c0, w);
+  fp_from_raw(r.c1, w + 12);
+}
+__device__ __forceinline__ void fp2_to_raw(uint32_t* w, const fp2& a) {
+  fp_to_raw(w, a.c0);
+  fp_to_raw(w + 12, a.c1);
+}
 __device__ __forceinline__ bool words_all_zero(const uint32_t* w, int n) {
   uint32_t o = 0;
   for (int k = 0; k < n; k++) o |= w[k];
@@ -74,16 +84,16 @@ __device__ __forceinline__ bool words_all_zero(const uint32_t* w, int n) {
 __device__ __forceinline__ void load_g1_pt(g1_jac& p, const uint8_t* base, size_t i, int fmt) {
   if (fmt == 0) {
     const uint32_t* w = (const uint32_t*)(base + i * 144);
-    fp_load(p.x, w);
-    fp_load(p.y, w + 12);
-    fp_load(p.z, w + 24);
+    fp_from_raw(p.x, w);
+    fp_from_raw(p.y, w + 12);
+    fp_from_raw(p.z, w + 24);
   } else {
     const uint32_t* w = (const uint32_t*)(base + i * 96);
     if (words_all_zero(w, 24)) {
       jac_set_inf(p);
     } else {
-      fp_load(p.x, w);
-      fp_load(p.y, w + 12);
+      fp_from_raw(p.x, w);
+      fp_from_raw(p.y, w + 12);
       fp_one(p.z);
     }
   }
@@ -91,31 +101,31 @@ __device__ __forceinline__ void load_g1_pt(g1_jac& p, const uint8_t* base, size_
 __device__ __forceinline__ void load_g2_pt(g2_jac& p, const uint8_t* base, size_t i, int fmt) {
   if (fmt == 0) {
     const uint32_t* w = (const uint32_t*)(base + i * 288);
-    fp2_load(p.x, w);
-    fp2_load(p.y, w + 24);
-    fp2_load(p.z, w + 48);
+    fp2_from_raw(p.x, w);
+    fp2_from_raw(p.y, w + 24);
+    fp2_from_raw(p.z, w + 48);
   } else {
     const uint32_t* w = (const uint32_t*)(base + i * 192);
     if (words_all_zero(w, 48)) {
       jac_set_inf(p);
     } else {
-      fp2_load(p.x, w);
-      fp2_load(p.y, w + 24);
+      fp2_from_raw(p.x, w);
+      fp2_from_raw(p.y, w + 24);
       fp2_one(p.z);
     }
   }
 }
 __device__ __forceinline__ void store_g1_pt(uint8_t* base, size_t i, const g1_jac& p) {
   uint32_t* w = (uint32_t*)(base + i * 144);
-  fp_store(w, p.x);
-  fp_store(w + 12, p.y);
-  fp_store(w + 24, p.z);
+  fp_to_raw(w, p.x);
+  fp_to_raw(w + 12, p.y);
+  fp_to_raw(w + 24, p.z);
 }
 __device__ __forceinline__ void store_g2_pt(uint8_t* base, size_t i, const g2_jac& p) {
   uint32_t* w = (uint32_t*)(base + i * 288);
-  fp2_store(w, p.x);
-  fp2_store(w + 24, p.y);
-  fp2_store(w + 48, p.z);
+  fp2_to_raw(w, p.x);
+  fp2_to_raw(w + 24, p.y);
+  fp2_to_raw(w + 48, p.z);
 }
 
 
@@ -123,8 +133,6 @@ __device__ __forceinline__ void store_g2_pt(uint8_t* base, size_t i, const g2_ja
 template <int SG>
 __global__ void k_prepare(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int aug, const uint8_t* msgs,
                           const uint64_t* offs, int single_msg, dst_arg dst, uint32_t* pairs, int32_t* status, int pre_status);
-__global__ void k_miller2(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws, int fixed_g2);
-__global__ void k_finalexp(size_t n, const uint32_t* fws, int32_t* status);
 __global__ void k_miller2s(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws, int fixed_g2);
 __global__ void k_finalexps(size_t n, const uint32_t* fws, int32_t* status);
 __global__ void k_miller1s(size_t n, size_t stride, const uint32_t* pairs, const int32_t* skip, uint32_t* fws);
@@ -136,9 +144,7 @@ template <int SG>
 __global__ void k_prepare_agg(size_t n, const uint8_t* pks, const uint8_t* sig, int fmt, int aug, const uint8_t* msgs,
                               const uint64_t* offs, dst_arg dst, uint32_t* pairs, int32_t* bad);
 __global__ void k_pairs_to_affine(size_t n, const uint8_t* g1s, const uint8_t* g2s, int fmt, uint32_t* pairs, int32_t* skip);
-__global__ void k_miller1(size_t n, size_t stride, const uint32_t* pairs, const int32_t* skip, uint32_t* fws);
 __global__ void k_f12_fold(size_t m, size_t half, uint32_t* fws, size_t stride);
-__global__ void k_finalexp_one(const uint32_t* fws, size_t stride, int32_t* verdict);
 __global__ void k_f12_import(size_t n, const uint8_t* src, uint32_t* fws, size_t stride);
 __global__ void k_f12_export(const uint32_t* fws, size_t stride, uint8_t* dst);
 __global__ void k_hash_to_g1(size_t n, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint8_t* out);
@@ -212,37 +218,7 @@ template __global__ void k_prepare<2>(size_t, const uint8_t*, const uint8_t*, in
 #endif
 #endif  // BLS_TU_PREPARE*
 
-#if defined(BLS_TU_MILLER)
-// stage 2: two-pair Miller loop per item
-// fixed_g2 != 0: the second pair's G2 member is -g2 (Bls12381G1Impl) and its lines come from the precomputed table
-__global__ void __launch_bounds__(BLS_BLOCK) k_miller2(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws, int fixed_g2) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (status[i] != BLS_OK) return;
-  g1_aff P[2];
-  g2_aff Q[2];
-  ws_ld_pair(P[0], Q[0], pairs, n, i, 0);
-  ws_ld_pair(P[1], Q[1], pairs, n, i, 1);
-  fp12 f;
-  if (fixed_g2) miller_loop_fixed_g2(f, P[0], Q[0], P[1]);
-  else miller_loop<2>(f, P, Q);
-  ws_st_fp12(fws, n, i, f);
-}
 
-#endif  // BLS_TU_MILLER (first part)
-
-#if defined(BLS_TU_FINALEXP)
-// stage 3: final exponentiation and verdict per item
-__global__ void __launch_bounds__(BLS_BLOCK) k_finalexp(size_t n, const uint32_t* fws, int32_t* status) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (status[i] != BLS_OK) return;
-  fp12 f;
-  ws_ld_fp12(f, fws, n, i);
-  status[i] = pairing_verdict(f);
-}
-
-#endif  // BLS_TU_FINALEXP (first part)
 
 #if defined(BLS_TU_AGG1) || defined(BLS_TU_AGG2)
 // =====================================================================================================
@@ -341,24 +317,6 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_pairs_to_affine(size_t n, const u
 
 #endif  // BLS_TU_POINTS (pairs_to_affine)
 
-#if defined(BLS_TU_MILLER)
-// one-pair Miller loop per item; skipped items write 1
-__global__ void __launch_bounds__(BLS_BLOCK) k_miller1(size_t n, size_t stride, const uint32_t* pairs, const int32_t* skip, uint32_t* fws) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  fp12 f;
-  if (skip[i]) {
-    fp12_one(f);
-  } else {
-    g1_aff P[1];
-    g2_aff Q[1];
-    ws_ld_pair(P[0], Q[0], pairs, stride, i, 0);
-    miller_loop<1>(f, P, Q);
-  }
-  ws_st_fp12(fws, stride, i, f);
-}
-
-#endif  // BLS_TU_MILLER
 
 #if defined(BLS_TU_FINALEXP)
 // product tree step: f[i] *= f[i + half] for i + half < m   (stride = workspace stride)
@@ -372,25 +330,23 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_f12_fold(size_t m, size_t half, u
   ws_st_fp12(fws, stride, i, a);
 }
 
-// final exponentiation of item 0 of a workspace -> *verdict (BLS_OK / BLS_ERR_INVALID_SIGNATURE)
-__global__ void __launch_bounds__(BLS_BLOCK) k_finalexp_one(const uint32_t* fws, size_t stride, int32_t* verdict) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  fp12 f;
-  ws_ld_fp12(f, fws, stride, 0);
-  *verdict = pairing_verdict(f);
-}
-
 // Fp12 partial products cross the C ABI as 576-byte records (c0.a0, c0.a1, c0.a2, c1.a0, c1.a1, c1.a2; each Fp2 =
 // c0 then c1; Montgomery limbs): array-of-records <-> word-major workspace
 __global__ void __launch_bounds__(BLS_BLOCK) k_f12_import(size_t n, const uint8_t* src, uint32_t* fws, size_t stride) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t* w = (const uint32_t*)(src + i * 576);
-  for (int k = 0; k < 144; k++) fws[(size_t)k * stride + i] = w[k];
+  for (int k = 0; k < 12; k++) {
+    fp t;
+    fp_from_raw(t, w + 12 * k);
+    ws_st_fp(fws, stride, i, W1 * k, t);
+  }
 }
 __global__ void __launch_bounds__(BLS_BLOCK) k_f12_export(const uint32_t* fws, size_t stride, uint8_t* dst) {
-  if (blockIdx.x != 0) return;
-  for (int k = threadIdx.x; k < 144; k += BLS_BLOCK) ((uint32_t*)dst)[k] = fws[(size_t)k * stride];
+  if (blockIdx.x != 0 || threadIdx.x >= 12) return;
+  fp t;
+  ws_ld_fp(t, fws, stride, 0, W1 * threadIdx.x);
+  fp_to_raw((uint32_t*)dst + 12 * threadIdx.x, t);
 }
 #endif  // BLS_TU_FINALEXP
 
@@ -565,26 +521,26 @@ template __global__ void k_sign<2>(size_t, const uint8_t*, int, const uint8_t*, 
 // lane-split variants (tower_split.cuh): two adjacent lanes per item, 64-thread workgroups = 32 items
 #include "tower_split.cuh"
 __device__ __forceinline__ void ws_ld_hfp2(hfp2& r, const uint32_t* ws, size_t stride, size_t i, int w0) {
-  ws_ld_fp(r.v, ws, stride, i, w0 + (lane_hi() ? 12 : 0));
+  ws_ld_fp(r.v, ws, stride, i, w0 + (lane_hi() ? W1 : 0));
 }
 __device__ __forceinline__ void ws_st_hfp2(uint32_t* ws, size_t stride, size_t i, int w0, const hfp2& a) {
-  ws_st_fp(ws, stride, i, w0 + (lane_hi() ? 12 : 0), a.v);
+  ws_st_fp(ws, stride, i, w0 + (lane_hi() ? W1 : 0), a.v);
 }
 __device__ __forceinline__ void ws_ld_hfp12(fp12_t<hfp2>& f, const uint32_t* ws, size_t stride, size_t i) {
   ws_ld_hfp2(f.c0.a0, ws, stride, i, 0);
-  ws_ld_hfp2(f.c0.a1, ws, stride, i, 24);
-  ws_ld_hfp2(f.c0.a2, ws, stride, i, 48);
-  ws_ld_hfp2(f.c1.a0, ws, stride, i, 72);
-  ws_ld_hfp2(f.c1.a1, ws, stride, i, 96);
-  ws_ld_hfp2(f.c1.a2, ws, stride, i, 120);
+  ws_ld_hfp2(f.c0.a1, ws, stride, i, W2);
+  ws_ld_hfp2(f.c0.a2, ws, stride, i, 2 * W2);
+  ws_ld_hfp2(f.c1.a0, ws, stride, i, 3 * W2);
+  ws_ld_hfp2(f.c1.a1, ws, stride, i, 4 * W2);
+  ws_ld_hfp2(f.c1.a2, ws, stride, i, 5 * W2);
 }
 __device__ __forceinline__ void ws_st_hfp12(uint32_t* ws, size_t stride, size_t i, const fp12_t<hfp2>& f) {
   ws_st_hfp2(ws, stride, i, 0, f.c0.a0);
-  ws_st_hfp2(ws, stride, i, 24, f.c0.a1);
-  ws_st_hfp2(ws, stride, i, 48, f.c0.a2);
-  ws_st_hfp2(ws, stride, i, 72, f.c1.a0);
-  ws_st_hfp2(ws, stride, i, 96, f.c1.a1);
-  ws_st_hfp2(ws, stride, i, 120, f.c1.a2);
+  ws_st_hfp2(ws, stride, i, W2, f.c0.a1);
+  ws_st_hfp2(ws, stride, i, 2 * W2, f.c0.a2);
+  ws_st_hfp2(ws, stride, i, 3 * W2, f.c1.a0);
+  ws_st_hfp2(ws, stride, i, 4 * W2, f.c1.a1);
+  ws_st_hfp2(ws, stride, i, 5 * W2, f.c1.a2);
 }
 #endif
 
@@ -597,11 +553,11 @@ __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_miller2s(size_t 
   aff<hfp2> Q[2];
 #pragma unroll
   for (int k = 0; k < 2; k++) {
-    const int w0 = k * 72;
+    const int w0 = k * 3 * W2;
     ws_ld_fp(P[k].x, pairs, n, i, w0);
-    ws_ld_fp(P[k].y, pairs, n, i, w0 + 12);
-    ws_ld_hfp2(Q[k].x, pairs, n, i, w0 + 24);
-    ws_ld_hfp2(Q[k].y, pairs, n, i, w0 + 48);
+    ws_ld_fp(P[k].y, pairs, n, i, w0 + W1);
+    ws_ld_hfp2(Q[k].x, pairs, n, i, w0 + W2);
+    ws_ld_hfp2(Q[k].y, pairs, n, i, w0 + 2 * W2);
     P[k].inf = false;
     Q[k].inf = false;
   }
@@ -624,9 +580,9 @@ __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_miller1s(size_t 
     g1_aff P[1];
     aff<hfp2> Q[1];
     ws_ld_fp(P[0].x, pairs, stride, i, 0);
-    ws_ld_fp(P[0].y, pairs, stride, i, 12);
-    ws_ld_hfp2(Q[0].x, pairs, stride, i, 24);
-    ws_ld_hfp2(Q[0].y, pairs, stride, i, 48);
+    ws_ld_fp(P[0].y, pairs, stride, i, W1);
+    ws_ld_hfp2(Q[0].x, pairs, stride, i, W2);
+    ws_ld_hfp2(Q[0].y, pairs, stride, i, 2 * W2);
     P[0].inf = false;
     Q[0].inf = false;
     miller_loop<1>(f, P, Q);
@@ -832,11 +788,11 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_pairing_coop(size_t n, const uint
   aff<hfp2> Q[2];
 #pragma unroll
   for (int k = 0; k < 2; k++) {
-    const int w0 = k * 72;
+    const int w0 = k * 3 * W2;
     ws_ld_fp(P[k].x, pairs, n, i, w0);
-    ws_ld_fp(P[k].y, pairs, n, i, w0 + 12);
-    ws_ld_fp(Q[k].x.v, pairs, n, i, w0 + 24 + (lane_hi() ? 12 : 0));
-    ws_ld_fp(Q[k].y.v, pairs, n, i, w0 + 48 + (lane_hi() ? 12 : 0));
+    ws_ld_fp(P[k].y, pairs, n, i, w0 + W1);
+    ws_ld_fp(Q[k].x.v, pairs, n, i, w0 + W2 + (lane_hi() ? W1 : 0));
+    ws_ld_fp(Q[k].y.v, pairs, n, i, w0 + 2 * W2 + (lane_hi() ? W1 : 0));
     P[k].inf = false;
     Q[k].inf = false;
   }
@@ -853,7 +809,7 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_finalexp_coop(const uint32_t* fws
   if (k < 6) {
     const int pw = (k < 3) ? 2 * k : 2 * (k - 3) + 1;
     hfp2 x;
-    ws_ld_fp(x.v, fws, stride, 0, 24 * k + (lane_hi() ? 12 : 0));
+    ws_ld_fp(x.v, fws, stride, 0, W2 * k + (lane_hi() ? W1 : 0));
     coop_st(S.f.c[pw], x);
   }
   __syncthreads();

@@ -15,15 +15,9 @@ struct g2_hom_t {
 };
 typedef g2_hom_t<fp2> g2_hom;
 
-template <class F2>
-BLS_FN void fp2_mul_3b(F2& r, const F2& a) {  // a * 3b' = a * 12 (1 + u)
-  F2 t, t2;
-  fp2_mul_xi(t, a);
-  fp2_dbl(t2, t);   // 2
-  fp2_add(t, t2, t);  // 3
-  fp2_dbl(t, t);    // 6
-  fp2_dbl(r, t);    // 12
-}
+// Bounds (fp.cuh): T enters and leaves the steps reduced; the line coefficients leave normalised (what
+// fp12_mul_by_line expects).  The small-constant multiples (3b' = 12 (1 + u), 3, 4, 12) are limb-wise additions, so
+// the steps fp_norm / fp_reduce where a chain would pass 2^31 or feed a product with more than 2^29 per limb.
 
 // T <- 2T and the tangent line at T evaluated at P = (xp, yp):
 //   l0 = Y^2 - 3b'Z^2,  l2 = -3X^2 xp,  l3 = 2YZ yp     (coefficients of w^0, w^2, w^3)
@@ -33,16 +27,24 @@ BLS_NOINLINE void miller_dbl_step(g2_hom_t<F2>& t, F2& l0, F2& l2, F2& l3, const
   fp2_mul(a, t.x, t.y);  // XY
   fp2_sqr(b, t.y);       // B = Y^2
   fp2_sqr(c, t.z);       // C = Z^2
-  fp2_mul_3b(e, c);      // E = 3b'C
+  fp2_mul_xi(e, c);
+  fp2_dbl(g, e);
+  fp2_add(e, g, e);      // 3 (1 + u) C
+  fp2_reduce(e, e);
+  fp2_dbl(e, e);
+  fp2_dbl(e, e);
+  fp2_norm(e, e);        // E = 3b'C = 12 (1 + u) C
   fp2_dbl(f, e);
   fp2_add(f, f, e);      // F = 3E
   fp2_add(h, t.y, t.z);
   fp2_sqr(h, h);
   fp2_sub(h, h, b);
   fp2_sub(h, h, c);      // H = 2YZ
+  fp2_norm(h, h);
   fp2_sqr(s, t.x);       // X^2
   // line
   fp2_sub(l0, b, e);
+  fp2_norm(l0, l0);
   fp2_dbl(g, s);
   fp2_add(g, g, s);      // 3X^2
   fp2_neg(g, g);
@@ -50,19 +52,25 @@ BLS_NOINLINE void miller_dbl_step(g2_hom_t<F2>& t, F2& l0, F2& l2, F2& l3, const
   fp2_mul_fp(l3, h, yp);
   // point: X3 = 2XY(B - F), Y3 = (B + F)^2 - 12E^2, Z3 = 4BH
   fp2_sub(g, b, f);
+  fp2_norm(g, g);
   fp2_mul(g, a, g);
-  fp2_dbl(t.x, g);
+  fp2_dbl(g, g);
+  fp2_reduce(t.x, g);
   fp2_add(g, b, f);
+  fp2_norm(g, g);
   fp2_sqr(g, g);
   fp2_sqr(s, e);
   fp2_dbl(a, s);
   fp2_add(a, a, s);      // 3E^2
+  fp2_norm(a, a);
   fp2_dbl(a, a);
   fp2_dbl(a, a);         // 12E^2
-  fp2_sub(t.y, g, a);
+  fp2_sub(g, g, a);
+  fp2_reduce(t.y, g);
   fp2_mul(g, b, h);
   fp2_dbl(g, g);
-  fp2_dbl(t.z, g);
+  fp2_dbl(g, g);
+  fp2_reduce(t.z, g);
 }
 
 // T <- T + Q and the chord line through T and Q evaluated at P:
@@ -78,6 +86,7 @@ BLS_NOINLINE void miller_add_step(g2_hom_t<F2>& t, F2& l0, F2& l2, F2& l3, const
   fp2_mul(l0, th, xq);
   fp2_mul(s, la, yq);
   fp2_sub(l0, l0, s);
+  fp2_norm(l0, l0);
   fp2_neg(s, th);
   fp2_mul_fp(l2, s, xp);
   fp2_mul_fp(l3, la, yp);
@@ -89,11 +98,13 @@ BLS_NOINLINE void miller_add_step(g2_hom_t<F2>& t, F2& l0, F2& l2, F2& l3, const
   fp2_add(h, e, f);
   fp2_sub(h, h, g);
   fp2_sub(h, h, g);
+  fp2_norm(h, h);
   fp2_mul(t.x, la, h);
   fp2_sub(s, g, h);
   fp2_mul(s, th, s);
   fp2_mul(g, e, t.y);
-  fp2_sub(t.y, s, g);
+  fp2_sub(s, s, g);
+  fp2_reduce(t.y, s);
   fp2_mul(t.z, t.z, e);
 }
 
@@ -150,9 +161,9 @@ BLS_FN void miller_loop_fixed_g2(fp12_t<F2>& f, const g1_aff& P0, const aff<F2>&
     miller_dbl_step(T, l0, l2, l3, P0.x, P0.y);
     fp12_mul_by_line(f, l0, l2, l3);
     fp2_load(l0, &G2NEG_LINES[row][0]);
-    fp2_load(t, &G2NEG_LINES[row][24]);
+    fp2_load(t, &G2NEG_LINES[row][2 * FP_NL]);
     fp2_mul_fp(l2, t, P1.x);
-    fp2_load(t, &G2NEG_LINES[row][48]);
+    fp2_load(t, &G2NEG_LINES[row][4 * FP_NL]);
     fp2_mul_fp(l3, t, P1.y);
     fp12_mul_by_line(f, l0, l2, l3);
     row++;
@@ -160,9 +171,9 @@ BLS_FN void miller_loop_fixed_g2(fp12_t<F2>& f, const g1_aff& P0, const aff<F2>&
       miller_add_step(T, l0, l2, l3, Q0.x, Q0.y, P0.x, P0.y);
       fp12_mul_by_line(f, l0, l2, l3);
       fp2_load(l0, &G2NEG_LINES[row][0]);
-      fp2_load(t, &G2NEG_LINES[row][24]);
+      fp2_load(t, &G2NEG_LINES[row][2 * FP_NL]);
       fp2_mul_fp(l2, t, P1.x);
-      fp2_load(t, &G2NEG_LINES[row][48]);
+      fp2_load(t, &G2NEG_LINES[row][4 * FP_NL]);
       fp2_mul_fp(l3, t, P1.y);
       fp12_mul_by_line(f, l0, l2, l3);
       row++;

@@ -13,11 +13,11 @@ struct fp2 {
 
 BLS_FN void fp2_load(fp2& r, const uint32_t* c) {
   fp_load(r.c0, c);
-  fp_load(r.c1, c + 12);
+  fp_load(r.c1, c + FP_NL);
 }
 BLS_FN void fp2_store(uint32_t* c, const fp2& a) {
   fp_store(c, a.c0);
-  fp_store(c + 12, a.c1);
+  fp_store(c + FP_NL, a.c1);
 }
 BLS_FN void fp2_zero(fp2& r) {
   fp_zero(r.c0);
@@ -53,6 +53,16 @@ BLS_FN void fp2_conj(fp2& r, const fp2& a) {
   r.c0 = a.c0;
   fp_neg(r.c1, a.c1);
 }
+// Bound contract of the Fp2 layer (fp.cuh explains the lazy representation): fp2_mul / fp2_sqr accept operands whose limbs
+// are below 2^29 + a few units ("2N+": the sum of two normalised elements) and return normalised limbs ("N+").
+BLS_FN void fp2_norm(fp2& r, const fp2& a) {
+  fp_norm(r.c0, a.c0);
+  fp_norm(r.c1, a.c1);
+}
+BLS_FN void fp2_reduce(fp2& r, const fp2& a) {
+  fp_reduce(r.c0, a.c0);
+  fp_reduce(r.c1, a.c1);
+}
 // Karatsuba: 3 Fp multiplications
 BLS_FN void fp2_mul(fp2& r, const fp2& a, const fp2& b) {
   fp t0, t1, s0, s1, m;
@@ -60,21 +70,28 @@ BLS_FN void fp2_mul(fp2& r, const fp2& a, const fp2& b) {
   fp_mul(t1, a.c1, b.c1);
   fp_add(s0, a.c0, a.c1);
   fp_add(s1, b.c0, b.c1);
+  fp_norm(s0, s0);
+  fp_norm(s1, s1);
   fp_mul(m, s0, s1);
   fp_sub(m, m, t0);
-  fp_sub(r.c1, m, t1);
-  fp_sub(r.c0, t0, t1);
+  fp_sub(m, m, t1);
+  fp_sub(t0, t0, t1);
+  fp_norm(r.c1, m);
+  fp_norm(r.c0, t0);
 }
 // complex squaring: 2 Fp multiplications
 BLS_FN void fp2_sqr(fp2& r, const fp2& a) {
   fp s, d, m;
   fp_add(s, a.c0, a.c1);
   fp_sub(d, a.c0, a.c1);
+  fp_norm(s, s);
+  fp_norm(d, d);
   fp_mul(m, a.c0, a.c1);
   fp_mul(r.c0, s, d);
-  fp_dbl(r.c1, m);
+  fp_dbl(m, m);
+  fp_norm(r.c1, m);
 }
-// a * k for a constant k stored as 24 Montgomery words
+// a * k for a constant k stored as 2 * FP_NL words (internal form)
 BLS_FN void fp2_mul_const(fp2& r, const fp2& a, const uint32_t* k) {
   fp2 g;
   fp2_load(g, k);
@@ -91,7 +108,7 @@ BLS_FN void fp2_mul_xi(fp2& r, const fp2& a) {
   fp_add(r.c1, a.c0, a.c1);
   r.c0 = t;
 }
-BLS_FN void fp2_inv(fp2& r, const fp2& a) {
+BLS_NOINLINE void fp2_inv(fp2& r, const fp2& a) {
   fp n, t;
   fp_sqr(n, a.c0);
   fp_sqr(t, a.c1);
@@ -109,7 +126,7 @@ BLS_FN bool fp2_is_square(const fp2& a) {
   return fp_is_square(n);
 }
 // some square root (complex method); false if a is not a square.  Callers fix the sign.
-BLS_FN bool fp2_sqrt(fp2& r, const fp2& a) {
+BLS_NOINLINE bool fp2_sqrt(fp2& r, const fp2& a) {
   if (fp_is_zero(a.c1)) {
     fp s;
     if (fp_sqrt(s, a.c0)) {
@@ -154,7 +171,7 @@ BLS_FN uint32_t fp2_sgn0(const fp2& a) {
   fp t0, t1;
   fp_from_mont(t0, a.c0);
   fp_from_mont(t1, a.c1);
-  uint32_t s0 = t0.l[0] & 1, z0 = fp_is_zero(t0) ? 1u : 0u, s1 = t1.l[0] & 1;
+  uint32_t s0 = (uint32_t)t0.l[0] & 1u, z0 = fp_is_zero(t0) ? 1u : 0u, s1 = (uint32_t)t1.l[0] & 1u;
   return s0 | (z0 & s1);
 }
 BLS_FN bool fp2_lex_largest(const fp2& a) {
@@ -193,6 +210,18 @@ BLS_FN void fp6_neg(fp6_t<F2>& r, const fp6_t<F2>& a) {
   fp2_neg(r.a1, a.a1);
   fp2_neg(r.a2, a.a2);
 }
+template <class F2>
+BLS_FN void fp6_norm(fp6_t<F2>& r, const fp6_t<F2>& a) {
+  fp2_norm(r.a0, a.a0);
+  fp2_norm(r.a1, a.a1);
+  fp2_norm(r.a2, a.a2);
+}
+template <class F2>
+BLS_FN void fp6_reduce(fp6_t<F2>& r, const fp6_t<F2>& a) {
+  fp2_reduce(r.a0, a.a0);
+  fp2_reduce(r.a1, a.a1);
+  fp2_reduce(r.a2, a.a2);
+}
 // multiply by v: (a0, a1, a2) -> (xi a2, a0, a1)
 template <class F2>
 BLS_FN void fp6_mul_v(fp6_t<F2>& r, const fp6_t<F2>& a) {
@@ -202,7 +231,7 @@ BLS_FN void fp6_mul_v(fp6_t<F2>& r, const fp6_t<F2>& a) {
   r.a1 = a.a0;
   r.a0 = t;
 }
-// Karatsuba: 6 Fp2 multiplications
+// Karatsuba: 6 Fp2 multiplications.  Operands: normalised limbs (N+); result: normalised limbs, value up to 8 p.
 template <class F2>
 BLS_FN void fp6_mul(fp6_t<F2>& r, const fp6_t<F2>& a, const fp6_t<F2>& b) {
   F2 v0, v1, v2, s, t, m;
@@ -233,7 +262,7 @@ BLS_FN void fp6_mul(fp6_t<F2>& r, const fp6_t<F2>& a, const fp6_t<F2>& b) {
   fp2_sub(m, m, v0);
   fp2_sub(m, m, v2);
   fp2_add(o.a2, m, v1);
-  r = o;
+  fp6_norm(r, o);
 }
 template <class F2>
 BLS_FN void fp6_inv(fp6_t<F2>& r, const fp6_t<F2>& a) {
@@ -249,6 +278,9 @@ BLS_FN void fp6_inv(fp6_t<F2>& r, const fp6_t<F2>& a) {
   fp2_sqr(t2, a.a1);
   fp2_mul(m, a.a0, a.a2);
   fp2_sub(t2, t2, m);  // a1^2 - a0 a2
+  fp2_norm(t0, t0);
+  fp2_norm(t1, t1);
+  fp2_norm(t2, t2);
   fp2_mul(d, a.a0, t0);
   F2 e;
   fp2_mul(m, a.a2, t1);
@@ -256,6 +288,7 @@ BLS_FN void fp6_inv(fp6_t<F2>& r, const fp6_t<F2>& a) {
   fp2_add(m, m, e);
   fp2_mul_xi(m, m);
   fp2_add(d, d, m);
+  fp2_reduce(d, d);
   fp2_inv(d, d);
   fp2_mul(r.a0, t0, d);
   fp2_mul(r.a1, t1, d);
@@ -287,6 +320,13 @@ BLS_FN void fp12_conj(fp12_t<F2>& r, const fp12_t<F2>& a) {
   r.c0 = a.c0;
   fp6_neg(r.c1, a.c1);
 }
+template <class F2>
+BLS_FN void fp12_reduce(fp12_t<F2>& r, const fp12_t<F2>& a) {
+  fp6_reduce(r.c0, a.c0);
+  fp6_reduce(r.c1, a.c1);
+}
+// Fp12 functions take reduced or normalised operands (limbs N+, value within a few p) and return reduced results
+// (exact limbs, value in (-0.52 p, 0.52 p)).
 // Karatsuba over Fp6: 18 Fp2 multiplications
 template <class F2>
 BLS_NOINLINE void fp12_mul(fp12_t<F2>& r, const fp12_t<F2>& a, const fp12_t<F2>& b) {
@@ -295,11 +335,15 @@ BLS_NOINLINE void fp12_mul(fp12_t<F2>& r, const fp12_t<F2>& a, const fp12_t<F2>&
   fp6_mul(t1, a.c1, b.c1);
   fp6_add(s, a.c0, a.c1);
   fp6_add(t, b.c0, b.c1);
+  fp6_norm(s, s);
+  fp6_norm(t, t);
   fp6_mul(m, s, t);
   fp6_sub(m, m, t0);
-  fp6_sub(r.c1, m, t1);
+  fp6_sub(m, m, t1);
+  fp6_reduce(r.c1, m);
   fp6_mul_v(t1, t1);
-  fp6_add(r.c0, t0, t1);
+  fp6_add(t0, t0, t1);
+  fp6_reduce(r.c0, t0);
 }
 // complex squaring: 12 Fp2 multiplications
 template <class F2>
@@ -309,11 +353,15 @@ BLS_NOINLINE void fp12_sqr(fp12_t<F2>& r, const fp12_t<F2>& a) {
   fp6_add(s0, a.c0, a.c1);
   fp6_mul_v(s1, a.c1);
   fp6_add(s1, s1, a.c0);
+  fp6_norm(s0, s0);
+  fp6_norm(s1, s1);
   fp6_mul(m, s0, s1);
   fp6_sub(m, m, t);
   fp6_mul_v(s0, t);
-  fp6_sub(r.c0, m, s0);
-  fp6_add(r.c1, t, t);
+  fp6_sub(m, m, s0);
+  fp6_reduce(r.c0, m);
+  fp6_add(t, t, t);
+  fp6_reduce(r.c1, t);
 }
 template <class F2>
 BLS_NOINLINE void fp12_inv(fp12_t<F2>& r, const fp12_t<F2>& a) {
@@ -322,15 +370,19 @@ BLS_NOINLINE void fp12_inv(fp12_t<F2>& r, const fp12_t<F2>& a) {
   fp6_mul(t1, a.c1, a.c1);
   fp6_mul_v(t1, t1);
   fp6_sub(t0, t0, t1);
+  fp6_reduce(t0, t0);
   fp6_inv(t0, t0);
-  fp6_mul(r.c0, a.c0, t0);
+  fp6_reduce(t0, t0);
+  fp6_mul(t1, a.c0, t0);
+  fp6_reduce(r.c0, t1);
   fp6_mul(t1, a.c1, t0);
-  fp6_neg(r.c1, t1);
+  fp6_neg(t1, t1);
+  fp6_reduce(r.c1, t1);
 }
 // a^(p^J), J = 1 or 2:  coefficient of w^k -> conj^J(c_k) * FROBJ[k]
 template <int J, class F2>
 BLS_FN void fp12_frob(fp12_t<F2>& r, const fp12_t<F2>& a) {
-  const uint32_t(*tab)[24] = (J == 1) ? FROB1 : FROB2;
+  const uint32_t(*tab)[2 * FP_NL] = (J == 1) ? FROB1 : FROB2;
   F2 c;
 #define FROB_ONE(dst, src, k)        \
   if (J == 1) fp2_conj(c, src);      \
@@ -355,11 +407,13 @@ BLS_FN void fp4_sqr(F2& c0, F2& c1, const F2& a, const F2& b) {
   fp2_sqr(t0, a);
   fp2_sqr(t1, b);
   fp2_mul_xi(t2, t1);
-  fp2_add(c0, t2, t0);
+  fp2_add(t2, t2, t0);
+  fp2_norm(c0, t2);
   fp2_add(t2, a, b);
   fp2_sqr(t2, t2);
   fp2_sub(t2, t2, t0);
-  fp2_sub(c1, t2, t1);
+  fp2_sub(t2, t2, t1);
+  fp2_norm(c1, t2);
 }
 template <class F2>
 BLS_NOINLINE void fp12_cyclotomic_sqr(fp12_t<F2>& r, const fp12_t<F2>& f) {
@@ -381,18 +435,19 @@ BLS_NOINLINE void fp12_cyclotomic_sqr(fp12_t<F2>& r, const fp12_t<F2>& f) {
   fp2_dbl(z5, z5);
   fp2_add(z5, z5, t1);
   fp2_mul_xi(t0, t3);
+  fp2_norm(t0, t0);
   fp2_add(z2, t0, z2);
   fp2_dbl(z2, z2);
   fp2_add(z2, z2, t0);
   fp2_sub(z3, t2, z3);
   fp2_dbl(z3, z3);
   fp2_add(z3, z3, t2);
-  r.c0.a0 = z0;
-  r.c0.a1 = z4;
-  r.c0.a2 = z3;
-  r.c1.a0 = z2;
-  r.c1.a1 = z1;
-  r.c1.a2 = z5;
+  fp2_reduce(r.c0.a0, z0);
+  fp2_reduce(r.c0.a1, z4);
+  fp2_reduce(r.c0.a2, z3);
+  fp2_reduce(r.c1.a0, z2);
+  fp2_reduce(r.c1.a1, z1);
+  fp2_reduce(r.c1.a2, z5);
 }
 
 // f * (l0 + l2 w^2 + l3 w^3): the sparse line value of the Miller loop.  13 Fp2 multiplications.
@@ -417,6 +472,7 @@ BLS_NOINLINE void fp12_mul_by_line(fp12_t<F2>& f, const F2& l0, const F2& l2, co
     fp2_sub(t0.a1, y, v1);  // a0 l2 + a1 l0
     fp2_mul(z, a.a2, l0);
     fp2_add(t0.a2, z, v1);  // a2 l0 + a1 l2
+    fp6_norm(t0, t0);
   }
   // t1 = f.c1 * (l3 v) = (xi a2 l3, a0 l3, a1 l3), 3 mul
   {
@@ -428,9 +484,11 @@ BLS_NOINLINE void fp12_mul_by_line(fp12_t<F2>& f, const F2& l0, const F2& l2, co
   }
   // m = (f.c0 + f.c1) * (l0 + (l2 + l3) v), 5 mul
   fp6_add(s, f.c0, f.c1);
+  fp6_norm(s, s);
   {
     F2 l23, v0, v1;
     fp2_add(l23, l2, l3);
+    fp2_norm(l23, l23);
     fp2_mul(v0, s.a0, l0);
     fp2_mul(v1, s.a1, l23);
     fp2_mul(x, s.a2, l23);
@@ -445,7 +503,9 @@ BLS_NOINLINE void fp12_mul_by_line(fp12_t<F2>& f, const F2& l0, const F2& l2, co
     fp2_add(m.a2, z, v1);
   }
   fp6_sub(m, m, t0);
-  fp6_sub(f.c1, m, t1);
+  fp6_sub(m, m, t1);
+  fp6_reduce(f.c1, m);
   fp6_mul_v(t1, t1);
-  fp6_add(f.c0, t0, t1);
+  fp6_add(t0, t0, t1);
+  fp6_reduce(f.c0, t0);
 }

@@ -1,15 +1,17 @@
 // Lane-split Fp2: one Fp2 element per PAIR of adjacent lanes -- the even lane holds c0, the odd lane c1 -- so that one
 // item occupies two lanes.  Why: 65,536 items are exactly one wave per SIMD, and a lone wave issues one VALU instruction
 // per ~5 cycles while two waves per SIMD reach ~3.5 (profiles/ubench_r01.txt).  Splitting at Fp2 doubles the wave count,
-// halves the per-lane register state (an Fp12 is 72 dwords per lane) and balances perfectly:
-//     c0 = REDC(a0 b0 + (p - a1) b1)   on the even lane,      c1 = REDC(a0 b1 + a1 b0)   on the odd lane
+// halves the per-lane register state (an Fp12 is 84 dwords per lane) and balances perfectly:
+//     c0 = REDC(a0 b0 + (-a1) b1)      on the even lane,      c1 = REDC(a0 b1 + a1 b0)   on the odd lane
 // i.e. ONE fused two-product Montgomery pass per lane (lazy reduction for free) instead of three full multiplications
 // in one lane.  Partner components travel by DPP quad_perm [1,0,3,2] (full-rate VALU moves, no LDS).
 // Everything above Fp2 (Fp6, Fp12, Miller steps, final exponentiation) is the same template code as the one-lane path.
-// Device only.
+// On the host (tests/hostsim, no DPP) the same operations are emulated on a struct that holds both lanes' components,
+// with exactly the device's operation sequence per lane, so that the bound tracker of fp.cuh also covers this path.
 #pragma once
 #include "pairing.cuh"
 
+#if defined(__HIPCC__)
 struct hfp2 {
   fp v;  // this lane's component
 };
@@ -17,11 +19,11 @@ struct hfp2 {
 __device__ __forceinline__ bool lane_hi() { return (threadIdx.x & 1u) != 0; }
 __device__ __forceinline__ void fp_partner(fp& r, const fp& a) {
 #pragma unroll
-  for (int i = 0; i < 12; i++) r.l[i] = dpp_swap(a.l[i]);
+  for (int i = 0; i < FP_NL; i++) r.l[i] = dpp_swap(a.l[i]);
 }
 __device__ __forceinline__ void fp_sel(fp& r, bool c, const fp& a, const fp& b) {  // r = c ? a : b
 #pragma unroll
-  for (int i = 0; i < 12; i++) r.l[i] = c ? a.l[i] : b.l[i];
+  for (int i = 0; i < FP_NL; i++) r.l[i] = c ? a.l[i] : b.l[i];
 }
 
 __device__ __forceinline__ void fp2_zero(hfp2& r) { fp_zero(r.v); }
@@ -31,13 +33,13 @@ __device__ __forceinline__ void fp2_one(hfp2& r) {
   fp_zero(z);
   fp_sel(r.v, lane_hi(), z, one);
 }
-__device__ __forceinline__ void fp2_load(hfp2& r, const uint32_t* c) { fp_load(r.v, c + (lane_hi() ? 12 : 0)); }
+__device__ __forceinline__ void fp2_load(hfp2& r, const uint32_t* c) { fp_load(r.v, c + (lane_hi() ? FP_NL : 0)); }
 __device__ __forceinline__ bool fp2_is_zero(const hfp2& a) {
-  uint32_t z = fp_is_zero(a.v) ? 1u : 0u;
+  int32_t z = fp_is_zero(a.v) ? 1 : 0;
   return (z & dpp_swap(z)) != 0;
 }
 __device__ __forceinline__ bool fp2_eq(const hfp2& a, const hfp2& b) {
-  uint32_t e = fp_eq(a.v, b.v) ? 1u : 0u;
+  int32_t e = fp_eq(a.v, b.v) ? 1 : 0;
   return (e & dpp_swap(e)) != 0;
 }
 __device__ __forceinline__ void fp2_cmov(hfp2& r, const hfp2& a, bool c) { fp_cmov(r.v, a.v, c); }
@@ -45,6 +47,8 @@ __device__ __forceinline__ void fp2_add(hfp2& r, const hfp2& a, const hfp2& b) {
 __device__ __forceinline__ void fp2_sub(hfp2& r, const hfp2& a, const hfp2& b) { fp_sub(r.v, a.v, b.v); }
 __device__ __forceinline__ void fp2_neg(hfp2& r, const hfp2& a) { fp_neg(r.v, a.v); }
 __device__ __forceinline__ void fp2_dbl(hfp2& r, const hfp2& a) { fp_dbl(r.v, a.v); }
+__device__ __forceinline__ void fp2_norm(hfp2& r, const hfp2& a) { fp_norm(r.v, a.v); }
+__device__ __forceinline__ void fp2_reduce(hfp2& r, const hfp2& a) { fp_reduce(r.v, a.v); }
 __device__ __forceinline__ void fp2_conj(hfp2& r, const hfp2& a) {
   fp n;
   fp_neg(n, a.v);
@@ -60,6 +64,8 @@ __device__ __forceinline__ void fp2_sqr(hfp2& r, const hfp2& a) {
   fp_zero(z);
   fp_sel(t, hi, z, pa);
   fp_sub(y, a.v, t);          // even: a0 - a1, odd: a1
+  fp_norm(x, x);
+  fp_norm(y, y);
   fp_mul(r.v, x, y);
 }
 __device__ __forceinline__ void fp2_mul_fp(hfp2& r, const hfp2& a, const fp& k) { fp_mul(r.v, a.v, k); }
@@ -85,3 +91,67 @@ __device__ __forceinline__ void fp2_inv(hfp2& r, const hfp2& a) {
   fp_neg(n, t);
   fp_sel(r.v, lane_hi(), n, t);
 }
+#else
+// ---- host emulation: c[0] is the even lane's register file, c[1] the odd lane's; every function performs, for
+// each lane, the operations the device code above performs on that lane.
+struct hfp2 {
+  fp c[2];
+};
+static inline void fp2_zero(hfp2& r) { fp_zero(r.c[0]); fp_zero(r.c[1]); }
+static inline void fp2_one(hfp2& r) { fp_one(r.c[0]); fp_zero(r.c[1]); }
+static inline void fp2_load(hfp2& r, const uint32_t* c) { fp_load(r.c[0], c); fp_load(r.c[1], c + FP_NL); }
+static inline bool fp2_is_zero(const hfp2& a) { return fp_is_zero(a.c[0]) && fp_is_zero(a.c[1]); }
+static inline bool fp2_eq(const hfp2& a, const hfp2& b) { return fp_eq(a.c[0], b.c[0]) && fp_eq(a.c[1], b.c[1]); }
+static inline void fp2_cmov(hfp2& r, const hfp2& a, bool c) { fp_cmov(r.c[0], a.c[0], c); fp_cmov(r.c[1], a.c[1], c); }
+static inline void fp2_add(hfp2& r, const hfp2& a, const hfp2& b) { fp_add(r.c[0], a.c[0], b.c[0]); fp_add(r.c[1], a.c[1], b.c[1]); }
+static inline void fp2_sub(hfp2& r, const hfp2& a, const hfp2& b) { fp_sub(r.c[0], a.c[0], b.c[0]); fp_sub(r.c[1], a.c[1], b.c[1]); }
+static inline void fp2_neg(hfp2& r, const hfp2& a) { fp_neg(r.c[0], a.c[0]); fp_neg(r.c[1], a.c[1]); }
+static inline void fp2_dbl(hfp2& r, const hfp2& a) { fp_dbl(r.c[0], a.c[0]); fp_dbl(r.c[1], a.c[1]); }
+static inline void fp2_norm(hfp2& r, const hfp2& a) { fp_norm(r.c[0], a.c[0]); fp_norm(r.c[1], a.c[1]); }
+static inline void fp2_reduce(hfp2& r, const hfp2& a) { fp_reduce(r.c[0], a.c[0]); fp_reduce(r.c[1], a.c[1]); }
+static inline void fp2_conj(hfp2& r, const hfp2& a) { r.c[0] = a.c[0]; fp_neg(r.c[1], a.c[1]); }
+static inline void fp2_mul(hfp2& r, const hfp2& a, const hfp2& b) {
+  fp na1, c0, c1;
+  fp_neg(na1, a.c[1]);
+  fp_dotp2(c0, a.c[0], b.c[0], na1, b.c[1]);        // even lane
+  fp_dotp2(c1, a.c[0], b.c[1], a.c[1], b.c[0]);     // odd lane
+  r.c[0] = c0;
+  r.c[1] = c1;
+}
+static inline void fp2_sqr(hfp2& r, const hfp2& a) {
+  fp x0, y0, x1, y1;
+  fp_add(x0, a.c[0], a.c[1]);
+  fp_sub(y0, a.c[0], a.c[1]);
+  fp_add(x1, a.c[0], a.c[0]);
+  y1 = a.c[1];
+  fp_norm(x0, x0);
+  fp_norm(y0, y0);
+  fp_norm(x1, x1);
+  fp_norm(y1, y1);
+  fp_mul(r.c[0], x0, y0);
+  fp_mul(r.c[1], x1, y1);
+}
+static inline void fp2_mul_fp(hfp2& r, const hfp2& a, const fp& k) { fp_mul(r.c[0], a.c[0], k); fp_mul(r.c[1], a.c[1], k); }
+static inline void fp2_mul_xi(hfp2& r, const hfp2& a) {
+  fp d, s;
+  fp_sub(d, a.c[0], a.c[1]);
+  fp_add(s, a.c[1], a.c[0]);
+  r.c[0] = d;
+  r.c[1] = s;
+}
+static inline void fp2_mul_const(hfp2& r, const hfp2& a, const uint32_t* k) {
+  hfp2 kk;
+  fp2_load(kk, k);
+  fp2_mul(r, a, kk);
+}
+static inline void fp2_inv(hfp2& r, const hfp2& a) {
+  fp s0, s1, n, t;
+  fp_sqr(s0, a.c[0]);
+  fp_sqr(s1, a.c[1]);
+  fp_add(n, s0, s1);
+  fp_inv(n, n);
+  fp_mul(r.c[0], a.c[0], n);
+  fp_mul(t, a.c[1], n);
+  fp_neg(r.c[1], t);
+}
+#endif

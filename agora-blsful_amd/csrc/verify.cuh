@@ -58,7 +58,7 @@ BLS_FN void g2_apply_ninv(g2_aff& r, const g2_jac& p, const fp& ni) {
   fp2_mul(r.y, p.y, zi2);
   r.inf = false;
 }
-BLS_FN void fp2_norm(fp& n, const fp2& a) {
+BLS_FN void fp2_norm_sq(fp& n, const fp2& a) {
   fp t;
   fp_sqr(n, a.c0);
   fp_sqr(t, a.c1);
@@ -68,7 +68,7 @@ BLS_FN void fp2_norm(fp& n, const fp2& a) {
 // both of (pk, sig) to affine with one inversion; neither is infinity
 BLS_FN void g1g2_to_aff(g1_aff& a1, g2_aff& a2, const g1_jac& p1, const g2_jac& p2) {
   fp z1 = p1.z, n2;
-  fp2_norm(n2, p2.z);
+  fp2_norm_sq(n2, p2.z);
   fp_inv2(z1, n2);
   g1_apply_zinv(a1, p1, z1);
   g2_apply_ninv(a2, p2, n2);
@@ -113,7 +113,7 @@ BLS_FN int prepare_g1impl(g1_aff* P, g2_aff* Q, const g2_jac& pk, const g1_jac& 
       jac_to_aff(P[0], h);
     } else {
       fp zs = sig.z, zh = h.z, n;
-      fp2_norm(n, pk.z);
+      fp2_norm_sq(n, pk.z);
       fp_inv3(zs, zh, n);
       g1_apply_zinv(P[1], sig, zs);
       g1_apply_zinv(P[0], h, zh);
@@ -144,8 +144,8 @@ BLS_FN int prepare_g2impl(g1_aff* P, g2_aff* Q, const g1_jac& pk, const g2_jac& 
       jac_to_aff(Q[0], h);
     } else {
       fp zp = pk.z, ns, nh;
-      fp2_norm(ns, sig.z);
-      fp2_norm(nh, h.z);
+      fp2_norm_sq(ns, sig.z);
+      fp2_norm_sq(nh, h.z);
       fp_inv3(zp, ns, nh);
       g1_apply_zinv(P[0], pk, zp);
       g2_apply_ninv(Q[1], sig, ns);

@@ -3,30 +3,33 @@
 // It is never linked into libblsgpu.so and is not a CPU fallback: the product library has no host compute path.
 #include <string.h>
 #include "../../agora-blsful_amd/csrc/verify.cuh"
+#include "../../agora-blsful_amd/csrc/tower_split.cuh"
 
-static void load_g1_jac(g1_jac& p, const uint32_t* w) { fp_load(p.x, w); fp_load(p.y, w + 12); fp_load(p.z, w + 24); }
-static void load_g2_jac(g2_jac& p, const uint32_t* w) { fp2_load(p.x, w); fp2_load(p.y, w + 24); fp2_load(p.z, w + 48); }
+// callers pass blst-style Montgomery words (R = 2^384, 12 words per Fp) exactly like the RAW formats of the C ABI
+static void raw_fp2(fp2& r, const uint32_t* w) { fp_from_raw(r.c0, w); fp_from_raw(r.c1, w + 12); }
+static void load_g1_jac(g1_jac& p, const uint32_t* w) { fp_from_raw(p.x, w); fp_from_raw(p.y, w + 12); fp_from_raw(p.z, w + 24); }
+static void load_g2_jac(g2_jac& p, const uint32_t* w) { raw_fp2(p.x, w); raw_fp2(p.y, w + 24); raw_fp2(p.z, w + 48); }
+static void store_plain(uint32_t* out, const fp& a_mont) { fp t; fp_from_mont(t, a_mont); fp_get_words(out, t); }
 static void store_fp12_plain(uint32_t* out, const fp12& f) {
   // w-power order: k = 2 j + i for c_i . a_j
   const fp2* c[6] = {&f.c0.a0, &f.c1.a0, &f.c0.a1, &f.c1.a1, &f.c0.a2, &f.c1.a2};
   for (int k = 0; k < 6; k++) {
-    fp t;
-    fp_from_mont(t, c[k]->c0); fp_store(out + 24 * k, t);
-    fp_from_mont(t, c[k]->c1); fp_store(out + 24 * k + 12, t);
+    store_plain(out + 24 * k, c[k]->c0);
+    store_plain(out + 24 * k + 12, c[k]->c1);
   }
 }
 
 extern "C" {
 void hs_fp_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) {
-  fp x, y, z; fp_load(x, a); fp_load(y, b); fp_mul(z, x, y); fp_store(out, z);
+  fp x, y, z; fp_from_raw(x, a); fp_from_raw(y, b); fp_mul(z, x, y); fp_to_raw(out, z);
 }
 void hs_fp_ops(const uint32_t* a, const uint32_t* b, uint32_t* out) {  // add, sub, neg, inv, sqrt-flag
-  fp x, y, z; fp_load(x, a); fp_load(y, b);
-  fp_add(z, x, y); fp_store(out, z);
-  fp_sub(z, x, y); fp_store(out + 12, z);
-  fp_neg(z, x); fp_store(out + 24, z);
-  fp_inv(z, x); fp_store(out + 36, z);
-  out[48] = fp_sqrt(z, x) ? 1 : 0; fp_store(out + 49, z);
+  fp x, y, z; fp_from_raw(x, a); fp_from_raw(y, b);
+  fp_add(z, x, y); fp_to_raw(out, z);
+  fp_sub(z, x, y); fp_to_raw(out + 12, z);
+  fp_neg(z, x); fp_to_raw(out + 24, z);
+  fp_inv(z, x); fp_to_raw(out + 36, z);
+  out[48] = fp_sqrt(z, x) ? 1 : 0; fp_to_raw(out + 49, z);
   out[61] = fp_lex_largest(x) ? 1 : 0;
 }
 void hs_fp12_check(const uint32_t* a, const uint32_t* b, uint32_t* out) {
@@ -34,7 +37,7 @@ void hs_fp12_check(const uint32_t* a, const uint32_t* b, uint32_t* out) {
   fp12 x, y, z;
   fp2* cx[6] = {&x.c0.a0, &x.c1.a0, &x.c0.a1, &x.c1.a1, &x.c0.a2, &x.c1.a2};
   fp2* cy[6] = {&y.c0.a0, &y.c1.a0, &y.c0.a1, &y.c1.a1, &y.c0.a2, &y.c1.a2};
-  for (int k = 0; k < 6; k++) { fp2_load(*cx[k], a + 24 * k); fp2_load(*cy[k], b + 24 * k); }
+  for (int k = 0; k < 6; k++) { raw_fp2(*cx[k], a + 24 * k); raw_fp2(*cy[k], b + 24 * k); }
   fp12_mul(z, x, y); store_fp12_plain(out, z);
   fp12_sqr(z, x); store_fp12_plain(out + 144, z);
   fp12_inv(z, x); store_fp12_plain(out + 288, z);
@@ -74,8 +77,8 @@ void hs_g2_clear_cofactor(const uint32_t* p, uint8_t* out) {
 void hs_pairing(int n, const uint32_t* g1s, const uint32_t* g2s, uint32_t* out_plain, uint32_t* out_miller_plain) {
   g1_aff P[2]; g2_aff Q[2];
   for (int i = 0; i < n; i++) {
-    fp_load(P[i].x, g1s + 24 * i); fp_load(P[i].y, g1s + 24 * i + 12); P[i].inf = false;
-    fp2_load(Q[i].x, g2s + 48 * i); fp2_load(Q[i].y, g2s + 48 * i + 24); Q[i].inf = false;
+    fp_from_raw(P[i].x, g1s + 24 * i); fp_from_raw(P[i].y, g1s + 24 * i + 12); P[i].inf = false;
+    raw_fp2(Q[i].x, g2s + 48 * i); raw_fp2(Q[i].y, g2s + 48 * i + 24); Q[i].inf = false;
   }
   fp12 f, e;
   if (n == 1) miller_loop<1>(f, P, Q); else miller_loop<2>(f, P, Q);
@@ -86,9 +89,9 @@ void hs_pairing(int n, const uint32_t* g1s, const uint32_t* g2s, uint32_t* out_p
 // Miller loop with the precomputed -g2 line table vs the generic two-pair loop with Q1 = -g2: raw Miller values
 int hs_miller_fixed_g2_matches(const uint32_t* p0, const uint32_t* q0, const uint32_t* p1) {
   g1_aff P[2]; g2_aff Q[2];
-  fp_load(P[0].x, p0); fp_load(P[0].y, p0 + 12); P[0].inf = false;
-  fp_load(P[1].x, p1); fp_load(P[1].y, p1 + 12); P[1].inf = false;
-  fp2_load(Q[0].x, q0); fp2_load(Q[0].y, q0 + 24); Q[0].inf = false;
+  fp_from_raw(P[0].x, p0); fp_from_raw(P[0].y, p0 + 12); P[0].inf = false;
+  fp_from_raw(P[1].x, p1); fp_from_raw(P[1].y, p1 + 12); P[1].inf = false;
+  raw_fp2(Q[0].x, q0); raw_fp2(Q[0].y, q0 + 24); Q[0].inf = false;
   g2_neg_gen(Q[1]);
   fp12 a, b;
   miller_loop<2>(a, P, Q);
@@ -100,8 +103,8 @@ int hs_miller_fixed_g2_matches(const uint32_t* p0, const uint32_t* q0, const uin
 // cyclotomic squaring vs generic squaring on an element of the cyclotomic subgroup
 int hs_cyclotomic_check(int n, const uint32_t* g1s, const uint32_t* g2s) {
   g1_aff P[1]; g2_aff Q[1];
-  fp_load(P[0].x, g1s); fp_load(P[0].y, g1s + 12); P[0].inf = false;
-  fp2_load(Q[0].x, g2s); fp2_load(Q[0].y, g2s + 24); Q[0].inf = false;
+  fp_from_raw(P[0].x, g1s); fp_from_raw(P[0].y, g1s + 12); P[0].inf = false;
+  raw_fp2(Q[0].x, g2s); raw_fp2(Q[0].y, g2s + 24); Q[0].inf = false;
   fp12 f, e, a, b;
   miller_loop<1>(f, P, Q);
   final_exponentiation(e, f);
@@ -121,6 +124,16 @@ int hs_decompress(int group, const uint8_t* in, int legacy, uint8_t* out) {
   g2_jac p; int rc = g2_decompress(p, in, legacy != 0); if (rc) return rc;
   g2_aff a; jac_to_aff(a, p); g2_compress(out, a, false); return 0;
 }
+// the lane-split tower (tower_split.cuh host emulation) on the same pairs: what k_miller2s / k_finalexps compute
+static void to_split(aff<hfp2>& r, const g2_aff& q) { r.x.c[0] = q.x.c0; r.x.c[1] = q.x.c1; r.y.c[0] = q.y.c0; r.y.c[1] = q.y.c1; r.inf = q.inf; }
+static int verdict_split(int sig_group, const g1_aff* P, const g2_aff* Q) {
+  aff<hfp2> QQ[2];
+  to_split(QQ[0], Q[0]); to_split(QQ[1], Q[1]);
+  fp12_t<hfp2> f;
+  if (sig_group == 1) miller_loop_fixed_g2(f, P[0], QQ[0], P[1]);
+  else miller_loop<2>(f, P, QQ);
+  return pairing_verdict(f);
+}
 int hs_verify(int sig_group, const uint32_t* pk, const uint32_t* sig, int aug, const uint8_t* msg, uint32_t len,
               const uint8_t* dst, uint32_t dlen) {
   g1_aff P[2]; g2_aff Q[2];
@@ -136,6 +149,8 @@ int hs_verify(int sig_group, const uint32_t* pk, const uint32_t* sig, int aug, c
   fp12 f;
   if (sig_group == 1) miller_loop_fixed_g2(f, P[0], Q[0], P[1]);   // as k_miller2 does for Bls12381G1Impl
   else miller_loop<2>(f, P, Q);
-  return pairing_verdict(f);
+  const int v = pairing_verdict(f);
+  const int vs = verdict_split(sig_group, P, Q);
+  return v == vs ? v : -100 - vs;    // the two tower instantiations must agree
 }
 }

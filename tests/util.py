@@ -74,10 +74,14 @@ def scalar_raw(k):
 def build_hostsim():
     src = os.path.join(ROOT, 'tests', 'hostsim', 'hostsim.cpp')
     so = os.path.join(ROOT, 'tests', 'hostsim', 'libhostsim.so')
+    if os.environ.get('BLS_HOSTSIM_SO'):          # a debug build (-O0 -g) for locating a tracked-bound violation
+        return ctypes.CDLL(os.environ['BLS_HOSTSIM_SO'])
     deps = [src] + [os.path.join(ROOT, 'agora-blsful_amd', 'csrc', f) for f in os.listdir(os.path.join(ROOT, 'agora-blsful_amd', 'csrc')) if f.endswith('.cuh')]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         import subprocess
-        subprocess.check_call(['g++', '-O2', '-shared', '-fPIC', '-o', so, src])
+        # BLS_TRACK_BOUNDS: every Fp value carries worst-case limb/value bounds that are checked on every operation
+        # (csrc/fp.cuh), so these tests also prove the placement of the carry/reduction passes for all inputs
+        subprocess.check_call(['g++', '-O2', '-DBLS_TRACK_BOUNDS', '-shared', '-fPIC', '-o', so, src])
     return ctypes.CDLL(so)
 
 
