@@ -234,8 +234,8 @@ BLS_FN void fp_redc_products(fp& r, const fp& a, const fp& b, const fp& c, const
 }
 
 #if defined(BLS_COUNT_FPMUL)
-extern "C" { uint64_t g_fpmul_count = 0; }   // tools/count_fpmul.py: host-side instruction-mix census
-#define FP_COUNT(n) g_fpmul_count += (n)
+extern "C" { uint64_t g_fpmul_halves = 0; }   // tools/count_fpmul.py: host-side census, in half multiplications
+#define FP_COUNT(n) g_fpmul_halves += (n)
 #else
 #define FP_COUNT(n)
 #endif
@@ -312,12 +312,12 @@ BLS_FN void fp2_mul_split(fp& r, const fp& a, const fp& b) {
 }
 #else
 BLS_FN void fp_mul(fp& r, const fp& a, const fp& b) {
-  FP_COUNT(1);
+  FP_COUNT(2);
   fp_redc_products<1>(r, a, b, a, b);
 }
 // REDC(a b + c d): host twin of the lane-split product (tower_split.cuh's host emulation)
 BLS_FN void fp_dotp2(fp& r, const fp& a, const fp& b, const fp& c, const fp& d) {
-  FP_COUNT(1);  // 1.5 multiplication equivalents; two of these make one Fp2 product = 3 equivalents
+  FP_COUNT(3);  // two product streams + one reduction = 1.5 multiplications; two of these make one Fp2 product
   fp_redc_products<2>(r, a, b, c, d);
 }
 #endif

@@ -28,7 +28,8 @@ SEED = hashlib.sha256(b'blsgpu-bench-v1').digest()
 S0 = int.from_bytes(SEED, 'big') % R_ORDER
 ALG_BYTES_PER_VERIFY = 468          # pk 288 + sig 144 + msg 32 + status 4
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FPMUL_PEAK_G = 58.0                 # profiles/ubench_r01.txt: fp_mul/s chip-wide at 4 waves/SIMD (integer-VALU roofline)
+FPMUL_PEAK_G = 66.6                 # profiles/ubench_r01_fp28.txt: best measured Fp-multiplication-equivalent rate of the 28-bit-limb
+                                    # multiplier chip-wide (fused two-product pass, 2-4 waves/SIMD): the integer-VALU roofline
 
 
 def gen_inputs(n, base):
@@ -158,7 +159,7 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': dom[0], 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_ms': dom_ms,
                          'algorithmic_bytes_per_launch': ALG_BYTES_PER_VERIFY * n,
-                         'note': 'integer-VALU bound path: see valu_roofline'},
+                         'note': 'integer-VALU bound path: see valu_roofline; traffic is scratch (by-reference Fp12 operands), not input data'},
             'kernel_ms': kernels,
         }
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')

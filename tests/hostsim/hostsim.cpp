@@ -20,6 +20,7 @@ static void store_fp12_plain(uint32_t* out, const fp12& f) {
 }
 
 extern "C" {
+int hs_device_path_only = 0;   // tools/count_fpmul.py: run exactly what the kernels run (prepare, then the lane-split pairing)
 void hs_fp_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) {
   fp x, y, z; fp_from_raw(x, a); fp_from_raw(y, b); fp_mul(z, x, y); fp_to_raw(out, z);
 }
@@ -146,6 +147,7 @@ int hs_verify(int sig_group, const uint32_t* pk, const uint32_t* sig, int aug, c
     st = prepare_g2impl(P, Q, k, s, aug, msg, len, dst, dlen);
   }
   if (st != BLS_OK) return st;
+  if (hs_device_path_only) return verdict_split(sig_group, P, Q);
   fp12 f;
   if (sig_group == 1) miller_loop_fixed_g2(f, P[0], Q[0], P[1]);   // as k_miller2 does for Bls12381G1Impl
   else miller_loop<2>(f, P, Q);

@@ -1,13 +1,14 @@
 // Microbenchmarks that size the integer-VALU roofline of the path ("the integer MAD rate is not in the
 // guides, must be measured"): cycles per wave-instruction for the candidate multiply primitives at 1/2/4 waves per
-// SIMD, and Fp-multiplication throughput of the candidate fp_mul formulations.
+// SIMD, including the carry-chain forms (v_addc_co_u32 with s_nop padding) that decided the field representation.
+// Fp-multiplication throughput of the chosen 28-bit-limb form: tools/ubench/ubench28.hip.  (The numbers of the earlier
+// saturated 12 x 32-bit multiplier, 58 G fp_mul/s, are kept in profiles/ubench_r01.txt.)
 // Build: hipcc --offload-arch=gfx950 -O3 -o ubench tools/ubench/ubench.hip ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
 #include <algorithm>
-#include "../../agora-blsful_amd/csrc/fp.cuh"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -94,28 +95,6 @@ __global__ void __launch_bounds__(256) k_rate(uint64_t* cycles, uint32_t* sink, 
   if ((threadIdx.x & 63) == 0) cycles[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
 }
 
-// ---- fp_mul variants: NCH independent dependent-chains per lane
-template <int VAR, int NCH>
-__global__ void __launch_bounds__(256) k_fpmul(uint32_t* out, const uint32_t* in, int iters, uint64_t* cycles) {
-  int id = blockIdx.x * blockDim.x + threadIdx.x;
-  fp x[NCH], y;
-  for (int c = 0; c < NCH; c++) fp_load(x[c], in + 12 * ((id + c * 7) & 1023));
-  fp_load(y, in + 12 * ((id + 3) & 1023));
-  uint64_t t0 = __builtin_amdgcn_s_memtime();
-  for (int it = 0; it < iters; it++) {
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
-      if (VAR == 0) fp_mul_c(x[c], x[c], y);
-      else fp_mul_asm(x[c], x[c], y);
-    }
-  }
-  uint64_t t1 = __builtin_amdgcn_s_memtime();
-  fp acc = x[0];
-  for (int c = 1; c < NCH; c++) fp_add(acc, acc, x[c]);
-  fp_store(out + 12 * id, acc);
-  if ((threadIdx.x & 63) == 0) cycles[id >> 6] = t1 - t0;
-}
-
 static double median_cycles(std::vector<uint64_t>& v) {
   std::sort(v.begin(), v.end());
   return (double)v[v.size() / 2];
@@ -143,56 +122,16 @@ static void run_rate(int wps, uint64_t* dcy, uint32_t* dsink) {
          med / n_inst, med / n_inst / wps, ms, (double)blocks * 256 * n_inst / (ms * 1e-3) / 1e12);
 }
 
-template <int VAR, int NCH>
-static void run_fpmul(int wps, uint32_t* dout, uint32_t* din, uint64_t* dcy, std::vector<uint32_t>& ref_out, bool check) {
-  int blocks = 256 * wps, iters = 200;
-  hipEvent_t e0, e1;
-  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  k_fpmul<VAR, NCH><<<blocks, 256>>>(dout, din, iters, dcy);
-  CK(hipDeviceSynchronize());
-  CK(hipEventRecord(e0));
-  k_fpmul<VAR, NCH><<<blocks, 256>>>(dout, din, iters, dcy);
-  CK(hipEventRecord(e1));
-  CK(hipDeviceSynchronize());
-  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-  std::vector<uint64_t> cy(blocks * 4);
-  CK(hipMemcpy(cy.data(), dcy, cy.size() * 8, hipMemcpyDeviceToHost));
-  double med = median_cycles(cy);
-  std::vector<uint32_t> o(12 * 1024);
-  CK(hipMemcpy(o.data(), dout, o.size() * 4, hipMemcpyDeviceToHost));
-  const char* ok = "";
-  if (check) ok = (o == ref_out) ? " [matches variant 0]" : " [MISMATCH vs variant 0]";
-  else ref_out = o;
-  double nmul = (double)iters * NCH;
-  printf("fp_mul var=%d chains=%d wps=%d  cyc/mul(wave)=%8.1f  wall=%.3f ms  chip=%.2f G fp_mul/s%s\n", VAR, NCH, wps, med / nmul, ms,
-         (double)blocks * 256 * nmul / (ms * 1e-3) / 1e9, ok);
-}
-
 int main() {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   printf("device %s  CUs=%d  clock=%d kHz\n", prop.name, prop.multiProcessorCount, prop.clockRate);
-  uint64_t* dcy; uint32_t *dsink, *din, *dout;
+  uint64_t* dcy; uint32_t* dsink;
   CK(hipMalloc(&dcy, 8 * 4 * 256 * 8)); CK(hipMalloc(&dsink, 64));
-  CK(hipMalloc(&din, 12 * 4 * 1024)); CK(hipMalloc(&dout, 12 * 4 * 256 * 256 * 8));
-  std::vector<uint32_t> hin(12 * 1024);
-  srand(7);
-  for (int i = 0; i < 1024; i++) {
-    for (int j = 0; j < 12; j++) hin[12 * i + j] = ((uint32_t)rand() << 16) ^ rand();
-    hin[12 * i + 11] &= 0x0fffffff;  // < p
-  }
-  CK(hipMemcpy(din, hin.data(), hin.size() * 4, hipMemcpyHostToDevice));
   for (int wps = 1; wps <= 4; wps *= 2) {
     run_rate<I_ADD32>(wps, dcy, dsink); run_rate<I_MAD64>(wps, dcy, dsink); run_rate<I_MULLO>(wps, dcy, dsink);
     run_rate<I_MULHI>(wps, dcy, dsink); run_rate<I_MAD24>(wps, dcy, dsink); run_rate<I_LSHLADD64>(wps, dcy, dsink);
     run_rate<I_FMA64>(wps, dcy, dsink); run_rate<I_FMA32>(wps, dcy, dsink); run_rate<I_ADDC>(wps, dcy, dsink);
     run_rate<I_MADCARRY>(wps, dcy, dsink); run_rate<I_CHAIN_NOP>(wps, dcy, dsink); run_rate<I_CHAIN2_NOP0>(wps, dcy, dsink);
-  }
-  std::vector<uint32_t> ref1, ref2;
-  for (int wps = 1; wps <= 4; wps *= 2) {
-    run_fpmul<0, 1>(wps, dout, din, dcy, ref1, false);
-    run_fpmul<1, 1>(wps, dout, din, dcy, ref1, true);
-    run_fpmul<0, 3>(wps, dout, din, dcy, ref2, false);
-    run_fpmul<1, 3>(wps, dout, din, dcy, ref2, true);
   }
   return 0;
 }
