@@ -229,7 +229,8 @@ def secure_coefficients(key_bytes_list):
     blob = b''.join(key_bytes_list)
     _check(lib.blsgpu_secure_coefficients(_ptr(blob), n, width, ctypes.cast(perm, ctypes.c_void_p), ctypes.cast(scal, ctypes.c_void_p),
                                           ctypes.byref(st)))
-    return st.value, list(perm)[:n], [int.from_bytes(scal.raw[32 * i:32 * i + 32], 'little') for i in range(n)]
+    sc = scal.raw
+    return st.value, list(perm)[:n], [int.from_bytes(sc[32 * i:32 * i + 32], 'little') for i in range(n)]
 
 
 def hash_to_point(group, msgs, dst):
@@ -240,7 +241,8 @@ def hash_to_point(group, msgs, dst):
     out = ctypes.create_string_buffer(sz * n)
     fn = lib.blsgpu_hash_to_g1 if group == 1 else lib.blsgpu_hash_to_g2
     _check(fn(_ptr(blob), ctypes.cast(offs, ctypes.c_void_p), n, _ptr(dst), len(dst), ctypes.cast(out, ctypes.c_void_p)))
-    return [out.raw[sz * i:sz * (i + 1)] for i in range(n)]
+    raw = out.raw
+    return [raw[sz * i:sz * (i + 1)] for i in range(n)]
 
 
 def point_sum(group, pts, scalars=None, fmt=FMT_RAW_PROJ):
@@ -297,7 +299,8 @@ def deserialize(group, blobs, legacy=False):
     blob = b''.join(blobs)
     _check(lib.blsgpu_deserialize(group, _ptr(blob), n, FMT_LEGACY if legacy else FMT_COMPRESSED, ctypes.cast(out, ctypes.c_void_p),
                                   ctypes.cast(st, ctypes.c_void_p)))
-    return [out.raw[osz * i:osz * (i + 1)] for i in range(n)], list(st)[:n]
+    raw = out.raw
+    return [raw[osz * i:osz * (i + 1)] for i in range(n)], list(st)[:n]
 
 
 def serialize(group, pts, fmt_in=FMT_RAW_PROJ, legacy=False):
@@ -307,7 +310,8 @@ def serialize(group, pts, fmt_in=FMT_RAW_PROJ, legacy=False):
     out = ctypes.create_string_buffer(osz * max(n, 1))
     blob = b''.join(pts)
     _check(lib.blsgpu_serialize(group, _ptr(blob), n, fmt_in, FMT_LEGACY if legacy else FMT_COMPRESSED, ctypes.cast(out, ctypes.c_void_p), None))
-    return [out.raw[osz * i:osz * (i + 1)] for i in range(n)]
+    raw = out.raw
+    return [raw[osz * i:osz * (i + 1)] for i in range(n)]
 
 
 def sign_batch(sig_group, scheme, sks, msgs):
@@ -321,7 +325,8 @@ def sign_batch(sig_group, scheme, sks, msgs):
     skb = b''.join(int(s).to_bytes(32, 'little') for s in sks)
     _check(lib.blsgpu_sign_batch(sig_group, scheme, _ptr(skb), _ptr(blob), ctypes.cast(offs, ctypes.c_void_p), n,
                                  ctypes.cast(opk, ctypes.c_void_p), ctypes.cast(osg, ctypes.c_void_p)))
-    return ([opk.raw[pksz * i:pksz * (i + 1)] for i in range(n)], [osg.raw[sgsz * i:sgsz * (i + 1)] for i in range(n)])
+    pk_raw, sg_raw = opk.raw, osg.raw          # .raw copies the whole buffer: take it once
+    return ([pk_raw[pksz * i:pksz * (i + 1)] for i in range(n)], [sg_raw[sgsz * i:sgsz * (i + 1)] for i in range(n)])
 
 
 def aggregate_partial(sig_group, scheme, pks, msgs, sig=None, fmt=FMT_RAW_PROJ):

@@ -37,6 +37,7 @@ BLS_NOINLINE void miller_dbl_step(g2_hom_t<F2>& t, F2& l0, F2& l2, F2& l3, const
   fp2_dbl(f, e);
   fp2_add(f, f, e);      // F = 3E
   fp2_add(h, t.y, t.z);
+  fp2_norm(h, h);
   fp2_sqr(h, h);
   fp2_sub(h, h, b);
   fp2_sub(h, h, c);      // H = 2YZ
@@ -83,6 +84,8 @@ BLS_NOINLINE void miller_add_step(g2_hom_t<F2>& t, F2& l0, F2& l2, F2& l3, const
   fp2_sub(th, t.y, th);  // theta = Y - yq Z
   fp2_mul(la, xq, t.z);
   fp2_sub(la, t.x, la);  // lambda = X - xq Z
+  fp2_norm(th, th);
+  fp2_norm(la, la);
   fp2_mul(l0, th, xq);
   fp2_mul(s, la, yq);
   fp2_sub(l0, l0, s);

@@ -53,8 +53,9 @@ BLS_FN void fp2_conj(fp2& r, const fp2& a) {
   r.c0 = a.c0;
   fp_neg(r.c1, a.c1);
 }
-// Bound contract of the Fp2 layer (fp.cuh explains the lazy representation): fp2_mul / fp2_sqr accept operands whose limbs
-// are below 2^29 + a few units ("2N+": the sum of two normalised elements) and return normalised limbs ("N+").
+// Bound contract of the Fp2 layer (fp.cuh explains the lazy representation): fp2_mul accepts operands whose limbs are
+// below 2^29 + a few units ("2N+": the sum of two normalised elements), fp2_sqr a normalised operand ("N+", limbs up to
+// 2^28 + a few units: it forms a0 +- a1 itself); both return normalised limbs.
 BLS_FN void fp2_norm(fp2& r, const fp2& a) {
   fp_norm(r.c0, a.c0);
   fp_norm(r.c1, a.c1);
@@ -410,6 +411,7 @@ BLS_FN void fp4_sqr(F2& c0, F2& c1, const F2& a, const F2& b) {
   fp2_add(t2, t2, t0);
   fp2_norm(c0, t2);
   fp2_add(t2, a, b);
+  fp2_norm(t2, t2);
   fp2_sqr(t2, t2);
   fp2_sub(t2, t2, t0);
   fp2_sub(t2, t2, t1);

@@ -64,9 +64,7 @@ __device__ __forceinline__ void fp2_sqr(hfp2& r, const hfp2& a) {
   fp_zero(z);
   fp_sel(t, hi, z, pa);
   fp_sub(y, a.v, t);          // even: a0 - a1, odd: a1
-  fp_norm(x, x);
-  fp_norm(y, y);
-  fp_mul(r.v, x, y);
+  fp_mul(r.v, x, y);          // operand limbs below 2^29 each for a normalised a: no carry pass needed
 }
 __device__ __forceinline__ void fp2_mul_fp(hfp2& r, const hfp2& a, const fp& k) { fp_mul(r.v, a.v, k); }
 __device__ __forceinline__ void fp2_mul_xi(hfp2& r, const hfp2& a) {
@@ -124,10 +122,6 @@ static inline void fp2_sqr(hfp2& r, const hfp2& a) {
   fp_sub(y0, a.c[0], a.c[1]);
   fp_add(x1, a.c[0], a.c[0]);
   y1 = a.c[1];
-  fp_norm(x0, x0);
-  fp_norm(y0, y0);
-  fp_norm(x1, x1);
-  fp_norm(y1, y1);
   fp_mul(r.c[0], x0, y0);
   fp_mul(r.c[1], x1, y1);
 }
