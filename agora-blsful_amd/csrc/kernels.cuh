@@ -561,9 +561,13 @@ __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_miller2s(size_t 
     P[k].inf = false;
     Q[k].inf = false;
   }
+  __shared__ uint32_t fsh[F12_SH_WORDS * BLS_BLOCK];   // the accumulator, packed (tower_split.cuh)
+  f12_sh acc = {fsh + threadIdx.x};
+  if (fixed_g2) miller_loop_fixed_g2(acc, P[0], Q[0], P[1]);
+  else miller_loop<2>(acc, P, Q);
   fp12_t<hfp2> f;
-  if (fixed_g2) miller_loop_fixed_g2(f, P[0], Q[0], P[1]);
-  else miller_loop<2>(f, P, Q);
+  sh_ld_f12(f, acc.sh);
+  fp12_conj(f, f);
   ws_st_hfp12(fws, n, i, f);
 }
 #endif
@@ -573,6 +577,8 @@ __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_miller2s(size_t 
 __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_miller1s(size_t n, size_t stride, const uint32_t* pairs, const int32_t* skip, uint32_t* fws) {
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
   if (i >= n) return;
+  __shared__ uint32_t fsh[F12_SH_WORDS * BLS_BLOCK];
+  f12_sh acc = {fsh + threadIdx.x};
   fp12_t<hfp2> f;
   if (skip[i]) {
     fp12_one(f);
@@ -585,7 +591,9 @@ __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_miller1s(size_t 
     ws_ld_hfp2(Q[0].y, pairs, stride, i, 2 * W2);
     P[0].inf = false;
     Q[0].inf = false;
-    miller_loop<1>(f, P, Q);
+    miller_loop<1>(acc, P, Q);
+    sh_ld_f12(f, acc.sh);
+    fp12_conj(f, f);
   }
   ws_st_hfp12(fws, stride, i, f);
 }

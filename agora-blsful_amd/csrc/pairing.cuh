@@ -111,9 +111,20 @@ BLS_NOINLINE void miller_add_step(g2_hom_t<F2>& t, F2& l0, F2& l2, F2& l3, const
   fp2_mul(t.z, t.z, e);
 }
 
+// The Miller accumulator is addressed through acc_* so that the same loops run with f in private memory (an fp12_t, below)
+// or in LDS (the lane-split kernels' f12_sh handle, tower_split.cuh).
+template <class F2>
+BLS_FN void acc_one(fp12_t<F2>& f) { fp12_one(f); }
+template <class F2>
+BLS_FN void acc_sqr(fp12_t<F2>& f) { fp12_sqr(f, f); }
+template <class F2>
+BLS_FN void acc_mul_line(fp12_t<F2>& f, const F2& l0, const F2& l2, const F2& l3) { fp12_mul_by_line(f, l0, l2, l3); }
+template <class F2>
+BLS_FN void acc_finish(fp12_t<F2>& f) { fp12_conj(f, f); }   // x < 0
+
 // f <- conj( prod_i f_{|x|,Q_i}(P_i) ).  Pairs with a point at infinity contribute 1.
-template <int N, class F2>
-BLS_FN void miller_loop(fp12_t<F2>& f, const g1_aff* P, const aff<F2>* Q) {
+template <int N, class ACC, class F2>
+BLS_FN void miller_loop(ACC& f, const g1_aff* P, const aff<F2>* Q) {
   g2_hom_t<F2> T[N];
   bool skip[N];
 #pragma unroll
@@ -123,15 +134,15 @@ BLS_FN void miller_loop(fp12_t<F2>& f, const g1_aff* P, const aff<F2>* Q) {
     T[k].y = Q[k].y;
     fp2_one(T[k].z);
   }
-  fp12_one(f);
+  acc_one(f);
   F2 l0, l2, l3;
   for (int i = 62; i >= 0; i--) {
-    if (i != 62) fp12_sqr(f, f);
+    if (i != 62) acc_sqr(f);
 #pragma unroll
     for (int k = 0; k < N; k++) {
       if (!skip[k]) {
         miller_dbl_step(T[k], l0, l2, l3, P[k].x, P[k].y);
-        fp12_mul_by_line(f, l0, l2, l3);
+        acc_mul_line(f, l0, l2, l3);
       }
     }
     if ((BLS_X_ABS >> i) & 1) {
@@ -139,50 +150,50 @@ BLS_FN void miller_loop(fp12_t<F2>& f, const g1_aff* P, const aff<F2>* Q) {
       for (int k = 0; k < N; k++) {
         if (!skip[k]) {
           miller_add_step(T[k], l0, l2, l3, Q[k].x, Q[k].y, P[k].x, P[k].y);
-          fp12_mul_by_line(f, l0, l2, l3);
+          acc_mul_line(f, l0, l2, l3);
         }
       }
     }
   }
-  fp12_conj(f, f);
+  acc_finish(f);
 }
 
 // The same product for exactly two pairs whose SECOND G2 argument is the constant -g2 (core_verify of Bls12381G1Impl:
 // e(H(m), pk) e(sig, -g2), reference src/traits/sig_core.rs:136-138): that pair's point arithmetic is replaced by the
 // precomputed table G2NEG_LINES (tools/gen_g2_lines.py); only the two Fp2-by-Fp scalings by (xP, yP) remain.
-template <class F2>
-BLS_FN void miller_loop_fixed_g2(fp12_t<F2>& f, const g1_aff& P0, const aff<F2>& Q0, const g1_aff& P1) {
+template <class ACC, class F2>
+BLS_FN void miller_loop_fixed_g2(ACC& f, const g1_aff& P0, const aff<F2>& Q0, const g1_aff& P1) {
   g2_hom_t<F2> T;
   T.x = Q0.x;
   T.y = Q0.y;
   fp2_one(T.z);
-  fp12_one(f);
+  acc_one(f);
   F2 l0, l2, l3, t;
   int row = 0;
   for (int i = 62; i >= 0; i--) {
-    if (i != 62) fp12_sqr(f, f);
+    if (i != 62) acc_sqr(f);
     miller_dbl_step(T, l0, l2, l3, P0.x, P0.y);
-    fp12_mul_by_line(f, l0, l2, l3);
+    acc_mul_line(f, l0, l2, l3);
     fp2_load(l0, &G2NEG_LINES[row][0]);
     fp2_load(t, &G2NEG_LINES[row][2 * FP_NL]);
     fp2_mul_fp(l2, t, P1.x);
     fp2_load(t, &G2NEG_LINES[row][4 * FP_NL]);
     fp2_mul_fp(l3, t, P1.y);
-    fp12_mul_by_line(f, l0, l2, l3);
+    acc_mul_line(f, l0, l2, l3);
     row++;
     if ((BLS_X_ABS >> i) & 1) {
       miller_add_step(T, l0, l2, l3, Q0.x, Q0.y, P0.x, P0.y);
-      fp12_mul_by_line(f, l0, l2, l3);
+      acc_mul_line(f, l0, l2, l3);
       fp2_load(l0, &G2NEG_LINES[row][0]);
       fp2_load(t, &G2NEG_LINES[row][2 * FP_NL]);
       fp2_mul_fp(l2, t, P1.x);
       fp2_load(t, &G2NEG_LINES[row][4 * FP_NL]);
       fp2_mul_fp(l3, t, P1.y);
-      fp12_mul_by_line(f, l0, l2, l3);
+      acc_mul_line(f, l0, l2, l3);
       row++;
     }
   }
-  fp12_conj(f, f);
+  acc_finish(f);
 }
 
 // a^x for a in the cyclotomic subgroup (x < 0: conjugate of a^|x|)

@@ -326,11 +326,13 @@ BLS_FN void fp12_reduce(fp12_t<F2>& r, const fp12_t<F2>& a) {
   fp6_reduce(r.c0, a.c0);
   fp6_reduce(r.c1, a.c1);
 }
+// The four hot functions come as an inlinable NAME_body plus the non-inlined NAME the template code calls; the lane-split
+// kernels also wrap the bodies in variants whose accumulator lives in LDS (tower_split.cuh).
 // Fp12 functions take reduced or normalised operands (limbs N+, value within a few p) and return reduced results
 // (exact limbs, value in (-0.52 p, 0.52 p)).
 // Karatsuba over Fp6: 18 Fp2 multiplications
 template <class F2>
-BLS_NOINLINE void fp12_mul(fp12_t<F2>& r, const fp12_t<F2>& a, const fp12_t<F2>& b) {
+BLS_FN void fp12_mul_body(fp12_t<F2>& r, const fp12_t<F2>& a, const fp12_t<F2>& b) {
   fp6_t<F2> t0, t1, s, t, m;
   fp6_mul(t0, a.c0, b.c0);
   fp6_mul(t1, a.c1, b.c1);
@@ -346,9 +348,13 @@ BLS_NOINLINE void fp12_mul(fp12_t<F2>& r, const fp12_t<F2>& a, const fp12_t<F2>&
   fp6_add(t0, t0, t1);
   fp6_reduce(r.c0, t0);
 }
+template <class F2>
+BLS_NOINLINE void fp12_mul(fp12_t<F2>& r, const fp12_t<F2>& a, const fp12_t<F2>& b) {
+  fp12_mul_body(r, a, b);
+}
 // complex squaring: 12 Fp2 multiplications
 template <class F2>
-BLS_NOINLINE void fp12_sqr(fp12_t<F2>& r, const fp12_t<F2>& a) {
+BLS_FN void fp12_sqr_body(fp12_t<F2>& r, const fp12_t<F2>& a) {
   fp6_t<F2> t, s0, s1, m;
   fp6_mul(t, a.c0, a.c1);
   fp6_add(s0, a.c0, a.c1);
@@ -363,6 +369,10 @@ BLS_NOINLINE void fp12_sqr(fp12_t<F2>& r, const fp12_t<F2>& a) {
   fp6_reduce(r.c0, m);
   fp6_add(t, t, t);
   fp6_reduce(r.c1, t);
+}
+template <class F2>
+BLS_NOINLINE void fp12_sqr(fp12_t<F2>& r, const fp12_t<F2>& a) {
+  fp12_sqr_body(r, a);
 }
 template <class F2>
 BLS_NOINLINE void fp12_inv(fp12_t<F2>& r, const fp12_t<F2>& a) {
@@ -418,7 +428,7 @@ BLS_FN void fp4_sqr(F2& c0, F2& c1, const F2& a, const F2& b) {
   fp2_norm(c1, t2);
 }
 template <class F2>
-BLS_NOINLINE void fp12_cyclotomic_sqr(fp12_t<F2>& r, const fp12_t<F2>& f) {
+BLS_FN void fp12_cyclotomic_sqr_body(fp12_t<F2>& r, const fp12_t<F2>& f) {
   F2 z0 = f.c0.a0, z4 = f.c0.a1, z3 = f.c0.a2, z2 = f.c1.a0, z1 = f.c1.a1, z5 = f.c1.a2;
   F2 t0, t1, t2, t3;
   fp4_sqr(t0, t1, z0, z1);
@@ -451,10 +461,14 @@ BLS_NOINLINE void fp12_cyclotomic_sqr(fp12_t<F2>& r, const fp12_t<F2>& f) {
   fp2_reduce(r.c1.a1, z1);
   fp2_reduce(r.c1.a2, z5);
 }
+template <class F2>
+BLS_NOINLINE void fp12_cyclotomic_sqr(fp12_t<F2>& r, const fp12_t<F2>& f) {
+  fp12_cyclotomic_sqr_body(r, f);
+}
 
 // f * (l0 + l2 w^2 + l3 w^3): the sparse line value of the Miller loop.  13 Fp2 multiplications.
 template <class F2>
-BLS_NOINLINE void fp12_mul_by_line(fp12_t<F2>& f, const F2& l0, const F2& l2, const F2& l3) {
+BLS_FN void fp12_mul_by_line_body(fp12_t<F2>& f, const F2& l0, const F2& l2, const F2& l3) {
   // L0 = (l0, l2, 0), L1 = (0, l3, 0) in Fp6
   fp6_t<F2> t0, t1, s, m;
   F2 x, y, z;
@@ -510,4 +524,8 @@ BLS_NOINLINE void fp12_mul_by_line(fp12_t<F2>& f, const F2& l0, const F2& l2, co
   fp6_mul_v(t1, t1);
   fp6_add(t0, t0, t1);
   fp6_reduce(f.c0, t0);
+}
+template <class F2>
+BLS_NOINLINE void fp12_mul_by_line(fp12_t<F2>& f, const F2& l0, const F2& l2, const F2& l3) {
+  fp12_mul_by_line_body(f, l0, l2, l3);
 }

@@ -12,6 +12,7 @@
 #include "pairing.cuh"
 
 #if defined(__HIPCC__)
+#define BLS_SH_STRIDE 64   // lanes per workgroup of the lane-split kernels (= BLS_BLOCK)
 struct hfp2 {
   fp v;  // this lane's component
 };
@@ -88,6 +89,107 @@ __device__ __forceinline__ void fp2_inv(hfp2& r, const hfp2& a) {
   fp_mul(t, a.v, n);
   fp_neg(n, t);
   fp_sel(r.v, lane_hi(), n, t);
+}
+
+// ---- Fp12 accumulator in LDS ---------------------------------------------------------------------------------------
+// The Miller accumulator f and the running power of fp12_pow_x are read and written by every step; held in private
+// memory they travel through scratch (by-reference operands of the non-inlined functions), which at 65,536 items is
+// ~300 MB of live scratch -- more than L2 and the Infinity Cache hold -- and cost 13-19 % of the Miller kernel
+// (measured with f behind a flat pointer into LDS).  160 KB of LDS per CU / 8 resident waves = 80 dwords per lane, and a
+// lane's share of an Fp12 is 6 x 14 = 84; but a REDUCED element (fp_reduce: limbs 0..12 in [0, 2^28), top limb within
+// +-2^19) packs into 13 words -- the top limb rides in the four spare bits of words 0..4 -- i.e. 78 dwords per lane.
+// Word k of a lane sits at sh[k * 64]: consecutive lanes hit consecutive banks.
+#define F12_SH_WORDS 78
+struct f12_sh {
+  uint32_t* sh;   // this lane's column: &array[threadIdx.x]
+};
+__device__ __forceinline__ void sh_st_fp(uint32_t* sh, int w0, const fp& a) {
+  const uint32_t top = (uint32_t)a.l[FP_NL - 1];
+#pragma unroll
+  for (int i = 0; i < FP_NL - 1; i++) {
+    uint32_t w = (uint32_t)a.l[i];
+    if (i < 5) w |= ((top >> (4 * i)) & 0xFu) << FP_LB;
+    sh[(w0 + i) * BLS_SH_STRIDE] = w;
+  }
+}
+__device__ __forceinline__ void sh_ld_fp(fp& r, const uint32_t* sh, int w0) {
+  uint32_t top = 0;
+#pragma unroll
+  for (int i = 0; i < FP_NL - 1; i++) {
+    const uint32_t w = sh[(w0 + i) * BLS_SH_STRIDE];
+    if (i < 5) {
+      top |= (w >> FP_LB) << (4 * i);
+      r.l[i] = (int32_t)(w & FP_MASK);
+    } else {
+      r.l[i] = (int32_t)w;
+    }
+  }
+  r.l[FP_NL - 1] = ((int32_t)(top << 12)) >> 12;   // sign-extend the 20-bit top limb
+}
+__device__ __forceinline__ void sh_ld_f12(fp12_t<hfp2>& f, const uint32_t* sh) {
+  sh_ld_fp(f.c0.a0.v, sh, 0);
+  sh_ld_fp(f.c0.a1.v, sh, 13);
+  sh_ld_fp(f.c0.a2.v, sh, 26);
+  sh_ld_fp(f.c1.a0.v, sh, 39);
+  sh_ld_fp(f.c1.a1.v, sh, 52);
+  sh_ld_fp(f.c1.a2.v, sh, 65);
+}
+__device__ __forceinline__ void sh_st_f12(uint32_t* sh, const fp12_t<hfp2>& f) {
+  sh_st_fp(sh, 0, f.c0.a0.v);
+  sh_st_fp(sh, 13, f.c0.a1.v);
+  sh_st_fp(sh, 26, f.c0.a2.v);
+  sh_st_fp(sh, 39, f.c1.a0.v);
+  sh_st_fp(sh, 52, f.c1.a1.v);
+  sh_st_fp(sh, 65, f.c1.a2.v);
+}
+// one non-inlined function per step: load the accumulator from LDS, run the inlined body on registers, store it back
+__device__ __noinline__ void f12_sh_sqr(uint32_t* sh) {
+  fp12_t<hfp2> a, r;
+  sh_ld_f12(a, sh);
+  fp12_sqr_body(r, a);
+  sh_st_f12(sh, r);
+}
+__device__ __noinline__ void f12_sh_cyclotomic_sqr(uint32_t* sh) {
+  fp12_t<hfp2> a, r;
+  sh_ld_f12(a, sh);
+  fp12_cyclotomic_sqr_body(r, a);
+  sh_st_f12(sh, r);
+}
+__device__ __noinline__ void f12_sh_mul_line(uint32_t* sh, const hfp2& l0, const hfp2& l2, const hfp2& l3) {
+  fp12_t<hfp2> a;
+  sh_ld_f12(a, sh);
+  fp12_mul_by_line_body(a, l0, l2, l3);
+  sh_st_f12(sh, a);
+}
+__device__ __noinline__ void f12_sh_mul(uint32_t* sh, const fp12_t<hfp2>& b) {
+  fp12_t<hfp2> a, r;
+  sh_ld_f12(a, sh);
+  fp12_mul_body(r, a, b);
+  sh_st_f12(sh, r);
+}
+__device__ __forceinline__ void acc_one(f12_sh& f) {
+  fp12_t<hfp2> one;
+  fp12_one(one);
+  sh_st_f12(f.sh, one);
+}
+__device__ __forceinline__ void acc_sqr(f12_sh& f) { f12_sh_sqr(f.sh); }
+__device__ __forceinline__ void acc_mul_line(f12_sh& f, const hfp2& l0, const hfp2& l2, const hfp2& l3) { f12_sh_mul_line(f.sh, l0, l2, l3); }
+__device__ __forceinline__ void acc_finish(f12_sh&) {}   // the kernel conjugates when it reads the accumulator out (negated limbs do not pack)
+
+// a^x (x < 0) for a in the cyclotomic subgroup with the running power in LDS; picked over the pairing.cuh template for
+// the lane-split tower (non-template overload)
+__device__ __noinline__ void fp12_pow_x(fp12_t<hfp2>& r, const fp12_t<hfp2>& a) {
+  __shared__ uint32_t pow_sh[F12_SH_WORDS * BLS_SH_STRIDE];
+  uint32_t* sh = pow_sh + threadIdx.x;
+  fp12_t<hfp2> acc;
+  fp12_reduce(acc, a);      // a may carry negated limbs (a conjugate): only reduced elements pack
+  sh_st_f12(sh, acc);
+  for (int i = 62; i >= 0; i--) {
+    f12_sh_cyclotomic_sqr(sh);
+    if ((BLS_X_ABS >> i) & 1) f12_sh_mul(sh, a);
+  }
+  sh_ld_f12(acc, sh);
+  fp12_conj(r, acc);
 }
 #else
 // ---- host emulation: c[0] is the even lane's register file, c[1] the odd lane's; every function performs, for

@@ -6,7 +6,7 @@ pkg=ge.import_pkg(); api=pkg.api; api.init()
 N=65536
 sks=[0x1111+i for i in range(N)]; msgs=[hashlib.sha256(i.to_bytes(4,'big')).digest() for i in range(N)]
 t0=time.perf_counter(); pks,sigs=api.sign_batch(1, api.POP, sks, msgs); print('signed %.1f s' % (time.perf_counter()-t0), flush=True)
-for n in (32768, 40960, 49152, 53248, 57344, 61440, 65536):
+for n in (int(x) for x in os.environ.get("OCC_NS", "32768,40960,49152,53248,57344,61440,65536").split(",")):
     api.verify_batch(1, api.POP, pks[:n], sigs[:n], msgs[:n])
     api.profile_enable(True)
     st=api.verify_batch(1, api.POP, pks[:n], sigs[:n], msgs[:n])
