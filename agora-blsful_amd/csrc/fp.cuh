@@ -188,6 +188,8 @@ BLS_FN bool fp_eq(const fp& a, const fp& b) {
 // Product scanning, R = 2^392:  r = REDC(a b)  or, with STREAMS == 2,  r = REDC(a b + c d)  in one pass (one reduction
 // for two products: the Fp2 product of tower_split.cuh).  Every partial product is one 32 x 32 + 64 multiply-add into a
 // signed 64-bit column accumulator; the column sum stays below 2^63 under the limb bounds stated at the top.
+// STREAMS == 0: squaring, r = REDC(a a): the off-diagonal products are taken once against a doubled operand
+// (105 multiply-adds instead of 196 for the product part; same column sums as the general form).
 template <int STREAMS>
 BLS_FN void fp_redc_products(fp& r, const fp& a, const fp& b, const fp& c, const fp& d) {
 #if defined(BLS_TRACK_BOUNDS) && !defined(__HIPCC__)
@@ -201,13 +203,23 @@ BLS_FN void fp_redc_products(fp& r, const fp& a, const fp& b, const fp& c, const
   int64_t acc = 0, acc2 = 0;
   int32_t m[FP_NL];
   int32_t t[FP_NL];
+  int32_t a2[FP_NL];
+  if (STREAMS == 0) {
+#pragma unroll
+    for (int i = 0; i < FP_NL; i++) a2[i] = a.l[i] + a.l[i];
+  }
 #pragma unroll
   for (int k = 0; k < 2 * FP_NL - 1; k++) {
     const int lo = k > FP_NL - 1 ? k - (FP_NL - 1) : 0, hi = k < FP_NL - 1 ? k : FP_NL - 1;
 #pragma unroll
     for (int i = lo; i <= hi; i++) {
-      acc += (int64_t)a.l[i] * b.l[k - i];
-      if (STREAMS == 2) acc2 += (int64_t)c.l[i] * d.l[k - i];
+      if (STREAMS == 0) {
+        if (2 * i < k) acc += (int64_t)a.l[i] * a2[k - i];
+        else if (2 * i == k) acc += (int64_t)a.l[i] * a.l[i];
+      } else {
+        acc += (int64_t)a.l[i] * b.l[k - i];
+        if (STREAMS == 2) acc2 += (int64_t)c.l[i] * d.l[k - i];
+      }
     }
     if (STREAMS == 2) {
       acc += acc2;
@@ -262,6 +274,27 @@ __device__ __noinline__ i32x14 fp_mul_leaf(i32x14 av, i32x14 bv) {
   for (int i = 0; i < FP_NL; i++) o[i] = r.l[i];
   return o;
 }
+__device__ __noinline__ i32x14 fp_sqr_leaf(i32x14 av) {
+  fp a, r;
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) {
+    a.l[i] = av[i];
+    FP_OPAQUE(a.l[i]);
+  }
+  fp_redc_products<0>(r, a, a, a, a);
+  i32x14 o;
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) o[i] = r.l[i];
+  return o;
+}
+BLS_FN void fp_sqr(fp& r, const fp& a) {
+  i32x14 x;
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) x[i] = a.l[i];
+  i32x14 o = fp_sqr_leaf(x);
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) r.l[i] = o[i];
+}
 BLS_FN void fp_mul(fp& r, const fp& a, const fp& b) {
   i32x14 x, y;
 #pragma unroll
@@ -315,14 +348,16 @@ BLS_FN void fp_mul(fp& r, const fp& a, const fp& b) {
   FP_COUNT(2);
   fp_redc_products<1>(r, a, b, a, b);
 }
+BLS_FN void fp_sqr(fp& r, const fp& a) {
+  FP_COUNT(2);
+  fp_redc_products<0>(r, a, a, a, a);
+}
 // REDC(a b + c d): host twin of the lane-split product (tower_split.cuh's host emulation)
 BLS_FN void fp_dotp2(fp& r, const fp& a, const fp& b, const fp& c, const fp& d) {
   FP_COUNT(3);  // two product streams + one reduction = 1.5 multiplications; two of these make one Fp2 product
   fp_redc_products<2>(r, a, b, c, d);
 }
 #endif
-
-BLS_FN void fp_sqr(fp& r, const fp& a) { fp_mul(r, a, a); }
 
 // ---- conversions ---------------------------------------------------------------------------------
 // 12 little-endian 32-bit words of a plain integer < 2^384  ->  limbs of the same integer
