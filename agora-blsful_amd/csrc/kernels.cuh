@@ -562,7 +562,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_miller2s(size_t 
     Q[k].inf = false;
   }
   __shared__ uint32_t fsh[F12_SH_WORDS * BLS_BLOCK];   // the accumulator, packed (tower_split.cuh)
-  f12_sh acc = {fsh + threadIdx.x};
+  f12_sh acc = {lds_column(fsh)};
   if (fixed_g2) miller_loop_fixed_g2(acc, P[0], Q[0], P[1]);
   else miller_loop<2>(acc, P, Q);
   fp12_t<hfp2> f;
@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_miller1s(size_t 
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
   if (i >= n) return;
   __shared__ uint32_t fsh[F12_SH_WORDS * BLS_BLOCK];
-  f12_sh acc = {fsh + threadIdx.x};
+  f12_sh acc = {lds_column(fsh)};
   fp12_t<hfp2> f;
   if (skip[i]) {
     fp12_one(f);

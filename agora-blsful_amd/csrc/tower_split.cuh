@@ -100,10 +100,12 @@ __device__ __forceinline__ void fp2_inv(hfp2& r, const hfp2& a) {
 // +-2^19) packs into 13 words -- the top limb rides in the four spare bits of words 0..4 -- i.e. 78 dwords per lane.
 // Word k of a lane sits at sh[k * 64]: consecutive lanes hit consecutive banks.
 #define F12_SH_WORDS 78
+typedef __attribute__((address_space(3))) uint32_t lds_u32;   // LDS-qualified: ds_read / ds_write instead of flat accesses
 struct f12_sh {
-  uint32_t* sh;   // this lane's column: &array[threadIdx.x]
+  lds_u32* sh;    // this lane's column: &array[threadIdx.x]
 };
-__device__ __forceinline__ void sh_st_fp(uint32_t* sh, int w0, const fp& a) {
+__device__ __forceinline__ lds_u32* lds_column(uint32_t* shared_array) { return (lds_u32*)shared_array + threadIdx.x; }
+__device__ __forceinline__ void sh_st_fp(lds_u32* sh, int w0, const fp& a) {
   const uint32_t top = (uint32_t)a.l[FP_NL - 1];
 #pragma unroll
   for (int i = 0; i < FP_NL - 1; i++) {
@@ -112,7 +114,7 @@ __device__ __forceinline__ void sh_st_fp(uint32_t* sh, int w0, const fp& a) {
     sh[(w0 + i) * BLS_SH_STRIDE] = w;
   }
 }
-__device__ __forceinline__ void sh_ld_fp(fp& r, const uint32_t* sh, int w0) {
+__device__ __forceinline__ void sh_ld_fp(fp& r, const lds_u32* sh, int w0) {
   uint32_t top = 0;
 #pragma unroll
   for (int i = 0; i < FP_NL - 1; i++) {
@@ -126,7 +128,7 @@ __device__ __forceinline__ void sh_ld_fp(fp& r, const uint32_t* sh, int w0) {
   }
   r.l[FP_NL - 1] = ((int32_t)(top << 12)) >> 12;   // sign-extend the 20-bit top limb
 }
-__device__ __forceinline__ void sh_ld_f12(fp12_t<hfp2>& f, const uint32_t* sh) {
+__device__ __forceinline__ void sh_ld_f12(fp12_t<hfp2>& f, const lds_u32* sh) {
   sh_ld_fp(f.c0.a0.v, sh, 0);
   sh_ld_fp(f.c0.a1.v, sh, 13);
   sh_ld_fp(f.c0.a2.v, sh, 26);
@@ -134,7 +136,7 @@ __device__ __forceinline__ void sh_ld_f12(fp12_t<hfp2>& f, const uint32_t* sh) {
   sh_ld_fp(f.c1.a1.v, sh, 52);
   sh_ld_fp(f.c1.a2.v, sh, 65);
 }
-__device__ __forceinline__ void sh_st_f12(uint32_t* sh, const fp12_t<hfp2>& f) {
+__device__ __forceinline__ void sh_st_f12(lds_u32* sh, const fp12_t<hfp2>& f) {
   sh_st_fp(sh, 0, f.c0.a0.v);
   sh_st_fp(sh, 13, f.c0.a1.v);
   sh_st_fp(sh, 26, f.c0.a2.v);
@@ -143,25 +145,25 @@ __device__ __forceinline__ void sh_st_f12(uint32_t* sh, const fp12_t<hfp2>& f) {
   sh_st_fp(sh, 65, f.c1.a2.v);
 }
 // one non-inlined function per step: load the accumulator from LDS, run the inlined body on registers, store it back
-__device__ __noinline__ void f12_sh_sqr(uint32_t* sh) {
+__device__ __noinline__ void f12_sh_sqr(lds_u32* sh) {
   fp12_t<hfp2> a, r;
   sh_ld_f12(a, sh);
   fp12_sqr_body(r, a);
   sh_st_f12(sh, r);
 }
-__device__ __noinline__ void f12_sh_cyclotomic_sqr(uint32_t* sh) {
+__device__ __noinline__ void f12_sh_cyclotomic_sqr(lds_u32* sh) {
   fp12_t<hfp2> a, r;
   sh_ld_f12(a, sh);
   fp12_cyclotomic_sqr_body(r, a);
   sh_st_f12(sh, r);
 }
-__device__ __noinline__ void f12_sh_mul_line(uint32_t* sh, const hfp2& l0, const hfp2& l2, const hfp2& l3) {
+__device__ __noinline__ void f12_sh_mul_line(lds_u32* sh, const hfp2& l0, const hfp2& l2, const hfp2& l3) {
   fp12_t<hfp2> a;
   sh_ld_f12(a, sh);
   fp12_mul_by_line_body(a, l0, l2, l3);
   sh_st_f12(sh, a);
 }
-__device__ __noinline__ void f12_sh_mul(uint32_t* sh, const fp12_t<hfp2>& b) {
+__device__ __noinline__ void f12_sh_mul(lds_u32* sh, const fp12_t<hfp2>& b) {
   fp12_t<hfp2> a, r;
   sh_ld_f12(a, sh);
   fp12_mul_body(r, a, b);
@@ -180,7 +182,7 @@ __device__ __forceinline__ void acc_finish(f12_sh&) {}   // the kernel conjugate
 // the lane-split tower (non-template overload)
 __device__ __noinline__ void fp12_pow_x(fp12_t<hfp2>& r, const fp12_t<hfp2>& a) {
   __shared__ uint32_t pow_sh[F12_SH_WORDS * BLS_SH_STRIDE];
-  uint32_t* sh = pow_sh + threadIdx.x;
+  lds_u32* sh = lds_column(pow_sh);
   fp12_t<hfp2> acc;
   fp12_reduce(acc, a);      // a may carry negated limbs (a conjugate): only reduced elements pack
   sh_st_f12(sh, acc);
