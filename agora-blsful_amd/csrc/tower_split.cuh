@@ -151,11 +151,48 @@ __device__ __noinline__ void f12_sh_sqr(lds_u32* sh) {
   fp12_sqr_body(r, a);
   sh_st_f12(sh, r);
 }
+// Granger-Scott squaring streamed through LDS: the three Fp4 squarings touch disjoint coefficient pairs, so only two to
+// six coefficients are live in registers at a time (loading all six first made the compiler spill through scratch).
+// LDS slots (tower order c0.a0, c0.a1, c0.a2, c1.a0, c1.a1, c1.a2) hold z0, z4, z3, z2, z1, z5 of fp12_cyclotomic_sqr_body.
+__device__ __forceinline__ void cyc_store_minus(lds_u32* sh, int w0, const hfp2& t, const hfp2& z) {   // 3 t - 2 z
+  hfp2 r;
+  fp2_sub(r, t, z);
+  fp2_dbl(r, r);
+  fp2_add(r, r, t);
+  fp2_reduce(r, r);
+  sh_st_fp(sh, w0, r.v);
+}
+__device__ __forceinline__ void cyc_store_plus(lds_u32* sh, int w0, const hfp2& t, const hfp2& z) {    // 3 t + 2 z
+  hfp2 r;
+  fp2_add(r, t, z);
+  fp2_dbl(r, r);
+  fp2_add(r, r, t);
+  fp2_reduce(r, r);
+  sh_st_fp(sh, w0, r.v);
+}
 __device__ __noinline__ void f12_sh_cyclotomic_sqr(lds_u32* sh) {
-  fp12_t<hfp2> a, r;
-  sh_ld_f12(a, sh);
-  fp12_cyclotomic_sqr_body(r, a);
-  sh_st_f12(sh, r);
+  hfp2 t0, t1;
+  {
+    hfp2 z0, z1;
+    sh_ld_fp(z0.v, sh, 0);
+    sh_ld_fp(z1.v, sh, 52);
+    fp4_sqr(t0, t1, z0, z1);
+    cyc_store_minus(sh, 0, t0, z0);
+    cyc_store_plus(sh, 52, t1, z1);
+  }
+  hfp2 z2, z3, z4, z5, t2, t3;
+  sh_ld_fp(z2.v, sh, 39);
+  sh_ld_fp(z3.v, sh, 26);
+  fp4_sqr(t0, t1, z2, z3);
+  sh_ld_fp(z4.v, sh, 13);
+  sh_ld_fp(z5.v, sh, 65);
+  fp4_sqr(t2, t3, z4, z5);
+  cyc_store_minus(sh, 13, t0, z4);
+  cyc_store_plus(sh, 65, t1, z5);
+  fp2_mul_xi(t0, t3);
+  fp2_norm(t0, t0);
+  cyc_store_plus(sh, 39, t0, z2);
+  cyc_store_minus(sh, 26, t2, z3);
 }
 __device__ __noinline__ void f12_sh_mul_line(lds_u32* sh, const hfp2& l0, const hfp2& l2, const hfp2& l3) {
   fp12_t<hfp2> a;
