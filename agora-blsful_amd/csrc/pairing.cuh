@@ -120,6 +120,10 @@ BLS_FN void acc_sqr(fp12_t<F2>& f) { fp12_sqr(f, f); }
 template <class F2>
 BLS_FN void acc_mul_line(fp12_t<F2>& f, const F2& l0, const F2& l2, const F2& l3) { fp12_mul_by_line(f, l0, l2, l3); }
 template <class F2>
+BLS_FN void acc_mul_2lines(fp12_t<F2>& f, const F2& a0, const F2& a2, const F2& a3, const F2& b0, const F2& b2, const F2& b3) {
+  fp12_mul_by_2lines(f, a0, a2, a3, b0, b2, b3);
+}
+template <class F2>
 BLS_FN void acc_finish(fp12_t<F2>& f) { fp12_conj(f, f); }   // x < 0
 
 // f <- conj( prod_i f_{|x|,Q_i}(P_i) ).  Pairs with a point at infinity contribute 1.
@@ -135,22 +139,29 @@ BLS_FN void miller_loop(ACC& f, const g1_aff* P, const aff<F2>* Q) {
     fp2_one(T[k].z);
   }
   acc_one(f);
-  F2 l0, l2, l3;
+  F2 l0, l2, l3, m0, m2, m3;
+  const bool both = (N == 2) && !skip[0] && !skip[N - 1];
   for (int i = 62; i >= 0; i--) {
     if (i != 62) acc_sqr(f);
+    for (int step = 0; step < 2; step++) {          // 0: doubling, 1: addition (only at set bits of |x|)
+      if (step == 1 && !((BLS_X_ABS >> i) & 1)) break;
+      if (both) {                                     // two pairs: merge their line values before touching f
+        if (step == 0) {
+          miller_dbl_step(T[0], l0, l2, l3, P[0].x, P[0].y);
+          miller_dbl_step(T[N - 1], m0, m2, m3, P[N - 1].x, P[N - 1].y);
+        } else {
+          miller_add_step(T[0], l0, l2, l3, Q[0].x, Q[0].y, P[0].x, P[0].y);
+          miller_add_step(T[N - 1], m0, m2, m3, Q[N - 1].x, Q[N - 1].y, P[N - 1].x, P[N - 1].y);
+        }
+        acc_mul_2lines(f, l0, l2, l3, m0, m2, m3);
+      } else {
 #pragma unroll
-    for (int k = 0; k < N; k++) {
-      if (!skip[k]) {
-        miller_dbl_step(T[k], l0, l2, l3, P[k].x, P[k].y);
-        acc_mul_line(f, l0, l2, l3);
-      }
-    }
-    if ((BLS_X_ABS >> i) & 1) {
-#pragma unroll
-      for (int k = 0; k < N; k++) {
-        if (!skip[k]) {
-          miller_add_step(T[k], l0, l2, l3, Q[k].x, Q[k].y, P[k].x, P[k].y);
-          acc_mul_line(f, l0, l2, l3);
+        for (int k = 0; k < N; k++) {
+          if (!skip[k]) {
+            if (step == 0) miller_dbl_step(T[k], l0, l2, l3, P[k].x, P[k].y);
+            else miller_add_step(T[k], l0, l2, l3, Q[k].x, Q[k].y, P[k].x, P[k].y);
+            acc_mul_line(f, l0, l2, l3);
+          }
         }
       }
     }
@@ -168,28 +179,20 @@ BLS_FN void miller_loop_fixed_g2(ACC& f, const g1_aff& P0, const aff<F2>& Q0, co
   T.y = Q0.y;
   fp2_one(T.z);
   acc_one(f);
-  F2 l0, l2, l3, t;
+  F2 l0, l2, l3, m0, m2, m3, t;
   int row = 0;
   for (int i = 62; i >= 0; i--) {
     if (i != 62) acc_sqr(f);
-    miller_dbl_step(T, l0, l2, l3, P0.x, P0.y);
-    acc_mul_line(f, l0, l2, l3);
-    fp2_load(l0, &G2NEG_LINES[row][0]);
-    fp2_load(t, &G2NEG_LINES[row][2 * FP_NL]);
-    fp2_mul_fp(l2, t, P1.x);
-    fp2_load(t, &G2NEG_LINES[row][4 * FP_NL]);
-    fp2_mul_fp(l3, t, P1.y);
-    acc_mul_line(f, l0, l2, l3);
-    row++;
-    if ((BLS_X_ABS >> i) & 1) {
-      miller_add_step(T, l0, l2, l3, Q0.x, Q0.y, P0.x, P0.y);
-      acc_mul_line(f, l0, l2, l3);
-      fp2_load(l0, &G2NEG_LINES[row][0]);
+    for (int step = 0; step < 2; step++) {          // 0: doubling, 1: addition (only at set bits of |x|)
+      if (step == 1 && !((BLS_X_ABS >> i) & 1)) break;
+      if (step == 0) miller_dbl_step(T, l0, l2, l3, P0.x, P0.y);
+      else miller_add_step(T, l0, l2, l3, Q0.x, Q0.y, P0.x, P0.y);
+      fp2_load(m0, &G2NEG_LINES[row][0]);
       fp2_load(t, &G2NEG_LINES[row][2 * FP_NL]);
-      fp2_mul_fp(l2, t, P1.x);
+      fp2_mul_fp(m2, t, P1.x);
       fp2_load(t, &G2NEG_LINES[row][4 * FP_NL]);
-      fp2_mul_fp(l3, t, P1.y);
-      acc_mul_line(f, l0, l2, l3);
+      fp2_mul_fp(m3, t, P1.y);
+      acc_mul_2lines(f, l0, l2, l3, m0, m2, m3);
       row++;
     }
   }

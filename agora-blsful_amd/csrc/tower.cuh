@@ -529,3 +529,81 @@ template <class F2>
 BLS_NOINLINE void fp12_mul_by_line(fp12_t<F2>& f, const F2& l0, const F2& l2, const F2& l3) {
   fp12_mul_by_line_body(f, l0, l2, l3);
 }
+
+// x * (y1 v + y2 v^2) in Fp6: 5 Fp2 multiplications.  Operands and result as fp6_mul.
+template <class F2>
+BLS_FN void fp6_mul_by_12(fp6_t<F2>& r, const fp6_t<F2>& x, const F2& y1, const F2& y2) {
+  F2 v1, v2, s, t, m, o0, o1, o2;
+  fp2_mul(v1, x.a1, y1);
+  fp2_mul(v2, x.a2, y2);
+  fp2_add(s, x.a1, x.a2);
+  fp2_add(t, y1, y2);
+  fp2_mul(m, s, t);
+  fp2_sub(m, m, v1);
+  fp2_sub(m, m, v2);        // x1 y2 + x2 y1
+  fp2_mul_xi(o0, m);
+  fp2_mul(m, x.a0, y1);
+  fp2_mul_xi(t, v2);
+  fp2_add(o1, m, t);        // x0 y1 + xi x2 y2
+  fp2_mul(m, x.a0, y2);
+  fp2_add(o2, m, v1);       // x0 y2 + x1 y1
+  fp2_norm(r.a0, o0);
+  fp2_norm(r.a1, o1);
+  fp2_norm(r.a2, o2);
+}
+// f * (a0 + a2 w^2 + a3 w^3)(b0 + b2 w^2 + b3 w^3): the two line values of one Miller step merged first (6 Fp2
+// multiplications; the product has no w^1 term), then ONE Fp12 multiplication with that structure (6 + 5 + 6): 23 Fp2
+// multiplications instead of 2 x 13, and the accumulator is read and written once.
+template <class F2>
+BLS_FN void fp12_mul_by_2lines_body(fp12_t<F2>& f, const F2& a0, const F2& a2, const F2& a3, const F2& b0, const F2& b2, const F2& b3) {
+  fp6_t<F2> L0, L1s;        // L0 = (c0, c2, c4), L1 = (0, c3, c5)
+  {
+    F2 p00, p22, p33, s, t, m;
+    fp2_mul(p00, a0, b0);
+    fp2_mul(p22, a2, b2);
+    fp2_mul(p33, a3, b3);
+    fp2_mul_xi(m, p33);
+    fp2_add(m, m, p00);
+    fp2_norm(L0.a0, m);      // c0 = a0 b0 + xi a3 b3
+    fp2_add(s, a0, a2);
+    fp2_add(t, b0, b2);
+    fp2_mul(m, s, t);
+    fp2_sub(m, m, p00);
+    fp2_sub(m, m, p22);
+    fp2_norm(L0.a1, m);      // c2 = a0 b2 + a2 b0
+    L0.a2 = p22;             // c4
+    fp2_add(s, a0, a3);
+    fp2_add(t, b0, b3);
+    fp2_mul(m, s, t);
+    fp2_sub(m, m, p00);
+    fp2_sub(m, m, p33);
+    fp2_norm(L1s.a1, m);     // c3 = a0 b3 + a3 b0
+    fp2_add(s, a2, a3);
+    fp2_add(t, b2, b3);
+    fp2_mul(m, s, t);
+    fp2_sub(m, m, p22);
+    fp2_sub(m, m, p33);
+    fp2_norm(L1s.a2, m);     // c5 = a2 b3 + a3 b2
+  }
+  fp6_t<F2> t0, t1, s, m, Ls;
+  fp6_mul(t0, f.c0, L0);
+  fp6_mul_by_12(t1, f.c1, L1s.a1, L1s.a2);
+  fp6_add(s, f.c0, f.c1);
+  fp6_norm(s, s);
+  Ls.a0 = L0.a0;
+  fp2_add(Ls.a1, L0.a1, L1s.a1);
+  fp2_add(Ls.a2, L0.a2, L1s.a2);
+  fp2_norm(Ls.a1, Ls.a1);
+  fp2_norm(Ls.a2, Ls.a2);
+  fp6_mul(m, s, Ls);
+  fp6_sub(m, m, t0);
+  fp6_sub(m, m, t1);
+  fp6_reduce(f.c1, m);
+  fp6_mul_v(t1, t1);
+  fp6_add(t0, t0, t1);
+  fp6_reduce(f.c0, t0);
+}
+template <class F2>
+BLS_NOINLINE void fp12_mul_by_2lines(fp12_t<F2>& f, const F2& a0, const F2& a2, const F2& a3, const F2& b0, const F2& b2, const F2& b3) {
+  fp12_mul_by_2lines_body(f, a0, a2, a3, b0, b2, b3);
+}

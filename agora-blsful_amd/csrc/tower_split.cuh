@@ -200,6 +200,12 @@ __device__ __noinline__ void f12_sh_mul_line(lds_u32* sh, const hfp2& l0, const 
   fp12_mul_by_line_body(a, l0, l2, l3);
   sh_st_f12(sh, a);
 }
+__device__ __noinline__ void f12_sh_mul_2lines(lds_u32* sh, const hfp2& a0, const hfp2& a2, const hfp2& a3, const hfp2& b0, const hfp2& b2, const hfp2& b3) {
+  fp12_t<hfp2> a;
+  sh_ld_f12(a, sh);
+  fp12_mul_by_2lines_body(a, a0, a2, a3, b0, b2, b3);
+  sh_st_f12(sh, a);
+}
 __device__ __noinline__ void f12_sh_mul(lds_u32* sh, const fp12_t<hfp2>& b) {
   fp12_t<hfp2> a, r;
   sh_ld_f12(a, sh);
@@ -213,6 +219,9 @@ __device__ __forceinline__ void acc_one(f12_sh& f) {
 }
 __device__ __forceinline__ void acc_sqr(f12_sh& f) { f12_sh_sqr(f.sh); }
 __device__ __forceinline__ void acc_mul_line(f12_sh& f, const hfp2& l0, const hfp2& l2, const hfp2& l3) { f12_sh_mul_line(f.sh, l0, l2, l3); }
+__device__ __forceinline__ void acc_mul_2lines(f12_sh& f, const hfp2& a0, const hfp2& a2, const hfp2& a3, const hfp2& b0, const hfp2& b2, const hfp2& b3) {
+  f12_sh_mul_2lines(f.sh, a0, a2, a3, b0, b2, b3);
+}
 __device__ __forceinline__ void acc_finish(f12_sh&) {}   // the kernel conjugates when it reads the accumulator out (negated limbs do not pack)
 
 // a^x (x < 0) for a in the cyclotomic subgroup with the running power in LDS; picked over the pairing.cuh template for
