@@ -33,6 +33,23 @@ void hs_fp_ops(const uint32_t* a, const uint32_t* b, uint32_t* out) {  // add, s
   out[48] = fp_sqrt(z, x) ? 1 : 0; fp_to_raw(out + 49, z);
   out[61] = fp_lex_largest(x) ? 1 : 0;
 }
+// Lazy-limb primitives on caller-chosen limb vectors (14 signed 32-bit limbs, any redundant form within the stated
+// bounds).  out: [0..13] fp_norm limbs, [14..27] fp_reduce limbs, [28..41] fp_canon limbs, [42] fp_is_zero,
+// [43..54] fp_get_words(fp_canon).  lb / vb: the caller's bound claims for the tracker.
+void hs_fp_lazy(const int32_t* limbs, double lb, double vb, int32_t* out) {
+  fp a, t;
+  for (int i = 0; i < FP_NL; i++) a.l[i] = limbs[i];
+  FP_TRK(a.lb = lb; a.vb = vb;)
+  (void)lb; (void)vb;
+  fp_norm(t, a);
+  for (int i = 0; i < FP_NL; i++) out[i] = t.l[i];
+  fp_reduce(t, a);
+  for (int i = 0; i < FP_NL; i++) out[14 + i] = t.l[i];
+  fp_canon(t, a);
+  for (int i = 0; i < FP_NL; i++) out[28 + i] = t.l[i];
+  out[42] = fp_is_zero(a) ? 1 : 0;
+  fp_get_words((uint32_t*)out + 43, t);
+}
 void hs_fp12_check(const uint32_t* a, const uint32_t* b, uint32_t* out) {
   // a, b: fp12 as 6 fp2 in w-power order, Montgomery.  out: mul, sqr(a), inv(a), frob1(a), frob2(a) plain w-order
   fp12 x, y, z;

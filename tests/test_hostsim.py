@@ -34,6 +34,65 @@ def test_fp_ops(hs):
         assert bool(int.from_bytes(r[244:248], 'little')) == (a > (P - 1) // 2)
 
 
+def test_fp_lazy_limbs(hs):
+    """fp_norm / fp_reduce / fp_canon / fp_is_zero on redundant signed-limb vectors: exact multiples of p in lazy form,
+    values at the rounding boundary of the quotient estimate, negative values, maximal limb magnitudes."""
+    rng = random.Random(5)
+    M = (1 << 28) - 1
+
+    def val(l):
+        return sum(int(x) << (28 * i) for i, x in enumerate(l))
+
+    def limbs_of(v):          # canonical limbs of a non-negative integer < 2^392
+        return [(v >> (28 * i)) & M for i in range(14)]
+
+    def scramble(l, spread):  # same integer, redundant limbs: move multiples of 2^28 between neighbours
+        l = list(l)
+        for i in range(13):
+            d = rng.randint(-spread, spread)
+            l[i] += d << 28
+            l[i + 1] -= d
+        return l
+
+    cases = []
+    for k in (-100, -7, -3, -1, 0, 1, 2, 5, 64, 100):                       # exact multiples of p
+        v = k * P
+        base = limbs_of(v % (1 << 392))
+        if v < 0:
+            base[13] -= 1 << 28                                              # two's-complement top limb -> signed value
+        assert val(base) == v
+        cases.append(base)
+        cases.append(scramble(base, 3))
+    for k in (-9, -1, 0, 1, 8):                                              # around the rounding boundary k p +- p/2
+        for d in (-2, -1, 0, 1, 2):
+            v = k * P + P // 2 + d
+            base = limbs_of(v % (1 << 392))
+            if v < 0:
+                base[13] -= 1 << 28
+            cases.append(scramble(base, 2))
+    for _ in range(300):                                                     # random values within +-110 p, lazy limbs
+        v = rng.randrange(-110 * P, 110 * P)
+        base = limbs_of(v % (1 << 392))
+        if v < 0:
+            base[13] -= 1 << 28
+        cases.append(scramble(base, rng.choice((0, 1, 3, 7))))
+    out = (ctypes.c_int32 * 55)()
+    for l in cases:
+        v = val(l)
+        assert all(abs(x) < 2**31 - 2**8 for x in l)
+        lb = float(max(abs(x) for x in l) + 1)
+        arr = (ctypes.c_int32 * 14)(*l)
+        hs.hs_fp_lazy(arr, ctypes.c_double(lb), ctypes.c_double(abs(v) / P + 1e-9), out)
+        o = list(out)
+        nrm, red, can = o[0:14], o[14:28], o[28:42]
+        assert val(nrm) == v and all(-16 <= x <= M + 16 for x in nrm[:13])
+        assert (val(red) - v) % P == 0 and all(0 <= x <= M for x in red[:13]) and abs(val(red)) * 100 <= 52 * P
+        assert val(can) == v % P and all(0 <= x <= M for x in can)
+        assert o[42] == (1 if v % P == 0 else 0)
+        words = [x & 0xffffffff for x in o[43:55]]
+        assert sum(w << (32 * i) for i, w in enumerate(words)) == v % P
+
+
 def test_fp12_ops(hs):
     rng = random.Random(2)
     for _ in range(5):
