@@ -267,9 +267,8 @@ BLS_NOINLINE void sswu_g2(fp2& x, fp2& y, const fp2& u) {
     fp2_mul(x1, x1, t);
   }
   fp2_curve_rhs_iso(gx, x1);
-  if (fp2_is_square(gx)) {
+  if (fp2_sqrt(y, gx)) {           // the root attempt decides squareness (an element is a square iff its norm is)
     x = x1;
-    fp2_sqrt(y, gx);
   } else {
     fp2_mul(x, zu2, x1);
     fp2_curve_rhs_iso(gx, x);

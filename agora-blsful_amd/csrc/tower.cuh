@@ -142,30 +142,37 @@ BLS_NOINLINE bool fp2_sqrt(fp2& r, const fp2& a) {
     r.c1 = s;
     return ok;
   }
-  fp n, t, half, s;
+  // a1 != 0.  With n = |a| (the square root of the norm, which exists iff a is a square) and t = (a0 + n) / 2:
+  //   s = t^((p+1)/4) satisfies s^2 = t or s^2 = -t (p = 3 mod 4), and a0 = t - a1^2 / (4 t), so
+  //   sqrt(a) = s + a1/(2s) u   when s^2 = t,      a1/(2s) + s u   when s^2 = -t.
+  // Three exponentiations: sqrt(norm), s, 1/(2s).
+  fp n, t, h, s, c2, d;
   fp_sqr(n, a.c0);
   fp_sqr(t, a.c1);
   fp_add(n, n, t);
   if (!fp_sqrt(n, n)) return false;
-  fp two;
-  fp_one(half);
-  fp_dbl(two, half);
-  fp_inv(half, two);
+  fp_load(h, FP_HALF);
   fp_add(t, a.c0, n);
-  fp_mul(t, t, half);
-  if (!fp_sqrt(s, t)) {
-    fp_sub(t, a.c0, n);
-    fp_mul(t, t, half);
-    if (!fp_sqrt(s, t)) return false;
-  }
-  fp d;
+  fp_mul(t, t, h);
+  fp_pow(s, t, EXP_PM3D4, EXP_PM3D4_BITS);
+  fp_mul(s, s, t);
+  fp_sqr(c2, s);
+  const bool direct = fp_eq(c2, t);
   fp_dbl(d, s);
   fp_inv(d, d);
-  r.c0 = s;
-  fp_mul(r.c1, a.c1, d);
+  fp_mul(d, a.c1, d);
+  fp2 cand;
+  cand.c0 = s;
+  cand.c1 = d;
+  if (!direct) {
+    cand.c0 = d;
+    cand.c1 = s;
+  }
   fp2 chk;
-  fp2_sqr(chk, r);
-  return fp2_eq(chk, a);
+  fp2_sqr(chk, cand);
+  if (!fp2_eq(chk, a)) return false;
+  r = cand;
+  return true;
 }
 // RFC 9380 sgn0 for m = 2
 BLS_FN uint32_t fp2_sgn0(const fp2& a) {
