@@ -5,9 +5,11 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -367,6 +369,9 @@ bool hash_to_scalar_le(const uint8_t hash[32], uint8_t out[32]) {
 // host part of hash_public_keys_with_sorted (reference src/secure_aggregation.rs:41-103): stable sort by serialised
 // bytes, H = SHA-256(concat), t_i = SHA-256(BE32(i) || H) mod r.  Returns BLSGPU_OK or BLSGPU_INVALID_COEFFICIENT.
 int secure_coefficients_host(const uint8_t* kb, size_t n, size_t width, std::vector<uint32_t>& perm, std::vector<uint8_t>& scalars) {
+  const bool trace = getenv("BLSGPU_HOST_TRACE") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_start = now();
   perm.resize(n);
   std::iota(perm.begin(), perm.end(), 0u);
   // byte-lexicographic, stable (Rust's sort_by is stable): compare the first 8 bytes as a big-endian word first
@@ -380,20 +385,42 @@ int secure_coefficients_host(const uint8_t* kb, size_t n, size_t width, std::vec
     if (pre[a] != pre[b]) return pre[a] < pre[b];
     return memcmp(kb + (size_t)a * width + 8, kb + (size_t)b * width + 8, width - 8) < 0;
   });
+  const double t_sorted = now();
   host_sha256 h;
   for (size_t i = 0; i < n; i++) h.update(kb + (size_t)perm[i] * width, width);
   uint8_t H[32];
   h.final(H);
+  const double t_hashed = now();
   scalars.resize(32 * n);
-  for (size_t i = 0; i < n; i++) {
-    uint8_t buf[36] = {(uint8_t)(i >> 24), (uint8_t)(i >> 16), (uint8_t)(i >> 8), (uint8_t)i};
-    memcpy(buf + 4, H, 32);
-    uint8_t d[32];
-    host_sha256 hi;
-    hi.update(buf, 36);
-    hi.final(d);
-    if (!hash_to_scalar_le(d, &scalars[32 * i])) return BLSGPU_INVALID_COEFFICIENT;
+  // t_i = SHA256(BE32(i) || H): independent one-block hashes, spread over the host cores (the sorted-key hash above is one
+  // sequential stream and stays on one core)
+  unsigned nthr = std::thread::hardware_concurrency();
+  if (nthr > 16) nthr = 16;
+  if (nthr < 1 || n < 4096) nthr = 1;
+  std::vector<int> bad(nthr, 0);
+  auto work = [&](unsigned t) {
+    const size_t lo = n * t / nthr, hi = n * (t + 1) / nthr;
+    for (size_t i = lo; i < hi; i++) {
+      uint8_t buf[36] = {(uint8_t)(i >> 24), (uint8_t)(i >> 16), (uint8_t)(i >> 8), (uint8_t)i};
+      memcpy(buf + 4, H, 32);
+      uint8_t d[32];
+      host_sha256 hi2;
+      hi2.update(buf, 36);
+      hi2.final(d);
+      if (!hash_to_scalar_le(d, &scalars[32 * i])) bad[t] = 1;
+    }
+  };
+  if (nthr == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nthr; t++) pool.emplace_back(work, t);
+    for (auto& th : pool) th.join();
   }
+  for (unsigned t = 0; t < nthr; t++)
+    if (bad[t]) return BLSGPU_INVALID_COEFFICIENT;
+  if (trace) fprintf(stderr, "[blsgpu] secure coefficients n=%zu: sort %.2f ms, key hash %.2f ms, coefficient hashes %.2f ms\n", n,
+                     t_sorted - t_start, t_hashed - t_sorted, now() - t_hashed);
   return BLSGPU_OK;
 }
 
