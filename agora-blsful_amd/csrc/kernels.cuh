@@ -180,7 +180,7 @@ __global__ void k_decompress(size_t n, const uint8_t* bytes, int legacy, uint8_t
 // verify_batch stage 1: identity checks, to-affine, Aug prefix, hash-to-curve  ->  two affine pairs per item.
 // single_msg != 0: every item uses message [offs[0], offs[1]) (multi_verify / verify_secure tail).
 template <int SG>
-__global__ void __launch_bounds__(BLS_BLOCK) k_prepare(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int aug,
+__global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int aug,
                                                      const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst,
                                                      uint32_t* pairs, int32_t* status, int pre_status) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -227,7 +227,7 @@ template __global__ void k_prepare<2>(size_t, const uint8_t*, const uint8_t*, in
 // mode 1: aggregate verify: pk[i] + message i -> pair (H(m_i), pk_i) in the G1-first order of src/helpers.rs;
 //         item n (the extra lane) carries (sig, -g).  bad[i] = 1 when pk_i is the identity.
 template <int SG>
-__global__ void __launch_bounds__(BLS_BLOCK) k_prepare_agg(size_t n, const uint8_t* pks, const uint8_t* sig, int fmt, int aug,
+__global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare_agg(size_t n, const uint8_t* pks, const uint8_t* sig, int fmt, int aug,
                                                          const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint32_t* pairs,
                                                          int32_t* bad) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
