@@ -241,39 +241,103 @@ BLS_NOINLINE void hash_to_g1(g1_jac& r, const uint8_t* pre, uint32_t pre_len, co
 }
 
 // ------------------------------------------------------------------ G2: simplified SWU (RFC 9380 6.6.2, generic form)
-BLS_FN void fp2_curve_rhs_iso(fp2& r, const fp2& x) {  // x^3 + A' x + B' on E'2
-  fp2 A, B, t;
+// Projective form: x1 = xn / xd with xn = B (tv2 + 1), xd = -A tv2 (Z A when tv2 = 0), g(x1) = num / xd^3, so
+// y1 = sqrt(num xd) / xd^2; the one Fp inversion for 1 / xd rides in the square root's own inversion (fp2_sqrt_inv).
+// When g(x1) is not a square, x2 = (Z u^2) x1 and g(x2) = (Z u^2)^3 g(x1).
+BLS_NOINLINE void sswu_g2(fp2& x, fp2& y, const fp2& u) {
+  fp2 A, B, Z, tv1, tv2, xn, xd, xd2, xd3, num, w, t, Y;
   fp2_load(A, SSWU2_A);
   fp2_load(B, SSWU2_B);
-  fp2_sqr(t, x);
-  fp2_add(t, t, A);
-  fp2_mul(t, t, x);
-  fp2_add(r, t, B);
-}
-BLS_NOINLINE void sswu_g2(fp2& x, fp2& y, const fp2& u) {
-  fp2 Z, zu2, tv1, x1, gx, one, t;
   fp2_load(Z, SSWU2_Z);
-  fp2_sqr(zu2, u);
-  fp2_mul(zu2, Z, zu2);
-  fp2_sqr(tv1, zu2);
-  fp2_add(tv1, tv1, zu2);
-  if (fp2_is_zero(tv1)) {
-    fp2_load(x1, SSWU2_BZA);
-  } else {
-    fp2_inv(t, tv1);
-    fp2_one(one);
-    fp2_add(t, t, one);
-    fp2_load(x1, SSWU2_NBA);
-    fp2_mul(x1, x1, t);
+  fp2_sqr(tv1, u);
+  fp2_mul(tv1, Z, tv1);              // Z u^2
+  fp2_sqr(tv2, tv1);
+  fp2_add(tv2, tv2, tv1);
+  fp2_reduce(tv2, tv2);
+  fp2_one(t);
+  fp2_add(t, tv2, t);
+  fp2_mul(xn, B, t);                 // B (tv2 + 1)
+  fp2_neg(t, tv2);
+  fp2_cmov(t, Z, fp2_is_zero(tv2));
+  fp2_mul(xd, A, t);
+  fp2_sqr(xd2, xd);
+  fp2_mul(xd3, xd2, xd);
+  fp2_sqr(num, xn);
+  fp2_mul(t, A, xd2);
+  fp2_add(num, num, t);
+  fp2_mul(num, num, xn);
+  fp2_mul(t, B, xd3);
+  fp2_add(num, num, t);              // xn^3 + A xn xd^2 + B xd^3
+  fp2_mul(w, num, xd);
+  fp nxd, nt, inxd;
+  fp_sqr(nxd, xd.c0);
+  fp_sqr(nt, xd.c1);
+  fp_add(nxd, nxd, nt);
+  fp_reduce(nxd, nxd);               // norm(xd), non-zero
+  // Branch-free choice between x1 and x2 (lanes of a wave would otherwise run the square root twice):
+  // sn = norm(w)^((p+1)/4) is a root of norm(w) when g(x1) is a square and satisfies sn^2 = -norm(w) otherwise; in that
+  // case norm(w tv1^3) = norm(w) (norm(Z) norm(u)^2)^3 has the root sn * cZ * norm(u)^3 with the constant cZ^2 = -norm(Z)^3.
+  fp n, sn, c2, nu, nu3, cz, root;
+  fp_sqr(n, w.c0);
+  fp_sqr(nt, w.c1);
+  fp_add(n, n, nt);
+  fp_reduce(n, n);
+  fp_pow(sn, n, EXP_PM3D4, EXP_PM3D4_BITS);
+  fp_mul(sn, sn, n);
+  fp_sqr(c2, sn);
+  const bool sq1 = fp_eq(c2, n);
+  fp_sqr(nu, u.c0);
+  fp_sqr(nt, u.c1);
+  fp_add(nu, nu, nt);
+  fp_reduce(nu, nu);
+  fp_sqr(nu3, nu);
+  fp_mul(nu3, nu3, nu);
+  fp_load(cz, SSWU2_CZ);
+  fp_mul(root, sn, cz);
+  fp_mul(root, root, nu3);
+  fp_cmov(root, sn, sq1);
+  {
+    fp2 t3, w2, xn2;
+    fp2_sqr(t3, tv1);
+    fp2_mul(t3, t3, tv1);
+    fp2_mul(w2, w, t3);
+    fp2_mul(xn2, tv1, xn);
+    fp2_cmov(w2, w, sq1);
+    fp2_cmov(xn2, xn, sq1);
+    w = w2;
+    xn = xn2;
   }
-  fp2_curve_rhs_iso(gx, x1);
-  if (fp2_sqrt(y, gx)) {           // the root attempt decides squareness (an element is a square iff its norm is)
-    x = x1;
-  } else {
-    fp2_mul(x, zu2, x1);
-    fp2_curve_rhs_iso(gx, x);
-    fp2_sqrt(y, gx);
+  if (fp_is_zero(w.c1)) {            // real w (probability 2^-381): the generic routine handles it
+    fp2_sqrt_inv(Y, w, &nxd, &inxd);
+  } else {                           // complex method with the root of the norm already in hand (tower.cuh fp2_sqrt_inv)
+    fp h, tt, s, d, prod, pi;
+    fp_load(h, FP_HALF);
+    fp_add(tt, w.c0, root);
+    fp_mul(tt, tt, h);
+    fp_pow(s, tt, EXP_PM3D4, EXP_PM3D4_BITS);
+    fp_mul(s, s, tt);
+    fp_sqr(c2, s);
+    const bool direct = fp_eq(c2, tt);
+    fp_dbl(d, s);
+    fp_reduce(d, d);
+    fp_mul(prod, d, nxd);
+    fp_inv(pi, prod);
+    fp_mul(inxd, pi, d);
+    fp_mul(d, pi, nxd);
+    fp_mul(d, w.c1, d);
+    Y.c0 = s;
+    Y.c1 = d;
+    fp2 alt;
+    alt.c0 = d;
+    alt.c1 = s;
+    fp2_cmov(Y, alt, !direct);
   }
+  fp2 xdi;
+  fp2_conj(xdi, xd);
+  fp2_mul_fp(xdi, xdi, inxd);        // 1 / xd
+  fp2_mul(x, xn, xdi);
+  fp2_sqr(t, xdi);
+  fp2_mul(y, Y, t);
   if (fp2_sgn0(u) != fp2_sgn0(y)) fp2_neg(y, y);
 }
 BLS_FN void iso2_poly(fp2& r, const uint32_t (*k)[2 * FP_NL], int deg, const fp2& x) {

@@ -127,19 +127,28 @@ BLS_FN bool fp2_is_square(const fp2& a) {
   return fp_is_square(n);
 }
 // some square root (complex method); false if a is not a square.  Callers fix the sign.
-BLS_NOINLINE bool fp2_sqrt(fp2& r, const fp2& a) {
+// e / einv (optional): an extra non-zero Fp value whose inverse the caller needs anyway -- it shares the exponentiation
+// of the 1/(2s) step (Montgomery's trick), e.g. the denominator of the SSWU map.  einv is written only on success.
+BLS_NOINLINE bool fp2_sqrt_inv(fp2& r, const fp2& a, const fp* e, fp* einv) {
   if (fp_is_zero(a.c1)) {
     fp s;
+    bool ok;
+    fp2 cand;
     if (fp_sqrt(s, a.c0)) {
-      r.c0 = s;
-      fp_zero(r.c1);
-      return true;
+      cand.c0 = s;
+      fp_zero(cand.c1);
+      ok = true;
+    } else {
+      fp na;
+      fp_neg(na, a.c0);
+      ok = fp_sqrt(s, na);  // sqrt(-1) = u
+      fp_zero(cand.c0);
+      cand.c1 = s;
     }
-    fp na;
-    fp_neg(na, a.c0);
-    bool ok = fp_sqrt(s, na);  // sqrt(-1) = u
-    fp_zero(r.c0);
-    r.c1 = s;
+    if (ok) {
+      r = cand;
+      if (e) fp_inv(*einv, *e);
+    }
     return ok;
   }
   // a1 != 0.  With n = |a| (the square root of the norm, which exists iff a is a square) and t = (a0 + n) / 2:
@@ -159,7 +168,17 @@ BLS_NOINLINE bool fp2_sqrt(fp2& r, const fp2& a) {
   fp_sqr(c2, s);
   const bool direct = fp_eq(c2, t);
   fp_dbl(d, s);
-  fp_inv(d, d);
+  fp_reduce(d, d);
+  fp ei;
+  if (e) {                  // 1/(2s) and 1/e from one exponentiation
+    fp prod, pi;
+    fp_mul(prod, d, *e);
+    fp_inv(pi, prod);
+    fp_mul(ei, pi, d);
+    fp_mul(d, pi, *e);
+  } else {
+    fp_inv(d, d);
+  }
   fp_mul(d, a.c1, d);
   fp2 cand;
   cand.c0 = s;
@@ -172,8 +191,10 @@ BLS_NOINLINE bool fp2_sqrt(fp2& r, const fp2& a) {
   fp2_sqr(chk, cand);
   if (!fp2_eq(chk, a)) return false;
   r = cand;
+  if (e) *einv = ei;
   return true;
 }
+BLS_FN bool fp2_sqrt(fp2& r, const fp2& a) { return fp2_sqrt_inv(r, a, nullptr, nullptr); }
 // RFC 9380 sgn0 for m = 2
 BLS_FN uint32_t fp2_sgn0(const fp2& a) {
   fp t0, t1;
