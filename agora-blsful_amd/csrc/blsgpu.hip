@@ -185,7 +185,9 @@ void prof_flush(Ctx* c) {
     hipLaunchKernelGGL(kern, grid, block, 0, c->stream, __VA_ARGS__);           \
     prof_post(c);                                                               \
   } while (0)
-#define MILLER1_LAUNCH(cnt, ...) KL(KID_MILLER1, k_miller1s, dim3(blocks_for(2 * (cnt))), dim3(BLS_BLOCK), cnt, __VA_ARGS__)
+// one Miller loop per two items: leaves (cnt + 1) / 2 partial products at the start of the Fp12 workspace
+#define MILLER1_LAUNCH(cnt, ...) KL(KID_MILLER1, k_miller1s, dim3(blocks_for(2 * (((cnt) + 1) / 2))), dim3(BLS_BLOCK), cnt, __VA_ARGS__)
+#define MILLER1_OUTPUTS(cnt) (((cnt) + 1) / 2)
 #define SYNC_FLUSH(c)                          \
   do {                                         \
     HIPCK(hipStreamSynchronize((c)->stream));  \
@@ -662,7 +664,7 @@ int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const ui
     if ((rc = stage_in(c, msg_offsets, 8 * m, &d_offs))) return rc;
     int32_t* d_bad = (int32_t*)arena_take(c, 4 * m);
     int32_t* d_verdict = (int32_t*)arena_take(c, 4);
-    uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)72 * 4 * m);
+    uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)WS_PAIR1_WORDS * 4 * m);
     uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * m);
     if (!d_bad || !d_verdict || !d_pairs || !d_f) return fail(BLSGPU_E_HIP, "internal: arena too small");
     dst_arg dst = scheme_dst(sig_group, scheme);
@@ -690,7 +692,7 @@ int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const ui
     }
     if (st == BLSGPU_OK) {
       MILLER1_LAUNCH(m, m, d_pairs, d_bad, d_f);
-      if ((rc = run_f12_product_verdict(c, d_f, m, m, d_verdict))) return rc;
+      if ((rc = run_f12_product_verdict(c, d_f, MILLER1_OUTPUTS(m), m, d_verdict))) return rc;
       HIPCK(hipMemcpyAsync(&st, d_verdict, 4, hipMemcpyDeviceToHost, c->stream));
       SYNC_FLUSH(c);
     }
@@ -879,12 +881,12 @@ int blsgpu_pairing_product_is_one(const void* g1s, const void* g2s, size_t n, in
     if ((rc = stage_in(c, g1s, g1_size(fmt) * n, &d1))) return rc;
     if ((rc = stage_in(c, g2s, g2_size(fmt) * n, &d2))) return rc;
     int32_t* d_skip = (int32_t*)arena_take(c, 4 * n + 4);
-    uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)72 * 4 * n);
+    uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)WS_PAIR1_WORDS * 4 * n);
     uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * n);
     if (!d_skip || !d_pairs || !d_f) return fail(BLSGPU_E_HIP, "internal: arena too small");
     KL(KID_PAIRS_AFF, k_pairs_to_affine, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d1, (const uint8_t*)d2, fmt, d_pairs, d_skip);
     MILLER1_LAUNCH(n, n, d_pairs, d_skip, d_f);
-    if ((rc = run_f12_product_verdict(c, d_f, n, n, d_skip + n))) return rc;
+    if ((rc = run_f12_product_verdict(c, d_f, MILLER1_OUTPUTS(n), n, d_skip + n))) return rc;
     HIPCK(hipMemcpyAsync(&verdict, d_skip + n, 4, hipMemcpyDeviceToHost, c->stream));
     SYNC_FLUSH(c);
   }
@@ -1110,7 +1112,7 @@ int blsgpu_aggregate_partial(int sig_group, int scheme, const void* pks, const u
   if ((rc = stage_in(c, msgs, total, &d_msgs))) return rc;
   if ((rc = stage_in(c, msg_offsets, 8 * m, &d_offs))) return rc;
   int32_t* d_bad = (int32_t*)arena_take(c, 4 * m);
-  uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)72 * 4 * m);
+  uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)WS_PAIR1_WORDS * 4 * m);
   uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * m);
   uint8_t* d_out = (uint8_t*)arena_take(c, 576);
   if (!d_bad || !d_pairs || !d_f || !d_out) return fail(BLSGPU_E_HIP, "internal: arena too small");
@@ -1148,7 +1150,7 @@ int blsgpu_aggregate_partial(int sig_group, int scheme, const void* pks, const u
     HIPCK(hipMemcpy(out_f12, one.data(), 576, is_device_ptr(out_f12) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
     return 0;
   }
-  if ((rc = run_f12_fold(c, d_f, mm, m))) return rc;
+  if ((rc = run_f12_fold(c, d_f, MILLER1_OUTPUTS(mm), m))) return rc;
   KL(KID_F12_IO, k_f12_export, dim3(1), dim3(BLS_BLOCK), d_f, m, d_out);
   HIPCK(hipGetLastError());
   if ((rc = copy_out(c, out_f12, d_out, 576))) return rc;

@@ -10,6 +10,7 @@
 #define W1 FP_NL               // workspace words per Fp (internal 28-bit-limb form, fp.cuh)
 #define W2 (2 * FP_NL)         // per Fp2
 #define WS_PAIRS_WORDS (6 * W2)  // P0(2 Fp) Q0(2 Fp2) P1 Q1, affine, internal form
+#define WS_PAIR1_WORDS (3 * W2)  // one (P, Q) pair: the one-pair-per-item workspaces of aggregate verify / pairing products
 #define WS_F_WORDS (6 * W2)      // Fp12
 
 struct dst_arg {
@@ -573,29 +574,34 @@ __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_miller2s(size_t 
 #endif
 
 #if defined(BLS_TU_MILLERS)
-// one pair per item (aggregate verify / pairing product), two lanes per item; skipped items write 1
+// Pairing products (aggregate verify / pairing_product_is_one): every lane pair runs ONE Miller loop over TWO items,
+// g and g + half (half = ceil(n / 2)), so that the accumulator squarings are shared and the two line values of a step are
+// merged before they touch f -- the product over all items is all that is needed.  Writes half partial products; skipped
+// items contribute 1.
 __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_miller1s(size_t n, size_t stride, const uint32_t* pairs, const int32_t* skip, uint32_t* fws) {
-  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
-  if (i >= n) return;
+  const size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1, half = (n + 1) / 2;
+  if (g >= half) return;
   __shared__ uint32_t fsh[F12_SH_WORDS * BLS_BLOCK];
   f12_sh acc = {lds_column(fsh)};
-  fp12_t<hfp2> f;
-  if (skip[i]) {
-    fp12_one(f);
-  } else {
-    g1_aff P[1];
-    aff<hfp2> Q[1];
-    ws_ld_fp(P[0].x, pairs, stride, i, 0);
-    ws_ld_fp(P[0].y, pairs, stride, i, W1);
-    ws_ld_hfp2(Q[0].x, pairs, stride, i, W2);
-    ws_ld_hfp2(Q[0].y, pairs, stride, i, 2 * W2);
-    P[0].inf = false;
-    Q[0].inf = false;
-    miller_loop<1>(acc, P, Q);
-    sh_ld_f12(f, acc.sh);
-    fp12_conj(f, f);
+  g1_aff P[2];
+  aff<hfp2> Q[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const size_t j = g + (k ? half : 0);
+    const bool have = j < n;
+    const size_t jj = have ? j : g;
+    ws_ld_fp(P[k].x, pairs, stride, jj, 0);
+    ws_ld_fp(P[k].y, pairs, stride, jj, W1);
+    ws_ld_hfp2(Q[k].x, pairs, stride, jj, W2);
+    ws_ld_hfp2(Q[k].y, pairs, stride, jj, 2 * W2);
+    P[k].inf = !have || skip[jj] != 0;
+    Q[k].inf = false;
   }
-  ws_st_hfp12(fws, stride, i, f);
+  miller_loop<2>(acc, P, Q);
+  fp12_t<hfp2> f;
+  sh_ld_f12(f, acc.sh);
+  fp12_conj(f, f);
+  ws_st_hfp12(fws, stride, g, f);
 }
 #endif
 
