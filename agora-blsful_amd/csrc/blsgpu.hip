@@ -622,6 +622,9 @@ int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const ui
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCK(hipSetDevice(c->dev));
   uint64_t aux_h[2] = {0, 0};
+  const bool trace = getenv("BLSGPU_HOST_TRACE") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_start = now();
   // host views of offsets (and of messages for the Basic duplicate check)
   std::vector<uint64_t> offs_h(n + 1);
   if (is_device_ptr(msg_offsets)) HIPCK(hipMemcpy(offs_h.data(), msg_offsets, 8 * (n + 1), hipMemcpyDeviceToHost));
@@ -637,20 +640,61 @@ int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const ui
       HIPCK(hipMemcpy(tmp.data(), msgs, total, hipMemcpyDeviceToHost));
       mh = tmp.data();
     }
-    std::unordered_map<std::string, uint64_t> seen;
-    seen.reserve(n * 2);
-    for (size_t i = 0; i < n && st == BLSGPU_OK; i++) {
-      std::string key((const char*)mh + offs_h[i], (size_t)(offs_h[i + 1] - offs_h[i]));
-      auto it = seen.find(key);
-      if (it != seen.end()) {
-        st = BLSGPU_DUPLICATE_MESSAGE;
-        aux_h[0] = it->second;
-        aux_h[1] = i;
+    // open-addressing table of message indices keyed by a 64-bit hash (computed on all host cores), equality verified on
+    // the bytes; the scan is sequential so that the FIRST i with an earlier equal message is reported, as the reference does
+    std::vector<uint64_t> hs(n);
+    {
+      unsigned nthr = std::thread::hardware_concurrency();
+      if (nthr > 16) nthr = 16;
+      if (nthr < 1 || n < 16384) nthr = 1;
+      auto work = [&](unsigned t) {
+        for (size_t i = n * t / nthr; i < n * (t + 1) / nthr; i++) {
+          const uint8_t* p = mh + offs_h[i];
+          size_t len = (size_t)(offs_h[i + 1] - offs_h[i]);
+          uint64_t h = 0x9e3779b97f4a7c15ull ^ (len * 0xff51afd7ed558ccdull);
+          while (len >= 8) {
+            uint64_t w;
+            memcpy(&w, p, 8);
+            h = (h ^ w) * 0xc4ceb9fe1a85ec53ull;
+            h ^= h >> 29;
+            p += 8;
+            len -= 8;
+          }
+          uint64_t w = 0;
+          memcpy(&w, p, len);
+          h = (h ^ w) * 0xff51afd7ed558ccdull;
+          h ^= h >> 32;
+          hs[i] = h;
+        }
+      };
+      if (nthr == 1) {
+        work(0);
       } else {
-        seen.emplace(std::move(key), i);
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nthr; t++) pool.emplace_back(work, t);
+        for (auto& th : pool) th.join();
       }
     }
+    size_t cap = 16;
+    while (cap < 2 * n) cap <<= 1;
+    std::vector<uint32_t> tab(cap, 0);          // index + 1, 0 = empty
+    for (size_t i = 0; i < n && st == BLSGPU_OK; i++) {
+      const size_t len = (size_t)(offs_h[i + 1] - offs_h[i]);
+      size_t slot = (size_t)hs[i] & (cap - 1);
+      while (tab[slot]) {
+        const size_t j = tab[slot] - 1;
+        if (hs[j] == hs[i] && (size_t)(offs_h[j + 1] - offs_h[j]) == len && memcmp(mh + offs_h[j], mh + offs_h[i], len) == 0) {
+          st = BLSGPU_DUPLICATE_MESSAGE;
+          aux_h[0] = j;
+          aux_h[1] = i;
+          break;
+        }
+        slot = (slot + 1) & (cap - 1);
+      }
+      if (st == BLSGPU_OK) tab[slot] = (uint32_t)(i + 1);
+    }
   }
+  const double t_dup = now();
   if (st == BLSGPU_OK) {
     const size_t m = n + 1, psz = pk_size(sig_group, fmt);
     size_t need = pad256(psz * n) + pad256(sig_size(sig_group, fmt)) + pad256(total) + pad256(8 * m) + pad256(4 * m) +
@@ -662,6 +706,8 @@ int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const ui
     if ((rc = stage_in(c, sig, sig_size(sig_group, fmt), &d_sig))) return rc;
     if ((rc = stage_in(c, msgs, total, &d_msgs))) return rc;
     if ((rc = stage_in(c, msg_offsets, 8 * m, &d_offs))) return rc;
+    const double t_staged = now();
+    if (trace) fprintf(stderr, "[blsgpu] aggregate_verify n=%zu: duplicate check %.2f ms, staging %.2f ms\n", n, t_dup - t_start, t_staged - t_dup);
     int32_t* d_bad = (int32_t*)arena_take(c, 4 * m);
     int32_t* d_verdict = (int32_t*)arena_take(c, 4);
     uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)WS_PAIR1_WORDS * 4 * m);
