@@ -288,10 +288,12 @@ struct msm_plan {
 };
 msm_plan msm_make_plan(size_t n) {
   msm_plan p;
-  p.c = n >= 16384 ? 11 : 8;
+  p.c = n >= 16384 ? 12 : 8;           // measured at 65,536 points (tools/dbg/msm.py): c = 12, CH = 8 beats 11 / 32 by 20 %
+  p.CH = 8;                            // short chunks: the 2^(c w) doublings of the chunk lanes dominate their critical path
+  if (const char* e = getenv("BLSGPU_MSM_C")) p.c = atoi(e);        // tuning overrides (window bits, buckets per chunk lane)
+  if (const char* e = getenv("BLSGPU_MSM_CH")) p.CH = atoi(e);
   p.W = 255 / p.c;                      // scalars are < r < 2^255
   p.clast = 255 - p.c * (p.W - 1);      // the last window takes the remainder: c <= clast < 2c
-  p.CH = 32;
   p.nb = ((size_t)(p.W - 1) << p.c) + ((size_t)1 << p.clast);
   p.nchunks = p.nb / p.CH;
   return p;
