@@ -220,7 +220,12 @@ __device__ __forceinline__ void acc_one(f12_sh& f) {
 __device__ __forceinline__ void acc_sqr(f12_sh& f) { f12_sh_sqr(f.sh); }
 __device__ __forceinline__ void acc_mul_line(f12_sh& f, const hfp2& l0, const hfp2& l2, const hfp2& l3) { f12_sh_mul_line(f.sh, l0, l2, l3); }
 __device__ __forceinline__ void acc_mul_2lines(f12_sh& f, const hfp2& a0, const hfp2& a2, const hfp2& a3, const hfp2& b0, const hfp2& b2, const hfp2& b3) {
+#if BLS_MERGE_LINES
   f12_sh_mul_2lines(f.sh, a0, a2, a3, b0, b2, b3);
+#else
+  f12_sh_mul_line(f.sh, a0, a2, a3);
+  f12_sh_mul_line(f.sh, b0, b2, b3);
+#endif
 }
 __device__ __forceinline__ void acc_finish(f12_sh&) {}   // the kernel conjugates when it reads the accumulator out (negated limbs do not pack)
 
