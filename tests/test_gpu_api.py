@@ -353,6 +353,44 @@ def test_verify_batch_large_property(api):
     assert api.verify_batch(1, api.POP, pks, sigs2, msgs2) == expect
 
 
+@pytest.mark.parametrize('sg', [1, 2])
+def test_verify_batch_ragged_sizes(api, sg):
+    """Batch sizes around the wave (32 items), workgroup and cooperative/lane-split (1,024 items) boundaries, empty batch
+    included: one tampered item per batch, exact verdict vectors, both orientations."""
+    sizes = (0, 1, 2, 31, 32, 33, 63, 65, 1023, 1024, 1025, 1057) if sg == 1 else (0, 1, 33, 1025)
+    nmax = max(sizes)
+    sks = [0x5151 + 3 * i for i in range(nmax)]
+    msgs = [hashlib.sha256(b'ragged%d' % i).digest() for i in range(nmax)]
+    pks, sigs = api.sign_batch(sg, api.POP, sks, msgs)
+    for n in sizes:
+        m = list(msgs[:n])
+        expect = [0] * n
+        if n:
+            j = (7 * n) // 11
+            m[j] = m[j] + b'!'
+            expect[j] = 1
+        assert api.verify_batch(sg, api.POP, pks[:n], sigs[:n], m) == expect, n
+
+
+@pytest.mark.parametrize('sg', [1, 2])
+def test_aggregate_verify_pair_grouping(api, sg):
+    """The pairing-product kernels run one Miller loop per two items: odd and even counts, including the lone tail item."""
+    nmax = 35
+    sks = [0x7000 + 5 * i for i in range(nmax)]
+    msgs = [hashlib.sha256(b'pairs%d' % i).digest() for i in range(nmax)]
+    pks, sigs = api.sign_batch(sg, api.POP, sks, msgs)
+    for n in (1, 2, 3, 4, 5, 32, 33, 34, 35):
+        agg = api.point_sum(sg, sigs[:n])          # signatures live in G_sg
+        assert api.aggregate_verify(sg, api.POP, pks[:n], msgs[:n], agg)[0] == api.OK, n
+        bad = list(msgs[:n])
+        bad[n - 1] = b'tail item tampered'
+        assert api.aggregate_verify(sg, api.POP, pks[:n], bad, agg)[0] == api.INVALID_SIGNATURE, n
+        if n > 2:
+            bad = list(msgs[:n])
+            bad[(n - 1) // 2] = b'middle item tampered'
+            assert api.aggregate_verify(sg, api.POP, pks[:n], bad, agg)[0] == api.INVALID_SIGNATURE, n
+
+
 @pytest.mark.parametrize('group', [1, 2])
 def test_msm_pippenger_closed_form(api, group):
     """Bucket-method MSM at n = 1,500 (8-bit windows) and 20,000 (11-bit windows): points sk_i * g made on the device,
