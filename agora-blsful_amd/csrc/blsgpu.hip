@@ -378,17 +378,39 @@ int secure_coefficients_host(const uint8_t* kb, size_t n, size_t width, std::vec
   const double t_start = now();
   perm.resize(n);
   std::iota(perm.begin(), perm.end(), 0u);
-  // byte-lexicographic, stable (Rust's sort_by is stable): compare the first 8 bytes as a big-endian word first
+  // byte-lexicographic and stable (Rust's sort_by is stable): LSD radix sort (4 x 16 bits, stable) on the first 8 bytes
+  // read as a big-endian word, then a stable comparison sort of every run of equal prefixes on the remaining bytes
   std::vector<uint64_t> pre(n);
   for (size_t i = 0; i < n; i++) {
     uint64_t v = 0;
     for (int k = 0; k < 8; k++) v = (v << 8) | kb[i * width + k];
     pre[i] = v;
   }
-  std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) {
-    if (pre[a] != pre[b]) return pre[a] < pre[b];
-    return memcmp(kb + (size_t)a * width + 8, kb + (size_t)b * width + 8, width - 8) < 0;
-  });
+  {
+    std::vector<uint32_t> tmp(n), cnt(65536);
+    for (int pass = 0; pass < 4; pass++) {
+      const int sh = 16 * pass;
+      std::fill(cnt.begin(), cnt.end(), 0u);
+      for (size_t i = 0; i < n; i++) cnt[(pre[perm[i]] >> sh) & 0xffff]++;
+      uint32_t run = 0;
+      for (size_t d = 0; d < 65536; d++) {
+        const uint32_t c0 = cnt[d];
+        cnt[d] = run;
+        run += c0;
+      }
+      for (size_t i = 0; i < n; i++) tmp[cnt[(pre[perm[i]] >> sh) & 0xffff]++] = perm[i];
+      perm.swap(tmp);
+    }
+  }
+  for (size_t a = 0; a < n;) {
+    size_t b = a + 1;
+    while (b < n && pre[perm[b]] == pre[perm[a]]) b++;
+    if (b - a > 1)
+      std::stable_sort(perm.begin() + a, perm.begin() + b, [&](uint32_t x, uint32_t y) {
+        return memcmp(kb + (size_t)x * width + 8, kb + (size_t)y * width + 8, width - 8) < 0;
+      });
+    a = b;
+  }
   const double t_sorted = now();
   host_sha256 h;
   for (size_t i = 0; i < n; i++) h.update(kb + (size_t)perm[i] * width, width);

@@ -237,6 +237,18 @@ def test_secure_coefficients_golden(api):
     kb[7] = kb[30]
     perm_o, _, ts_o = ref.secure_coefficients(kb)
     assert api.secure_coefficients(kb) == (0, perm_o, ts_o)
+    # shared 8-byte prefixes (the device library radix-sorts the prefix word and comparison-sorts the runs), keys that
+    # differ only in the last byte, exact duplicates far apart: the order must stay the stable byte-lexicographic one
+    for width in (48, 96):
+        kb = []
+        for i in range(300):
+            prefix = bytes([rng.randrange(3)] * 8)
+            body = bytes(rng.randrange(2) for _ in range(width - 9)) + bytes([rng.randrange(256)])
+            kb.append(prefix + body)
+        kb[250] = kb[3]
+        kb[299] = kb[3]
+        perm_o, _, ts_o = ref.secure_coefficients(kb)
+        assert api.secure_coefficients(kb) == (0, perm_o, ts_o)
 
 
 def test_verify_secure_reference_kats(api, pkg):
