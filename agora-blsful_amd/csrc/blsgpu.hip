@@ -185,9 +185,9 @@ void prof_flush(Ctx* c) {
     hipLaunchKernelGGL(kern, grid, block, 0, c->stream, __VA_ARGS__);           \
     prof_post(c);                                                               \
   } while (0)
-// one Miller loop per two items: leaves (cnt + 1) / 2 partial products at the start of the Fp12 workspace
-#define MILLER1_LAUNCH(cnt, ...) KL(KID_MILLER1, k_miller1s, dim3(blocks_for(2 * (((cnt) + 1) / 2))), dim3(BLS_BLOCK), cnt, __VA_ARGS__)
-#define MILLER1_OUTPUTS(cnt) (((cnt) + 1) / 2)
+// one Miller loop per MILLER1_GROUP items: leaves ceil(cnt / MILLER1_GROUP) partial products at the start of the Fp12 workspace
+#define MILLER1_OUTPUTS(cnt) (((cnt) + MILLER1_GROUP - 1) / MILLER1_GROUP)
+#define MILLER1_LAUNCH(cnt, ...) KL(KID_MILLER1, k_miller1s, dim3(blocks_for(2 * MILLER1_OUTPUTS(cnt))), dim3(BLS_BLOCK), cnt, __VA_ARGS__)
 #define SYNC_FLUSH(c)                          \
   do {                                         \
     HIPCK(hipStreamSynchronize((c)->stream));  \

@@ -12,6 +12,7 @@
 #define WS_PAIRS_WORDS (6 * W2)  // P0(2 Fp) Q0(2 Fp2) P1 Q1, affine, internal form
 #define WS_PAIR1_WORDS (3 * W2)  // one (P, Q) pair: the one-pair-per-item workspaces of aggregate verify / pairing products
 #define WS_F_WORDS (6 * W2)      // Fp12
+#define MILLER1_GROUP 2          // items per Miller loop in the pairing-product kernel (k_miller1s); 4 was measured slower (state of four points spills)
 
 struct dst_arg {
   uint8_t b[256];
@@ -574,20 +575,19 @@ __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_miller2s(size_t 
 #endif
 
 #if defined(BLS_TU_MILLERS)
-// Pairing products (aggregate verify / pairing_product_is_one): every lane pair runs ONE Miller loop over TWO items,
-// g and g + half (half = ceil(n / 2)), so that the accumulator squarings are shared and the two line values of a step are
-// merged before they touch f -- the product over all items is all that is needed.  Writes half partial products; skipped
-// items contribute 1.
+// Pairing products (aggregate verify / pairing_product_is_one): every lane pair runs ONE Miller loop over MILLER1_GROUP
+// items (g, g + q, g + 2q, ...; q = ceil(n / MILLER1_GROUP)), so that the accumulator squarings are shared -- the product
+// over all items is all that is needed.  Writes q partial products; skipped items contribute 1.
 __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_miller1s(size_t n, size_t stride, const uint32_t* pairs, const int32_t* skip, uint32_t* fws) {
-  const size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1, half = (n + 1) / 2;
-  if (g >= half) return;
+  const size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1, q = (n + MILLER1_GROUP - 1) / MILLER1_GROUP;
+  if (g >= q) return;
   __shared__ uint32_t fsh[F12_SH_WORDS * BLS_BLOCK];
   f12_sh acc = {lds_column(fsh)};
-  g1_aff P[2];
-  aff<hfp2> Q[2];
+  g1_aff P[MILLER1_GROUP];
+  aff<hfp2> Q[MILLER1_GROUP];
 #pragma unroll
-  for (int k = 0; k < 2; k++) {
-    const size_t j = g + (k ? half : 0);
+  for (int k = 0; k < MILLER1_GROUP; k++) {
+    const size_t j = g + (size_t)k * q;
     const bool have = j < n;
     const size_t jj = have ? j : g;
     ws_ld_fp(P[k].x, pairs, stride, jj, 0);
@@ -597,7 +597,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_miller1s(size_t 
     P[k].inf = !have || skip[jj] != 0;
     Q[k].inf = false;
   }
-  miller_loop<2>(acc, P, Q);
+  miller_loop<MILLER1_GROUP>(acc, P, Q);
   fp12_t<hfp2> f;
   sh_ld_f12(f, acc.sh);
   fp12_conj(f, f);
