@@ -214,11 +214,12 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
                      const uint64_t* d_offs, int single_msg, const dst_arg& dst, size_t n, uint32_t* d_pairs, uint32_t* d_f,
                      int32_t* d_status, int pre_status = 0) {
   if (n == 0) return 0;
-  unsigned nb = blocks_for(n);
+  const int two_lanes = n <= coop_max_items() ? 1 : 0;   // latency mode: the two SSWU maps of an item on two lanes
+  unsigned nb = blocks_for(two_lanes ? 2 * n : n);
   if (sg == 1)
-    KL(KID_PREPARE, k_prepare<1>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status, pre_status);
+    KL(KID_PREPARE, k_prepare<1>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status, pre_status, two_lanes);
   else
-    KL(KID_PREPARE, k_prepare<2>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status, pre_status);
+    KL(KID_PREPARE, k_prepare<2>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status, pre_status, two_lanes);
   if (n <= coop_max_items()) {  // small batches and single-item tails: one wave per item
     KL(KID_PAIRING_COOP, k_pairing_coop, dim3((unsigned)n), dim3(BLS_BLOCK), n, d_pairs, d_status, sg == 1 ? 1 : 0);
   } else {                      // two lanes per item (tower_split.cuh)

@@ -222,18 +222,43 @@ BLS_NOINLINE void iso_map_g1(g1_jac& r, const fp& xn, const fp& xd, const fp& y)
   fp_mul(r.y, t, y);      // Y = y YN zx^3 YD^2
 }
 
+// lane2 >= 0 (device only, latency mode for single verifications): the item occupies two adjacent lanes, lane2 = 0 / 1 maps
+// u0 / u1 and the two points are exchanged by DPP, so the two SSWU maps -- half of the hash -- run side by side; both lanes
+// then continue with identical operands (q0 + q1 in that order on both) and produce bit-identical results.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void fp_lane_swap(fp& r, const fp& a) {
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) r.l[i] = dpp_swap(a.l[i]);
+}
+#endif
 BLS_NOINLINE void hash_to_g1(g1_jac& r, const uint8_t* pre, uint32_t pre_len, const uint8_t* m, uint32_t m_len,
-                       const uint8_t* dst, uint32_t dst_len) {
+                       const uint8_t* dst, uint32_t dst_len, int lane2 = -1) {
   uint8_t ub[128];
   expand_message_xmd<128>(ub, pre, pre_len, m, m_len, dst, dst_len);
   fp u0, u1, xn, xd, y;
-  fp_from_be64(u0, ub);
-  fp_from_be64(u1, ub + 64);
   g1_jac q0, q1;
-  sswu_g1(xn, xd, y, u0);
-  iso_map_g1(q0, xn, xd, y);
-  sswu_g1(xn, xd, y, u1);
-  iso_map_g1(q1, xn, xd, y);
+#if defined(__HIPCC__)
+  if (lane2 >= 0) {
+    g1_jac mine, other;
+    fp_from_be64(u0, ub + 64 * lane2);
+    sswu_g1(xn, xd, y, u0);
+    iso_map_g1(mine, xn, xd, y);
+    fp_lane_swap(other.x, mine.x);
+    fp_lane_swap(other.y, mine.y);
+    fp_lane_swap(other.z, mine.z);
+    q0 = lane2 ? other : mine;
+    q1 = lane2 ? mine : other;
+  } else
+#endif
+  {
+    (void)lane2;
+    fp_from_be64(u0, ub);
+    fp_from_be64(u1, ub + 64);
+    sswu_g1(xn, xd, y, u0);
+    iso_map_g1(q0, xn, xd, y);
+    sswu_g1(xn, xd, y, u1);
+    iso_map_g1(q1, xn, xd, y);
+  }
   jac_add(q0, q0, q1);
   // clear cofactor: h_eff = 1 - x = 1 + |x|
   jac_mul_u64(q1, q0, BLS_X_ABS);
@@ -367,19 +392,39 @@ BLS_NOINLINE void iso_map_g2(g2_jac& r, const fp2& x, const fp2& y) {
   fp2_mul(r.y, t, y);
 }
 BLS_NOINLINE void hash_to_g2(g2_jac& r, const uint8_t* pre, uint32_t pre_len, const uint8_t* m, uint32_t m_len,
-                       const uint8_t* dst, uint32_t dst_len) {
+                       const uint8_t* dst, uint32_t dst_len, int lane2 = -1) {
   uint8_t ub[256];
   expand_message_xmd<256>(ub, pre, pre_len, m, m_len, dst, dst_len);
   fp2 u0, u1, x, y;
-  fp_from_be64(u0.c0, ub);
-  fp_from_be64(u0.c1, ub + 64);
-  fp_from_be64(u1.c0, ub + 128);
-  fp_from_be64(u1.c1, ub + 192);
   g2_jac q0, q1;
-  sswu_g2(x, y, u0);
-  iso_map_g2(q0, x, y);
-  sswu_g2(x, y, u1);
-  iso_map_g2(q1, x, y);
+#if defined(__HIPCC__)
+  if (lane2 >= 0) {          // see hash_to_g1
+    g2_jac mine, other;
+    fp_from_be64(u0.c0, ub + 128 * lane2);
+    fp_from_be64(u0.c1, ub + 128 * lane2 + 64);
+    sswu_g2(x, y, u0);
+    iso_map_g2(mine, x, y);
+    fp_lane_swap(other.x.c0, mine.x.c0);
+    fp_lane_swap(other.x.c1, mine.x.c1);
+    fp_lane_swap(other.y.c0, mine.y.c0);
+    fp_lane_swap(other.y.c1, mine.y.c1);
+    fp_lane_swap(other.z.c0, mine.z.c0);
+    fp_lane_swap(other.z.c1, mine.z.c1);
+    q0 = lane2 ? other : mine;
+    q1 = lane2 ? mine : other;
+  } else
+#endif
+  {
+    (void)lane2;
+    fp_from_be64(u0.c0, ub);
+    fp_from_be64(u0.c1, ub + 64);
+    fp_from_be64(u1.c0, ub + 128);
+    fp_from_be64(u1.c1, ub + 192);
+    sswu_g2(x, y, u0);
+    iso_map_g2(q0, x, y);
+    sswu_g2(x, y, u1);
+    iso_map_g2(q1, x, y);
+  }
   jac_add(q0, q0, q1);
   g2_clear_cofactor(r, q0);
 }

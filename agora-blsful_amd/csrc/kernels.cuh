@@ -134,7 +134,7 @@ __device__ __forceinline__ void store_g2_pt(uint8_t* base, size_t i, const g2_ja
 // ---- kernel prototypes (each kernel is defined in exactly one translation unit, see the BLS_TU_* sections)
 template <int SG>
 __global__ void k_prepare(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int aug, const uint8_t* msgs,
-                          const uint64_t* offs, int single_msg, dst_arg dst, uint32_t* pairs, int32_t* status, int pre_status);
+                          const uint64_t* offs, int single_msg, dst_arg dst, uint32_t* pairs, int32_t* status, int pre_status, int two_lanes);
 __global__ void k_miller2s(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws, int fixed_g2);
 __global__ void k_finalexps(size_t n, const uint32_t* fws, int32_t* status);
 __global__ void k_miller1s(size_t n, size_t stride, const uint32_t* pairs, const int32_t* skip, uint32_t* fws);
@@ -184,8 +184,12 @@ __global__ void k_decompress(size_t n, const uint8_t* bytes, int legacy, uint8_t
 template <int SG>
 __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int aug,
                                                      const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst,
-                                                     uint32_t* pairs, int32_t* status, int pre_status) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                     uint32_t* pairs, int32_t* status, int pre_status, int two_lanes) {
+  // two_lanes (small batches, single-verify tails): two adjacent lanes per item run the two SSWU maps of the hash side by
+  // side (h2c.cuh) and everything else redundantly with identical operands; lane 0 of the pair stores.
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = two_lanes ? gid >> 1 : gid;
+  const int lane2 = two_lanes ? (int)(gid & 1) : -1;
   if (i >= n) return;
   if (pre_status && status[i] != BLS_OK) return;   // the item already failed to decode
   size_t mi = single_msg ? 0 : i;
@@ -199,24 +203,24 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare(size_t n, const uint8_
     g1_jac sig;
     load_g2_pt(pk, pks, i, fmt);
     load_g1_pt(sig, sigs, i, fmt);
-    st = prepare_g1impl(P, Q, pk, sig, aug, m, mlen, dst.b, dst.len);
+    st = prepare_g1impl(P, Q, pk, sig, aug, m, mlen, dst.b, dst.len, lane2);
   } else {
     g1_jac pk;
     g2_jac sig;
     load_g1_pt(pk, pks, i, fmt);
     load_g2_pt(sig, sigs, i, fmt);
-    st = prepare_g2impl(P, Q, pk, sig, aug, m, mlen, dst.b, dst.len);
+    st = prepare_g2impl(P, Q, pk, sig, aug, m, mlen, dst.b, dst.len, lane2);
   }
+  if (lane2 > 0) return;
   status[i] = st;
   if (st != BLS_OK) return;
   ws_st_pair(pairs, n, i, 0, P[0], Q[0]);
   ws_st_pair(pairs, n, i, 1, P[1], Q[1]);
 }
-
 #if defined(BLS_TU_PREPARE1)
-template __global__ void k_prepare<1>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, int, dst_arg, uint32_t*, int32_t*, int);
+template __global__ void k_prepare<1>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, int, dst_arg, uint32_t*, int32_t*, int, int);
 #else
-template __global__ void k_prepare<2>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, int, dst_arg, uint32_t*, int32_t*, int);
+template __global__ void k_prepare<2>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, int, dst_arg, uint32_t*, int32_t*, int, int);
 #endif
 #endif  // BLS_TU_PREPARE*
 

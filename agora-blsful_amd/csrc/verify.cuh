@@ -95,7 +95,7 @@ BLS_FN void g2_neg_gen(g2_aff& r) {
 // mode: 0 = message as given, 1 = MessageAugmentation (key bytes || message, reference src/traits/sig_aug.rs:20-24),
 //       2 = proof of possession (the message IS the key bytes, reference src/traits/sig_pop.rs:67-70)
 BLS_FN int prepare_g1impl(g1_aff* P, g2_aff* Q, const g2_jac& pk, const g1_jac& sig, int mode, const uint8_t* msg,
-                          uint32_t msg_len, const uint8_t* dst, uint32_t dst_len) {
+                          uint32_t msg_len, const uint8_t* dst, uint32_t dst_len, int lane2 = -1) {
   if (jac_is_inf(sig)) return BLS_ERR_SIG_IDENTITY;
   if (jac_is_inf(pk)) return BLS_ERR_PK_IDENTITY;
   g1_jac h;
@@ -103,11 +103,11 @@ BLS_FN int prepare_g1impl(g1_aff* P, g2_aff* Q, const g2_jac& pk, const g1_jac& 
     g1g2_to_aff(P[1], Q[0], sig, pk);
     uint8_t pre[96];
     g2_compress(pre, Q[0], false);
-    if (mode == 1) hash_to_g1(h, pre, 96, msg, msg_len, dst, dst_len);
-    else hash_to_g1(h, nullptr, 0, pre, 96, dst, dst_len);
+    if (mode == 1) hash_to_g1(h, pre, 96, msg, msg_len, dst, dst_len, lane2);
+    else hash_to_g1(h, nullptr, 0, pre, 96, dst, dst_len, lane2);
     jac_to_aff(P[0], h);
   } else {
-    hash_to_g1(h, nullptr, 0, msg, msg_len, dst, dst_len);
+    hash_to_g1(h, nullptr, 0, msg, msg_len, dst, dst_len, lane2);
     if (jac_is_inf(h)) {            // cannot happen for a hash output in practice; keep the generic path correct
       g1g2_to_aff(P[1], Q[0], sig, pk);
       jac_to_aff(P[0], h);
@@ -126,7 +126,7 @@ BLS_FN int prepare_g1impl(g1_aff* P, g2_aff* Q, const g2_jac& pk, const g1_jac& 
 
 // Bls12381G2Impl: P[0] = pk, Q[0] = H(m), P[1] = -g1, Q[1] = sig
 BLS_FN int prepare_g2impl(g1_aff* P, g2_aff* Q, const g1_jac& pk, const g2_jac& sig, int mode, const uint8_t* msg,
-                          uint32_t msg_len, const uint8_t* dst, uint32_t dst_len) {
+                          uint32_t msg_len, const uint8_t* dst, uint32_t dst_len, int lane2 = -1) {
   if (jac_is_inf(sig)) return BLS_ERR_SIG_IDENTITY;
   if (jac_is_inf(pk)) return BLS_ERR_PK_IDENTITY;
   g2_jac h;
@@ -134,11 +134,11 @@ BLS_FN int prepare_g2impl(g1_aff* P, g2_aff* Q, const g1_jac& pk, const g2_jac& 
     g1g2_to_aff(P[0], Q[1], pk, sig);
     uint8_t pre[48];
     g1_compress(pre, P[0], false);
-    if (mode == 1) hash_to_g2(h, pre, 48, msg, msg_len, dst, dst_len);
-    else hash_to_g2(h, nullptr, 0, pre, 48, dst, dst_len);
+    if (mode == 1) hash_to_g2(h, pre, 48, msg, msg_len, dst, dst_len, lane2);
+    else hash_to_g2(h, nullptr, 0, pre, 48, dst, dst_len, lane2);
     jac_to_aff(Q[0], h);
   } else {
-    hash_to_g2(h, nullptr, 0, msg, msg_len, dst, dst_len);
+    hash_to_g2(h, nullptr, 0, msg, msg_len, dst, dst_len, lane2);
     if (jac_is_inf(h)) {
       g1g2_to_aff(P[0], Q[1], pk, sig);
       jac_to_aff(Q[0], h);
