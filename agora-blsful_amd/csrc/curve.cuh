@@ -228,19 +228,20 @@ BLS_NOINLINE void jac_mul_scalar(jac<F>& r, const jac<F>& p, const uint32_t* k) 
   r = acc;
 }
 
-// ---- psi (untwist-Frobenius-twist) on G2, Jacobian form: (conj X * cx, conj Y * cy, conj Z)
-BLS_FN void g2_psi(g2_jac& r, const g2_jac& p) {
-  fp2 cx, cy, t;
-  fp2_load(cx, PSI_CX);
-  fp2_load(cy, PSI_CY);
+// ---- psi (untwist-Frobenius-twist) on G2, Jacobian form: (conj X * cx, conj Y * cy, conj Z).  Templates over the Fp2
+// representation: the one-lane fp2 and the lane-split hfp2 (tower_split.cuh), whose latency mode halves these steps.
+template <class F2>
+BLS_FN void g2_psi(jac<F2>& r, const jac<F2>& p) {
+  F2 t;
   fp2_conj(t, p.x);
-  fp2_mul(r.x, t, cx);
+  fp2_mul_const(r.x, t, PSI_CX);
   fp2_conj(t, p.y);
-  fp2_mul(r.y, t, cy);
+  fp2_mul_const(r.y, t, PSI_CY);
   fp2_conj(r.z, p.z);
 }
 // psi^2: (X * cx2, Y * cy2, Z) with cx2, cy2 in Fp
-BLS_FN void g2_psi2(g2_jac& r, const g2_jac& p) {
+template <class F2>
+BLS_FN void g2_psi2(jac<F2>& r, const jac<F2>& p) {
   fp cx2, cy2;
   fp_load(cx2, PSI2_CX);
   fp_load(cy2, PSI2_CY);
@@ -250,8 +251,9 @@ BLS_FN void g2_psi2(g2_jac& r, const g2_jac& p) {
 }
 
 // RFC 9380 Appendix G.3 clear_cofactor_bls12381_g2 (x is negative: [x]P = -[|x|]P)
-BLS_NOINLINE void g2_clear_cofactor(g2_jac& r, const g2_jac& p) {
-  g2_jac t1, t2, t3, n;
+template <class F2>
+BLS_NOINLINE void g2_clear_cofactor(jac<F2>& r, const jac<F2>& p) {
+  jac<F2> t1, t2, t3, n;
   jac_mul_u64(t1, p, BLS_X_ABS);
   jac_neg(t1, t1);  // t1 = x P
   g2_psi(t2, p);    // t2 = psi(P)

@@ -4,6 +4,7 @@
 // backend (reference call sites src/impls/g1.rs:18 and src/impls/g2.rs:16; DST passed in by the scheme traits).
 #pragma once
 #include "curve.cuh"
+#include "tower_split.cuh"
 
 // ------------------------------------------------------------------ SHA-256 (streaming, one lane = one hash)
 struct sha256_ctx {
@@ -398,8 +399,8 @@ BLS_NOINLINE void hash_to_g2(g2_jac& r, const uint8_t* pre, uint32_t pre_len, co
   fp2 u0, u1, x, y;
   g2_jac q0, q1;
 #if defined(__HIPCC__)
-  if (lane2 >= 0) {          // see hash_to_g1
-    g2_jac mine, other;
+  if (lane2 >= 0) {          // see hash_to_g1; in addition the point addition and the cofactor clearing -- Fp2 arithmetic -- run
+    g2_jac mine, other;      // on the lane-split tower (tower_split.cuh): this lane keeps its component of every coordinate
     fp_from_be64(u0.c0, ub + 128 * lane2);
     fp_from_be64(u0.c1, ub + 128 * lane2 + 64);
     sswu_g2(x, y, u0);
@@ -412,19 +413,37 @@ BLS_NOINLINE void hash_to_g2(g2_jac& r, const uint8_t* pre, uint32_t pre_len, co
     fp_lane_swap(other.z.c1, mine.z.c1);
     q0 = lane2 ? other : mine;
     q1 = lane2 ? mine : other;
-  } else
-#endif
-  {
-    (void)lane2;
-    fp_from_be64(u0.c0, ub);
-    fp_from_be64(u0.c1, ub + 64);
-    fp_from_be64(u1.c0, ub + 128);
-    fp_from_be64(u1.c1, ub + 192);
-    sswu_g2(x, y, u0);
-    iso_map_g2(q0, x, y);
-    sswu_g2(x, y, u1);
-    iso_map_g2(q1, x, y);
+    jac<hfp2> s0, s1, sum, h;
+    s0.x.v = lane2 ? q0.x.c1 : q0.x.c0;
+    s0.y.v = lane2 ? q0.y.c1 : q0.y.c0;
+    s0.z.v = lane2 ? q0.z.c1 : q0.z.c0;
+    s1.x.v = lane2 ? q1.x.c1 : q1.x.c0;
+    s1.y.v = lane2 ? q1.y.c1 : q1.y.c0;
+    s1.z.v = lane2 ? q1.z.c1 : q1.z.c0;
+    jac_add(sum, s0, s1);
+    g2_clear_cofactor(h, sum);
+    fp px, py, pz;
+    fp_lane_swap(px, h.x.v);
+    fp_lane_swap(py, h.y.v);
+    fp_lane_swap(pz, h.z.v);
+    r.x.c0 = lane2 ? px : h.x.v;
+    r.x.c1 = lane2 ? h.x.v : px;
+    r.y.c0 = lane2 ? py : h.y.v;
+    r.y.c1 = lane2 ? h.y.v : py;
+    r.z.c0 = lane2 ? pz : h.z.v;
+    r.z.c1 = lane2 ? h.z.v : pz;
+    return;
   }
+#endif
+  (void)lane2;
+  fp_from_be64(u0.c0, ub);
+  fp_from_be64(u0.c1, ub + 64);
+  fp_from_be64(u1.c0, ub + 128);
+  fp_from_be64(u1.c1, ub + 192);
+  sswu_g2(x, y, u0);
+  iso_map_g2(q0, x, y);
+  sswu_g2(x, y, u1);
+  iso_map_g2(q1, x, y);
   jac_add(q0, q0, q1);
   g2_clear_cofactor(r, q0);
 }

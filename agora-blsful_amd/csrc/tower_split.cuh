@@ -304,3 +304,26 @@ static inline void fp2_inv(hfp2& r, const hfp2& a) {
   fp_neg(r.c[1], t);
 }
 #endif
+
+// ---- uniform field interface of curve.cuh for the lane-split Fp2, so that the Jacobian point code (jac_add, jac_dbl,
+// jac_mul_u64, g2_clear_cofactor, ...) also runs two lanes per point.  fe_sqr normalises first: the point formulas square
+// sums, and the split squaring takes a normalised operand.
+BLS_FN void fe_add(hfp2& r, const hfp2& a, const hfp2& b) { fp2_add(r, a, b); }
+BLS_FN void fe_sub(hfp2& r, const hfp2& a, const hfp2& b) { fp2_sub(r, a, b); }
+BLS_FN void fe_mul(hfp2& r, const hfp2& a, const hfp2& b) { fp2_mul(r, a, b); }
+BLS_FN void fe_sqr(hfp2& r, const hfp2& a) {
+  hfp2 t;
+  fp2_norm(t, a);
+  fp2_sqr(r, t);
+}
+BLS_FN void fe_neg(hfp2& r, const hfp2& a) { fp2_neg(r, a); }
+BLS_FN void fe_dbl(hfp2& r, const hfp2& a) { fp2_dbl(r, a); }
+BLS_FN void fe_inv(hfp2& r, const hfp2& a) { fp2_inv(r, a); }
+BLS_FN bool fe_is_zero(const hfp2& a) { return fp2_is_zero(a); }
+BLS_FN bool fe_eq(const hfp2& a, const hfp2& b) { return fp2_eq(a, b); }
+BLS_FN void fe_zero(hfp2& r) { fp2_zero(r); }
+BLS_FN void fe_one(hfp2& r) { fp2_one(r); }
+BLS_FN void fe_cmov(hfp2& r, const hfp2& a, bool c) { fp2_cmov(r, a, c); }
+BLS_FN void fe_norm(hfp2& r, const hfp2& a) { fp2_norm(r, a); }
+BLS_FN void fe_reduce(hfp2& r, const hfp2& a) { fp2_reduce(r, a); }
+

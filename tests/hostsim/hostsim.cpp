@@ -133,6 +133,22 @@ int hs_cyclotomic_check(int n, const uint32_t* g1s, const uint32_t* g2s) {
   (void)n;
   return memcmp(wa, wb, sizeof wa) == 0;
 }
+// the lane-split point arithmetic (jac<hfp2>, host emulation) against the one-lane code: P + Q, 2P, clear_cofactor(P)
+static void split_jac(jac<hfp2>& r, const g2_jac& p) {
+  r.x.c[0] = p.x.c0; r.x.c[1] = p.x.c1; r.y.c[0] = p.y.c0; r.y.c[1] = p.y.c1; r.z.c[0] = p.z.c0; r.z.c[1] = p.z.c1;
+}
+static void unsplit_jac(g2_jac& r, const jac<hfp2>& p) {
+  r.x.c0 = p.x.c[0]; r.x.c1 = p.x.c[1]; r.y.c0 = p.y.c[0]; r.y.c1 = p.y.c[1]; r.z.c0 = p.z.c[0]; r.z.c1 = p.z.c[1];
+}
+void hs_g2_split_ops(const uint32_t* p, const uint32_t* q, uint8_t* out_add, uint8_t* out_dbl, uint8_t* out_clear) {
+  g2_jac a, b, r; g2_aff f;
+  load_g2_jac(a, p); load_g2_jac(b, q);
+  jac<hfp2> sa, sb, sr;
+  split_jac(sa, a); split_jac(sb, b);
+  jac_add(sr, sa, sb); unsplit_jac(r, sr); jac_to_aff(f, r); g2_compress(out_add, f, false);
+  jac_dbl(sr, sa); unsplit_jac(r, sr); jac_to_aff(f, r); g2_compress(out_dbl, f, false);
+  g2_clear_cofactor(sr, sa); unsplit_jac(r, sr); jac_to_aff(f, r); g2_compress(out_clear, f, false);
+}
 // checked decompression: returns the status code; on success writes the re-compressed (modern) bytes
 int hs_decompress(int group, const uint8_t* in, int legacy, uint8_t* out) {
   if (group == 1) {

@@ -150,6 +150,26 @@ def test_group_ops(hs):
     assert out.raw == c.g2_compress(c.g2_clear_cofactor(pt))
 
 
+def test_g2_split_point_ops(hs):
+    """Jacobian G2 arithmetic instantiated over the lane-split Fp2 (host emulation, bound tracker on) vs the oracle."""
+    rng = random.Random(9)
+    for _ in range(3):
+        a = c.E2.mul(c.G2_GEN, rng.randrange(1, c.R))
+        b = c.E2.mul(c.G2_GEN, rng.randrange(1, c.R))
+        oa, od, oc = (ctypes.create_string_buffer(96) for _ in range(3))
+        hs.hs_g2_split_ops(util.g2_raw(a, rng), util.g2_raw(b, rng), oa, od, oc)
+        assert oa.raw == c.g2_compress(c.E2.add(a, b))
+        assert od.raw == c.g2_compress(c.E2.add(a, a))
+        assert oc.raw == c.g2_compress(c.g2_clear_cofactor(a))
+    # equal and opposite operands take the exceptional branches
+    a = c.E2.mul(c.G2_GEN, 12345)
+    oa, od, oc = (ctypes.create_string_buffer(96) for _ in range(3))
+    hs.hs_g2_split_ops(util.g2_raw(a, rng), util.g2_raw(a, rng), oa, od, oc)
+    assert oa.raw == c.g2_compress(c.E2.add(a, a))
+    hs.hs_g2_split_ops(util.g2_raw(a, rng), util.g2_raw(c.E2.neg(a), rng), oa, od, oc)
+    assert oa.raw == c.g2_compress(None)
+
+
 def test_pairing_values(hs):
     """GT values (after the final exponentiation) equal the oracle's exactly; cyclotomic squaring == generic squaring."""
     rng = random.Random(4)
