@@ -170,6 +170,7 @@ __global__ void k_msm_bucket(size_t nb, const uint8_t* pts, int fmt, const uint3
                              const uint32_t* idx, uint8_t* sums);
 template <int G>
 __global__ void k_msm_chunk(int c, int W, int clast, int CH, const uint8_t* sums, uint8_t* partials);
+__global__ void k_msm_chunk_g2s(int c, int W, int clast, int CH, const uint8_t* sums, uint8_t* partials);
 template <int G>
 __global__ void k_normalize(uint8_t* pt);
 // wire bytes (48/96 B, modern or legacy header) -> RAW_PROJ with the checks of from_compressed; status[i] = 0 / 7 / 8.
@@ -780,6 +781,53 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_decompress(size_t n, const uint8_
   msm_pt<G>::store(out, i, p);
   status[i] = rc;
 }
+#if defined(BLS_TU_MSM2)
+// k_msm_chunk for G2 on TWO lanes per chunk (jac<hfp2>, tower_split.cuh): the 2^(c w) doublings are the critical path of
+// the chunk lanes, and a lane-split Fp2 doubling costs half the instructions per lane.  Each lane converts and keeps its
+// own component (real / imaginary) of every coordinate.
+__device__ __forceinline__ void msm_ld_g2s(jac<hfp2>& p, const uint8_t* base, size_t i) {
+  const uint32_t* w = (const uint32_t*)(base + i * 288) + (lane_hi() ? 12 : 0);
+  fp_from_raw(p.x.v, w);
+  fp_from_raw(p.y.v, w + 24);
+  fp_from_raw(p.z.v, w + 48);
+}
+__device__ __forceinline__ void msm_st_g2s(uint8_t* base, size_t i, const jac<hfp2>& p) {
+  uint32_t* w = (uint32_t*)(base + i * 288) + (lane_hi() ? 12 : 0);
+  fp_to_raw(w, p.x.v);
+  fp_to_raw(w + 24, p.y.v);
+  fp_to_raw(w + 48, p.z.v);
+}
+__global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm_chunk_g2s(int c, int W, int clast, int CH, const uint8_t* sums, uint8_t* partials) {
+  const size_t cpw = ((size_t)1 << c) / CH, cpl = ((size_t)1 << clast) / CH;   // chunks per regular / last window
+  const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  if (t >= cpw * (W - 1) + cpl) return;
+  const bool last = t >= cpw * (W - 1);
+  const int w = last ? W - 1 : (int)(t / cpw);
+  const size_t lo = (last ? t - cpw * (W - 1) : t % cpw) * CH;
+  const int wbits = last ? clast : c;
+  jac<hfp2> run, acc, s;
+  jac_set_inf(run);
+  jac_set_inf(acc);
+  for (int d = CH - 1; d >= 0; d--) {
+    msm_ld_g2s(s, sums, ((size_t)w << c) + lo + d);
+    jac_add(run, run, s);
+    jac_add(acc, acc, run);   // acc = sum_d (d + 1) S_{lo + d}
+  }
+  if (lo == 0) {              // sum_d (lo + d) S = acc + (lo - 1) run
+    jac_neg(s, run);
+  } else {
+    jac_set_inf(s);
+    const uint32_t mlt = (uint32_t)(lo - 1);
+    for (int bit = wbits; bit >= 0; bit--) {
+      jac_dbl(s, s);
+      if ((mlt >> bit) & 1u) jac_add(s, s, run);
+    }
+  }
+  jac_add(acc, acc, s);
+  for (int k = 0; k < c * w; k++) jac_dbl(acc, acc);   // weight 2^(c w)
+  msm_st_g2s(partials, t, acc);
+}
+#endif
 #if defined(BLS_TU_MSM1)
 template __global__ void k_decompress<1>(size_t, const uint8_t*, int, uint8_t*, int32_t*, int);
 template __global__ void k_msm_bucket<1>(size_t, const uint8_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*);
