@@ -171,6 +171,8 @@ __global__ void k_msm_bucket(size_t nb, const uint8_t* pts, int fmt, const uint3
 template <int G>
 __global__ void k_msm_chunk(int c, int W, int clast, int CH, const uint8_t* sums, uint8_t* partials);
 __global__ void k_msm_chunk_g2s(int c, int W, int clast, int CH, const uint8_t* sums, uint8_t* partials);
+__global__ void k_msm_bucket_g2s(size_t nb, const uint8_t* pts, int fmt, const uint32_t* perm, const uint32_t* cnt, const uint32_t* off,
+                                 const uint32_t* idx, uint8_t* sums);
 template <int G>
 __global__ void k_normalize(uint8_t* pt);
 // wire bytes (48/96 B, modern or legacy header) -> RAW_PROJ with the checks of from_compressed; status[i] = 0 / 7 / 8.
@@ -796,6 +798,37 @@ __device__ __forceinline__ void msm_st_g2s(uint8_t* base, size_t i, const jac<hf
   fp_to_raw(w, p.x.v);
   fp_to_raw(w + 24, p.y.v);
   fp_to_raw(w + 48, p.z.v);
+}
+// caller-format G2 point (RAW_PROJ or RAW_AFFINE), this lane's components
+__device__ __forceinline__ void msm_ld_g2s_fmt(jac<hfp2>& p, const uint8_t* base, size_t i, int fmt) {
+  if (fmt == 0) {
+    msm_ld_g2s(p, base, i);
+  } else {
+    const uint32_t* w0 = (const uint32_t*)(base + i * 192);
+    if (words_all_zero(w0, 48)) {
+      jac_set_inf(p);
+    } else {
+      const uint32_t* w = w0 + (lane_hi() ? 12 : 0);
+      fp_from_raw(p.x.v, w);
+      fp_from_raw(p.y.v, w + 24);
+      fp2_one(p.z);
+    }
+  }
+}
+// k_msm_bucket for G2 on two lanes per bucket
+__global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm_bucket_g2s(size_t nb, const uint8_t* pts, int fmt, const uint32_t* perm, const uint32_t* cnt,
+                                                            const uint32_t* off, const uint32_t* idx, uint8_t* sums) {
+  const size_t b = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  if (b >= nb) return;
+  jac<hfp2> acc, p;
+  jac_set_inf(acc);
+  const uint32_t n = cnt[b], o = off[b];
+  for (uint32_t j = 0; j < n; j++) {
+    const uint32_t i = idx[o + j];
+    msm_ld_g2s_fmt(p, pts, perm ? perm[i] : i, fmt);
+    jac_add(acc, acc, p);
+  }
+  msm_st_g2s(sums, b, acc);
 }
 __global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm_chunk_g2s(int c, int W, int clast, int CH, const uint8_t* sums, uint8_t* partials) {
   const size_t cpw = ((size_t)1 << c) / CH, cpl = ((size_t)1 << clast) / CH;   // chunks per regular / last window
