@@ -214,7 +214,10 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
                      const uint64_t* d_offs, int single_msg, const dst_arg& dst, size_t n, uint32_t* d_pairs, uint32_t* d_f,
                      int32_t* d_status, int pre_status = 0) {
   if (n == 0) return 0;
-  const int two_lanes = n <= coop_max_items() ? 1 : 0;   // latency mode: the two SSWU maps of an item on two lanes
+  // two lanes per item (the two SSWU maps side by side, G2 point arithmetic on the lane-split tower): always for
+  // Bls12381G2Impl, whose hash-to-G2 halves its per-lane work that way; for Bls12381G1Impl only in latency mode (the
+  // Fp-only remainder would run redundantly and a full batch is faster with one lane per item -- both measured)
+  const int two_lanes = (sg == 2 || n <= coop_max_items()) ? 1 : 0;
   unsigned nb = blocks_for(two_lanes ? 2 * n : n);
   if (sg == 1)
     KL(KID_PREPARE, k_prepare<1>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status, pre_status, two_lanes);
