@@ -747,10 +747,10 @@ int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const ui
     int aug = scheme == BLSGPU_SCHEME_AUG;
     if (sig_group == 1)
       KL(KID_PREPARE_AGG, k_prepare_agg<1>, dim3(blocks_for(m)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, aug,
-                         (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad);
+                         (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad, 0);
     else
-      KL(KID_PREPARE_AGG, k_prepare_agg<2>, dim3(blocks_for(m)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, aug,
-                         (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad);
+      KL(KID_PREPARE_AGG, k_prepare_agg<2>, dim3(blocks_for(2 * m)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, aug,
+                         (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad, 1);
     HIPCK(hipGetLastError());
     std::vector<int32_t> bad(m);
     HIPCK(hipMemcpyAsync(bad.data(), d_bad, 4 * m, hipMemcpyDeviceToHost, c->stream));
@@ -1201,11 +1201,11 @@ int blsgpu_aggregate_partial(int sig_group, int scheme, const void* pks, const u
   if (mm > 0) {
     // the workspace stride is always n + 1 (k_prepare_agg's layout); lanes >= mm are never read
     if (sig_group == 1) {
-      if (sig) KL(KID_PREPARE_AGG, k_prepare_agg<1>, dim3(blocks_for(m)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, aug, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad);
-      else KL(KID_PREPARE_AGG, k_prepare_agg<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_pks, fmt, aug, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad);
+      if (sig) KL(KID_PREPARE_AGG, k_prepare_agg<1>, dim3(blocks_for(m)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, aug, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad, 0);
+      else KL(KID_PREPARE_AGG, k_prepare_agg<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_pks, fmt, aug, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad, 0);
     } else {
-      if (sig) KL(KID_PREPARE_AGG, k_prepare_agg<2>, dim3(blocks_for(m)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, aug, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad);
-      else KL(KID_PREPARE_AGG, k_prepare_agg<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_pks, fmt, aug, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad);
+      if (sig) KL(KID_PREPARE_AGG, k_prepare_agg<2>, dim3(blocks_for(2 * m)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, aug, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad, 1);
+      else KL(KID_PREPARE_AGG, k_prepare_agg<2>, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_pks, fmt, aug, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad, 1);
     }
     HIPCK(hipGetLastError());
     HIPCK(hipMemcpyAsync(bad.data(), d_bad, 4 * mm, hipMemcpyDeviceToHost, c->stream));

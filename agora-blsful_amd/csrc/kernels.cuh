@@ -144,7 +144,7 @@ __global__ void k_pairing_coop(size_t n, const uint32_t* pairs, int32_t* status,
 __global__ void k_finalexp_coop(const uint32_t* fws, size_t stride, int32_t* verdict);
 template <int SG>
 __global__ void k_prepare_agg(size_t n, const uint8_t* pks, const uint8_t* sig, int fmt, int aug, const uint8_t* msgs,
-                              const uint64_t* offs, dst_arg dst, uint32_t* pairs, int32_t* bad);
+                              const uint64_t* offs, dst_arg dst, uint32_t* pairs, int32_t* bad, int two_lanes);
 __global__ void k_pairs_to_affine(size_t n, const uint8_t* g1s, const uint8_t* g2s, int fmt, uint32_t* pairs, int32_t* skip);
 __global__ void k_f12_fold(size_t m, size_t half, uint32_t* fws, size_t stride);
 __global__ void k_f12_import(size_t n, const uint8_t* src, uint32_t* fws, size_t stride);
@@ -238,8 +238,11 @@ template __global__ void k_prepare<2>(size_t, const uint8_t*, const uint8_t*, in
 template <int SG>
 __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare_agg(size_t n, const uint8_t* pks, const uint8_t* sig, int fmt, int aug,
                                                          const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint32_t* pairs,
-                                                         int32_t* bad) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                         int32_t* bad, int two_lanes) {
+  // two_lanes: as k_prepare (two adjacent lanes per item, the hash's two SSWU maps side by side; lane 0 stores)
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = two_lanes ? gid >> 1 : gid;
+  const int lane2 = two_lanes ? (int)(gid & 1) : -1;
   if (i > n) return;
   const size_t stride = n + 1;
   g1_aff P;
@@ -248,19 +251,21 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare_agg(size_t n, const ui
     if (SG == 1) {
       g1_jac s;
       load_g1_pt(s, sig, 0, fmt);
-      bad[i] = jac_is_inf(s) ? 1 : 0;
-      if (bad[i]) return;
+      const bool inf = jac_is_inf(s);
+      if (lane2 <= 0) bad[i] = inf ? 1 : 0;
+      if (inf) return;
       jac_to_aff(P, s);
       g2_neg_gen(Q);
     } else {
       g2_jac s;
       load_g2_pt(s, sig, 0, fmt);
-      bad[i] = jac_is_inf(s) ? 1 : 0;
-      if (bad[i]) return;
+      const bool inf = jac_is_inf(s);
+      if (lane2 <= 0) bad[i] = inf ? 1 : 0;
+      if (inf) return;
       jac_to_aff(Q, s);
       g1_neg_gen(P);
     }
-    ws_st_pair(pairs, stride, i, 0, P, Q);
+    if (lane2 <= 0) ws_st_pair(pairs, stride, i, 0, P, Q);
     return;
   }
   const uint8_t* m = msgs + offs[i];
@@ -268,8 +273,9 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare_agg(size_t n, const ui
   if (SG == 1) {
     g2_jac pk;
     load_g2_pt(pk, pks, i, fmt);
-    bad[i] = jac_is_inf(pk) ? 1 : 0;
-    if (bad[i]) return;
+    const bool inf = jac_is_inf(pk);
+    if (lane2 <= 0) bad[i] = inf ? 1 : 0;
+    if (inf) return;
     jac_to_aff(Q, pk);
     uint8_t pre[96];
     uint32_t pre_len = 0;
@@ -278,13 +284,14 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare_agg(size_t n, const ui
       pre_len = 96;
     }
     g1_jac h;
-    hash_to_g1(h, pre, pre_len, m, mlen, dst.b, dst.len);
+    hash_to_g1(h, pre, pre_len, m, mlen, dst.b, dst.len, lane2);
     jac_to_aff(P, h);
   } else {
     g1_jac pk;
     load_g1_pt(pk, pks, i, fmt);
-    bad[i] = jac_is_inf(pk) ? 1 : 0;
-    if (bad[i]) return;
+    const bool inf = jac_is_inf(pk);
+    if (lane2 <= 0) bad[i] = inf ? 1 : 0;
+    if (inf) return;
     jac_to_aff(P, pk);
     uint8_t pre[48];
     uint32_t pre_len = 0;
@@ -293,16 +300,16 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare_agg(size_t n, const ui
       pre_len = 48;
     }
     g2_jac h;
-    hash_to_g2(h, pre, pre_len, m, mlen, dst.b, dst.len);
+    hash_to_g2(h, pre, pre_len, m, mlen, dst.b, dst.len, lane2);
     jac_to_aff(Q, h);
   }
-  ws_st_pair(pairs, stride, i, 0, P, Q);
+  if (lane2 <= 0) ws_st_pair(pairs, stride, i, 0, P, Q);
 }
 
 #if defined(BLS_TU_AGG1)
-template __global__ void k_prepare_agg<1>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, dst_arg, uint32_t*, int32_t*);
+template __global__ void k_prepare_agg<1>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, dst_arg, uint32_t*, int32_t*, int);
 #else
-template __global__ void k_prepare_agg<2>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, dst_arg, uint32_t*, int32_t*);
+template __global__ void k_prepare_agg<2>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, dst_arg, uint32_t*, int32_t*, int);
 #endif
 #endif  // BLS_TU_AGG*
 
