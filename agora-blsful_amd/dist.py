@@ -9,6 +9,9 @@ the reference's semantics and error precedence.
   verify_secure      local compress -> all-gather of the serialised keys (n * 48/96 B) -> every rank derives the same
                      sort / H / t_i -> local MSM over its own keys with their coefficients -> all-gather of one group
                      element per rank -> fold -> one core_verify
+  pop_verify_batch   independent (key, proof) items like verify_batch
+  aggregate_secure   the sign-side twin of verify_secure: same gathered keys and coefficients, local MSM over the local
+                     SIGNATURES, all-gather of one group element per rank -> fold
 
 `backend` is the C-ABI wrapper module (agora-blsful_amd/api.py); `pg` is torch.distributed (backend "nccl" = RCCL over
 xGMI on MI355X; the payloads are tiny so the exchange is latency-bound) or None for a single process.  RCCL has no
@@ -18,6 +21,7 @@ import hashlib
 
 OK, INVALID_SIGNATURE, SIG_IDENTITY, PK_IDENTITY, DUPLICATE_MESSAGE, INVALID_COEFFICIENT = 0, 1, 2, 3, 4, 5
 BASIC, AUG, POP = 0, 1, 2
+R_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 
 
 def shard_range(n, rank, world):
@@ -102,3 +106,34 @@ class Sharded:
         partial = self.be.point_sum(pk_group, pks, scal)
         apk = self.be.point_sum(pk_group, self._gather_fixed(partial))
         return self.be.core_verify(sig_group, self.be.DST[(sig_group, scheme)], [apk], [sig], [msg])[0]
+
+
+    # ---- N3: ProofOfPossession::verify, independent items (reference src/proof_of_possession.rs:79-81)
+    def pop_verify_batch(self, sig_group, pks, proofs):
+        local = self.be.pop_verify_batch(sig_group, pks, proofs)
+        return [s for part in self._gather_objects(local) for s in part]
+
+    # ---- N1: aggregate_secure[_with_mode] (reference src/secure_aggregation.rs:110-169,338-352)
+    def aggregate_secure(self, sig_group, pks, sigs, base, ser_format=0):
+        """(status, RAW_PROJ aggregate signature) on every rank.  The reference looks every sorted key up with `position`,
+        so duplicated keys all take the signature of their FIRST occurrence: that owner adds up their coefficients."""
+        pk_group = 2 if sig_group == 1 else 1
+        local_bytes = self.be.serialize(pk_group, pks, legacy=bool(ser_format)) if pks else []
+        parts = self._gather_objects((base, local_bytes))
+        parts.sort(key=lambda p: p[0])
+        all_bytes = [b for (_, bs) in parts for b in bs]
+        if not all_bytes:
+            return OK, self.be.point_sum(sig_group, [])
+        st, perm, ts = self.be.secure_coefficients(all_bytes)
+        if st != OK:
+            return st, None
+        first = {}
+        for g, b in enumerate(all_bytes):
+            first.setdefault(b, g)
+        coef = {}
+        for p, orig in enumerate(perm):
+            owner = first[all_bytes[orig]]
+            coef[owner] = (coef.get(owner, 0) + ts[p]) % R_ORDER
+        mine = [(sigs[i], coef[base + i]) for i in range(len(pks)) if coef.get(base + i)]
+        partial = self.be.point_sum(sig_group, [m[0] for m in mine], [m[1] for m in mine])
+        return OK, self.be.point_sum(sig_group, self._gather_fixed(partial))

@@ -67,6 +67,20 @@ def main():
             res['secure_ok_%d_%d' % (sg, mode)] = sh.verify_secure(sg, ref.AUG, praw[lo:hi], sigraw(agg, rng), m1, lo, mode)
             res['secure_sub_%d_%d' % (sg, mode)] = sh.verify_secure(sg, ref.AUG, praw[lo:hi][:-1] if rank == world - 1 else praw[lo:hi],
                                                                     sigraw(agg, rng), m1, lo, mode)
+        # N3: proofs of possession, one forged
+        pops = [ref.pop_prove(C, s) for s in sks]
+        pops[2] = pops[3]
+        popraw = [sigraw(q, rng) for q in pops]
+        res['pop_%d' % sg] = sh.pop_verify_batch(sg, praw[lo:hi], popraw[lo:hi])
+        # N1: sign-side secure aggregation, with a duplicated key across the shard boundary (first occurrence wins)
+        for mode in modes:
+            dk, ds = list(pks), list(ssigs)
+            dk[5], ds[5] = dk[1], ssigs[5]
+            want = ref.aggregate_secure(C, dk, ds, None if sg == 1 else mode)
+            dkraw, dsraw = [pkraw(p, rng) for p in dk], [sigraw(s, rng) for s in ds]
+            st, agg_raw = sh.aggregate_secure(sg, dkraw[lo:hi], dsraw[lo:hi], lo, mode)
+            got = be.serialize(sg, [agg_raw])[0]
+            res['aggsec_%d_%d' % (sg, mode)] = [st, got.hex() == (c.g1_compress(want) if sg == 1 else c.g2_compress(want)).hex()]
         res['secure_empty_%d' % sg] = [sh.verify_secure(sg, ref.BASIC, [], sigraw(None), m1, 0), sh.verify_secure(sg, ref.BASIC, [], sigraw(msig, rng), m1, 0)]
     json.dump(res, open(outfile, 'w'))
     dist.destroy_process_group()

@@ -59,6 +59,11 @@ def core_verify(sg, dst, pks, sigs, msgs):
     return [_status(lambda: ref.core_verify(C, _pk(sg, p), _sig(sg, s), m, dst)) for p, s, m in zip(pks, sigs, msgs)]
 
 
+def pop_verify_batch(sg, pks, proofs):
+    C = _impl(sg)
+    return [_status(lambda: ref.pop_verify(C, _pk(sg, p), _sig(sg, s))) for p, s in zip(pks, proofs)]
+
+
 def point_sum(group, pts, scalars=None):
     E, dec, enc = (c.E1, g1_from_raw, util.g1_raw) if group == 1 else (c.E2, g2_from_raw, util.g2_raw)
     acc = None

@@ -43,6 +43,9 @@ def check(res):
             assert res['secure_ok_%d_%d' % (sg, mode)] == 0
             assert res['secure_sub_%d_%d' % (sg, mode)] == 1
         assert res['secure_empty_%d' % sg] == [0, 1]
+        assert res['pop_%d' % sg] == [0, 0, 1, 0, 0, 0, 0]
+        for mode in ([0] if sg == 1 else [0, 1]):
+            assert res['aggsec_%d_%d' % (sg, mode)] == [0, True]
 
 
 def test_shard_range(pkg):
