@@ -274,7 +274,8 @@ int run_point_sum(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_scalar
   if (d_scalars)
     KL(KID_ACCUM, (k_accumulate<G, 1>), dim3(nb), dim3(BLS_BLOCK), n, d_pts, fmt, d_scalars, d_perm, d_partials, T);
   else
-    KL(KID_ACCUM, (k_accumulate<G, 0>), dim3(nb), dim3(BLS_BLOCK), n, d_pts, fmt, d_scalars, d_perm, d_partials, T);
+    if (G == 2 && !d_perm) KL(KID_ACCUM, k_accumulate_g2s, dim3(blocks_for(2 * T)), dim3(BLS_BLOCK), n, d_pts, fmt, d_partials, T);
+    else KL(KID_ACCUM, (k_accumulate<G, 0>), dim3(nb), dim3(BLS_BLOCK), n, d_pts, fmt, d_scalars, d_perm, d_partials, T);
   size_t cur = T;
   while (cur > 1) {
     size_t half = (cur + 1) / 2;

@@ -130,6 +130,36 @@ __device__ __forceinline__ void store_g2_pt(uint8_t* base, size_t i, const g2_ja
   fp2_to_raw(w + 48, p.z);
 }
 
+// ---- lane-split G2 points (jac<hfp2>, tower_split.cuh): each lane of a pair converts and keeps its own component
+// (real / imaginary) of every coordinate of a caller-format point
+__device__ __forceinline__ void ld_g2s(jac<hfp2>& p, const uint8_t* base, size_t i) {
+  const uint32_t* w = (const uint32_t*)(base + i * 288) + (lane_hi() ? 12 : 0);
+  fp_from_raw(p.x.v, w);
+  fp_from_raw(p.y.v, w + 24);
+  fp_from_raw(p.z.v, w + 48);
+}
+__device__ __forceinline__ void st_g2s(uint8_t* base, size_t i, const jac<hfp2>& p) {
+  uint32_t* w = (uint32_t*)(base + i * 288) + (lane_hi() ? 12 : 0);
+  fp_to_raw(w, p.x.v);
+  fp_to_raw(w + 24, p.y.v);
+  fp_to_raw(w + 48, p.z.v);
+}
+__device__ __forceinline__ void ld_g2s_fmt(jac<hfp2>& p, const uint8_t* base, size_t i, int fmt) {
+  if (fmt == 0) {
+    ld_g2s(p, base, i);
+  } else {
+    const uint32_t* w0 = (const uint32_t*)(base + i * 192);
+    if (words_all_zero(w0, 48)) {
+      jac_set_inf(p);
+    } else {
+      const uint32_t* w = w0 + (lane_hi() ? 12 : 0);
+      fp_from_raw(p.x.v, w);
+      fp_from_raw(p.y.v, w + 24);
+      fp2_one(p.z);
+    }
+  }
+}
+
 
 // ---- kernel prototypes (each kernel is defined in exactly one translation unit, see the BLS_TU_* sections)
 template <int SG>
@@ -154,6 +184,7 @@ __global__ void k_hash_to_g2(size_t n, const uint8_t* msgs, const uint64_t* offs
 template <int G, int WITH_SCALARS>
 __global__ void k_accumulate(size_t n, const uint8_t* pts, int fmt, const uint8_t* scalars, const uint32_t* perm,
                              uint8_t* partials, size_t T);
+__global__ void k_accumulate_g2s(size_t n, const uint8_t* pts, int fmt, uint8_t* partials, size_t T);
 template <int G>
 __global__ void k_point_fold(size_t m, size_t half, uint8_t* partials);
 template <int G>
@@ -413,6 +444,18 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_accumulate(size_t n, const uint8_
     }
     store_g2_pt(partials, t, acc);
   }
+}
+// The same for G2 without scalars on two lanes per accumulator (MultiPublicKey::from_public_keys over G2 keys)
+__global__ void __launch_bounds__(BLS_BLOCK, 2) k_accumulate_g2s(size_t n, const uint8_t* pts, int fmt, uint8_t* partials, size_t T) {
+  const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  if (t >= T) return;
+  jac<hfp2> acc, p;
+  jac_set_inf(acc);
+  for (size_t i = t; i < n; i += T) {
+    ld_g2s_fmt(p, pts, i, fmt);
+    jac_add(acc, acc, p);
+  }
+  st_g2s(partials, t, acc);
 }
 // Stage 2: partial[i] += partial[i + half]
 template <int G>
@@ -794,34 +837,6 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_decompress(size_t n, const uint8_
 // k_msm_chunk for G2 on TWO lanes per chunk (jac<hfp2>, tower_split.cuh): the 2^(c w) doublings are the critical path of
 // the chunk lanes, and a lane-split Fp2 doubling costs half the instructions per lane.  Each lane converts and keeps its
 // own component (real / imaginary) of every coordinate.
-__device__ __forceinline__ void msm_ld_g2s(jac<hfp2>& p, const uint8_t* base, size_t i) {
-  const uint32_t* w = (const uint32_t*)(base + i * 288) + (lane_hi() ? 12 : 0);
-  fp_from_raw(p.x.v, w);
-  fp_from_raw(p.y.v, w + 24);
-  fp_from_raw(p.z.v, w + 48);
-}
-__device__ __forceinline__ void msm_st_g2s(uint8_t* base, size_t i, const jac<hfp2>& p) {
-  uint32_t* w = (uint32_t*)(base + i * 288) + (lane_hi() ? 12 : 0);
-  fp_to_raw(w, p.x.v);
-  fp_to_raw(w + 24, p.y.v);
-  fp_to_raw(w + 48, p.z.v);
-}
-// caller-format G2 point (RAW_PROJ or RAW_AFFINE), this lane's components
-__device__ __forceinline__ void msm_ld_g2s_fmt(jac<hfp2>& p, const uint8_t* base, size_t i, int fmt) {
-  if (fmt == 0) {
-    msm_ld_g2s(p, base, i);
-  } else {
-    const uint32_t* w0 = (const uint32_t*)(base + i * 192);
-    if (words_all_zero(w0, 48)) {
-      jac_set_inf(p);
-    } else {
-      const uint32_t* w = w0 + (lane_hi() ? 12 : 0);
-      fp_from_raw(p.x.v, w);
-      fp_from_raw(p.y.v, w + 24);
-      fp2_one(p.z);
-    }
-  }
-}
 // k_msm_bucket for G2 on two lanes per bucket
 __global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm_bucket_g2s(size_t nb, const uint8_t* pts, int fmt, const uint32_t* perm, const uint32_t* cnt,
                                                             const uint32_t* off, const uint32_t* idx, uint8_t* sums) {
@@ -832,10 +847,10 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm_bucket_g2s(size_t nb, cons
   const uint32_t n = cnt[b], o = off[b];
   for (uint32_t j = 0; j < n; j++) {
     const uint32_t i = idx[o + j];
-    msm_ld_g2s_fmt(p, pts, perm ? perm[i] : i, fmt);
+    ld_g2s_fmt(p, pts, perm ? perm[i] : i, fmt);
     jac_add(acc, acc, p);
   }
-  msm_st_g2s(sums, b, acc);
+  st_g2s(sums, b, acc);
 }
 __global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm_chunk_g2s(int c, int W, int clast, int CH, const uint8_t* sums, uint8_t* partials) {
   const size_t cpw = ((size_t)1 << c) / CH, cpl = ((size_t)1 << clast) / CH;   // chunks per regular / last window
@@ -849,7 +864,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm_chunk_g2s(int c, int W, in
   jac_set_inf(run);
   jac_set_inf(acc);
   for (int d = CH - 1; d >= 0; d--) {
-    msm_ld_g2s(s, sums, ((size_t)w << c) + lo + d);
+    ld_g2s(s, sums, ((size_t)w << c) + lo + d);
     jac_add(run, run, s);
     jac_add(acc, acc, run);   // acc = sum_d (d + 1) S_{lo + d}
   }
@@ -865,7 +880,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm_chunk_g2s(int c, int W, in
   }
   jac_add(acc, acc, s);
   for (int k = 0; k < c * w; k++) jac_dbl(acc, acc);   // weight 2^(c w)
-  msm_st_g2s(partials, t, acc);
+  st_g2s(partials, t, acc);
 }
 #endif
 #if defined(BLS_TU_MSM1)
