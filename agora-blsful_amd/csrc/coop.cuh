@@ -21,7 +21,7 @@ struct coop_f12 {
 struct coop_shared {
   coop_f12 f, t, u, v, acc;
   uint32_t prod[36][COOP_FP2_WORDS];
-  uint32_t line[3][COOP_FP2_WORDS];
+  uint32_t line[2][3][COOP_FP2_WORDS];   // the line values of the two pairs of one Miller step
   int flag;
 };
 
@@ -122,13 +122,13 @@ __device__ __noinline__ void coop_sqr(coop_shared& S, coop_f12& dst, const coop_
   __syncthreads();
   coop_reduce<1>(S, dst);
 }
-// f *= (l0 + l2 w^2 + l3 w^3), the line in S.line[0..2]
-__device__ __noinline__ void coop_mul_line(coop_shared& S, coop_f12& f) {
+// f *= (l0 + l2 w^2 + l3 w^3), the line in S.line[set][0..2]
+__device__ __noinline__ void coop_mul_line(coop_shared& S, coop_f12& f, int set) {
   const int q = coop_pair();
   if (q < 18) {
     hfp2 x, y, p;
     coop_ld(x, f.c[q / 3]);
-    coop_ld(y, S.line[q % 3]);
+    coop_ld(y, S.line[set][q % 3]);
     fp2_mul(p, x, y);
     coop_st(S.prod[q], p);
   }
@@ -193,22 +193,28 @@ __device__ __noinline__ void coop_pow_x(coop_shared& S, coop_f12& dst, const coo
 }
 
 // Miller loop of two pairs into S.f.  fixed_g2: pair 1's G2 member is -g2 (line table), else both pairs are general.
+// Lane pair 0 carries pair 0's point T, lane pair 1 carries pair 1's (or scales the table row): the two point steps of an
+// iteration -- nine dependent Fp2 products each, the serial part of the loop -- run side by side, then the two sparse
+// multiplications use all lane pairs.
 __device__ __noinline__ void coop_miller2(coop_shared& S, const g1_aff* P, const aff<hfp2>* Q, int fixed_g2) {
-  const bool lead = coop_pair() == 0;
-  g2_hom_t<hfp2> T0, T1;
-  T0.x = Q[0].x;
-  T0.y = Q[0].y;
-  fp2_one(T0.z);
-  T1.x = Q[1].x;
-  T1.y = Q[1].y;
-  fp2_one(T1.z);
+  const int me = coop_pair();                 // 0, 1: point work; everyone: products
+  const bool second = me == 1;
+  g1_aff Pm;
+  aff<hfp2> Qm;
+  fp_sel(Pm.x, second, P[1].x, P[0].x);
+  fp_sel(Pm.y, second, P[1].y, P[0].y);
+  fp_sel(Qm.x.v, second, Q[1].x.v, Q[0].x.v);
+  fp_sel(Qm.y.v, second, Q[1].y.v, Q[0].y.v);
+  g2_hom_t<hfp2> T;
+  T.x = Qm.x;
+  T.y = Qm.y;
+  fp2_one(T.z);
   {  // f = 1
-    const int k = coop_pair();
-    if (k < 6) {
+    if (me < 6) {
       hfp2 x;
-      if (k == 0) fp2_one(x);
+      if (me == 0) fp2_one(x);
       else fp2_zero(x);
-      coop_st(S.f.c[k], x);
+      coop_st(S.f.c[me], x);
     }
     __syncthreads();
   }
@@ -218,33 +224,25 @@ __device__ __noinline__ void coop_miller2(coop_shared& S, const g1_aff* P, const
     if (i != 62) coop_sqr(S, S.f, S.f);
     for (int step = 0; step < 2; step++) {          // 0: doubling, 1: addition (only at set bits of |x|)
       if (step == 1 && !((BLS_X_ABS >> i) & 1)) break;
-      if (lead) {
-        if (step == 0) miller_dbl_step(T0, l0, l2, l3, P[0].x, P[0].y);
-        else miller_add_step(T0, l0, l2, l3, Q[0].x, Q[0].y, P[0].x, P[0].y);
-        coop_st(S.line[0], l0);
-        coop_st(S.line[1], l2);
-        coop_st(S.line[2], l3);
-      }
-      __syncthreads();
-      coop_mul_line(S, S.f);
-      if (lead) {
-        if (fixed_g2) {
+      if (me < 2) {
+        if (second && fixed_g2) {
           fp2_load(l0, &G2NEG_LINES[row][0]);
           fp2_load(t, &G2NEG_LINES[row][2 * FP_NL]);
-          fp2_mul_fp(l2, t, P[1].x);
+          fp2_mul_fp(l2, t, Pm.x);
           fp2_load(t, &G2NEG_LINES[row][4 * FP_NL]);
-          fp2_mul_fp(l3, t, P[1].y);
+          fp2_mul_fp(l3, t, Pm.y);
         } else if (step == 0) {
-          miller_dbl_step(T1, l0, l2, l3, P[1].x, P[1].y);
+          miller_dbl_step(T, l0, l2, l3, Pm.x, Pm.y);
         } else {
-          miller_add_step(T1, l0, l2, l3, Q[1].x, Q[1].y, P[1].x, P[1].y);
+          miller_add_step(T, l0, l2, l3, Qm.x, Qm.y, Pm.x, Pm.y);
         }
-        coop_st(S.line[0], l0);
-        coop_st(S.line[1], l2);
-        coop_st(S.line[2], l3);
+        coop_st(S.line[me][0], l0);
+        coop_st(S.line[me][1], l2);
+        coop_st(S.line[me][2], l3);
       }
       __syncthreads();
-      coop_mul_line(S, S.f);
+      coop_mul_line(S, S.f, 0);
+      coop_mul_line(S, S.f, 1);
       row++;
     }
   }
