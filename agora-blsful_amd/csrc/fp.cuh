@@ -200,7 +200,7 @@ BLS_FN void fp_redc_products(fp& r, const fp& a, const fp& b, const fp& c, const
     if (vprod > 256.0) fp_trk_fail("REDC input |a||b| + |c||d| <= 256 p^2", a.vb * b.vb, STREAMS == 2 ? c.vb * d.vb : 0.0);
   }
 #endif
-  int64_t acc = 0, acc2 = 0;
+  int64_t acc = 0;
   int32_t m[FP_NL];
   int32_t t[FP_NL];
   int32_t a2[FP_NL];
@@ -218,12 +218,8 @@ BLS_FN void fp_redc_products(fp& r, const fp& a, const fp& b, const fp& c, const
         else if (2 * i == k) acc += (int64_t)a.l[i] * a.l[i];
       } else {
         acc += (int64_t)a.l[i] * b.l[k - i];
-        if (STREAMS == 2) acc2 += (int64_t)c.l[i] * d.l[k - i];
+        if (STREAMS == 2) acc += (int64_t)c.l[i] * d.l[k - i];
       }
-    }
-    if (STREAMS == 2) {
-      acc += acc2;
-      acc2 = 0;
     }
 #pragma unroll
     for (int i = lo; i <= hi; i++) {
