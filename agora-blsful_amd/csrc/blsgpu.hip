@@ -199,7 +199,7 @@ size_t coop_max_items() {
   static long v = -1;
   if (v < 0) {
     const char* e = getenv("BLSGPU_COOP_MAX");
-    v = e ? atol(e) : 1024;
+    v = e ? atol(e) : 4096;
     if (v < 0) v = 0;
   }
   return (size_t)v;

@@ -900,7 +900,7 @@ template __global__ void k_normalize<2>(uint8_t*);
 // =====================================================================================================
 #include "coop.cuh"
 // Miller loop of the item's two pairs + final exponentiation + verdict, one workgroup (= one wave) per item
-__global__ void __launch_bounds__(BLS_BLOCK) k_pairing_coop(size_t n, const uint32_t* pairs, int32_t* status, int fixed_g2) {
+__global__ void __launch_bounds__(BLS_BLOCK, 2) k_pairing_coop(size_t n, const uint32_t* pairs, int32_t* status, int fixed_g2) {
   __shared__ coop_shared S;
   const size_t i = blockIdx.x;
   if (i >= n) return;
@@ -922,7 +922,7 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_pairing_coop(size_t n, const uint
   if (threadIdx.x == 0) status[i] = st;
 }
 // final exponentiation + verdict of workspace item 0
-__global__ void __launch_bounds__(BLS_BLOCK) k_finalexp_coop(const uint32_t* fws, size_t stride, int32_t* verdict) {
+__global__ void __launch_bounds__(BLS_BLOCK, 2) k_finalexp_coop(const uint32_t* fws, size_t stride, int32_t* verdict) {
   __shared__ coop_shared S;
   if (blockIdx.x != 0) return;
   // workspace order is the tower order c0.a0, c0.a1, c0.a2, c1.a0, c1.a1, c1.a2 -> powers 0, 2, 4, 1, 3, 5
