@@ -22,6 +22,8 @@ struct coop_shared {
   coop_f12 f, t, u, v, acc;
   uint32_t prod[36][COOP_FP2_WORDS];
   uint32_t line[2][3][COOP_FP2_WORDS];   // the line values of the two pairs of one Miller step
+  uint32_t job[2][6][2][COOP_FP2_WORDS];  // operand pairs of the point-step products of the two pairs (coop_jobs)
+  uint32_t res[2][6][COOP_FP2_WORDS];     // ... and their results
   int flag;
 };
 
@@ -192,19 +194,52 @@ __device__ __noinline__ void coop_pow_x(coop_shared& S, coop_f12& dst, const coo
   coop_conj(dst, S.acc);
 }
 
+// Up to six independent Fp2 products per point step and pair: the owners (lane pair k for pair k) stage operand pairs in
+// S.job[k][j], lane pair 6 k + j multiplies, the owners read S.res[k][j].  Every lane pair runs the same product code.
+__device__ __forceinline__ void coop_jobs(coop_shared& S, int njobs) {
+  __syncthreads();
+  const int me = coop_pair();
+  if (me < 12) {
+    const int k = me / 6, j = me % 6;
+    if (j < njobs) {
+      hfp2 x, y, p;
+      coop_ld(x, S.job[k][j][0]);
+      coop_ld(y, S.job[k][j][1]);
+      fp2_mul(p, x, y);
+      coop_st(S.res[k][j], p);
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void coop_job_put(coop_shared& S, int k, int j, const hfp2& a, const hfp2& b) {
+  coop_st(S.job[k][j][0], a);
+  coop_st(S.job[k][j][1], b);
+}
+
 // Miller loop of two pairs into S.f.  fixed_g2: pair 1's G2 member is -g2 (line table), else both pairs are general.
-// Lane pair 0 carries pair 0's point T, lane pair 1 carries pair 1's (or scales the table row): the two point steps of an
-// iteration -- nine dependent Fp2 products each, the serial part of the loop -- run side by side, then the two sparse
-// multiplications use all lane pairs.
+// Lane pair k (k = 0, 1) owns pair k's point T.  The doubling step -- nine dependent Fp2 products when one lane pair runs
+// it alone, the serial part of the loop -- is cut into two rounds of independent products spread over lane pairs
+// (coop_jobs: XY, Y^2, Z^2, X^2, (Y+Z)^2, then XY(B-F), (B+F)^2, E^2, BH and the two line scalings), with the owner doing
+// the limb-wise glue in between exactly as miller_dbl_step does (pairing.cuh; same bounds).  The five addition steps of
+// the loop stay on the owners.
 __device__ __noinline__ void coop_miller2(coop_shared& S, const g1_aff* P, const aff<hfp2>* Q, int fixed_g2) {
-  const int me = coop_pair();                 // 0, 1: point work; everyone: products
+  const int me = coop_pair();
   const bool second = me == 1;
+  const bool owner = me < 2;
+  const bool table = second && fixed_g2;          // this owner scales rows of the -g2 line table instead of stepping a point
   g1_aff Pm;
   aff<hfp2> Qm;
   fp_sel(Pm.x, second, P[1].x, P[0].x);
   fp_sel(Pm.y, second, P[1].y, P[0].y);
   fp_sel(Qm.x.v, second, Q[1].x.v, Q[0].x.v);
   fp_sel(Qm.y.v, second, Q[1].y.v, Q[0].y.v);
+  hfp2 xp2, yp2;                                 // (xP, 0), (yP, 0): Fp scalings as Fp2 products, so that all jobs are alike
+  {
+    fp z;
+    fp_zero(z);
+    fp_sel(xp2.v, lane_hi(), z, Pm.x);
+    fp_sel(yp2.v, lane_hi(), z, Pm.y);
+  }
   g2_hom_t<hfp2> T;
   T.x = Qm.x;
   T.y = Qm.y;
@@ -222,17 +257,105 @@ __device__ __noinline__ void coop_miller2(coop_shared& S, const g1_aff* P, const
   int row = 0;
   for (int i = 62; i >= 0; i--) {
     if (i != 62) coop_sqr(S, S.f, S.f);
-    for (int step = 0; step < 2; step++) {          // 0: doubling, 1: addition (only at set bits of |x|)
-      if (step == 1 && !((BLS_X_ABS >> i) & 1)) break;
-      if (me < 2) {
-        if (second && fixed_g2) {
+    // ---- doubling step
+    hfp2 a, b, c, e, f, h, g, s;
+    if (owner) {
+      if (table) {
+        fp2_load(l0, &G2NEG_LINES[row][0]);
+        fp2_load(t, &G2NEG_LINES[row][2 * FP_NL]);
+        coop_job_put(S, me, 0, t, xp2);
+        fp2_load(t, &G2NEG_LINES[row][4 * FP_NL]);
+        coop_job_put(S, me, 1, t, yp2);
+      } else {
+        fp2_add(h, T.y, T.z);
+        fp2_norm(h, h);
+        coop_job_put(S, me, 0, T.x, T.y);
+        coop_job_put(S, me, 1, T.y, T.y);
+        coop_job_put(S, me, 2, T.z, T.z);
+        coop_job_put(S, me, 3, T.x, T.x);
+        coop_job_put(S, me, 4, h, h);
+      }
+    }
+    coop_jobs(S, 5);
+    if (owner) {
+      if (table) {
+        coop_ld(l2, S.res[me][0]);
+        coop_ld(l3, S.res[me][1]);
+      } else {
+        coop_ld(a, S.res[me][0]);       // XY
+        coop_ld(b, S.res[me][1]);       // B = Y^2
+        coop_ld(c, S.res[me][2]);       // C = Z^2
+        coop_ld(s, S.res[me][3]);       // X^2
+        coop_ld(h, S.res[me][4]);       // (Y + Z)^2
+        fp2_mul_xi(e, c);
+        fp2_dbl(g, e);
+        fp2_add(e, g, e);
+        fp2_reduce(e, e);
+        fp2_dbl(e, e);
+        fp2_dbl(e, e);
+        fp2_norm(e, e);                 // E = 3b'C
+        fp2_dbl(f, e);
+        fp2_add(f, f, e);               // F = 3E
+        fp2_sub(h, h, b);
+        fp2_sub(h, h, c);
+        fp2_norm(h, h);                 // H = 2YZ
+        fp2_sub(l0, b, e);
+        fp2_norm(l0, l0);
+        fp2_dbl(g, s);
+        fp2_add(g, g, s);
+        fp2_neg(g, g);
+        fp2_norm(g, g);                 // -3X^2
+        fp2_sub(t, b, f);
+        fp2_norm(t, t);
+        coop_job_put(S, me, 0, a, t);   // XY (B - F)
+        fp2_add(t, b, f);
+        fp2_norm(t, t);
+        coop_job_put(S, me, 1, t, t);   // (B + F)^2
+        coop_job_put(S, me, 2, e, e);   // E^2
+        coop_job_put(S, me, 3, b, h);   // BH
+        coop_job_put(S, me, 4, g, xp2); // l2
+        coop_job_put(S, me, 5, h, yp2); // l3
+      }
+    }
+    coop_jobs(S, 6);
+    if (owner) {
+      if (!table) {
+        coop_ld(g, S.res[me][0]);
+        fp2_dbl(g, g);
+        fp2_reduce(T.x, g);             // X3 = 2XY(B - F)
+        coop_ld(g, S.res[me][1]);
+        coop_ld(s, S.res[me][2]);
+        fp2_dbl(a, s);
+        fp2_add(a, a, s);
+        fp2_norm(a, a);
+        fp2_dbl(a, a);
+        fp2_dbl(a, a);                  // 12E^2
+        fp2_sub(g, g, a);
+        fp2_reduce(T.y, g);             // Y3 = (B + F)^2 - 12E^2
+        coop_ld(g, S.res[me][3]);
+        fp2_dbl(g, g);
+        fp2_dbl(g, g);
+        fp2_reduce(T.z, g);             // Z3 = 4BH
+        coop_ld(l2, S.res[me][4]);
+        coop_ld(l3, S.res[me][5]);
+      }
+      coop_st(S.line[me][0], l0);
+      coop_st(S.line[me][1], l2);
+      coop_st(S.line[me][2], l3);
+    }
+    __syncthreads();
+    coop_mul_line(S, S.f, 0);
+    coop_mul_line(S, S.f, 1);
+    row++;
+    // ---- addition step (set bits of |x|)
+    if ((BLS_X_ABS >> i) & 1) {
+      if (owner) {
+        if (table) {
           fp2_load(l0, &G2NEG_LINES[row][0]);
           fp2_load(t, &G2NEG_LINES[row][2 * FP_NL]);
           fp2_mul_fp(l2, t, Pm.x);
           fp2_load(t, &G2NEG_LINES[row][4 * FP_NL]);
           fp2_mul_fp(l3, t, Pm.y);
-        } else if (step == 0) {
-          miller_dbl_step(T, l0, l2, l3, Pm.x, Pm.y);
         } else {
           miller_add_step(T, l0, l2, l3, Qm.x, Qm.y, Pm.x, Pm.y);
         }
