@@ -84,7 +84,7 @@ BLS_FN void jac_from_aff(jac<F>& r, const aff<F>& a) {
 // from dozens of sites (inlining all of them made single translation units compile for the better part of an hour).
 // doubling on y^2 = x^3 + b (a = 0), dbl-2009-l: 2M + 5S
 template <class F>
-BLS_NOINLINE void jac_dbl(jac<F>& r, const jac<F>& p) {
+BLS_FN void jac_dbl_body(jac<F>& r, const jac<F>& p) {
   F A, B, C, D, E, Fq, t;
   fe_sqr(A, p.x);
   fe_sqr(B, p.y);
@@ -117,11 +117,15 @@ BLS_NOINLINE void jac_dbl(jac<F>& r, const jac<F>& p) {
   r.x = x3;
   fe_reduce(r.z, z3);
 }
+template <class F>
+BLS_NOINLINE void jac_dbl(jac<F>& r, const jac<F>& p) {
+  jac_dbl_body(r, p);
+}
 
 // general addition, add-2007-bl with the exceptional cases handled (inputs are attacker-chosen: equal or opposite
 // points do occur, e.g. duplicated public keys in an aggregate)
 template <class F>
-BLS_NOINLINE void jac_add(jac<F>& r, const jac<F>& p, const jac<F>& q) {
+BLS_FN void jac_add_body(jac<F>& r, const jac<F>& p, const jac<F>& q) {
   if (jac_is_inf(p)) {
     r = q;
     return;
@@ -178,6 +182,10 @@ BLS_NOINLINE void jac_add(jac<F>& r, const jac<F>& p, const jac<F>& q) {
   fe_reduce(r.y, y3);
   r.z = z3;
 }
+template <class F>
+BLS_NOINLINE void jac_add(jac<F>& r, const jac<F>& p, const jac<F>& q) {
+  jac_add_body(r, p, q);
+}
 
 // mixed addition with an affine second operand (Z2 = 1)
 template <class F>
@@ -210,8 +218,8 @@ BLS_NOINLINE void jac_mul_u64(jac<F>& r, const jac<F>& p, uint64_t k) {
   jac<F> acc;
   jac_set_inf(acc);
   for (int i = 63; i >= 0; i--) {
-    jac_dbl(acc, acc);
-    if ((k >> i) & 1) jac_add(acc, acc, p);
+    jac_dbl_body(acc, acc);                       // inlined here: the accumulator stays in registers across the 64 steps
+    if ((k >> i) & 1) jac_add_body(acc, acc, p);
   }
   r = acc;
 }
