@@ -206,11 +206,38 @@ __device__ __noinline__ void f12_sh_mul_2lines(lds_u32* sh, const hfp2& a0, cons
   fp12_mul_by_2lines_body(a, a0, a2, a3, b0, b2, b3);
   sh_st_f12(sh, a);
 }
+__device__ __forceinline__ void sh_ld_f6(fp6_t<hfp2>& r, const lds_u32* sh, int w0) {
+  sh_ld_fp(r.a0.v, sh, w0);
+  sh_ld_fp(r.a1.v, sh, w0 + 13);
+  sh_ld_fp(r.a2.v, sh, w0 + 26);
+}
+__device__ __forceinline__ void sh_st_f6(lds_u32* sh, int w0, const fp6_t<hfp2>& a) {
+  sh_st_fp(sh, w0, a.a0.v);
+  sh_st_fp(sh, w0 + 13, a.a1.v);
+  sh_st_fp(sh, w0 + 26, a.a2.v);
+}
+// accumulator *= b: the Karatsuba product of fp12_mul_body with the accumulator's halves fetched from LDS where they are
+// needed (and fetched again for the sum) instead of held across the three Fp6 products
 __device__ __noinline__ void f12_sh_mul(lds_u32* sh, const fp12_t<hfp2>& b) {
-  fp12_t<hfp2> a, r;
-  sh_ld_f12(a, sh);
-  fp12_mul_body(r, a, b);
-  sh_st_f12(sh, r);
+  fp6_t<hfp2> x, y, t0, t1, m;
+  sh_ld_f6(x, sh, 0);
+  fp6_mul(t0, x, b.c0);
+  sh_ld_f6(x, sh, 39);
+  fp6_mul(t1, x, b.c1);
+  sh_ld_f6(y, sh, 0);
+  fp6_add(x, x, y);
+  fp6_norm(x, x);
+  fp6_add(y, b.c0, b.c1);
+  fp6_norm(y, y);
+  fp6_mul(m, x, y);
+  fp6_sub(m, m, t0);
+  fp6_sub(m, m, t1);
+  fp6_reduce(m, m);
+  sh_st_f6(sh, 39, m);
+  fp6_mul_v(t1, t1);
+  fp6_add(t0, t0, t1);
+  fp6_reduce(t0, t0);
+  sh_st_f6(sh, 0, t0);
 }
 __device__ __forceinline__ void acc_one(f12_sh& f) {
   fp12_t<hfp2> one;
