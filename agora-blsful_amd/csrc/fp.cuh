@@ -437,6 +437,11 @@ BLS_NOINLINE void fp_pow(fp& r, const fp& a, const uint32_t* e, int nbits) {
 struct fp_divstep_mat {
   int32_t u, v, q, r;
 };
+#if defined(__HIPCC__)
+#define FP_OPAQUE32(x) asm volatile("" : "+v"(x))   // keeps the operand a plain 32-bit value here: v_mad_i64_i32 selects
+#else
+#define FP_OPAQUE32(x)
+#endif
 BLS_FN int32_t fp_divsteps_28(int32_t eta, uint32_t f0, uint32_t g0, fp_divstep_mat& t) {
   uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
 #pragma unroll 4
@@ -462,7 +467,17 @@ BLS_FN int32_t fp_divsteps_28(int32_t eta, uint32_t f0, uint32_t g0, fp_divstep_
   return eta;
 }
 // (f, g) <- t (f, g) / 2^28 (exact)
-BLS_FN void fp_divstep_update_fg(int32_t* f, int32_t* g, const fp_divstep_mat& t) {
+BLS_FN void fp_divstep_update_fg(int32_t* f, int32_t* g, const fp_divstep_mat& tt) {
+  fp_divstep_mat t = tt;
+  FP_OPAQUE32(t.u);
+  FP_OPAQUE32(t.v);
+  FP_OPAQUE32(t.q);
+  FP_OPAQUE32(t.r);
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) {   // masked limbs are known non-negative, which would turn the signed products into mixed ones
+    FP_OPAQUE32(f[i]);
+    FP_OPAQUE32(g[i]);
+  }
   int64_t cf = (int64_t)t.u * f[0] + (int64_t)t.v * g[0];
   int64_t cg = (int64_t)t.q * f[0] + (int64_t)t.r * g[0];
   cf >>= FP_LB;
@@ -480,21 +495,39 @@ BLS_FN void fp_divstep_update_fg(int32_t* f, int32_t* g, const fp_divstep_mat& t
   g[FP_NL - 1] = (int32_t)cg;
 }
 // (d, e) <- t (d, e) / 2^28 mod p, keeping d, e in (-2p, p)
-BLS_FN void fp_divstep_update_de(int32_t* d, int32_t* e, const fp_divstep_mat& t) {
+BLS_FN void fp_divstep_update_de(int32_t* d, int32_t* e, const fp_divstep_mat& tt) {
+  fp_divstep_mat t = tt;
+  FP_OPAQUE32(t.u);
+  FP_OPAQUE32(t.v);
+  FP_OPAQUE32(t.q);
+  FP_OPAQUE32(t.r);
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) {
+    FP_OPAQUE32(d[i]);
+    FP_OPAQUE32(e[i]);
+  }
+  int32_t pl[FP_NL];
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) {
+    pl[i] = (int32_t)FP_P[i];
+    FP_OPAQUE32(pl[i]);
+  }
   const int32_t sd = d[FP_NL - 1] >> 31, se = e[FP_NL - 1] >> 31;
   int32_t md = (t.u & sd) + (t.v & se), me = (t.q & sd) + (t.r & se);
   int64_t cd = (int64_t)t.u * d[0] + (int64_t)t.v * e[0];
   int64_t ce = (int64_t)t.q * d[0] + (int64_t)t.r * e[0];
   md -= (int32_t)((FP_PINV28 * (uint32_t)cd + (uint32_t)md) & FP_MASK);
   me -= (int32_t)((FP_PINV28 * (uint32_t)ce + (uint32_t)me) & FP_MASK);
-  cd += (int64_t)(int32_t)FP_P[0] * md;
-  ce += (int64_t)(int32_t)FP_P[0] * me;
+  FP_OPAQUE32(md);
+  FP_OPAQUE32(me);
+  cd += (int64_t)pl[0] * md;
+  ce += (int64_t)pl[0] * me;
   cd >>= FP_LB;
   ce >>= FP_LB;
 #pragma unroll
   for (int i = 1; i < FP_NL; i++) {
-    cd += (int64_t)t.u * d[i] + (int64_t)t.v * e[i] + (int64_t)(int32_t)FP_P[i] * md;
-    ce += (int64_t)t.q * d[i] + (int64_t)t.r * e[i] + (int64_t)(int32_t)FP_P[i] * me;
+    cd += (int64_t)t.u * d[i] + (int64_t)t.v * e[i] + (int64_t)pl[i] * md;
+    ce += (int64_t)t.q * d[i] + (int64_t)t.r * e[i] + (int64_t)pl[i] * me;
     d[i - 1] = (int32_t)((uint32_t)cd & FP_MASK);
     e[i - 1] = (int32_t)((uint32_t)ce & FP_MASK);
     cd >>= FP_LB;
