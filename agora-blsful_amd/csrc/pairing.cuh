@@ -222,6 +222,131 @@ BLS_NOINLINE void fp12_pow_x(fp12_t<F2>& r, const fp12_t<F2>& a) {
   fp12_conj(r, acc);
 }
 
+// ---- a^|x| with Karabina's compressed squarings ----------------------------------------------------------------------
+// In the cyclotomic subgroup the Granger-Scott update of the coefficient pairs (z2, z3) and (z4, z5) (notation of
+// fp12_cyclotomic_sqr_body) does not involve (z0, z1): a squaring of the COMPRESSED element (z2, z3, z4, z5) is two Fp4
+// squarings instead of three.  |x| = 2^63 + 2^62 + 2^60 + 2^57 + 2^48 + 2^16, so a^|x| is the product of six of the 63
+// successive squarings; those six are decompressed together,
+//     z1 = (xi z5^2 + 3 z4^2 - 2 z3) / (4 z2),      z0 = (2 z1^2 + z2 z5 - 3 z3 z4) xi + 1,
+// with ONE Fp2 inversion for the six denominators (Montgomery's trick; the inversion itself is the safegcd of fp.cuh).
+// Checked against the plain chain in tests/hostsim for both tower instantiations.  Returns false -- the caller then runs the
+// plain chain -- when one of the six has z2 = 0 (the other decompression formula; never seen for honest inputs).
+template <class F2>
+struct cyc_c {
+  F2 z2, z3, z4, z5;
+};
+template <class F2>
+BLS_FN void cyc_compress(cyc_c<F2>& c, const fp12_t<F2>& f) {
+  c.z2 = f.c1.a0;
+  c.z3 = f.c0.a2;
+  c.z4 = f.c0.a1;
+  c.z5 = f.c1.a2;
+}
+template <class F2>
+BLS_FN void cyc_out(F2& r, const F2& t, const F2& z, bool plus) {   // 3 t +- 2 z, reduced
+  F2 u;
+  if (plus) fp2_add(u, t, z);
+  else fp2_sub(u, t, z);
+  fp2_dbl(u, u);
+  fp2_add(u, u, t);
+  fp2_reduce(r, u);
+}
+template <class F2>
+BLS_FN void cyc_c_sqr(cyc_c<F2>& r, const cyc_c<F2>& a) {
+  F2 t0, t1, t2, t3, x;
+  fp4_sqr(t0, t1, a.z2, a.z3);
+  fp4_sqr(t2, t3, a.z4, a.z5);
+  cyc_c<F2> o;
+  cyc_out(o.z4, t0, a.z4, false);
+  cyc_out(o.z5, t1, a.z5, true);
+  fp2_mul_xi(x, t3);
+  fp2_norm(x, x);
+  cyc_out(o.z2, x, a.z2, true);
+  cyc_out(o.z3, t2, a.z3, false);
+  r = o;
+}
+// f = the cyclotomic element whose compressed form is c, given inv4z2 = 1 / (4 z2)
+template <class F2>
+BLS_FN void cyc_decompress(fp12_t<F2>& f, const cyc_c<F2>& c, const F2& inv4z2) {
+  F2 n, t, z1, z0, one;
+  fp2_sqr(n, c.z5);
+  fp2_mul_xi(n, n);
+  fp2_sqr(t, c.z4);
+  fp2_dbl(z1, t);
+  fp2_add(t, z1, t);            // 3 z4^2
+  fp2_add(n, n, t);
+  fp2_dbl(t, c.z3);
+  fp2_sub(n, n, t);
+  fp2_reduce(n, n);
+  fp2_mul(z1, n, inv4z2);
+  fp2_sqr(z0, z1);
+  fp2_dbl(z0, z0);              // 2 z1^2
+  fp2_mul(t, c.z2, c.z5);
+  fp2_add(z0, z0, t);
+  fp2_mul(t, c.z3, c.z4);
+  fp2_dbl(n, t);
+  fp2_add(t, n, t);             // 3 z3 z4
+  fp2_sub(z0, z0, t);
+  fp2_reduce(z0, z0);
+  fp2_mul_xi(z0, z0);
+  fp2_one(one);
+  fp2_add(z0, z0, one);
+  fp2_reduce(f.c0.a0, z0);
+  f.c1.a1 = z1;
+  f.c1.a0 = c.z2;
+  f.c0.a2 = c.z3;
+  f.c0.a1 = c.z4;
+  f.c1.a2 = c.z5;
+}
+// the six saved squarings -> acc = their product; false if a z2 vanishes
+template <class F2>
+BLS_NOINLINE bool cyc_product6(fp12_t<F2>& acc, const cyc_c<F2>* s) {
+  F2 d[6], pre[6], inv, t;
+  bool ok = true;
+  for (int i = 0; i < 6; i++) {
+    if (fp2_is_zero(s[i].z2)) ok = false;
+    fp2_dbl(t, s[i].z2);
+    fp2_dbl(t, t);
+    fp2_norm(d[i], t);                       // 4 z2
+  }
+  if (!ok) return false;
+  pre[0] = d[0];
+  for (int i = 1; i < 6; i++) fp2_mul(pre[i], pre[i - 1], d[i]);
+  fp2_inv(inv, pre[5]);
+  for (int i = 5; i >= 0; i--) {
+    F2 di;
+    if (i) {
+      fp2_mul(di, inv, pre[i - 1]);          // 1 / d_i
+      fp2_mul(inv, inv, d[i]);
+    } else {
+      di = inv;
+    }
+    fp12_t<F2> e;
+    cyc_decompress(e, s[i], di);
+    if (i == 5) acc = e;
+    else fp12_mul(acc, acc, e);
+  }
+  return true;
+}
+template <class F2>
+BLS_NOINLINE bool fp12_pow_x_compressed(fp12_t<F2>& r, const fp12_t<F2>& a) {
+  cyc_c<F2> c, s[6];
+  {
+    fp12_t<F2> ar;
+    fp12_reduce(ar, a);                      // a may carry negated limbs (a conjugate)
+    cyc_compress(c, ar);
+  }
+  int k = 0;
+  for (int i = 1; i <= 63; i++) {
+    cyc_c_sqr(c, c);
+    if ((BLS_X_ABS >> i) & 1) s[k++] = c;
+  }
+  fp12_t<F2> acc;
+  if (!cyc_product6(acc, s)) return false;
+  fp12_conj(r, acc);
+  return true;
+}
+
 // f^(3 (p^12 - 1)/r), using 3 (p^4 - p^2 + 1)/r = (x-1)^2 (x+p) (x^2+p^2-1) + 3
 template <class F2>
 BLS_FN void final_exponentiation(fp12_t<F2>& r, const fp12_t<F2>& fin) {

@@ -256,11 +256,24 @@ __device__ __forceinline__ void acc_mul_2lines(f12_sh& f, const hfp2& a0, const 
 }
 __device__ __forceinline__ void acc_finish(f12_sh&) {}   // the kernel conjugates when it reads the accumulator out (negated limbs do not pack)
 
-// a^x (x < 0) for a in the cyclotomic subgroup with the running power in LDS; picked over the pairing.cuh template for
-// the lane-split tower (non-template overload)
-__device__ __noinline__ void fp12_pow_x(fp12_t<hfp2>& r, const fp12_t<hfp2>& a) {
-  __shared__ uint32_t pow_sh[F12_SH_WORDS * BLS_SH_STRIDE];
-  lds_u32* sh = lds_column(pow_sh);
+// compressed squaring (pairing.cuh cyc_c_sqr) on the LDS slots of z2, z3, z4, z5: the last two thirds of the function above
+__device__ __noinline__ void f12_sh_cyc_c_sqr(lds_u32* sh) {
+  hfp2 t0, t1, z2, z3, z4, z5, t2, t3;
+  sh_ld_fp(z2.v, sh, 39);
+  sh_ld_fp(z3.v, sh, 26);
+  fp4_sqr(t0, t1, z2, z3);
+  sh_ld_fp(z4.v, sh, 13);
+  sh_ld_fp(z5.v, sh, 65);
+  fp4_sqr(t2, t3, z4, z5);
+  cyc_store_minus(sh, 13, t0, z4);
+  cyc_store_plus(sh, 65, t1, z5);
+  fp2_mul_xi(t0, t3);
+  fp2_norm(t0, t0);
+  cyc_store_plus(sh, 39, t0, z2);
+  cyc_store_minus(sh, 26, t2, z3);
+}
+// the plain chain (Granger-Scott squarings, five multiplications) with the running power in LDS: fallback of fp12_pow_x
+__device__ __noinline__ void fp12_pow_x_plain_sh(fp12_t<hfp2>& r, const fp12_t<hfp2>& a, lds_u32* sh) {
   fp12_t<hfp2> acc;
   fp12_reduce(acc, a);      // a may carry negated limbs (a conjugate): only reduced elements pack
   sh_st_f12(sh, acc);
@@ -270,6 +283,36 @@ __device__ __noinline__ void fp12_pow_x(fp12_t<hfp2>& r, const fp12_t<hfp2>& a) 
   }
   sh_ld_f12(acc, sh);
   fp12_conj(r, acc);
+}
+// a^x (x < 0) for a in the cyclotomic subgroup; picked over the pairing.cuh template for the lane-split tower
+// (non-template overload).  63 compressed squarings with the running (z2, z3, z4, z5) in LDS, the six needed powers
+// decompressed with one shared inversion and multiplied (pairing.cuh, "Karabina's compressed squarings").
+__device__ __noinline__ void fp12_pow_x(fp12_t<hfp2>& r, const fp12_t<hfp2>& a) {
+  __shared__ uint32_t pow_sh[F12_SH_WORDS * BLS_SH_STRIDE];
+  lds_u32* sh = lds_column(pow_sh);
+  cyc_c<hfp2> s[6];
+  {
+    fp12_t<hfp2> ar;
+    fp12_reduce(ar, a);
+    sh_st_fp(sh, 39, ar.c1.a0.v);
+    sh_st_fp(sh, 26, ar.c0.a2.v);
+    sh_st_fp(sh, 13, ar.c0.a1.v);
+    sh_st_fp(sh, 65, ar.c1.a2.v);
+  }
+  int k = 0;
+  for (int i = 1; i <= 63; i++) {
+    f12_sh_cyc_c_sqr(sh);
+    if ((BLS_X_ABS >> i) & 1) {
+      sh_ld_fp(s[k].z2.v, sh, 39);
+      sh_ld_fp(s[k].z3.v, sh, 26);
+      sh_ld_fp(s[k].z4.v, sh, 13);
+      sh_ld_fp(s[k].z5.v, sh, 65);
+      k++;
+    }
+  }
+  fp12_t<hfp2> acc;
+  if (cyc_product6(acc, s)) fp12_conj(r, acc);
+  else fp12_pow_x_plain_sh(r, a, sh);
 }
 #else
 // ---- host emulation: c[0] is the even lane's register file, c[1] the odd lane's; every function performs, for

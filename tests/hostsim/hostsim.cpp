@@ -149,6 +149,34 @@ void hs_g2_split_ops(const uint32_t* p, const uint32_t* q, uint8_t* out_add, uin
   jac_dbl(sr, sa); unsplit_jac(r, sr); jac_to_aff(f, r); g2_compress(out_dbl, f, false);
   g2_clear_cofactor(sr, sa); unsplit_jac(r, sr); jac_to_aff(f, r); g2_compress(out_clear, f, false);
 }
+// a^x by compressed squarings vs the plain Granger-Scott chain, on the cyclotomic element of a pairing; both towers
+int hs_pow_x_compressed_check(const uint32_t* g1s, const uint32_t* g2s) {
+  g1_aff P[1]; g2_aff Q[1];
+  fp_from_raw(P[0].x, g1s); fp_from_raw(P[0].y, g1s + 12); P[0].inf = false;
+  raw_fp2(Q[0].x, g2s); raw_fp2(Q[0].y, g2s + 24); Q[0].inf = false;
+  fp12 f, e, a, b;
+  miller_loop<1>(f, P, Q);
+  final_exponentiation(e, f);
+  fp12_pow_x(a, e);
+  if (!fp12_pow_x_compressed(b, e)) return -1;
+  uint32_t wa[144], wb[144];
+  store_fp12_plain(wa, a); store_fp12_plain(wb, b);
+  if (memcmp(wa, wb, sizeof wa)) return 0;
+  // the lane-split instantiation
+  fp12_t<hfp2> es, as, bs;
+  const fp2* src[6] = {&e.c0.a0, &e.c0.a1, &e.c0.a2, &e.c1.a0, &e.c1.a1, &e.c1.a2};
+  hfp2* dst[6] = {&es.c0.a0, &es.c0.a1, &es.c0.a2, &es.c1.a0, &es.c1.a1, &es.c1.a2};
+  for (int k = 0; k < 6; k++) { dst[k]->c[0] = src[k]->c0; dst[k]->c[1] = src[k]->c1; }
+  fp12_pow_x(as, es);
+  if (!fp12_pow_x_compressed(bs, es)) return -2;
+  const hfp2* ra[6] = {&as.c0.a0, &as.c0.a1, &as.c0.a2, &as.c1.a0, &as.c1.a1, &as.c1.a2};
+  const hfp2* rb[6] = {&bs.c0.a0, &bs.c0.a1, &bs.c0.a2, &bs.c1.a0, &bs.c1.a1, &bs.c1.a2};
+  for (int k = 0; k < 6; k++)
+    if (!fp2_eq(*ra[k], *rb[k])) return -3;
+  // and against the one-lane result
+  fp2 chk; chk.c0 = as.c0.a0.c[0]; chk.c1 = as.c0.a0.c[1];
+  return fp2_eq(chk, a.c0.a0) ? 1 : -4;
+}
 // checked decompression: returns the status code; on success writes the re-compressed (modern) bytes
 int hs_decompress(int group, const uint8_t* in, int legacy, uint8_t* out) {
   if (group == 1) {

@@ -183,6 +183,7 @@ def test_pairing_values(hs):
     hs.hs_pairing(2, util.g1_aff_raw(P1) + util.g1_aff_raw(P2), util.g2_aff_raw(Q1) + util.g2_aff_raw(Q2), out, None)
     assert util.f12_from_plain_words(out.raw) == c.final_exponentiation(c.miller_loop([(P1, Q1), (P2, Q2)]))
     assert hs.hs_cyclotomic_check(1, util.g1_aff_raw(P1), util.g2_aff_raw(Q1)) == 1
+    assert hs.hs_pow_x_compressed_check(util.g1_aff_raw(P1), util.g2_aff_raw(Q1)) == 1   # Karabina chain == plain chain
     # the precomputed -g2 line table (tools/gen_g2_lines.py) reproduces the generic loop's Miller value bit for bit
     assert hs.hs_miller_fixed_g2_matches(util.g1_aff_raw(P1), util.g2_aff_raw(Q1), util.g1_aff_raw(P2)) == 1
 
