@@ -310,9 +310,43 @@ __device__ __noinline__ void fp12_pow_x(fp12_t<hfp2>& r, const fp12_t<hfp2>& a) 
       k++;
     }
   }
+  // the six powers: one shared inversion for the denominators 4 z2, each power decompressed and multiplied into the
+  // product, which lives in LDS (the compressed state is no longer needed there)
+  hfp2 d[6], pre[6], inv, t;
+  bool ok = true;
+  for (int i = 0; i < 6; i++) {
+    if (fp2_is_zero(s[i].z2)) ok = false;
+    fp2_dbl(t, s[i].z2);
+    fp2_dbl(t, t);
+    fp2_norm(d[i], t);
+  }
+  if (!ok) {
+    fp12_pow_x_plain_sh(r, a, sh);
+    return;
+  }
+  pre[0] = d[0];
+  for (int i = 1; i < 6; i++) fp2_mul(pre[i], pre[i - 1], d[i]);
+  fp2_inv(inv, pre[5]);
+  for (int i = 5; i >= 0; i--) {
+    hfp2 di;
+    if (i) {
+      fp2_mul(di, inv, pre[i - 1]);
+      fp2_mul(inv, inv, d[i]);
+    } else {
+      di = inv;
+    }
+    fp12_t<hfp2> e;
+    cyc_decompress(e, s[i], di);
+    if (i == 5) {
+      fp12_reduce(e, e);
+      sh_st_f12(sh, e);
+    } else {
+      f12_sh_mul(sh, e);
+    }
+  }
   fp12_t<hfp2> acc;
-  if (cyc_product6(acc, s)) fp12_conj(r, acc);
-  else fp12_pow_x_plain_sh(r, a, sh);
+  sh_ld_f12(acc, sh);
+  fp12_conj(r, acc);
 }
 #else
 // ---- host emulation: c[0] is the even lane's register file, c[1] the odd lane's; every function performs, for
