@@ -211,9 +211,10 @@ BLS_FN void miller_loop_fixed_g2(ACC& f, const g1_aff& P0, const aff<F2>& Q0, co
   acc_finish(f);
 }
 
-// a^x for a in the cyclotomic subgroup (x < 0: conjugate of a^|x|)
+// a^x for a in the cyclotomic subgroup (x < 0: conjugate of a^|x|): the plain chain of 63 Granger-Scott squarings and five
+// multiplications; fp12_pow_x below prefers the compressed chain
 template <class F2>
-BLS_NOINLINE void fp12_pow_x(fp12_t<F2>& r, const fp12_t<F2>& a) {
+BLS_NOINLINE void fp12_pow_x_plain(fp12_t<F2>& r, const fp12_t<F2>& a) {
   fp12_t<F2> acc = a;
   for (int i = 62; i >= 0; i--) {
     fp12_cyclotomic_sqr(acc, acc);
@@ -345,6 +346,11 @@ BLS_NOINLINE bool fp12_pow_x_compressed(fp12_t<F2>& r, const fp12_t<F2>& a) {
   if (!cyc_product6(acc, s)) return false;
   fp12_conj(r, acc);
   return true;
+}
+
+template <class F2>
+BLS_FN void fp12_pow_x(fp12_t<F2>& r, const fp12_t<F2>& a) {
+  if (!fp12_pow_x_compressed(r, a)) fp12_pow_x_plain(r, a);
 }
 
 // f^(3 (p^12 - 1)/r), using 3 (p^4 - p^2 + 1)/r = (x-1)^2 (x+p) (x^2+p^2-1) + 3
