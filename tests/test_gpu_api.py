@@ -1,5 +1,6 @@
 """GPU parity for the rest of the C ABI: MultiSignature::verify, AggregateSignature::verify, verify_secure[_with_mode],
 hash_to_point, point sums / MSM, pairing products, serialisation.  Each test cites the reference test it mirrors."""
+import ctypes
 import hashlib
 import json
 import os
@@ -363,6 +364,44 @@ def test_verify_batch_large_property(api):
         sigs2[i] = sigs[(i + 1) % n]
         expect[i] = 1
     assert api.verify_batch(1, api.POP, pks, sigs2, msgs2) == expect
+
+
+@pytest.mark.parametrize('sg', [1, 2])
+def test_verify_batch_vs_c_oracle_lane_split_path(api, sg):
+    """4,608 device-signed items (beyond the cooperative threshold: the lane-split Miller / final-exponentiation kernels)
+    with tampered messages, swapped signatures and swapped keys, both orientations, all three schemes' DSTs: the status
+    vector must equal the C oracle's, item by item."""
+    import os
+    n = 4608
+    bo = util.load_c_oracle()
+    rng = random.Random(100 + sg)
+    for scheme in (api.BASIC, api.AUG, api.POP):
+        sks = [rng.randrange(1, 2**200) for _ in range(n)]
+        msgs = [hashlib.sha256(b'co%d-%d' % (scheme, i)).digest()[:rng.randrange(1, 33)] for i in range(n)]
+        pks, sigs = api.sign_batch(sg, scheme, sks, msgs)
+        pks, sigs, msgs = list(pks), list(sigs), list(msgs)
+        for i in range(0, n, 7):
+            k = i % 21
+            if k == 0:
+                msgs[i] = msgs[i] + b'?'
+            elif k == 7:
+                sigs[i] = sigs[(i + 1) % n]
+            else:
+                pks[i] = pks[(i + 2) % n]
+        got = api.verify_batch(sg, scheme, pks, sigs, msgs)
+        blob = b''.join(msgs)
+        offs = (ctypes.c_uint64 * (n + 1))()
+        o = 0
+        for i, m in enumerate(msgs):
+            offs[i] = o
+            o += len(m)
+        offs[n] = o
+        st = (ctypes.c_int32 * n)()
+        V = lambda x: ctypes.cast(x, ctypes.c_void_p)  # noqa: E731
+        bo.bo_verify_batch(sg, scheme, V(ctypes.c_char_p(b''.join(pks))), V(ctypes.c_char_p(b''.join(sigs))), V(ctypes.c_char_p(blob)), V(offs), n,
+                           V(st), min(16, os.cpu_count() or 1))
+        assert got == list(st), scheme
+        assert sum(got) > n // 8          # the tampering took
 
 
 @pytest.mark.parametrize('sg', [1, 2])
