@@ -24,6 +24,7 @@ MODERN, LEGACY = 0, 1
 
 OK, INVALID_SIGNATURE, SIG_IDENTITY, PK_IDENTITY, DUPLICATE_MESSAGE, INVALID_COEFFICIENT, BAD_LENGTH, BAD_ENCODING, \
     LEGACY_FORMAT = range(9)
+COMMITMENT_IDENTITY, PROOF_IDENTITY, ZERO_CHALLENGE = 9, 10, 11    # blsgpu_sig_proof_verify_batch only
 
 EXPORTS = [
     'blsgpu_init', 'blsgpu_shutdown', 'blsgpu_last_error', 'blsgpu_verify_batch', 'blsgpu_multi_verify',
@@ -32,6 +33,7 @@ EXPORTS = [
     'blsgpu_pairing_product_is_one', 'blsgpu_serialize', 'blsgpu_sign_batch',
     'blsgpu_profile_enable', 'blsgpu_profile_count', 'blsgpu_profile_get',
     'blsgpu_aggregate_partial', 'blsgpu_fp12_product_is_one', 'blsgpu_core_verify', 'blsgpu_deserialize', 'blsgpu_pop_verify_batch', 'blsgpu_aggregate_secure',
+    'blsgpu_signcrypt_valid_batch', 'blsgpu_sig_proof_verify_batch', 'blsgpu_pairing2_check_batch',
 ]
 
 
@@ -124,6 +126,9 @@ def load_library(path=None):
         lib.blsgpu_deserialize.argtypes = [ci, u8p, sz, ci, vp, i32p]
         lib.blsgpu_pop_verify_batch.argtypes = [ci, vp, vp, sz, ci, i32p]
         lib.blsgpu_aggregate_secure.argtypes = [ci, vp, vp, sz, ci, ci, vp, i32p]
+        lib.blsgpu_signcrypt_valid_batch.argtypes = [ci, ci, vp, vp, u8p, u64p, sz, ci, i32p]
+        lib.blsgpu_sig_proof_verify_batch.argtypes = [ci, ci, vp, vp, vp, u8p, u8p, u64p, sz, ci, i32p]
+        lib.blsgpu_pairing2_check_batch.argtypes = [vp, vp, vp, vp, sz, ci, i32p]
         lib.blsgpu_profile_get.argtypes = [ci, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
         _lib = lib
     return _lib
@@ -276,6 +281,50 @@ def pop_verify_batch(sig_group, pks, proofs, fmt=FMT_RAW_PROJ):
     a, b = b''.join(pks), b''.join(proofs)
     _check(lib.blsgpu_pop_verify_batch(sig_group, _ptr(a), _ptr(b), n, fmt, ctypes.cast(st, ctypes.c_void_p)))
     return list(st)[:n]
+
+
+def signcrypt_valid_batch(sig_group, scheme, us, ws, vs, fmt=FMT_RAW_PROJ):
+    """SignCryptCiphertext::is_valid per ciphertext (u, v, w): list of bool (the reference returns a Choice)."""
+    lib = init()
+    n = len(vs)
+    offs, blob = _offsets(vs)
+    st = (ctypes.c_int32 * max(n, 1))()
+    ub, wb = b''.join(us), b''.join(ws)
+    _check(lib.blsgpu_signcrypt_valid_batch(sig_group, scheme, _ptr(ub), _ptr(wb), _ptr(blob), ctypes.cast(offs, ctypes.c_void_p), n, fmt,
+                                            ctypes.cast(st, ctypes.c_void_p)))
+    return [s == OK for s in list(st)[:n]]
+
+
+def proof_error_from_status(st):
+    """Status of blsgpu_sig_proof_verify_batch -> the BlsError of BlsSignatureProof::verify (src/traits/sig_proof.rs:110-140)."""
+    return {OK: None, INVALID_SIGNATURE: BlsError('InvalidProof'),
+            COMMITMENT_IDENTITY: BlsError('InvalidInputs', 'commitment is the identity point'),
+            PROOF_IDENTITY: BlsError('InvalidInputs', 'proof is the identity point'),
+            PK_IDENTITY: BlsError('InvalidInputs', 'pk is the identity point'),
+            ZERO_CHALLENGE: BlsError('InvalidInputs', 'y is the zero')}.get(st, BlsError('Unknown', str(st)))
+
+
+def sig_proof_verify_batch(sig_group, scheme, commitments, proofs, pks, ys, msgs, fmt=FMT_RAW_PROJ):
+    """status list of ProofOfKnowledge::verify(pk, msg, y) for n proofs (u, v); ys: ints or 32-byte LE scalars."""
+    lib = init()
+    n = len(msgs)
+    offs, blob = _offsets(msgs)
+    st = (ctypes.c_int32 * max(n, 1))()
+    ub, vb, pkb = b''.join(commitments), b''.join(proofs), b''.join(pks)
+    yb = b''.join(y.to_bytes(32, 'little') if isinstance(y, int) else y for y in ys)
+    _check(lib.blsgpu_sig_proof_verify_batch(sig_group, scheme, _ptr(ub), _ptr(vb), _ptr(pkb), _ptr(yb), _ptr(blob),
+                                             ctypes.cast(offs, ctypes.c_void_p), n, fmt, ctypes.cast(st, ctypes.c_void_p)))
+    return list(st)[:n]
+
+
+def pairing2_check_batch(g1a, g2a, g1b, g2b, fmt=FMT_RAW_PROJ):
+    """[Pairing::pairing(&[(a1, a2), (b1, b2)]).is_identity()] for n independent items."""
+    lib = init()
+    n = len(g1a)
+    out = (ctypes.c_int32 * max(n, 1))()
+    _check(lib.blsgpu_pairing2_check_batch(_ptr(b''.join(g1a)), _ptr(b''.join(g2a)), _ptr(b''.join(g1b)), _ptr(b''.join(g2b)), n, fmt,
+                                           ctypes.cast(out, ctypes.c_void_p)))
+    return [bool(x) for x in list(out)[:n]]
 
 
 def aggregate_secure(sig_group, pks, sigs, ser_format=MODERN, fmt=FMT_RAW_PROJ):

@@ -209,6 +209,19 @@ unsigned blocks_for(size_t n) { return (unsigned)((n + BLS_BLOCK - 1) / BLS_BLOC
 
 // ---- shared device pipelines (stream-ordered; caller holds the context mutex) ------------------------
 
+// the two-pair pairing check of every item whose status is still BLS_OK: status <- OK / INVALID_SIGNATURE.
+// fixed_g2: the second pair's G2 member is -g2 (precomputed lines)
+int run_pairing2(Ctx* c, size_t n, uint32_t* d_pairs, uint32_t* d_f, int32_t* d_status, int fixed_g2) {
+  if (n <= coop_max_items()) {  // small batches and single-item tails: one wave per item
+    KL(KID_PAIRING_COOP, k_pairing_coop, dim3((unsigned)n), dim3(BLS_BLOCK), n, d_pairs, d_status, fixed_g2);
+  } else {                      // two lanes per item (tower_split.cuh)
+    KL(KID_MILLER2, k_miller2s, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_pairs, d_status, d_f, fixed_g2);
+    KL(KID_FINALEXP, k_finalexps, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_f, d_status);
+  }
+  HIPCK(hipGetLastError());
+  return 0;
+}
+
 // one core_verify per item: statuses end up in d_status (device)
 int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_t* d_sigs, int fmt, const uint8_t* d_msgs,
                      const uint64_t* d_offs, int single_msg, const dst_arg& dst, size_t n, uint32_t* d_pairs, uint32_t* d_f,
@@ -223,14 +236,7 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
     KL(KID_PREPARE, k_prepare<1>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status, pre_status, two_lanes);
   else
     KL(KID_PREPARE, k_prepare<2>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status, pre_status, two_lanes);
-  if (n <= coop_max_items()) {  // small batches and single-item tails: one wave per item
-    KL(KID_PAIRING_COOP, k_pairing_coop, dim3((unsigned)n), dim3(BLS_BLOCK), n, d_pairs, d_status, sg == 1 ? 1 : 0);
-  } else {                      // two lanes per item (tower_split.cuh)
-    KL(KID_MILLER2, k_miller2s, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_pairs, d_status, d_f, sg == 1 ? 1 : 0);
-    KL(KID_FINALEXP, k_finalexps, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_f, d_status);
-  }
-  HIPCK(hipGetLastError());
-  return 0;
+  return run_pairing2(c, n, d_pairs, d_f, d_status, sg == 1 ? 1 : 0);
 }
 
 // product of m Fp12 values in a workspace (stride given) folded into item 0
@@ -1238,11 +1244,9 @@ int blsgpu_aggregate_partial(int sig_group, int scheme, const void* pks, const u
 /* BlsSignatureCore::core_verify(pk, sig, msg, dst) with an explicit DST (reference src/traits/sig_core.rs:120-146):
  * n items share one DST; no message augmentation.  Used by the sharded verify_secure tail and by PoP checks
  * (pop_verify = core_verify(pk, sig, pk_bytes, POP_DST), src/traits/sig_pop.rs:67-70). */
-int blsgpu_core_verify(int sig_group, const uint8_t* dst, size_t dst_len, const void* pks, const void* sigs, const uint8_t* msgs,
-                       const uint64_t* msg_offsets, size_t n, int fmt, int32_t* status) {
-  int rc = check_common(sig_group, 0, fmt);
-  if (rc) return rc;
-  if (dst_len > 255 || (!dst && dst_len)) return fail(BLSGPU_E_ARG, "dst must be at most 255 bytes");
+static int core_verify_entry(int sig_group, const dst_arg& dst, int aug, const void* pks, const void* sigs, const uint8_t* msgs,
+                             const uint64_t* msg_offsets, size_t n, int fmt, int32_t* status) {
+  int rc = 0;
   if (n == 0) return 0;
   if (!pks || !sigs || !msg_offsets || !status) return fail(BLSGPU_E_ARG, "null argument");
   Ctx* c = g_ctx;
@@ -1264,10 +1268,110 @@ int blsgpu_core_verify(int sig_group, const uint8_t* dst, size_t dst_len, const 
   uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)WS_PAIRS_WORDS * 4 * n);
   uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * n);
   if (!d_status || !d_pairs || !d_f) return fail(BLSGPU_E_HIP, "internal: arena too small");
-  rc = run_verify_items(c, sig_group, 0, (const uint8_t*)d_pks, (const uint8_t*)d_sigs, fmt, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, 0,
-                        make_dst(dst, dst_len), n, d_pairs, d_f, d_status);
+  rc = run_verify_items(c, sig_group, aug, (const uint8_t*)d_pks, (const uint8_t*)d_sigs, fmt, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, 0,
+                        dst, n, d_pairs, d_f, d_status);
   if (rc) return rc;
   if ((rc = copy_out(c, status, d_status, 4 * n))) return rc;
+  SYNC_FLUSH(c);
+  return 0;
+}
+int blsgpu_core_verify(int sig_group, const uint8_t* dst, size_t dst_len, const void* pks, const void* sigs, const uint8_t* msgs,
+                       const uint64_t* msg_offsets, size_t n, int fmt, int32_t* status) {
+  int rc = check_common(sig_group, 0, fmt);
+  if (rc) return rc;
+  if (dst_len > 255 || (!dst && dst_len)) return fail(BLSGPU_E_ARG, "dst must be at most 255 bytes");
+  return core_verify_entry(sig_group, make_dst(dst, dst_len), 0, pks, sigs, msgs, msg_offsets, n, fmt, status);
+}
+
+/* SignCryptCiphertext::is_valid for n ciphertexts (reference src/sign_crypt_ciphertext.rs:86-101 -> BlsSignCrypt::valid,
+ * src/traits/sign_crypt.rs:69-77): W' = H(U.to_bytes() || V) under the scheme's DST, then e(W, -g) * e(W', U) == 1 with
+ * U and W not the identity.  That is core_verify(pk := U, sig := W, msg := U.to_bytes() || V, dst): the key-prefixed hash is
+ * the augmentation path of k_prepare.  status[i] == 0 <=> valid (Choice 1); any other status <=> Choice 0. */
+int blsgpu_signcrypt_valid_batch(int sig_group, int scheme, const void* us, const void* ws, const uint8_t* vs,
+                                 const uint64_t* v_offsets, size_t n, int fmt, int32_t* status) {
+  int rc = check_common(sig_group, scheme, fmt);
+  if (rc) return rc;
+  return core_verify_entry(sig_group, scheme_dst(sig_group, scheme), 1, us, ws, vs, v_offsets, n, fmt, status);
+}
+
+/* ProofOfKnowledge::verify for n proofs (reference src/proof_of_knowledge.rs:132-164 -> BlsSignatureProof::verify,
+ * src/traits/sig_proof.rs:102-142; verify_timestamp_proof :145-175 derives y and calls the same check): status[i] in
+ * {OK, COMMITMENT_IDENTITY, PROOF_IDENTITY, PK_IDENTITY, ZERO_CHALLENGE, INVALID_SIGNATURE (= BlsError::InvalidProof)}.
+ * The message is hashed as given under the scheme's DST (the reference does not prefix the key here, even for
+ * MessageAugmentation). */
+int blsgpu_sig_proof_verify_batch(int sig_group, int scheme, const void* commitments, const void* proofs, const void* pks,
+                                  const uint8_t* ys, const uint8_t* msgs, const uint64_t* msg_offsets, size_t n, int fmt,
+                                  int32_t* status) {
+  int rc = check_common(sig_group, scheme, fmt);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  if (!commitments || !proofs || !pks || !ys || !msg_offsets || !status) return fail(BLSGPU_E_ARG, "null argument");
+  Ctx* c = g_ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCK(hipSetDevice(c->dev));
+  uint64_t total = 0;
+  if (is_device_ptr(msg_offsets)) HIPCK(hipMemcpy(&total, msg_offsets + n, 8, hipMemcpyDeviceToHost));
+  else total = msg_offsets[n];
+  const size_t pkb = pk_size(sig_group, fmt) * n, sgb = sig_size(sig_group, fmt) * n;
+  size_t need = pad256(pkb) + 2 * pad256(sgb) + pad256(32 * n) + pad256(total) + pad256(8 * (n + 1)) + pad256(4 * n) +
+                2 * pad256((size_t)WS_PAIRS_WORDS * 4 * n) + 4096;
+  if ((rc = arena_reserve(c, need))) return rc;
+  c->arena_off = 0;
+  const void *d_u, *d_v, *d_pks, *d_ys, *d_msgs, *d_offs;
+  if ((rc = stage_in(c, commitments, sgb, &d_u))) return rc;
+  if ((rc = stage_in(c, proofs, sgb, &d_v))) return rc;
+  if ((rc = stage_in(c, pks, pkb, &d_pks))) return rc;
+  if ((rc = stage_in(c, ys, 32 * n, &d_ys))) return rc;
+  if ((rc = stage_in(c, msgs, total, &d_msgs))) return rc;
+  if ((rc = stage_in(c, msg_offsets, 8 * (n + 1), &d_offs))) return rc;
+  int32_t* d_status = (int32_t*)arena_take(c, 4 * n);
+  uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)WS_PAIRS_WORDS * 4 * n);
+  uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * n);
+  if (!d_status || !d_pairs || !d_f) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  const dst_arg dst = scheme_dst(sig_group, scheme);
+  if (sig_group == 1)
+    KL(KID_PREPARE, k_prepare_proof<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_u, (const uint8_t*)d_v, (const uint8_t*)d_pks,
+       (const uint8_t*)d_ys, fmt, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_status);
+  else
+    KL(KID_PREPARE, k_prepare_proof<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_u, (const uint8_t*)d_v, (const uint8_t*)d_pks,
+       (const uint8_t*)d_ys, fmt, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_status);
+  if ((rc = run_pairing2(c, n, d_pairs, d_f, d_status, sig_group == 1 ? 1 : 0))) return rc;
+  if ((rc = copy_out(c, status, d_status, 4 * n))) return rc;
+  SYNC_FLUSH(c);
+  return 0;
+}
+
+/* n independent two-pair checks  e(g1a[i], g2a[i]) * e(g1b[i], g2b[i]) == 1  -- Pairing::pairing(&[(..), (..)]).is_identity()
+ * per item (reference src/traits/pairings.rs:50, glue src/helpers.rs:41-63), the shape of BlsSignCrypt::verify_share
+ * (src/traits/sign_crypt.rs:192-207) and the ElGamal / time-lock share checks.  is_one[i] = 1 / 0.  Points must be in the
+ * prime-order subgroups (every reference type guarantees it): a pair with an identity member contributes 1. */
+int blsgpu_pairing2_check_batch(const void* g1a, const void* g2a, const void* g1b, const void* g2b, size_t n, int fmt,
+                                int32_t* is_one) {
+  int rc = check_common(1, 0, fmt);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  if (!g1a || !g2a || !g1b || !g2b || !is_one) return fail(BLSGPU_E_ARG, "null argument");
+  Ctx* c = g_ctx;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCK(hipSetDevice(c->dev));
+  const size_t b1 = (fmt == BLSGPU_FMT_RAW_PROJ ? 144 : 96) * n, b2 = (fmt == BLSGPU_FMT_RAW_PROJ ? 288 : 192) * n;
+  size_t need = 2 * pad256(b1) + 2 * pad256(b2) + pad256(4 * n) + 2 * pad256((size_t)WS_PAIRS_WORDS * 4 * n) + 4096;
+  if ((rc = arena_reserve(c, need))) return rc;
+  c->arena_off = 0;
+  const void *d1a, *d2a, *d1b, *d2b;
+  if ((rc = stage_in(c, g1a, b1, &d1a))) return rc;
+  if ((rc = stage_in(c, g2a, b2, &d2a))) return rc;
+  if ((rc = stage_in(c, g1b, b1, &d1b))) return rc;
+  if ((rc = stage_in(c, g2b, b2, &d2b))) return rc;
+  int32_t* d_status = (int32_t*)arena_take(c, 4 * n);
+  uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)WS_PAIRS_WORDS * 4 * n);
+  uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * n);
+  if (!d_status || !d_pairs || !d_f) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  KL(KID_PAIRS_AFF, k_pairs2_to_affine, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d1a, (const uint8_t*)d2a, (const uint8_t*)d1b,
+     (const uint8_t*)d2b, fmt, d_pairs, d_status);
+  if ((rc = run_pairing2(c, n, d_pairs, d_f, d_status, 0))) return rc;
+  KL(KID_PAIRS_AFF, k_status_to_flag, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_status);
+  if ((rc = copy_out(c, is_one, d_status, 4 * n))) return rc;
   SYNC_FLUSH(c);
   return 0;
 }

@@ -176,6 +176,12 @@ template <int SG>
 __global__ void k_prepare_agg(size_t n, const uint8_t* pks, const uint8_t* sig, int fmt, int aug, const uint8_t* msgs,
                               const uint64_t* offs, dst_arg dst, uint32_t* pairs, int32_t* bad, int two_lanes);
 __global__ void k_pairs_to_affine(size_t n, const uint8_t* g1s, const uint8_t* g2s, int fmt, uint32_t* pairs, int32_t* skip);
+__global__ void k_pairs2_to_affine(size_t n, const uint8_t* g1a, const uint8_t* g2a, const uint8_t* g1b, const uint8_t* g2b, int fmt,
+                                   uint32_t* pairs, int32_t* status);
+__global__ void k_status_to_flag(size_t n, int32_t* status);
+template <int SG>
+__global__ void k_prepare_proof(size_t n, const uint8_t* commitments, const uint8_t* proofs, const uint8_t* pks, const uint8_t* ys,
+                                int fmt, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint32_t* pairs, int32_t* status);
 __global__ void k_f12_fold(size_t m, size_t half, uint32_t* fws, size_t stride);
 __global__ void k_f12_import(size_t n, const uint8_t* src, uint32_t* fws, size_t stride);
 __global__ void k_f12_export(const uint32_t* fws, size_t stride, uint8_t* dst);
@@ -360,6 +366,50 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_pairs_to_affine(size_t n, const u
   g2_aff Q;
   g1g2_to_aff(P, Q, a, b);
   ws_st_pair(pairs, n, i, 0, P, Q);
+}
+
+// n independent two-pair products e(a1, a2) * e(b1, b2) (Pairing::pairing on two pairs, reference src/helpers.rs:41-63):
+// both pairs of an item to affine in the layout the two-pair pairing stages read.  A pair with an identity member
+// contributes 1, as in the reference's multi_miller_loop: with both pairs trivial the item gets a fixed product that IS one
+// (e(g1, -g2) * e(-g1, -g2)); with exactly one trivial pair the product is a single pairing of two non-identity subgroup
+// points, which is never one (non-degeneracy), so the verdict is written here and the pairing stages skip the item.
+__global__ void __launch_bounds__(BLS_BLOCK) k_pairs2_to_affine(size_t n, const uint8_t* g1a, const uint8_t* g2a, const uint8_t* g1b,
+                                                              const uint8_t* g2b, int fmt, uint32_t* pairs, int32_t* status) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  g1_jac a1, b1;
+  g2_jac a2, b2;
+  load_g1_pt(a1, g1a, i, fmt);
+  load_g2_pt(a2, g2a, i, fmt);
+  load_g1_pt(b1, g1b, i, fmt);
+  load_g2_pt(b2, g2b, i, fmt);
+  const bool ta = jac_is_inf(a1) || jac_is_inf(a2), tb = jac_is_inf(b1) || jac_is_inf(b2);
+  g1_aff P[2];
+  g2_aff Q[2];
+  if (ta != tb) {
+    status[i] = BLS_ERR_INVALID_SIGNATURE;
+    return;
+  }
+  status[i] = BLS_OK;
+  if (ta) {
+    fp_load(P[0].x, G1_GEN_X);
+    fp_load(P[0].y, G1_GEN_Y);
+    P[0].inf = false;
+    g1_neg_gen(P[1]);
+    g2_neg_gen(Q[0]);
+    g2_neg_gen(Q[1]);
+  } else {
+    g1g2_to_aff(P[0], Q[0], a1, a2);
+    g1g2_to_aff(P[1], Q[1], b1, b2);
+  }
+  ws_st_pair(pairs, n, i, 0, P[0], Q[0]);
+  ws_st_pair(pairs, n, i, 1, P[1], Q[1]);
+}
+
+// status (0 = product is one) -> is_one flag (1 / 0)
+__global__ void __launch_bounds__(BLS_BLOCK) k_status_to_flag(size_t n, int32_t* status) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) status[i] = status[i] == BLS_OK ? 1 : 0;
 }
 
 #endif  // BLS_TU_POINTS (pairs_to_affine)
@@ -568,10 +618,80 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_sign(size_t n, const uint8_t* sks
     store_g2_pt(out_sigs, i, h);
   }
 }
+// Signature proof of knowledge, BlsSignatureProof::verify (reference src/traits/sig_proof.rs:102-142): the checks in the
+// reference's order (commitment, proof, pk identity; y zero), T = commitment + y * H(msg), and the pairs of
+//   e(proof, g) * e(T, pk) == 1   written as   e(T, pk) * e(-proof, -g) == 1,
+// i.e. core_verify's layout with H(m) := T and sig := -proof, so that the pairing stages (and the fixed -g2 lines) are shared.
+template <int SG>
+__global__ void __launch_bounds__(BLS_BLOCK) k_prepare_proof(size_t n, const uint8_t* commitments, const uint8_t* proofs,
+                                                           const uint8_t* pks, const uint8_t* ys, int fmt, const uint8_t* msgs,
+                                                           const uint64_t* offs, dst_arg dst, uint32_t* pairs, int32_t* status) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* y = (const uint32_t*)(ys + 32 * i);
+  const uint8_t* m = msgs + offs[i];
+  uint32_t mlen = (uint32_t)(offs[i + 1] - offs[i]);
+  g1_aff P[2];
+  g2_aff Q[2];
+  int st = BLS_OK;
+  if (SG == 1) {
+    g1_jac u, v, a;
+    g2_jac pk;
+    load_g1_pt(u, commitments, i, fmt);
+    load_g1_pt(v, proofs, i, fmt);
+    load_g2_pt(pk, pks, i, fmt);
+    if (jac_is_inf(u)) st = BLS_ERR_COMMITMENT_IDENTITY;
+    else if (jac_is_inf(v)) st = BLS_ERR_PROOF_IDENTITY;
+    else if (jac_is_inf(pk)) st = BLS_ERR_PK_IDENTITY;
+    else if (words_all_zero(y, 8)) st = BLS_ERR_ZERO_CHALLENGE;
+    if (st == BLS_OK) {
+      hash_to_g1(a, nullptr, 0, m, mlen, dst.b, dst.len);
+      jac_mul_scalar(a, a, y);
+      jac_add(a, a, u);
+      if (jac_is_inf(a)) {          // e(T, pk) = 1: the product is e(proof, g) with proof != identity, never one
+        st = BLS_ERR_INVALID_SIGNATURE;
+      } else {
+        jac_neg(v, v);
+        g1g2_to_aff(P[1], Q[0], v, pk);
+        jac_to_aff(P[0], a);
+        g2_neg_gen(Q[1]);
+      }
+    }
+  } else {
+    g2_jac u, v, a;
+    g1_jac pk;
+    load_g2_pt(u, commitments, i, fmt);
+    load_g2_pt(v, proofs, i, fmt);
+    load_g1_pt(pk, pks, i, fmt);
+    if (jac_is_inf(u)) st = BLS_ERR_COMMITMENT_IDENTITY;
+    else if (jac_is_inf(v)) st = BLS_ERR_PROOF_IDENTITY;
+    else if (jac_is_inf(pk)) st = BLS_ERR_PK_IDENTITY;
+    else if (words_all_zero(y, 8)) st = BLS_ERR_ZERO_CHALLENGE;
+    if (st == BLS_OK) {
+      hash_to_g2(a, nullptr, 0, m, mlen, dst.b, dst.len);
+      jac_mul_scalar(a, a, y);
+      jac_add(a, a, u);
+      if (jac_is_inf(a)) {
+        st = BLS_ERR_INVALID_SIGNATURE;
+      } else {
+        jac_neg(v, v);
+        g1g2_to_aff(P[0], Q[1], pk, v);
+        jac_to_aff(Q[0], a);
+        g1_neg_gen(P[1]);
+      }
+    }
+  }
+  status[i] = st;
+  if (st != BLS_OK) return;
+  ws_st_pair(pairs, n, i, 0, P[0], Q[0]);
+  ws_st_pair(pairs, n, i, 1, P[1], Q[1]);
+}
 #if defined(BLS_TU_SIGN1)
 template __global__ void k_sign<1>(size_t, const uint8_t*, int, const uint8_t*, const uint64_t*, dst_arg, uint8_t*, uint8_t*);
+template __global__ void k_prepare_proof<1>(size_t, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, int, const uint8_t*, const uint64_t*, dst_arg, uint32_t*, int32_t*);
 #else
 template __global__ void k_sign<2>(size_t, const uint8_t*, int, const uint8_t*, const uint64_t*, dst_arg, uint8_t*, uint8_t*);
+template __global__ void k_prepare_proof<2>(size_t, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, int, const uint8_t*, const uint64_t*, dst_arg, uint32_t*, int32_t*);
 #endif
 #endif  // BLS_TU_SIGN*
 

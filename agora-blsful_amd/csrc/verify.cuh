@@ -16,6 +16,9 @@
 #define BLS_ERR_BAD_LENGTH 6
 #define BLS_ERR_BAD_ENCODING 7
 #define BLS_ERR_LEGACY_FORMAT 8
+#define BLS_ERR_COMMITMENT_IDENTITY 9
+#define BLS_ERR_PROOF_IDENTITY 10
+#define BLS_ERR_ZERO_CHALLENGE 11
 
 // 1/a, 1/b, 1/c with one inversion (all three non-zero)
 BLS_FN void fp_inv3(fp& a, fp& b, fp& c) {

@@ -55,6 +55,11 @@ extern "C" {
 #define BLSGPU_BAD_LENGTH 6          /* BlsError::InvalidLength                public_key.rs:159-164 */
 #define BLSGPU_BAD_ENCODING 7        /* BlsError::DeserializationError         legacy.rs:76-78,110,121 */
 #define BLSGPU_LEGACY_FORMAT 8       /* BlsError::LegacyFormatError            legacy.rs:54-57 */
+/* blsgpu_sig_proof_verify_batch only (src/traits/sig_proof.rs:110-128); there BLSGPU_INVALID_SIGNATURE stands for
+ * BlsError::InvalidProof (:140) and BLSGPU_PK_IDENTITY for InvalidInputs("pk is the identity point") (:120-124) */
+#define BLSGPU_COMMITMENT_IDENTITY 9 /* InvalidInputs("commitment is the identity point")        sig_proof.rs:110-114 */
+#define BLSGPU_PROOF_IDENTITY 10     /* InvalidInputs("proof is the identity point")             sig_proof.rs:115-119 */
+#define BLSGPU_ZERO_CHALLENGE 11     /* InvalidInputs("y is the zero")                           sig_proof.rs:125-127 */
 
 /* runtime failures (< 0) */
 #define BLSGPU_E_NO_DEVICE (-1)
@@ -165,6 +170,32 @@ int blsgpu_deserialize(int group, const uint8_t* bytes, size_t n, int fmt_in, vo
 int blsgpu_aggregate_partial(int sig_group, int scheme, const void* pks, const uint8_t* msgs, const uint64_t* msg_offsets,
                              size_t n, const void* sig, int fmt, void* out_f12, int64_t* first_bad);
 int blsgpu_fp12_product_is_one(const void* f12s, size_t k, int32_t* is_one);
+
+/* ---- other two-pairing checks of the reference that reuse the same pairing stages ----
+ *
+ * SignCryptCiphertext::is_valid for n ciphertexts (u, v, w)               src/sign_crypt_ciphertext.rs:86-101
+ *   -> BlsSignCrypt::valid: W' = H(u.to_bytes() || v), e(w, -g) * e(W', u) == 1, u and w not the identity
+ *                                                                             src/traits/sign_crypt.rs:69-77,153-160
+ * vs is the concatenation of the v fields, v_offsets has n + 1 entries.  status[i] == BLSGPU_OK <=> Choice(1); any other
+ * status (INVALID_SIGNATURE, SIG_IDENTITY for w, PK_IDENTITY for u) <=> Choice(0). */
+int blsgpu_signcrypt_valid_batch(int sig_group, int scheme, const void* us, const void* ws, const uint8_t* vs,
+                                 const uint64_t* v_offsets, size_t n, int fmt, int32_t* status);
+
+/* ProofOfKnowledge::<C>::verify(pk, msg, y) for n proofs (u = commitment, v = proof)   src/proof_of_knowledge.rs:132-164
+ *   -> BlsSignatureProof::verify                                              src/traits/sig_proof.rs:102-142
+ * (ProofOfKnowledgeTimestamp::verify derives y from (u, t) and runs the same check, :145-175 / proof_of_knowledge.rs:287-326).
+ * ys: the challenges, 32 B little-endian canonical scalars.  status[i]: OK, COMMITMENT_IDENTITY, PROOF_IDENTITY,
+ * PK_IDENTITY, ZERO_CHALLENGE (checked in that order) or INVALID_SIGNATURE (= BlsError::InvalidProof). */
+int blsgpu_sig_proof_verify_batch(int sig_group, int scheme, const void* commitments, const void* proofs, const void* pks,
+                                  const uint8_t* ys, const uint8_t* msgs, const uint64_t* msg_offsets, size_t n, int fmt,
+                                  int32_t* status);
+
+/* n independent products of two pairings: is_one[i] = Pairing::pairing(&[(g1a_i, g2a_i), (g1b_i, g2b_i)]).is_identity()
+ * (src/traits/pairings.rs:50, src/helpers.rs:41-63) -- the shape of BlsSignCrypt::verify_share
+ * (src/traits/sign_crypt.rs:192-207: pairs (-W', share), (w, pk); its identity checks stay with the caller).
+ * Points must lie in the prime-order subgroups, which every reference type guarantees. */
+int blsgpu_pairing2_check_batch(const void* g1a, const void* g2a, const void* g1b, const void* g2b, size_t n, int fmt,
+                                int32_t* is_one);
 
 /* Measurement hooks (not part of the reference interface): when enabled, every kernel launch of the library is
  * bracketed by HIP events on the library's own stream; blsgpu_profile_get returns the accumulated device time and

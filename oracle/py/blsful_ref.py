@@ -10,6 +10,8 @@ Follows, function by function, the control flow and error order of dashpay/agora
   secure aggregation (sort, SHA-256 coefficients, sum t_i pk_i) src/secure_aggregation.rs:37-106,173-256,269-425
   legacy header transcode                                       src/impls/legacy.rs:19-82
   keygen used only to make test inputs                          src/helpers.rs:9-26, src/secret_key.rs:276-281
+  signature proof of knowledge, signcryption validity / share   src/traits/sig_proof.rs:14-142, src/traits/sign_crypt.rs:69-77,
+                                                                153-160,192-207
 
 Arithmetic comes from oracle/py/bls381.py.  Only tests/, smoke() and bench.py's cpu_baseline may import this.
 """
@@ -42,6 +44,7 @@ def InvalidInputs(m):
 
 InvalidSignature = BlsError('InvalidSignature')
 InvalidCoefficient = BlsError('InvalidCoefficient')
+InvalidProof = BlsError('InvalidProof')
 
 
 class _Impl:
@@ -168,6 +171,62 @@ def multi_sig_verify(C, scheme, pks, sig, msg):
 def pop_verify(C, pk, sig):
     """sig_pop.rs:67-70."""
     return core_verify(C, pk, sig, C.pk_to_bytes(pk), C.POP_DST)
+
+
+# ------------------------------------------------------------------ src/traits/sig_proof.rs
+def sig_proof_generate(C, sig, msg, dst, x, y):
+    """generate_commitment (sig_proof.rs:15-26) + generate_proof (:49-72) with the random x supplied by the caller:
+    (U, V) = (x * H(msg), -(x + y) * sig)."""
+    if x % c.R == 0:
+        raise InvalidInputs('x is the zero')
+    u = C.sig_curve.mul(C.hash_to_point(msg, dst), x)
+    if u is None:
+        raise InvalidInputs('commitment is the identity point')
+    if sig is None:
+        raise InvalidInputs('signature is the identity point')
+    if y % c.R == 0:
+        raise InvalidInputs('y is the zero')
+    return u, C.sig_curve.neg(C.sig_curve.mul(sig, (x + y) % c.R))
+
+
+def sig_proof_verify(C, commitment, proof, pk, y, msg, dst):
+    """BlsSignatureProof::verify, sig_proof.rs:102-142.  Order: commitment, proof, pk identity; y zero; pairing."""
+    if commitment is None:
+        raise InvalidInputs('commitment is the identity point')
+    if proof is None:
+        raise InvalidInputs('proof is the identity point')
+    if pk is None:
+        raise InvalidInputs('pk is the identity point')
+    if y % c.R == 0:
+        raise InvalidInputs('y is the zero')
+    a = C.hash_to_point(msg, dst)
+    t = C.sig_curve.add(commitment, C.sig_curve.mul(a, y))
+    if C.pairing_is_identity([(proof, C.pk_gen), (t, pk)]):
+        return
+    raise InvalidProof
+
+
+# ------------------------------------------------------------------ src/traits/sign_crypt.rs
+def signcrypt_compute_w(C, u, v, dst):
+    """compute_w, sign_crypt.rs:153-160: H(U.to_bytes() || V)."""
+    return C.hash_to_point(C.pk_to_bytes(u) + bytes(v), dst)
+
+
+def signcrypt_valid(C, u, v, w, dst):
+    """BlsSignCrypt::valid, sign_crypt.rs:69-77 (returns the Choice as a bool)."""
+    if u is None or w is None:                 # the Choice is masked by !u.is_identity() & !w.is_identity()
+        return False
+    w_tick = signcrypt_compute_w(C, u, v, dst)
+    g = C.pk_curve.neg(C.pk_gen)
+    return C.pairing_is_identity([(w, g), (w_tick, u)])
+
+
+def signcrypt_verify_share(C, share, pk, u, v, w, dst):
+    """BlsSignCrypt::verify_share, sign_crypt.rs:192-207."""
+    if share is None or pk is None or w is None:
+        return False
+    h = C.sig_curve.neg(signcrypt_compute_w(C, u, v, dst))
+    return C.pairing_is_identity([(h, share), (w, pk)])
 
 
 # ------------------------------------------------------------------ src/impls/legacy.rs

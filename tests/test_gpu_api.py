@@ -570,3 +570,110 @@ def test_aggregate_secure(api, C, sg):
     st, agg = api.aggregate_secure(sg, dpks, dsigs)
     assert st == 0 and api.verify_secure(sg, api.BASIC, dpks, agg, msg) == 0
     assert api.verify_secure(sg, api.BASIC, dpks[1:], agg, msg) == 1
+
+
+# ------------------------------------------------------------------ other two-pairing checks
+@pytest.mark.parametrize('C,sg', IMPLS, ids=['g1', 'g2'])
+def test_sig_proof_verify_batch(api, C, sg):
+    """ProofOfKnowledge::verify (reference src/proof_of_knowledge.rs:132-164 -> src/traits/sig_proof.rs:102-142; round trip
+    as in the reference's tests/proof_of_knowledge.rs): valid proofs under the three DSTs, a wrong challenge, a wrong
+    message, a proof for another key, and the four InvalidInputs cases in the reference's order."""
+    rng = random.Random(110 + sg)
+    pkraw, sigraw = raw_fns(sg)
+    sks, pks = keys(C, 3, 41)
+    cases = []          # (scheme, u, v, pk, y, msg)
+    for i, scheme in enumerate([ref.BASIC, ref.AUG, ref.POP]):
+        msg = b'proof of knowledge %d' % i
+        sig = C.sig_curve.mul(C.hash_to_point(msg, C.DST[scheme]), sks[i])     # the message is hashed as given (no key prefix)
+        x, y = rng.randrange(1, c.R), rng.randrange(1, c.R)
+        u, v = ref.sig_proof_generate(C, sig, msg, C.DST[scheme], x, y)
+        cases.append((scheme, u, v, pks[i], y, msg))
+    s0, u0, v0, pk0, y0, m0 = cases[0]
+    cases += [(s0, u0, v0, pk0, (y0 + 1) % c.R, m0), (s0, u0, v0, pk0, y0, m0 + b'!'), (s0, u0, v0, pks[1], y0, m0),
+              (ref.AUG, u0, v0, pk0, y0, m0),                     # right proof, wrong DST
+              (s0, None, v0, pk0, y0, m0), (s0, u0, None, pk0, y0, m0), (s0, u0, v0, None, y0, m0), (s0, u0, v0, pk0, 0, m0),
+              (s0, None, None, None, 0, m0)]
+    # y chosen so that T = U + y * H(m) is the identity: y = -x mod r
+    x1 = rng.randrange(1, c.R)
+    u1 = C.sig_curve.mul(C.hash_to_point(m0, C.DST[s0]), x1)
+    cases.append((s0, u1, v0, pk0, (-x1) % c.R, m0))
+    want = []
+    for scheme, u, v, pk, y, msg in cases:
+        try:
+            ref.sig_proof_verify(C, u, v, pk, y, msg, C.DST[scheme])
+            want.append(None)
+        except ref.BlsError as e:
+            want.append((e.kind, e.msg))
+    assert want[:3] == [None] * 3 and want[3:7] == [('InvalidProof', '')] * 4 and want[-1] == ('InvalidProof', '')
+    for scheme in (ref.BASIC, ref.AUG, ref.POP):
+        idx = [k for k, cs in enumerate(cases) if cs[0] == scheme]
+        st = api.sig_proof_verify_batch(sg, scheme, [sigraw(cases[k][1], rng) for k in idx], [sigraw(cases[k][2], rng) for k in idx],
+                                        [pkraw(cases[k][3], rng) for k in idx], [cases[k][4] for k in idx], [cases[k][5] for k in idx])
+        got = [api.proof_error_from_status(s) for s in st]
+        assert [None if g is None else (g.kind, g.msg) for g in got] == [want[k] for k in idx]
+
+
+@pytest.mark.parametrize('C,sg', IMPLS, ids=['g1', 'g2'])
+def test_signcrypt_valid_and_share_checks(api, C, sg):
+    """SignCryptCiphertext::is_valid (reference src/sign_crypt_ciphertext.rs:86-101 -> src/traits/sign_crypt.rs:69-77) and
+    BlsSignCrypt::verify_share (:192-207) through the generic two-pair check."""
+    rng = random.Random(120 + sg)
+    pkraw, sigraw = raw_fns(sg)
+    sks, pks = keys(C, 2, 51)
+    cts = []
+    for i, scheme in enumerate([ref.BASIC, ref.AUG, ref.POP, ref.BASIC]):
+        r = rng.randrange(1, c.R)
+        u = C.pk_curve.mul(C.pk_gen, r)                                # U = P^r                 sign_crypt.rs:46
+        v = bytes(rng.randrange(256) for _ in range(32 + 5 * i))       # V: opaque to the validity check
+        w = C.sig_curve.mul(ref.signcrypt_compute_w(C, u, v, C.DST[scheme]), r)     # W = H(U || V)^r   :59
+        cts.append((scheme, u, v, w))
+    s0, u0, v0, w0 = cts[0]
+    cts += [(s0, u0, v0[:-1] + bytes([v0[-1] ^ 1]), w0), (s0, u0, v0, cts[3][3]), (ref.POP, u0, v0, w0), (s0, None, v0, w0),
+            (s0, u0, v0, None)]
+    want = [ref.signcrypt_valid(C, u, v, w, C.DST[scheme]) for scheme, u, v, w in cts]
+    assert want == [True] * 4 + [False] * 5
+    for scheme in (ref.BASIC, ref.AUG, ref.POP):
+        idx = [k for k, ct in enumerate(cts) if ct[0] == scheme]
+        got = api.signcrypt_valid_batch(sg, scheme, [pkraw(cts[k][1], rng) for k in idx], [sigraw(cts[k][3], rng) for k in idx],
+                                        [cts[k][2] for k in idx])
+        assert got == [want[k] for k in idx]
+    # decryption shares: share_i = U * sk_i against pk_i = g * sk_i                     sign_crypt.rs:166-183,192-207
+    g1of = (lambda s, p: s) if sg == 1 else (lambda s, p: p)            # which member of a (sig-group, pk-group) pair is in G1
+    g2of = (lambda s, p: p) if sg == 1 else (lambda s, p: s)
+    items = []
+    for k, (share_sk, pk) in enumerate([(sks[0], pks[0]), (sks[1], pks[1]), (sks[0], pks[1])]):
+        share = C.pk_curve.mul(u0, share_sk)
+        items.append((share, pk))
+    want = [ref.signcrypt_verify_share(C, sh, pk, u0, v0, w0, C.DST[s0]) for sh, pk in items]
+    assert want == [True, True, False]
+    h = C.sig_curve.neg(ref.signcrypt_compute_w(C, u0, v0, C.DST[s0]))
+    r1, r2 = (util.g1_raw, util.g2_raw)
+    got = api.pairing2_check_batch([r1(g1of(h, sh), rng) for sh, _ in items], [r2(g2of(h, sh), rng) for sh, _ in items],
+                                   [r1(g1of(w0, pk), rng) for _, pk in items], [r2(g2of(w0, pk), rng) for _, pk in items])
+    assert got == want
+
+
+def test_pairing2_check_batch_identities_and_lane_split(api):
+    """Pairing::pairing on two pairs per item (reference src/helpers.rs:41-63): pairs with an identity member contribute 1
+    (both trivial -> one; exactly one trivial -> not one); 4,200 items take the lane-split kernels, checked by bilinearity."""
+    rng = random.Random(131)
+    g1, g2 = c.G1_GEN, c.G2_GEN
+    a, b = rng.randrange(1, c.R), rng.randrange(1, c.R)
+    pa, qb = c.E1.mul(g1, a), c.E2.mul(g2, b)
+    pab, nq = c.E1.mul(g1, a * b % c.R), c.E2.neg(g2)
+    items = [(pa, qb, pab, nq, True), (pa, qb, pa, nq, False), (None, qb, pab, None, True), (pa, None, None, None, True),
+             (pa, qb, None, nq, False), (None, qb, pab, nq, False)]
+    for p0, q0, p1, q1, w in items:
+        assert c.pairing_product_is_one([(p0, q0), (p1, q1)]) == w
+    got = api.pairing2_check_batch([util.g1_raw(t[0], rng) for t in items], [util.g2_raw(t[1], rng) for t in items],
+                                   [util.g1_raw(t[2], rng) for t in items], [util.g2_raw(t[3], rng) for t in items])
+    assert got == [t[4] for t in items]
+    # e(k g1, g2) * e(-g1, k g2) == 1 for device-made points; every 7th item gets a different scalar on one side
+    n = 4200
+    ks = [0x1357 + 11 * i for i in range(n)]
+    k2 = [k + (1 if i % 7 == 3 else 0) for i, k in enumerate(ks)]
+    g2pts, _ = api.sign_batch(1, api.BASIC, ks, [b''] * n)              # pk = k * g2 (RAW_PROJ)
+    g1pts, _ = api.sign_batch(2, api.BASIC, k2, [b''] * n)              # pk = k * g1
+    ng1 = util.g1_raw(c.E1.neg(g1))
+    got = api.pairing2_check_batch(g1pts, [util.g2_raw(g2)] * n, [ng1] * n, g2pts)
+    assert got == [i % 7 != 3 for i in range(n)]
