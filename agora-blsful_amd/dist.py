@@ -113,6 +113,17 @@ class Sharded:
         local = self.be.pop_verify_batch(sig_group, pks, proofs)
         return [s for part in self._gather_objects(local) for s in part]
 
+    # ---- N4: the other per-item two-pairing checks (independent items: shard, no data-path collective)
+    def sig_proof_verify_batch(self, sig_group, scheme, commitments, proofs, pks, ys, msgs):
+        """ProofOfKnowledge::verify per item (reference src/traits/sig_proof.rs:102-142): statuses in global order."""
+        local = self.be.sig_proof_verify_batch(sig_group, scheme, commitments, proofs, pks, ys, msgs)
+        return [s for part in self._gather_objects(local) for s in part]
+
+    def signcrypt_valid_batch(self, sig_group, scheme, us, ws, vs):
+        """SignCryptCiphertext::is_valid per item (reference src/traits/sign_crypt.rs:69-77): bools in global order."""
+        local = self.be.signcrypt_valid_batch(sig_group, scheme, us, ws, vs)
+        return [s for part in self._gather_objects(local) for s in part]
+
     # ---- N1: aggregate_secure[_with_mode] (reference src/secure_aggregation.rs:110-169,338-352)
     def aggregate_secure(self, sig_group, pks, sigs, base, ser_format=0):
         """(status, RAW_PROJ aggregate signature) on every rank.  The reference looks every sorted key up with `position`,

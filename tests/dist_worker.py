@@ -72,6 +72,21 @@ def main():
         pops[2] = pops[3]
         popraw = [sigraw(q, rng) for q in pops]
         res['pop_%d' % sg] = sh.pop_verify_batch(sg, praw[lo:hi], popraw[lo:hi])
+        # N4: proofs of knowledge (one with a wrong challenge, one with an identity commitment) and signcryption validity
+        us, vs, ys = [], [], []
+        for i, (s_, m) in enumerate(zip(sks, msgs)):
+            x, y = 1000 + i, 77 + i
+            u, v = ref.sig_proof_generate(C, ref.sign(C, ref.BASIC, s_, m), m, C.DST[ref.BASIC], x, y)
+            us.append(u), vs.append(v), ys.append(y)
+        ys[1] += 1
+        us[6] = None
+        uraw, vraw = [sigraw(q, rng) for q in us], [sigraw(q, rng) for q in vs]
+        res['proof_%d' % sg] = sh.sig_proof_verify_batch(sg, ref.BASIC, uraw[lo:hi], vraw[lo:hi], praw[lo:hi], ys[lo:hi], msgs[lo:hi])
+        cu = [C.pk_curve.mul(C.pk_gen, 31 + i) for i in range(n)]
+        cv = [b'ciphertext body %d' % i for i in range(n)]
+        cw = [C.sig_curve.mul(ref.signcrypt_compute_w(C, cu[i], cv[i], C.DST[ref.POP]), 31 + i) for i in range(n)]
+        cv[4] = b'tampered body'
+        res['signcrypt_%d' % sg] = sh.signcrypt_valid_batch(sg, ref.POP, [pkraw(q, rng) for q in cu][lo:hi], [sigraw(q, rng) for q in cw][lo:hi], cv[lo:hi])
         # N1: sign-side secure aggregation, with a duplicated key across the shard boundary (first occurrence wins)
         for mode in modes:
             dk, ds = list(pks), list(ssigs)

@@ -64,6 +64,24 @@ def pop_verify_batch(sg, pks, proofs):
     return [_status(lambda: ref.pop_verify(C, _pk(sg, p), _sig(sg, s))) for p, s in zip(pks, proofs)]
 
 
+def sig_proof_verify_batch(sg, scheme, us, vs, pks, ys, msgs):
+    C = _impl(sg)
+    codes = {'commitment is the identity point': 9, 'proof is the identity point': 10, 'pk is the identity point': 3, 'y is the zero': 11}
+    out = []
+    for u, v, p, y, m in zip(us, vs, pks, ys, msgs):
+        try:
+            ref.sig_proof_verify(C, _sig(sg, u), _sig(sg, v), _pk(sg, p), y, m, C.DST[scheme])
+            out.append(OK)
+        except ref.BlsError as e:
+            out.append(INVALID_SIGNATURE if e.kind == 'InvalidProof' else codes[e.msg])
+    return out
+
+
+def signcrypt_valid_batch(sg, scheme, us, ws, vs):
+    C = _impl(sg)
+    return [ref.signcrypt_valid(C, _pk(sg, u), v, _sig(sg, w), C.DST[scheme]) for u, w, v in zip(us, ws, vs)]
+
+
 def point_sum(group, pts, scalars=None):
     E, dec, enc = (c.E1, g1_from_raw, util.g1_raw) if group == 1 else (c.E2, g2_from_raw, util.g2_raw)
     acc = None

@@ -44,6 +44,8 @@ def check(res):
             assert res['secure_sub_%d_%d' % (sg, mode)] == 1
         assert res['secure_empty_%d' % sg] == [0, 1]
         assert res['pop_%d' % sg] == [0, 0, 1, 0, 0, 0, 0]
+        assert res['proof_%d' % sg] == [0, 1, 0, 0, 0, 0, 9]
+        assert res['signcrypt_%d' % sg] == [True, True, True, True, False, True, True]
         for mode in ([0] if sg == 1 else [0, 1]):
             assert res['aggsec_%d_%d' % (sg, mode)] == [0, True]
 
