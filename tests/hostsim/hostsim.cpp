@@ -20,6 +20,7 @@ static void store_fp12_plain(uint32_t* out, const fp12& f) {
 }
 
 extern "C" {
+uint64_t hs_phase_marks[3] = {0, 0, 0};   // BLS_COUNT_FPMUL builds: the census after prepare / Miller loop / final exponentiation
 int hs_device_path_only = 0;   // tools/count_fpmul.py: run exactly what the kernels run (prepare, then the lane-split pairing)
 void hs_fp_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) {
   fp x, y, z; fp_from_raw(x, a); fp_from_raw(y, b); fp_mul(z, x, y); fp_to_raw(out, z);
@@ -194,7 +195,14 @@ static int verdict_split(int sig_group, const g1_aff* P, const g2_aff* Q) {
   fp12_t<hfp2> f;
   if (sig_group == 1) miller_loop_fixed_g2(f, P[0], QQ[0], P[1]);
   else miller_loop<2>(f, P, QQ);
-  return pairing_verdict(f);
+#ifdef BLS_COUNT_FPMUL
+  hs_phase_marks[1] = g_fpmul_halves;
+#endif
+  const int v = pairing_verdict(f);
+#ifdef BLS_COUNT_FPMUL
+  hs_phase_marks[2] = g_fpmul_halves;
+#endif
+  return v;
 }
 int hs_verify(int sig_group, const uint32_t* pk, const uint32_t* sig, int aug, const uint8_t* msg, uint32_t len,
               const uint8_t* dst, uint32_t dlen) {
@@ -208,6 +216,9 @@ int hs_verify(int sig_group, const uint32_t* pk, const uint32_t* sig, int aug, c
     st = prepare_g2impl(P, Q, k, s, aug, msg, len, dst, dlen);
   }
   if (st != BLS_OK) return st;
+#ifdef BLS_COUNT_FPMUL
+  hs_phase_marks[0] = g_fpmul_halves;
+#endif
   if (hs_device_path_only) return verdict_split(sig_group, P, Q);
   fp12 f;
   if (sig_group == 1) miller_loop_fixed_g2(f, P[0], Q[0], P[1]);   // as k_miller2 does for Bls12381G1Impl

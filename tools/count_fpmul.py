@@ -21,5 +21,7 @@ for name, C, sg, pkraw, sigraw in (('g1impl', ref.G1Impl, 1, util.g2_raw, util.g
     st = hs.hs_verify(sg, pkraw(pk, rng), sigraw(sig, rng), 0, m, len(m), dst, len(dst))
     assert st == 0
     res['verify_%s_fp_mul_equiv' % name] = cnt.value // 2
+    marks = (ctypes.c_uint64 * 3).in_dll(hs, 'hs_phase_marks')
+    res['phases_%s' % name] = {'prepare': marks[0] // 2, 'miller': (marks[1] - marks[0]) // 2, 'finalexp': (marks[2] - marks[1]) // 2}
 print(res)
 json.dump(res, open(os.path.join(ROOT, 'profiles', 'fpmul_counts.json'), 'w'), indent=1)
