@@ -35,6 +35,7 @@ struct Ctx {
   uint8_t* arena = nullptr;
   size_t arena_cap = 0, arena_off = 0;
   std::mutex mu;
+  hipEvent_t ev_host = nullptr;   // "the host may read what was copied so far" marker (verify_secure)
   // optional per-kernel timing with HIP events on `stream` (blsgpu_profile_*)
   bool prof_on = false;
   struct Pending { int kid; hipEvent_t e0, e1; };
@@ -499,6 +500,7 @@ void blsgpu_shutdown(void) {
   (void)hipSetDevice(g_ctx->dev);
   (void)hipStreamSynchronize(g_ctx->stream);
   if (g_ctx->arena) (void)hipFree(g_ctx->arena);
+  if (g_ctx->ev_host) (void)hipEventDestroy(g_ctx->ev_host);
   (void)hipStreamDestroy(g_ctx->stream);
   delete g_ctx;
   g_ctx = nullptr;
@@ -599,14 +601,16 @@ int blsgpu_verify_batch(int sig_group, int scheme, const void* pks, const void* 
 // aug_prefix: MultiSignature::verify under MessageAugmentation prefixes the (aggregated) key bytes
 // (reference src/traits/sig_aug.rs:20-24); verify_secure_message_augmentation does NOT, it only switches the DST
 // (reference src/secure_aggregation.rs:236-246).
+// d_hash != nullptr: H(msg) (RAW_PROJ, device) has already been computed on this stream (verify_secure overlaps it with the
+// host's coefficient derivation); msg is then unused.
 static int verify_one_tail(Ctx* c, int sig_group, int scheme, int aug_prefix, const uint8_t* d_pk_proj, const void* sig, int fmt,
-                           const uint8_t* msg, size_t msg_len, int32_t* status) {
+                           const uint8_t* msg, size_t msg_len, int32_t* status, const uint8_t* d_hash = nullptr) {
   int rc;
   // bring the signature to RAW_PROJ next to the key so one k_prepare call (single fmt) serves both
   const void* d_sig_in;
   if ((rc = stage_in(c, sig, sig_size(sig_group, fmt), &d_sig_in))) return rc;
-  const void* d_msg;
-  if ((rc = stage_in(c, msg, msg_len, &d_msg))) return rc;
+  const void* d_msg = nullptr;
+  if (!d_hash && (rc = stage_in(c, msg, msg_len, &d_msg))) return rc;
   uint64_t offs_h[2] = {0, (uint64_t)msg_len};
   uint64_t* d_offs = (uint64_t*)arena_take(c, 16);
   int32_t* d_status = (int32_t*)arena_take(c, 4);
@@ -619,8 +623,14 @@ static int verify_one_tail(Ctx* c, int sig_group, int scheme, int aug_prefix, co
   if (sig_group == 1) rc = run_point_sum<1>(c, (const uint8_t*)d_sig_in, fmt, nullptr, nullptr, 1, d_sig_proj, 1);
   else rc = run_point_sum<2>(c, (const uint8_t*)d_sig_in, fmt, nullptr, nullptr, 1, d_sig_proj, 1);
   if (rc) return rc;
-  rc = run_verify_items(c, sig_group, aug_prefix, d_pk_proj, d_sig_proj, BLSGPU_FMT_RAW_PROJ, (const uint8_t*)d_msg, d_offs, 1,
-                        scheme_dst(sig_group, scheme), 1, d_pairs, d_f, d_status);
+  if (d_hash) {
+    if (sig_group == 1) KL(KID_PREPARE, k_prepare_hashed<1>, dim3(1), dim3(BLS_BLOCK), (size_t)1, d_pk_proj, (const uint8_t*)d_sig_proj, d_hash, d_pairs, d_status);
+    else KL(KID_PREPARE, k_prepare_hashed<2>, dim3(1), dim3(BLS_BLOCK), (size_t)1, d_pk_proj, (const uint8_t*)d_sig_proj, d_hash, d_pairs, d_status);
+    rc = run_pairing2(c, 1, d_pairs, d_f, d_status, sig_group == 1 ? 1 : 0);
+  } else {
+    rc = run_verify_items(c, sig_group, aug_prefix, d_pk_proj, d_sig_proj, BLSGPU_FMT_RAW_PROJ, (const uint8_t*)d_msg, d_offs, 1,
+                          scheme_dst(sig_group, scheme), 1, d_pairs, d_f, d_status);
+  }
   if (rc) return rc;
   if ((rc = copy_out(c, status, d_status, 4))) return rc;
   SYNC_FLUSH(c);
@@ -836,7 +846,22 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
     HIPCK(hipGetLastError());
     std::vector<uint8_t> kb(width * n);
     HIPCK(hipMemcpyAsync(kb.data(), d_bytes, width * n, hipMemcpyDeviceToHost, c->stream));
-    SYNC_FLUSH(c);
+    // The host waits for the key bytes only; behind them the stream hashes the message to the curve (H(msg) does not depend
+    // on the keys: verify_secure never prefixes them, reference src/secure_aggregation.rs:236-246), so the hash-to-curve of
+    // the final core_verify runs while the host sorts and derives the coefficients.
+    if (!c->ev_host) HIPCK(hipEventCreateWithFlags(&c->ev_host, hipEventDisableTiming));
+    HIPCK(hipEventRecord(c->ev_host, c->stream));
+    const void* d_msg0;
+    if ((rc = stage_in(c, msg, msg_len, &d_msg0))) return rc;
+    uint64_t* d_offs0 = (uint64_t*)arena_take(c, 16);
+    uint8_t* d_hash = (uint8_t*)arena_take(c, 288);
+    if (!d_offs0 || !d_hash) return fail(BLSGPU_E_HIP, "internal: arena too small");
+    const uint64_t offs0[2] = {0, (uint64_t)msg_len};
+    HIPCK(hipMemcpyAsync(d_offs0, offs0, 16, hipMemcpyHostToDevice, c->stream));
+    if (sig_group == 1) KL(KID_HASH, k_hash_to_g1, dim3(1), dim3(BLS_BLOCK), (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, scheme_dst(sig_group, scheme), d_hash, 1);
+    else KL(KID_HASH, k_hash_to_g2, dim3(1), dim3(BLS_BLOCK), (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, scheme_dst(sig_group, scheme), d_hash, 1);
+    HIPCK(hipGetLastError());
+    HIPCK(hipEventSynchronize(c->ev_host));
     std::vector<uint32_t> perm;
     std::vector<uint8_t> scal;
     st = secure_coefficients_host(kb.data(), n, width, perm, scal);
@@ -847,8 +872,9 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
       if (sig_group == 1) rc = run_point_sum<2>(c, (const uint8_t*)d_pks, fmt, d_scal, d_perm, n, d_part, T);
       else rc = run_point_sum<1>(c, (const uint8_t*)d_pks, fmt, d_scal, d_perm, n, d_part, T);
       if (rc) return rc;
-      return verify_one_tail(c, sig_group, scheme, 0, d_part, sig, fmt, msg, msg_len, status);
+      return verify_one_tail(c, sig_group, scheme, 0, d_part, sig, fmt, msg, msg_len, status, d_hash);
     }
+    SYNC_FLUSH(c);   // coefficient error: let the hash kernel (it reads the arena) drain before returning
   }
   if (is_device_ptr(status)) HIPCK(hipMemcpy(status, &st, 4, hipMemcpyHostToDevice));
   else *status = st;
@@ -900,8 +926,10 @@ static int hash_to_group(int group, const uint8_t* msgs, const uint64_t* msg_off
   uint8_t* d_out = is_device_ptr(out) ? (uint8_t*)out : (uint8_t*)arena_take(c, osz * n);
   if (!d_out) return fail(BLSGPU_E_HIP, "internal: arena too small");
   dst_arg d = make_dst(dst, dst_len);
-  if (group == 1) KL(KID_HASH, k_hash_to_g1, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out);
-  else KL(KID_HASH, k_hash_to_g2, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out);
+  // two lanes per message as in run_verify_items: always for G2, for G1 only in latency mode (small batches)
+  const int two = (group == 2 || n <= coop_max_items()) ? 1 : 0;
+  if (group == 1) KL(KID_HASH, k_hash_to_g1, dim3(blocks_for(two ? 2 * n : n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out, two);
+  else KL(KID_HASH, k_hash_to_g2, dim3(blocks_for(two ? 2 * n : n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out, two);
   HIPCK(hipGetLastError());
   if (d_out != out && (rc = copy_out(c, out, d_out, osz * n))) return rc;
   SYNC_FLUSH(c);

@@ -180,13 +180,15 @@ __global__ void k_pairs2_to_affine(size_t n, const uint8_t* g1a, const uint8_t* 
                                    uint32_t* pairs, int32_t* status);
 __global__ void k_status_to_flag(size_t n, int32_t* status);
 template <int SG>
+__global__ void k_prepare_hashed(size_t n, const uint8_t* pks, const uint8_t* sigs, const uint8_t* hashes, uint32_t* pairs, int32_t* status);
+template <int SG>
 __global__ void k_prepare_proof(size_t n, const uint8_t* commitments, const uint8_t* proofs, const uint8_t* pks, const uint8_t* ys,
                                 int fmt, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint32_t* pairs, int32_t* status);
 __global__ void k_f12_fold(size_t m, size_t half, uint32_t* fws, size_t stride);
 __global__ void k_f12_import(size_t n, const uint8_t* src, uint32_t* fws, size_t stride);
 __global__ void k_f12_export(const uint32_t* fws, size_t stride, uint8_t* dst);
-__global__ void k_hash_to_g1(size_t n, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint8_t* out);
-__global__ void k_hash_to_g2(size_t n, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint8_t* out);
+__global__ void k_hash_to_g1(size_t n, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint8_t* out, int two_lanes);
+__global__ void k_hash_to_g2(size_t n, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint8_t* out, int two_lanes);
 template <int G, int WITH_SCALARS>
 __global__ void k_accumulate(size_t n, const uint8_t* pts, int fmt, const uint8_t* scalars, const uint32_t* perm,
                              uint8_t* partials, size_t T);
@@ -406,6 +408,67 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_pairs2_to_affine(size_t n, const 
   ws_st_pair(pairs, n, i, 1, P[1], Q[1]);
 }
 
+// core_verify's stage 1 when H(msg) is already known (RAW_PROJ in `hashes`): the single-verify tail of verify_secure hashes
+// its message while the host still derives the coefficients, so only the identity checks (signature first, then key:
+// reference src/traits/sig_core.rs:126-135) and the shared-inversion conversion to affine pairs are left.
+template <int SG>
+__global__ void __launch_bounds__(BLS_BLOCK) k_prepare_hashed(size_t n, const uint8_t* pks, const uint8_t* sigs, const uint8_t* hashes,
+                                                            uint32_t* pairs, int32_t* status) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  g1_aff P[2];
+  g2_aff Q[2];
+  int st = BLS_OK;
+  if (SG == 1) {
+    g2_jac pk;
+    g1_jac sig, h;
+    load_g2_pt(pk, pks, i, 0);
+    load_g1_pt(sig, sigs, i, 0);
+    load_g1_pt(h, hashes, i, 0);
+    if (jac_is_inf(sig)) st = BLS_ERR_SIG_IDENTITY;
+    else if (jac_is_inf(pk)) st = BLS_ERR_PK_IDENTITY;
+    else if (jac_is_inf(h)) {
+      g1g2_to_aff(P[1], Q[0], sig, pk);
+      jac_to_aff(P[0], h);
+    } else {
+      fp zs = sig.z, zh = h.z, nn;
+      fp2_norm_sq(nn, pk.z);
+      fp_inv3(zs, zh, nn);
+      g1_apply_zinv(P[1], sig, zs);
+      g1_apply_zinv(P[0], h, zh);
+      g2_apply_ninv(Q[0], pk, nn);
+    }
+    g2_neg_gen(Q[1]);
+  } else {
+    g1_jac pk;
+    g2_jac sig, h;
+    load_g1_pt(pk, pks, i, 0);
+    load_g2_pt(sig, sigs, i, 0);
+    load_g2_pt(h, hashes, i, 0);
+    if (jac_is_inf(sig)) st = BLS_ERR_SIG_IDENTITY;
+    else if (jac_is_inf(pk)) st = BLS_ERR_PK_IDENTITY;
+    else if (jac_is_inf(h)) {
+      g1g2_to_aff(P[0], Q[1], pk, sig);
+      jac_to_aff(Q[0], h);
+    } else {
+      fp zp = pk.z, ns, nh;
+      fp2_norm_sq(ns, sig.z);
+      fp2_norm_sq(nh, h.z);
+      fp_inv3(zp, ns, nh);
+      g1_apply_zinv(P[0], pk, zp);
+      g2_apply_ninv(Q[1], sig, ns);
+      g2_apply_ninv(Q[0], h, nh);
+    }
+    g1_neg_gen(P[1]);
+  }
+  status[i] = st;
+  if (st != BLS_OK) return;
+  ws_st_pair(pairs, n, i, 0, P[0], Q[0]);
+  ws_st_pair(pairs, n, i, 1, P[1], Q[1]);
+}
+template __global__ void k_prepare_hashed<1>(size_t, const uint8_t*, const uint8_t*, const uint8_t*, uint32_t*, int32_t*);
+template __global__ void k_prepare_hashed<2>(size_t, const uint8_t*, const uint8_t*, const uint8_t*, uint32_t*, int32_t*);
+
 // status (0 = product is one) -> is_one flag (1 / 0)
 __global__ void __launch_bounds__(BLS_BLOCK) k_status_to_flag(size_t n, int32_t* status) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -450,19 +513,25 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_f12_export(const uint32_t* fws, s
 #if defined(BLS_TU_POINTS)
 // =====================================================================================================
 // hash_to_point batches
-__global__ void __launch_bounds__(BLS_BLOCK) k_hash_to_g1(size_t n, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint8_t* out) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// two_lanes: two adjacent lanes per message run the two SSWU maps side by side (and, for G2, the cofactor clearing on the
+// lane-split tower), as k_prepare does: the latency mode for the single message of a verify_secure tail
+__global__ void __launch_bounds__(BLS_BLOCK) k_hash_to_g1(size_t n, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint8_t* out, int two_lanes) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = two_lanes ? gid >> 1 : gid;
+  const int lane2 = two_lanes ? (int)(gid & 1) : -1;
   if (i >= n) return;
   g1_jac h;
-  hash_to_g1(h, nullptr, 0, msgs + offs[i], (uint32_t)(offs[i + 1] - offs[i]), dst.b, dst.len);
-  store_g1_pt(out, i, h);
+  hash_to_g1(h, nullptr, 0, msgs + offs[i], (uint32_t)(offs[i + 1] - offs[i]), dst.b, dst.len, lane2);
+  if (lane2 <= 0) store_g1_pt(out, i, h);
 }
-__global__ void __launch_bounds__(BLS_BLOCK) k_hash_to_g2(size_t n, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint8_t* out) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(BLS_BLOCK) k_hash_to_g2(size_t n, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint8_t* out, int two_lanes) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = two_lanes ? gid >> 1 : gid;
+  const int lane2 = two_lanes ? (int)(gid & 1) : -1;
   if (i >= n) return;
   g2_jac h;
-  hash_to_g2(h, nullptr, 0, msgs + offs[i], (uint32_t)(offs[i + 1] - offs[i]), dst.b, dst.len);
-  store_g2_pt(out, i, h);
+  hash_to_g2(h, nullptr, 0, msgs + offs[i], (uint32_t)(offs[i + 1] - offs[i]), dst.b, dst.len, lane2);
+  if (lane2 <= 0) store_g2_pt(out, i, h);
 }
 
 // =====================================================================================================

@@ -1,4 +1,4 @@
-"""Wall-clock of BASELINE.json configs 3-5 on one MI355X (parity-test cases, not the bench line): inputs are made on
+"""Wall-clock of BASELINE.json configs 1 and 3-5 on one MI355X (parity-test cases, not the bench line): inputs are made on
 the device with blsgpu_sign_batch and stay resident in HBM.  Prints one JSON object per config.
 usage: python tools/bench_configs.py [--scale 1.0]"""
 import argparse, ctypes, hashlib, json, os, sys, time
@@ -38,6 +38,23 @@ def main():
         return min(ts)
 
     st = ctypes.c_int32(-9)
+    # ---- config 1: 1,024 sequential single-item Signature::verify calls (the reference's own CPU-runnable case): the
+    # latency / plumbing number -- each call is one blsgpu_verify_batch of one item with host pointers, as a caller that
+    # keeps the reference's one-signature-per-call API would issue it
+    n1 = max(16, int(1024 * args.scale)); msg = hashlib.sha256(seed + b'fixed').digest()
+    sks1 = [(s0 + i) % R or 1 for i in range(n1)]
+    pks1, sigs1 = api.sign_batch(1, api.POP, sks1, [msg] * n1)
+    offs1 = (ctypes.c_uint64 * 2)(0, len(msg)); st1 = ctypes.c_int32(-9)
+    lat = []
+    for i in range(n1):
+        t = time.perf_counter()
+        api._check(lib.blsgpu_verify_batch(1, api.POP, api._ptr(pks1[i]), api._ptr(sigs1[i]), api._ptr(msg), ctypes.cast(offs1, ctypes.c_void_p), 1, 0,
+                                           ctypes.cast(ctypes.byref(st1), ctypes.c_void_p)))
+        lat.append(time.perf_counter() - t)
+        assert st1.value == 0
+    lat.sort()
+    print(json.dumps({'config': 1, 'n': n1, 'calls': 'sequential, one item each, host pointers', 'mean_ms': 1e3 * sum(lat) / n1,
+                      'p50_ms': 1e3 * lat[n1 // 2], 'p99_ms': 1e3 * lat[min(n1 - 1, int(n1 * 0.99))], 'verifications_per_s': n1 / sum(lat)}), flush=True)
     # ---- config 3: MultiSignature::verify, 1,048,576 G2 public keys, one message
     n = int(1048576 * args.scale); msg = hashlib.sha256(seed + b'fixed').digest()
     sks, d_pks, d_sigs, _, _ = make(1, api.POP, n, one_msg=msg)
