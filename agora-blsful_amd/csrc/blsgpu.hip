@@ -36,6 +36,8 @@ struct Ctx {
   size_t arena_cap = 0, arena_off = 0;
   std::mutex mu;
   hipEvent_t ev_host = nullptr;   // "the host may read what was copied so far" marker (verify_secure)
+  hipStream_t side = nullptr;     // side stream: the message hash of a multi_verify tail runs beside the key sum
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // optional per-kernel timing with HIP events on `stream` (blsgpu_profile_*)
   bool prof_on = false;
   struct Pending { int kid; hipEvent_t e0, e1; };
@@ -501,6 +503,9 @@ void blsgpu_shutdown(void) {
   (void)hipStreamSynchronize(g_ctx->stream);
   if (g_ctx->arena) (void)hipFree(g_ctx->arena);
   if (g_ctx->ev_host) (void)hipEventDestroy(g_ctx->ev_host);
+  if (g_ctx->ev_fork) (void)hipEventDestroy(g_ctx->ev_fork);
+  if (g_ctx->ev_join) (void)hipEventDestroy(g_ctx->ev_join);
+  if (g_ctx->side) (void)hipStreamDestroy(g_ctx->side);
   (void)hipStreamDestroy(g_ctx->stream);
   delete g_ctx;
   g_ctx = nullptr;
@@ -646,18 +651,50 @@ int blsgpu_multi_verify(int sig_group, int scheme, const void* pks, size_t n, co
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCK(hipSetDevice(c->dev));
   const size_t psz = pk_size(sig_group, fmt), T = accumulate_lanes(n);
-  size_t need = pad256(psz * n) + pad256(288 * T) + pad256(msg_len) + 8192;
+  size_t need = pad256(psz * n) + pad256(288 * T) + 2 * pad256(msg_len) + 8192;
   if ((rc = arena_reserve(c, need))) return rc;
   c->arena_off = 0;
   const void* d_pks;
   if ((rc = stage_in(c, pks, psz * n, &d_pks))) return rc;
   uint8_t* d_part = (uint8_t*)arena_take(c, 288 * T);
   if (!d_part) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  // Unless the scheme prefixes the aggregated key to the message (MessageAugmentation, reference src/traits/sig_aug.rs:20-24),
+  // H(msg) does not depend on the keys: hash it on a side stream (one wave) while the main stream sums the keys.
+  uint8_t* d_hash = nullptr;
+  if (scheme != BLSGPU_SCHEME_AUG && n > 0) {
+    const void* d_msg0;
+    if ((rc = stage_in(c, msg, msg_len, &d_msg0))) return rc;
+    uint64_t* d_offs0 = (uint64_t*)arena_take(c, 16);
+    d_hash = (uint8_t*)arena_take(c, 288);
+    if (!d_offs0 || !d_hash) return fail(BLSGPU_E_HIP, "internal: arena too small");
+    const uint64_t offs0[2] = {0, (uint64_t)msg_len};
+    HIPCK(hipMemcpyAsync(d_offs0, offs0, 16, hipMemcpyHostToDevice, c->stream));
+    if (!c->side) {
+      HIPCK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+      HIPCK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+      HIPCK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    HIPCK(hipEventRecord(c->ev_fork, c->stream));
+    HIPCK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    if (sig_group == 1)
+      hipLaunchKernelGGL(k_hash_to_g1, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0,
+                         scheme_dst(sig_group, scheme), d_hash, 1);
+    else
+      hipLaunchKernelGGL(k_hash_to_g2, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0,
+                         scheme_dst(sig_group, scheme), d_hash, 1);
+    HIPCK(hipGetLastError());
+    HIPCK(hipEventRecord(c->ev_join, c->side));
+  }
   // MultiPublicKey::from_public_keys: the serial `g += key` of reference src/traits/pk_multi.rs:7-13 as a tree sum
   if (sig_group == 1) rc = run_point_sum<2>(c, (const uint8_t*)d_pks, fmt, nullptr, nullptr, n, d_part, T);
   else rc = run_point_sum<1>(c, (const uint8_t*)d_pks, fmt, nullptr, nullptr, n, d_part, T);
+  if (d_hash) {
+    hipError_t e = hipStreamWaitEvent(c->stream, c->ev_join, 0);    // also on the error path: the side kernel reads the arena
+    if (rc) (void)hipStreamSynchronize(c->side);
+    if (e != hipSuccess) return fail(BLSGPU_E_HIP, "hipStreamWaitEvent failed");
+  }
   if (rc) return rc;
-  return verify_one_tail(c, sig_group, scheme, scheme == BLSGPU_SCHEME_AUG, d_part, sig, fmt, msg, msg_len, status);
+  return verify_one_tail(c, sig_group, scheme, scheme == BLSGPU_SCHEME_AUG, d_part, sig, fmt, msg, msg_len, status, d_hash);
 }
 
 int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const uint8_t* msgs, const uint64_t* msg_offsets,
