@@ -715,15 +715,17 @@ int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const ui
   else memcpy(offs_h.data(), msg_offsets, 8 * (n + 1));
   const uint64_t total = offs_h[n];
   int32_t st = BLSGPU_OK;
-  if (scheme == BLSGPU_SCHEME_BASIC) {
-    // reference src/traits/sig_basic.rs:46-58: first i whose message equals an earlier one, runs before anything else
-    std::vector<uint8_t> tmp;
-    const uint8_t* mh = msgs;
-    if (is_device_ptr(msgs)) {
-      tmp.resize(total);
-      HIPCK(hipMemcpy(tmp.data(), msgs, total, hipMemcpyDeviceToHost));
-      mh = tmp.data();
-    }
+  // reference src/traits/sig_basic.rs:46-58: first i whose message equals an earlier one.  In the reference this runs to
+  // completion before anything else; here the GPU already hashes the messages to the curve meanwhile (the verdict keeps
+  // the reference's precedence: a duplicate wins over whatever the device finds).
+  std::vector<uint8_t> tmp;
+  const uint8_t* mh = msgs;
+  if (scheme == BLSGPU_SCHEME_BASIC && is_device_ptr(msgs)) {
+    tmp.resize(total);
+    HIPCK(hipMemcpy(tmp.data(), msgs, total, hipMemcpyDeviceToHost));
+    mh = tmp.data();
+  }
+  auto duplicate_check = [&]() {
     // open-addressing table of message indices keyed by a 64-bit hash (computed on all host cores), equality verified on
     // the bytes; the scan is sequential so that the FIRST i with an earlier equal message is reported, as the reference does
     std::vector<uint64_t> hs(n);
@@ -777,9 +779,9 @@ int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const ui
       }
       if (st == BLSGPU_OK) tab[slot] = (uint32_t)(i + 1);
     }
-  }
+  };
   const double t_dup = now();
-  if (st == BLSGPU_OK) {
+  {
     const size_t m = n + 1, psz = pk_size(sig_group, fmt);
     size_t need = pad256(psz * n) + pad256(sig_size(sig_group, fmt)) + pad256(total) + pad256(8 * m) + pad256(4 * m) +
                   2 * pad256((size_t)WS_PAIRS_WORDS * 4 * m) + 8192;
@@ -791,7 +793,7 @@ int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const ui
     if ((rc = stage_in(c, msgs, total, &d_msgs))) return rc;
     if ((rc = stage_in(c, msg_offsets, 8 * m, &d_offs))) return rc;
     const double t_staged = now();
-    if (trace) fprintf(stderr, "[blsgpu] aggregate_verify n=%zu: duplicate check %.2f ms, staging %.2f ms\n", n, t_dup - t_start, t_staged - t_dup);
+    if (trace) fprintf(stderr, "[blsgpu] aggregate_verify n=%zu: host copies %.2f ms, staging %.2f ms\n", n, t_dup - t_start, t_staged - t_dup);
     int32_t* d_bad = (int32_t*)arena_take(c, 4 * m);
     int32_t* d_verdict = (int32_t*)arena_take(c, 4);
     uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)WS_PAIR1_WORDS * 4 * m);
@@ -806,11 +808,17 @@ int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const ui
       KL(KID_PREPARE_AGG, k_prepare_agg<2>, dim3(blocks_for(2 * m)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, aug,
                          (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad, 1);
     HIPCK(hipGetLastError());
+    if (scheme == BLSGPU_SCHEME_BASIC) {
+      duplicate_check();          // on the host, while k_prepare_agg runs
+      if (trace) fprintf(stderr, "[blsgpu] aggregate_verify n=%zu: duplicate check %.2f ms (overlapped)\n", n, now() - t_staged);
+    }
     std::vector<int32_t> bad(m);
     HIPCK(hipMemcpyAsync(bad.data(), d_bad, 4 * m, hipMemcpyDeviceToHost, c->stream));
     SYNC_FLUSH(c);
     // reference src/traits/sig_core.rs:155-167: signature identity first, then the first identity key (1-based)
-    if (bad[n]) {
+    if (st != BLSGPU_OK) {
+      // duplicate messages: reported before any identity check (sig_basic.rs:46-58 precedes core_aggregate_verify)
+    } else if (bad[n]) {
       st = BLSGPU_SIG_IDENTITY;
     } else {
       for (size_t i = 0; i < n; i++)
