@@ -677,3 +677,40 @@ def test_pairing2_check_batch_identities_and_lane_split(api):
     ng1 = util.g1_raw(c.E1.neg(g1))
     got = api.pairing2_check_batch(g1pts, [util.g2_raw(g2)] * n, [ng1] * n, g2pts)
     assert got == [i % 7 != 3 for i in range(n)]
+
+
+def test_concurrent_callers(api):
+    """The C ABI is blocking and thread-safe (threading row): four host threads issue different calls at once
+    (ctypes releases the GIL) and every result equals the one obtained sequentially."""
+    import threading
+    n = 300
+    jobs = []
+    for t in range(4):
+        sg = 1 + t % 2
+        sks = [0x9000 + 17 * t + i for i in range(n)]
+        msgs = [b'thread %d item %d' % (t, i) for i in range(n)]
+        pks, sigs = api.sign_batch(sg, api.POP, sks, msgs)
+        bad = list(msgs)
+        for i in range(t, n, 7):
+            bad[i] = b'x' + bad[i]
+        jobs.append((sg, pks, sigs, bad, [1 if i % 7 == t else 0 for i in range(n)]))
+    seq = [api.verify_batch(sg, api.POP, pks, sigs, m) for sg, pks, sigs, m, _ in jobs]
+    assert seq == [e for *_, e in jobs]
+    out = [None] * 4
+
+    def run(k):
+        sg, pks, sigs, m, _ = jobs[k]
+        res = []
+        for _ in range(3):
+            res.append(api.verify_batch(sg, api.POP, pks, sigs, m))
+            res.append(api.multi_verify(sg, api.POP, pks[:50], sigs[0], m[0]))
+        out[k] = res
+    th = [threading.Thread(target=run, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(4):
+        sg, pks, sigs, m, e = jobs[k]
+        single = api.multi_verify(sg, api.POP, pks[:50], sigs[0], m[0])
+        assert out[k] == [e, single] * 3
