@@ -808,31 +808,31 @@ int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const ui
       KL(KID_PREPARE_AGG, k_prepare_agg<2>, dim3(blocks_for(2 * m)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, aug,
                          (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad, 1);
     HIPCK(hipGetLastError());
+    // The Miller loops and the final exponentiation are enqueued at once (flagged pairs are skipped on the device); the
+    // identity flags come back together with the verdict, and the host applies the reference's precedence afterwards.
+    MILLER1_LAUNCH(m, m, d_pairs, d_bad, d_f);
+    if ((rc = run_f12_product_verdict(c, d_f, MILLER1_OUTPUTS(m), m, d_verdict))) return rc;
     if (scheme == BLSGPU_SCHEME_BASIC) {
-      duplicate_check();          // on the host, while k_prepare_agg runs
+      duplicate_check();          // on the host, while the device works
       if (trace) fprintf(stderr, "[blsgpu] aggregate_verify n=%zu: duplicate check %.2f ms (overlapped)\n", n, now() - t_staged);
     }
     std::vector<int32_t> bad(m);
+    int32_t verdict = BLSGPU_OK;
     HIPCK(hipMemcpyAsync(bad.data(), d_bad, 4 * m, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipMemcpyAsync(&verdict, d_verdict, 4, hipMemcpyDeviceToHost, c->stream));
     SYNC_FLUSH(c);
-    // reference src/traits/sig_core.rs:155-167: signature identity first, then the first identity key (1-based)
     if (st != BLSGPU_OK) {
       // duplicate messages: reported before any identity check (sig_basic.rs:46-58 precedes core_aggregate_verify)
-    } else if (bad[n]) {
+    } else if (bad[n]) {          // reference src/traits/sig_core.rs:155-167: signature identity first, ...
       st = BLSGPU_SIG_IDENTITY;
     } else {
       for (size_t i = 0; i < n; i++)
-        if (bad[i]) {
+        if (bad[i]) {             // ... then the first identity key (1-based)
           st = BLSGPU_PK_IDENTITY;
           aux_h[0] = i + 1;
           break;
         }
-    }
-    if (st == BLSGPU_OK) {
-      MILLER1_LAUNCH(m, m, d_pairs, d_bad, d_f);
-      if ((rc = run_f12_product_verdict(c, d_f, MILLER1_OUTPUTS(m), m, d_verdict))) return rc;
-      HIPCK(hipMemcpyAsync(&st, d_verdict, 4, hipMemcpyDeviceToHost, c->stream));
-      SYNC_FLUSH(c);
+      if (st == BLSGPU_OK) st = verdict;
     }
   }
   if (is_device_ptr(status)) HIPCK(hipMemcpy(status, &st, 4, hipMemcpyHostToDevice));
