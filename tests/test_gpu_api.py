@@ -372,7 +372,7 @@ def test_verify_batch_vs_c_oracle_lane_split_path(api, sg):
     with tampered messages, swapped signatures and swapped keys, both orientations, all three schemes' DSTs: the status
     vector must equal the C oracle's, item by item."""
     import os
-    n = 4608
+    n = int(os.environ.get('BLS_DIFF_N', '4608'))     # soak runs: BLS_DIFF_N=60000 (the C oracle then needs about a minute)
     bo = util.load_c_oracle()
     rng = random.Random(100 + sg)
     for scheme in (api.BASIC, api.AUG, api.POP):
