@@ -12,6 +12,7 @@
 //   MultiPublicKey<C>, MultiSignature<C>           src/multi_public_key.rs:79-83, src/multi_signature.rs:127-135
 //   AggregateSignature<C>                          src/aggregate_signature.rs:191-239
 //   ProofOfPossession<C>                           src/proof_of_possession.rs:79-81
+//   PublicKeyShare<C>, SignatureShare<C>           src/public_key_share.rs:53-72 (verify = the scheme's verify on the share values)
 //   verify_batch (additive; no reference entry)    n independent Signature::verify calls in one launch
 //
 // Header-only; link with -lblsgpu.  Every call goes to the GPU: there is no CPU path behind these types, and a missing
@@ -335,6 +336,21 @@ struct ProofOfPossession {
     if (rc) return detail::runtime_error(rc);
     return detail::from_status(st, nullptr, false);
   }
+};
+
+// Shamir shares of a key / a signature: identifier + value (vsss_rs share in the reference).  Only the partial-signature
+// check is on the accelerated path: PublicKeyShare::verify(sig_share, msg), src/public_key_share.rs:53-72, is the scheme's
+// verify on the two share values, i.e. one more item for blsgpu_verify_batch.
+template <class C>
+struct SignatureShare {
+  uint8_t identifier;
+  Signature<C> value;
+};
+template <class C>
+struct PublicKeyShare {
+  uint8_t identifier;
+  PublicKey<C> value;
+  BlsResult<Unit> verify(const SignatureShare<C>& sig, const Bytes& msg) const { return sig.value.verify(value, msg); }
 };
 
 }  // namespace blsful

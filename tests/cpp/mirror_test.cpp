@@ -130,6 +130,10 @@ static void test_schemes(uint8_t tag) {
     CHECK(sig.verify(pks[0], msg).is_ok());
     CHECK(sig.verify(pks[1], msg).unwrap_err().kind == BlsError::Kind::InvalidSignature);
     CHECK(sig.verify(pks[0], bytes_of("another message")).unwrap_err().kind == BlsError::Kind::InvalidSignature);
+    // partial signatures: PublicKeyShare::verify(sig_share, msg) (src/public_key_share.rs:53-72)
+    PublicKeyShare<C> pk_share{1, pks[0]};
+    CHECK(pk_share.verify(SignatureShare<C>{1, sig}, msg).is_ok());
+    CHECK((PublicKeyShare<C>{2, pks[1]}).verify(SignatureShare<C>{1, sig}, msg).unwrap_err().kind == BlsError::Kind::InvalidSignature);
     // wire round trip (to_bytes / try_from) keeps the key and the verdict
     auto pk2 = PublicKey<C>::try_from(pks[0].to_bytes()).unwrap();
     CHECK(pk2 == pks[0] && sig.verify(pk2, msg).is_ok());
