@@ -269,6 +269,37 @@ __device__ __forceinline__ void coop_job_put(coop_shared& S, int k, int j, const
   coop_st(S.job[k][j][1], b);
 }
 
+// f <- f^2 with the FIRST round of point-step products riding along: lane pairs 0..20 multiply the 21 coefficient pairs of
+// the squaring, lane pairs 21..30 the ten staged jobs S.job[k][0..4] (the same code on every lane pair: two LDS operands,
+// one product, one LDS result), so that a Miller iteration needs one product round less.
+__device__ __noinline__ void coop_sqr_with_jobs(coop_shared& S, coop_f12& f) {
+  __syncthreads();                 // the owners' job operands are staged
+  const int q = coop_pair();
+  const uint32_t *pa, *pb;
+  uint32_t* pd;
+  if (q < 21) {
+    int i, j, w;
+    coop_sqr_idx(q, i, j, w);
+    pa = f.c[i];
+    pb = f.c[j];
+    pd = S.prod[q];
+  } else {
+    const int jj = q < 31 ? q - 21 : 0, k = jj / 5, j = jj % 5;
+    pa = S.job[k][j][0];
+    pb = S.job[k][j][1];
+    pd = S.res[k][j];
+  }
+  if (q < 31) {
+    hfp2 x, y, p;
+    coop_ld(x, pa);
+    coop_ld(y, pb);
+    fp2_mul(p, x, y);
+    coop_st(pd, p);
+  }
+  __syncthreads();
+  coop_reduce<1>(S, f);
+}
+
 // Miller loop of two pairs into S.f.  fixed_g2: pair 1's G2 member is -g2 (line table), else both pairs are general.
 // Lane pair k (k = 0, 1) owns pair k's point T.  The doubling step -- nine dependent Fp2 products when one lane pair runs
 // it alone, the serial part of the loop -- is cut into two rounds of independent products spread over lane pairs
@@ -309,8 +340,7 @@ __device__ __noinline__ void coop_miller2(coop_shared& S, const g1_aff* P, const
   hfp2 l0, l2, l3, t;
   int row = 0;
   for (int i = 62; i >= 0; i--) {
-    if (i != 62) coop_sqr(S, S.f, S.f);
-    // ---- doubling step
+    // ---- doubling step (its first product round shares a round with the squaring of f)
     hfp2 a, b, c, e, f, h, g, s;
     if (owner) {
       if (table) {
@@ -329,7 +359,8 @@ __device__ __noinline__ void coop_miller2(coop_shared& S, const g1_aff* P, const
         coop_job_put(S, me, 4, h, h);
       }
     }
-    coop_jobs(S, 5);
+    if (i != 62) coop_sqr_with_jobs(S, S.f);
+    else coop_jobs(S, 5);
     if (owner) {
       if (table) {
         coop_ld(l2, S.res[me][0]);
