@@ -300,6 +300,35 @@ __device__ __noinline__ void coop_sqr_with_jobs(coop_shared& S, coop_f12& f) {
   coop_reduce<1>(S, f);
 }
 
+// f *= line `set` with the SECOND round of point-step products riding along (lane pairs 0..17: the 18 products of the
+// sparse multiplication; lane pairs 18..29: the staged jobs S.job[k][0..5]).  Used when pair 1's line comes from the -g2
+// table: that line is complete after the first round, so its multiplication need not wait for the general pair's step.
+__device__ __noinline__ void coop_mul_line_with_jobs(coop_shared& S, coop_f12& f, int set) {
+  __syncthreads();                 // line `set` and the owners' job operands are staged
+  const int q = coop_pair();
+  const uint32_t *pa, *pb;
+  uint32_t* pd;
+  if (q < 18) {
+    pa = f.c[q / 3];
+    pb = S.line[set][q % 3];
+    pd = S.prod[q];
+  } else {
+    const int jj = q < 30 ? q - 18 : 0, k = jj / 6, j = jj % 6;
+    pa = S.job[k][j][0];
+    pb = S.job[k][j][1];
+    pd = S.res[k][j];
+  }
+  if (q < 30) {
+    hfp2 x, y, p;
+    coop_ld(x, pa);
+    coop_ld(y, pb);
+    fp2_mul(p, x, y);
+    coop_st(pd, p);
+  }
+  __syncthreads();
+  coop_reduce<2>(S, f);
+}
+
 // Miller loop of two pairs into S.f.  fixed_g2: pair 1's G2 member is -g2 (line table), else both pairs are general.
 // Lane pair k (k = 0, 1) owns pair k's point T.  The doubling step -- nine dependent Fp2 products when one lane pair runs
 // it alone, the serial part of the loop -- is cut into two rounds of independent products spread over lane pairs
@@ -400,8 +429,14 @@ __device__ __noinline__ void coop_miller2(coop_shared& S, const g1_aff* P, const
         coop_job_put(S, me, 4, g, xp2); // l2
         coop_job_put(S, me, 5, h, yp2); // l3
       }
+      if (table) {                      // the table pair's line is complete: multiply it in while the other pair steps
+        coop_st(S.line[1][0], l0);
+        coop_st(S.line[1][1], l2);
+        coop_st(S.line[1][2], l3);
+      }
     }
-    coop_jobs(S, 6);
+    if (fixed_g2) coop_mul_line_with_jobs(S, S.f, 1);
+    else coop_jobs(S, 6);
     if (owner) {
       if (!table) {
         coop_ld(g, S.res[me][0]);
@@ -423,13 +458,15 @@ __device__ __noinline__ void coop_miller2(coop_shared& S, const g1_aff* P, const
         coop_ld(l2, S.res[me][4]);
         coop_ld(l3, S.res[me][5]);
       }
-      coop_st(S.line[me][0], l0);
-      coop_st(S.line[me][1], l2);
-      coop_st(S.line[me][2], l3);
+      if (!table) {
+        coop_st(S.line[me][0], l0);
+        coop_st(S.line[me][1], l2);
+        coop_st(S.line[me][2], l3);
+      }
     }
     __syncthreads();
     coop_mul_line(S, S.f, 0);
-    coop_mul_line(S, S.f, 1);
+    if (!fixed_g2) coop_mul_line(S, S.f, 1);
     row++;
     // ---- addition step (set bits of |x|)
     if ((BLS_X_ABS >> i) & 1) {
