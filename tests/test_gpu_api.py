@@ -368,11 +368,11 @@ def test_verify_batch_large_property(api):
 
 @pytest.mark.parametrize('sg', [1, 2])
 def test_verify_batch_vs_c_oracle_lane_split_path(api, sg):
-    """4,608 device-signed items (beyond the cooperative threshold: the lane-split Miller / final-exponentiation kernels)
+    """6,656 device-signed items (beyond the cooperative threshold of 6,144: the lane-split Miller / final-exponentiation kernels)
     with tampered messages, swapped signatures and swapped keys, both orientations, all three schemes' DSTs: the status
     vector must equal the C oracle's, item by item."""
     import os
-    n = int(os.environ.get('BLS_DIFF_N', '4608'))     # soak runs: BLS_DIFF_N=60000 (the C oracle then needs about a minute)
+    n = int(os.environ.get('BLS_DIFF_N', '6656'))     # soak runs: BLS_DIFF_N=60000 (the C oracle then needs about a minute)
     bo = util.load_c_oracle()
     rng = random.Random(100 + sg)
     for scheme in (api.BASIC, api.AUG, api.POP):
@@ -406,9 +406,9 @@ def test_verify_batch_vs_c_oracle_lane_split_path(api, sg):
 
 @pytest.mark.parametrize('sg', [1, 2])
 def test_verify_batch_ragged_sizes(api, sg):
-    """Batch sizes around the wave (32 items), workgroup and cooperative/lane-split (1,024 items) boundaries, empty batch
-    included: one tampered item per batch, exact verdict vectors, both orientations."""
-    sizes = (0, 1, 2, 31, 32, 33, 63, 65, 1023, 1024, 1025, 1057) if sg == 1 else (0, 1, 33, 1025)
+    """Batch sizes around the wave (32 items) and workgroup boundaries and on both sides of the cooperative / lane-split
+    threshold (6,144 items), empty batch included: one tampered item per batch, exact verdict vectors, both orientations."""
+    sizes = (0, 1, 2, 31, 32, 33, 63, 65, 1023, 1024, 1025, 1057, 6144, 6145, 6177) if sg == 1 else (0, 1, 33, 1025, 6145)
     nmax = max(sizes)
     sks = [0x5151 + 3 * i for i in range(nmax)]
     msgs = [hashlib.sha256(b'ragged%d' % i).digest() for i in range(nmax)]
