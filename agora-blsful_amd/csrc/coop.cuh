@@ -72,8 +72,9 @@ __device__ __forceinline__ void coop_reduce(coop_shared& S, coop_f12& dst) {
         else fp2_add(hiacc, hiacc, p);
       }
     }
-    // up to six staged products per half (limbs below 6 * 2^28): bring both halves back before xi doubles one of them
-    fp2_reduce(hiacc, hiacc);
+    // up to six staged products per half (limbs below 6 * 2^28 < 2^31): one carry pass brings the limbs of both halves
+    // back under 2^28 before xi doubles one of them; the value (below 20 p) is reduced once, at the end
+    fp2_norm(hiacc, hiacc);
     fp2_mul_xi(hiacc, hiacc);
     fp2_norm(lo, lo);
     fp2_add(lo, lo, hiacc);
