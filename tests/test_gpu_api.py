@@ -714,3 +714,22 @@ def test_concurrent_callers(api):
         sg, pks, sigs, m, e = jobs[k]
         single = api.multi_verify(sg, api.POP, pks[:50], sigs[0], m[0])
         assert out[k] == [e, single] * 3
+
+
+@pytest.mark.parametrize('C,sg', IMPLS, ids=['g1', 'g2'])
+def test_empty_message_through_the_overlapped_tails(api, C, sg):
+    """The zero-length message through MultiSignature::verify (message hashed on the side stream), verify_secure (message
+    hashed while the host derives the coefficients) and a single verify: the oracle's verdicts."""
+    rng = random.Random(140 + sg)
+    pkraw, sigraw = raw_fns(sg)
+    sks, pks = keys(C, 3, 61)
+    for msg in (b'', b'x'):
+        msig = ref.aggregate_signatures(C, [ref.sign(C, ref.POP, s, msg) for s in sks])
+        ref.multi_sig_verify(C, ref.POP, pks, msig, msg)
+        assert api.multi_verify(sg, api.POP, [pkraw(p, rng) for p in pks], sigraw(msig, rng), msg) == 0
+        assert api.multi_verify(sg, api.POP, [pkraw(p, rng) for p in pks[:2]], sigraw(msig, rng), msg) == 1
+        agg = ref.aggregate_secure(C, pks, [ref.sign(C, ref.BASIC, s, msg) for s in sks])
+        ref.verify_secure(C, ref.BASIC, pks, agg, msg)
+        assert api.verify_secure(sg, api.BASIC, [pkraw(p, rng) for p in pks], sigraw(agg, rng), msg) == 0
+        assert api.verify_secure(sg, api.BASIC, [pkraw(p, rng) for p in pks[:2]], sigraw(agg, rng), msg) == 1
+        assert api.verify_batch(sg, api.POP, [pkraw(pks[0], rng)], [sigraw(ref.sign(C, ref.POP, sks[0], msg), rng)], [msg]) == [0]
