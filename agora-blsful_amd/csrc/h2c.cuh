@@ -231,6 +231,60 @@ __device__ __forceinline__ void fp_lane_swap(fp& r, const fp& a) {
 #pragma unroll
   for (int i = 0; i < FP_NL; i++) r.l[i] = dpp_swap(a.l[i]);
 }
+// One G1 doubling by the TWO lanes of an item, which hold the same point: the seven field products of dbl-2009-l
+// (jac_dbl_body) run as FOUR steps instead of seven -- lane 0: A = X^2, F = (3A)^2, YZ, E (D - X3); lane 1: B = Y^2,
+// C = B^2, (X + B)^2 -- with the same operation order and reductions; lane 0 finishes the formulas (lane 1 executes the same
+// instructions on values it discards) and hands the result back.  The 64 doublings of the cofactor clearing are the
+// longest serial chain of a single verification's hash.
+__device__ __forceinline__ void jac_dbl_pair(g1_jac& p, bool hi) {
+  fp s1, s2, s3, in, a, b, o2, o3, D, E, t, x3, y3, z3, c8;
+  fp_sel(in, hi, p.y, p.x);
+  fp_sqr(s1, in);                 // lane 0: A = X^2          lane 1: B = Y^2
+  fp_dbl(E, s1);
+  fp_add(E, E, s1);
+  fp_reduce(E, E);                // lane 0: E = 3A
+  fp_sel(in, hi, s1, E);
+  fp_sqr(s2, in);                 // lane 0: F = E^2          lane 1: C = B^2
+  fp_add(t, p.x, s1);             //                          lane 1: X + B
+  fp_sel(a, hi, t, p.y);
+  fp_sel(b, hi, t, p.z);
+  fp_mul(s3, a, b);               // lane 0: Y Z              lane 1: (X + B)^2
+  fp_lane_swap(o2, s2);           // lane 0: C
+  fp_lane_swap(o3, s3);           // lane 0: (X + B)^2
+  fp_sub(t, o3, s1);
+  fp_sub(t, t, o2);
+  fp_dbl(D, t);
+  fp_reduce(D, D);                // D = 2((X + B)^2 - A - C)
+  fp_dbl(t, D);
+  fp_sub(t, s2, t);
+  fp_reduce(x3, t);               // X3 = F - 2D
+  fp_sub(t, D, x3);
+  fp_mul(t, E, t);                // E (D - X3)
+  fp_dbl(c8, o2);
+  fp_dbl(c8, c8);
+  fp_reduce(c8, c8);
+  fp_dbl(c8, c8);                 // 8C
+  fp_sub(t, t, c8);
+  fp_reduce(y3, t);
+  fp_dbl(z3, s3);
+  fp_reduce(z3, z3);              // Z3 = 2YZ
+  fp_lane_swap(a, x3);
+  fp_lane_swap(b, y3);
+  fp_lane_swap(t, z3);
+  fp_sel(p.x, hi, a, x3);
+  fp_sel(p.y, hi, b, y3);
+  fp_sel(p.z, hi, t, z3);
+}
+// [k] P as jac_mul_u64, the doublings shared by the two lanes (both hold the same P and end with the same result)
+__device__ __noinline__ void jac_mul_u64_pair(g1_jac& r, const g1_jac& p, uint64_t k, bool hi) {
+  g1_jac acc;
+  jac_set_inf(acc);
+  for (int i = 63; i >= 0; i--) {
+    jac_dbl_pair(acc, hi);
+    if ((k >> i) & 1) jac_add_body(acc, acc, p);
+  }
+  r = acc;
+}
 #endif
 BLS_NOINLINE void hash_to_g1(g1_jac& r, const uint8_t* pre, uint32_t pre_len, const uint8_t* m, uint32_t m_len,
                        const uint8_t* dst, uint32_t dst_len, int lane2 = -1) {
@@ -262,7 +316,11 @@ BLS_NOINLINE void hash_to_g1(g1_jac& r, const uint8_t* pre, uint32_t pre_len, co
   }
   jac_add(q0, q0, q1);
   // clear cofactor: h_eff = 1 - x = 1 + |x|
-  jac_mul_u64(q1, q0, BLS_X_ABS);
+#if defined(__HIPCC__)
+  if (lane2 >= 0) jac_mul_u64_pair(q1, q0, BLS_X_ABS, lane2 != 0);
+  else
+#endif
+    jac_mul_u64(q1, q0, BLS_X_ABS);
   jac_add(r, q1, q0);
 }
 
