@@ -366,13 +366,14 @@ def test_verify_batch_large_property(api):
     assert api.verify_batch(1, api.POP, pks, sigs2, msgs2) == expect
 
 
+@pytest.mark.parametrize('path', ['cooperative', 'lane_split'])
 @pytest.mark.parametrize('sg', [1, 2])
-def test_verify_batch_vs_c_oracle_lane_split_path(api, sg):
-    """6,656 device-signed items (beyond the cooperative threshold of 6,144: the lane-split Miller / final-exponentiation kernels)
-    with tampered messages, swapped signatures and swapped keys, both orientations, all three schemes' DSTs: the status
-    vector must equal the C oracle's, item by item."""
+def test_verify_batch_vs_c_oracle_lane_split_path(api, sg, path):
+    """Device-signed items with tampered messages, swapped signatures and swapped keys, both orientations, all three schemes'
+    DSTs: the status vector must equal the C oracle's, item by item.  704 items take the wave-cooperative pairing and the
+    two-lane prepare, 6,656 (beyond the threshold of 6,144) the lane-split Miller / final-exponentiation kernels."""
     import os
-    n = int(os.environ.get('BLS_DIFF_N', '6656'))     # soak runs: BLS_DIFF_N=60000 (the C oracle then needs about a minute)
+    n = 704 if path == 'cooperative' else int(os.environ.get('BLS_DIFF_N', '6656'))     # soak runs: BLS_DIFF_N=60000
     bo = util.load_c_oracle()
     rng = random.Random(100 + sg)
     for scheme in (api.BASIC, api.AUG, api.POP):
