@@ -154,7 +154,7 @@ BLS_NOINLINE bool fp2_sqrt_inv(fp2& r, const fp2& a, const fp* e, fp* einv) {
   // a1 != 0.  With n = |a| (the square root of the norm, which exists iff a is a square) and t = (a0 + n) / 2:
   //   s = t^((p+1)/4) satisfies s^2 = t or s^2 = -t (p = 3 mod 4), and a0 = t - a1^2 / (4 t), so
   //   sqrt(a) = s + a1/(2s) u   when s^2 = t,      a1/(2s) + s u   when s^2 = -t.
-  // Three exponentiations: sqrt(norm), s, 1/(2s).
+  // Two exponentiations (sqrt(norm), s) and the inversion 1/(2s) (safegcd, fp.cuh).
   fp n, t, h, s, c2, d;
   fp_sqr(n, a.c0);
   fp_sqr(t, a.c1);
