@@ -368,7 +368,7 @@ def test_verify_batch_large_property(api):
 
 @pytest.mark.parametrize('path', ['cooperative', 'lane_split'])
 @pytest.mark.parametrize('sg', [1, 2])
-def test_verify_batch_vs_c_oracle_lane_split_path(api, sg, path):
+def test_verify_batch_vs_c_oracle(api, sg, path):
     """Device-signed items with tampered messages, swapped signatures and swapped keys, both orientations, all three schemes'
     DSTs: the status vector must equal the C oracle's, item by item.  704 items take the wave-cooperative pairing and the
     two-lane prepare, 6,656 (beyond the threshold of 6,144) the lane-split Miller / final-exponentiation kernels."""
