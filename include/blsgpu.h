@@ -7,7 +7,7 @@
  * Conventions
  *   - Every buffer is caller-owned and borrowed for the duration of the call.  Pointers may be host pointers or
  *     HIP device pointers; the library detects which (hipPointerGetAttributes) and stages host buffers itself.
- *   - All calls are blocking, thread-safe (one internal stream guarded by a mutex) and deterministic.
+ *   - All calls are blocking, thread-safe (the internal streams are guarded by one mutex) and deterministic.
  *   - Return value: 0 = the call ran (look at the status outputs), < 0 = runtime failure (HIP error, bad argument);
  *     blsgpu_last_error() then gives a message.  There is NO CPU fallback: without a usable gfx950 device every
  *     compute entry point fails with BLSGPU_E_NO_DEVICE.
