@@ -210,6 +210,7 @@ __global__ void k_msm_bucket(size_t nb, const uint8_t* pts, int fmt, const uint3
 template <int G>
 __global__ void k_msm_chunk(int c, int W, int clast, int CH, const uint8_t* sums, uint8_t* partials);
 __global__ void k_msm_chunk_g2s(int c, int W, int clast, int CH, const uint8_t* sums, uint8_t* partials);
+__global__ void k_msm_chunk_g1p(int c, int W, int clast, int CH, const uint8_t* sums, uint8_t* partials);
 __global__ void k_msm_bucket_g2s(size_t nb, const uint8_t* pts, int fmt, const uint32_t* perm, const uint32_t* cnt, const uint32_t* off,
                                  const uint32_t* idx, uint8_t* sums);
 template <int G>
@@ -1073,6 +1074,41 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm_chunk_g2s(int c, int W, in
 }
 #endif
 #if defined(BLS_TU_MSM1)
+// k_msm_chunk for G1 on TWO lanes per chunk: everything runs on both lanes with identical operands except the doubling
+// chains -- the c-bit multiplier and, above all, the c * w doublings of the window weight, up to 240 in a row and the
+// critical path of the whole MSM (the kernel is latency-bound: a few hundred waves) -- which use the shared two-lane
+// doubling of h2c.cuh (four steps instead of seven products).
+__global__ void __launch_bounds__(BLS_BLOCK) k_msm_chunk_g1p(int c, int W, int clast, int CH, const uint8_t* sums, uint8_t* partials) {
+  const size_t cpw = ((size_t)1 << c) / CH, cpl = ((size_t)1 << clast) / CH;   // chunks per regular / last window
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, t = gid >> 1;
+  const bool hi = (gid & 1) != 0;
+  if (t >= cpw * (W - 1) + cpl) return;
+  const bool last = t >= cpw * (W - 1);
+  const int w = last ? W - 1 : (int)(t / cpw);
+  const size_t lo = (last ? t - cpw * (W - 1) : t % cpw) * CH;
+  const int wbits = last ? clast : c;
+  g1_jac run, acc, s;
+  jac_set_inf(run);
+  jac_set_inf(acc);
+  for (int d = CH - 1; d >= 0; d--) {
+    load_g1_pt(s, sums, ((size_t)w << c) + lo + d, 0);
+    jac_add(run, run, s);
+    jac_add(acc, acc, run);   // acc = sum_d (d + 1) S_{lo + d}
+  }
+  if (lo == 0) {              // sum_d (lo + d) S = acc + (lo - 1) run
+    jac_neg(s, run);
+  } else {
+    jac_set_inf(s);
+    const uint32_t mlt = (uint32_t)(lo - 1);
+    for (int bit = wbits; bit >= 0; bit--) {
+      jac_dbl_pair(s, hi);
+      if ((mlt >> bit) & 1u) jac_add(s, s, run);
+    }
+  }
+  jac_add(acc, acc, s);
+  for (int k = 0; k < c * w; k++) jac_dbl_pair(acc, hi);   // weight 2^(c w)
+  if (!hi) store_g1_pt(partials, t, acc);
+}
 template __global__ void k_decompress<1>(size_t, const uint8_t*, int, uint8_t*, int32_t*, int);
 template __global__ void k_msm_bucket<1>(size_t, const uint8_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*);
 template __global__ void k_msm_chunk<1>(int, int, int, int, const uint8_t*, uint8_t*);
