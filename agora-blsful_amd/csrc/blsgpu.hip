@@ -341,7 +341,7 @@ int run_msm_pippenger(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_sc
   KL(KID_MSM_SORT, k_msm_fill, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_scalars, p.c, p.W, p.clast, d_off, d_cur, d_idx);
   if (G == 2) KL(KID_MSM_BUCKET, k_msm_bucket_g2s, dim3(blocks_for(2 * p.nb)), dim3(BLS_BLOCK), p.nb, d_pts, fmt, d_perm, d_cnt, d_off, d_idx, d_sums);
   else KL(KID_MSM_BUCKET, k_msm_bucket<G>, dim3(blocks_for(p.nb)), dim3(BLS_BLOCK), p.nb, d_pts, fmt, d_perm, d_cnt, d_off, d_idx, d_sums);
-  if (G == 2) KL(KID_MSM_CHUNK, k_msm_chunk_g2s, dim3(blocks_for(2 * p.nchunks)), dim3(BLS_BLOCK), p.c, p.W, p.clast, p.CH, d_sums, d_part);
+  if (G == 2) KL(KID_MSM_CHUNK, k_msm_chunk_g2q, dim3(blocks_for(4 * p.nchunks)), dim3(BLS_BLOCK), p.c, p.W, p.clast, p.CH, d_sums, d_part);
   else KL(KID_MSM_CHUNK, k_msm_chunk_g1p, dim3(blocks_for(2 * p.nchunks)), dim3(BLS_BLOCK), p.c, p.W, p.clast, p.CH, d_sums, d_part);
   size_t cur = p.nchunks;
   while (cur > 1) {

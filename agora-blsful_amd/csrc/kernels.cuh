@@ -211,6 +211,7 @@ template <int G>
 __global__ void k_msm_chunk(int c, int W, int clast, int CH, const uint8_t* sums, uint8_t* partials);
 __global__ void k_msm_chunk_g2s(int c, int W, int clast, int CH, const uint8_t* sums, uint8_t* partials);
 __global__ void k_msm_chunk_g1p(int c, int W, int clast, int CH, const uint8_t* sums, uint8_t* partials);
+__global__ void k_msm_chunk_g2q(int c, int W, int clast, int CH, const uint8_t* sums, uint8_t* partials);
 __global__ void k_msm_bucket_g2s(size_t nb, const uint8_t* pts, int fmt, const uint32_t* perm, const uint32_t* cnt, const uint32_t* off,
                                  const uint32_t* idx, uint8_t* sums);
 template <int G>
@@ -1041,6 +1042,88 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm_bucket_g2s(size_t nb, cons
     jac_add(acc, acc, p);
   }
   st_g2s(sums, b, acc);
+}
+// One G2 doubling by the FOUR lanes of a chunk -- two lane pairs that hold the same lane-split point: the schedule of
+// jac_dbl_pair (h2c.cuh) one level up, lane PAIR 0 taking A = X^2, F = (3A)^2, YZ, E (D - X3) and lane pair 1 B = Y^2,
+// C = B^2, (X + B)^2; the pairs exchange by DPP quad_perm [2,3,0,1].  Same operation order and reductions as jac_dbl_body.
+__device__ __forceinline__ void hfp2_swap2(hfp2& r, const hfp2& a) {
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) r.v.l[i] = __builtin_amdgcn_mov_dpp(a.v.l[i], 0x4E, 0xF, 0xF, true);
+}
+__device__ __forceinline__ void hfp2_sel(hfp2& r, bool c, const hfp2& a, const hfp2& b) { fp_sel(r.v, c, a.v, b.v); }
+__device__ __forceinline__ void jac_dbl_quad(jac<hfp2>& p, bool hi2) {
+  hfp2 s1, s2, s3, in, a, b, o2, o3, D, E, t, x3, y3, z3, c8;
+  hfp2_sel(in, hi2, p.y, p.x);
+  fp2_sqr(s1, in);                // pair 0: A = X^2          pair 1: B = Y^2
+  fp2_dbl(E, s1);
+  fp2_add(E, E, s1);
+  fp2_reduce(E, E);               // pair 0: E = 3A
+  hfp2_sel(in, hi2, s1, E);
+  fp2_sqr(s2, in);                // pair 0: F = E^2          pair 1: C = B^2
+  fp2_add(t, p.x, s1);
+  fp2_norm(t, t);                 //                          pair 1: X + B
+  hfp2_sel(a, hi2, t, p.y);
+  hfp2_sel(b, hi2, t, p.z);
+  fp2_mul(s3, a, b);              // pair 0: Y Z              pair 1: (X + B)^2
+  hfp2_swap2(o2, s2);             // pair 0: C
+  hfp2_swap2(o3, s3);             // pair 0: (X + B)^2
+  fp2_sub(t, o3, s1);
+  fp2_sub(t, t, o2);
+  fp2_dbl(D, t);
+  fp2_reduce(D, D);               // D = 2((X + B)^2 - A - C)
+  fp2_dbl(t, D);
+  fp2_sub(t, s2, t);
+  fp2_reduce(x3, t);              // X3 = F - 2D
+  fp2_sub(t, D, x3);
+  fp2_norm(t, t);
+  fp2_mul(t, E, t);               // E (D - X3)
+  fp2_dbl(c8, o2);
+  fp2_dbl(c8, c8);
+  fp2_reduce(c8, c8);
+  fp2_dbl(c8, c8);                // 8C
+  fp2_sub(t, t, c8);
+  fp2_reduce(y3, t);
+  fp2_dbl(z3, s3);
+  fp2_reduce(z3, z3);             // Z3 = 2YZ
+  hfp2_swap2(a, x3);
+  hfp2_swap2(b, y3);
+  hfp2_swap2(t, z3);
+  hfp2_sel(p.x, hi2, a, x3);
+  hfp2_sel(p.y, hi2, b, y3);
+  hfp2_sel(p.z, hi2, t, z3);
+}
+// k_msm_chunk for G2 on FOUR lanes per chunk: as k_msm_chunk_g2s, the doubling chains (up to 240 doublings for the window
+// weight: the critical path of the MSM) shared by the two lane pairs
+__global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm_chunk_g2q(int c, int W, int clast, int CH, const uint8_t* sums, uint8_t* partials) {
+  const size_t cpw = ((size_t)1 << c) / CH, cpl = ((size_t)1 << clast) / CH;   // chunks per regular / last window
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, t = gid >> 2;
+  const bool hi2 = ((gid >> 1) & 1) != 0;
+  if (t >= cpw * (W - 1) + cpl) return;
+  const bool last = t >= cpw * (W - 1);
+  const int w = last ? W - 1 : (int)(t / cpw);
+  const size_t lo = (last ? t - cpw * (W - 1) : t % cpw) * CH;
+  const int wbits = last ? clast : c;
+  jac<hfp2> run, acc, s;
+  jac_set_inf(run);
+  jac_set_inf(acc);
+  for (int d = CH - 1; d >= 0; d--) {
+    ld_g2s(s, sums, ((size_t)w << c) + lo + d);
+    jac_add(run, run, s);
+    jac_add(acc, acc, run);   // acc = sum_d (d + 1) S_{lo + d}
+  }
+  if (lo == 0) {              // sum_d (lo + d) S = acc + (lo - 1) run
+    jac_neg(s, run);
+  } else {
+    jac_set_inf(s);
+    const uint32_t mlt = (uint32_t)(lo - 1);
+    for (int bit = wbits; bit >= 0; bit--) {
+      jac_dbl_quad(s, hi2);
+      if ((mlt >> bit) & 1u) jac_add(s, s, run);
+    }
+  }
+  jac_add(acc, acc, s);
+  for (int k = 0; k < c * w; k++) jac_dbl_quad(acc, hi2);   // weight 2^(c w)
+  if (!hi2) st_g2s(partials, t, acc);
 }
 __global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm_chunk_g2s(int c, int W, int clast, int CH, const uint8_t* sums, uint8_t* partials) {
   const size_t cpw = ((size_t)1 << c) / CH, cpl = ((size_t)1 << clast) / CH;   // chunks per regular / last window
