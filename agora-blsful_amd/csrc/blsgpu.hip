@@ -288,7 +288,8 @@ int run_point_sum(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_scalar
   size_t cur = T;
   while (cur > 1) {
     size_t half = (cur + 1) / 2;
-    KL(KID_POINT_FOLD, k_point_fold<G>, dim3(blocks_for(half)), dim3(BLS_BLOCK), cur, half, d_partials);
+    if (G == 2) KL(KID_POINT_FOLD, k_point_fold_g2s, dim3(blocks_for(2 * half)), dim3(BLS_BLOCK), cur, half, d_partials);
+    else KL(KID_POINT_FOLD, k_point_fold<G>, dim3(blocks_for(half)), dim3(BLS_BLOCK), cur, half, d_partials);
     cur = half;
   }
   HIPCK(hipGetLastError());
@@ -346,7 +347,8 @@ int run_msm_pippenger(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_sc
   size_t cur = p.nchunks;
   while (cur > 1) {
     size_t half = (cur + 1) / 2;
-    KL(KID_POINT_FOLD, k_point_fold<G>, dim3(blocks_for(half)), dim3(BLS_BLOCK), cur, half, d_part);
+    if (G == 2) KL(KID_POINT_FOLD, k_point_fold_g2s, dim3(blocks_for(2 * half)), dim3(BLS_BLOCK), cur, half, d_part);
+    else KL(KID_POINT_FOLD, k_point_fold<G>, dim3(blocks_for(half)), dim3(BLS_BLOCK), cur, half, d_part);
     cur = half;
   }
   KL(KID_MSM_CHUNK, k_normalize<G>, dim3(1), dim3(BLS_BLOCK), d_part);

@@ -195,6 +195,7 @@ __global__ void k_accumulate(size_t n, const uint8_t* pts, int fmt, const uint8_
 __global__ void k_accumulate_g2s(size_t n, const uint8_t* pts, int fmt, uint8_t* partials, size_t T);
 template <int G>
 __global__ void k_point_fold(size_t m, size_t half, uint8_t* partials);
+__global__ void k_point_fold_g2s(size_t m, size_t half, uint8_t* partials);
 template <int G>
 __global__ void k_compress(size_t n, const uint8_t* pts, int fmt, int legacy, uint8_t* out);
 template <int SG>
@@ -577,6 +578,18 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_accumulate_g2s(size_t n, const
     jac_add(acc, acc, p);
   }
   st_g2s(partials, t, acc);
+}
+// Stage 2 for G2 on two lanes per sum (jac<hfp2>): a fold level is one addition deep, i.e. latency-bound, and the
+// lane-split addition is less than half as long as the one-lane one (0.10 -> 0.05 ms per level; folding the last levels
+// inside one workgroup instead of one launch per level was measured too: no further gain)
+__global__ void __launch_bounds__(BLS_BLOCK, 2) k_point_fold_g2s(size_t m, size_t half, uint8_t* partials) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  if (i + half >= m || i >= half) return;
+  jac<hfp2> a, b;
+  ld_g2s(a, partials, i);
+  ld_g2s(b, partials, i + half);
+  jac_add(a, a, b);
+  st_g2s(partials, i, a);
 }
 // Stage 2: partial[i] += partial[i + half]
 template <int G>
