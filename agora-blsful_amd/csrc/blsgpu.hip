@@ -301,10 +301,13 @@ struct msm_plan {
   int c, W, clast, CH;
   size_t nb, nchunks;
 };
-msm_plan msm_make_plan(size_t n) {
+msm_plan msm_make_plan(size_t n, int G) {
   msm_plan p;
-  p.c = n >= 16384 ? 12 : 8;           // measured at 65,536 points (tools/dbg/msm.py): c = 12, CH = 8 beats 11 / 32 by 20 %
-  p.CH = 8;                            // short chunks: the 2^(c w) doublings of the chunk lanes dominate their critical path
+  // measured at 65,536 points (tools/dbg/msm.py).  The chunk kernel is latency-bound (doubling chains) and the bucket
+  // kernel throughput-bound, and a G2 addition costs about three G1 additions: G2 is best with 11-bit windows and 4-bucket
+  // chunks (sort 0.4 + buckets 3.3 + chunks 2.9 ms against 0.6 + 2.7 + 3.9 with 12 / 8), G1 with 12 / 8 (0.6 + 1.4 + 2.5)
+  p.c = n >= 16384 ? (G == 2 ? 11 : 12) : 8;
+  p.CH = (n >= 16384 && G == 2) ? 4 : 8;   // short chunks: the 2^(c w) doublings of the chunk lanes dominate their critical path
   if (const char* e = getenv("BLSGPU_MSM_C")) p.c = atoi(e);        // tuning overrides (window bits, buckets per chunk lane)
   if (const char* e = getenv("BLSGPU_MSM_CH")) p.CH = atoi(e);
   p.W = 255 / p.c;                      // scalars are < r < 2^255
@@ -313,9 +316,14 @@ msm_plan msm_make_plan(size_t n) {
   p.nchunks = p.nb / p.CH;
   return p;
 }
-size_t msm_ws_bytes(size_t n) {
-  msm_plan p = msm_make_plan(n);
-  return 3 * pad256(4 * p.nb) + pad256(4 * n * p.W) + pad256(288 * p.nb) + pad256(288 * p.nchunks) + 4096;
+size_t msm_ws_bytes(size_t n) {         // callers reserve for either group
+  size_t need = 0;
+  for (int G = 1; G <= 2; G++) {
+    msm_plan p = msm_make_plan(n, G);
+    size_t b = 3 * pad256(4 * p.nb) + pad256(4 * n * p.W) + pad256(288 * p.nb) + pad256(288 * p.nchunks) + 4096;
+    if (b > need) need = b;
+  }
+  return need;
 }
 bool msm_use_pippenger(size_t n) {
   static int force_naive = -1;
@@ -327,7 +335,7 @@ bool msm_use_pippenger(size_t n) {
 }
 template <int G>
 int run_msm_pippenger(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_scalars, const uint32_t* d_perm, size_t n, uint8_t* d_out) {
-  msm_plan p = msm_make_plan(n);
+  msm_plan p = msm_make_plan(n, G);
   uint32_t* d_cnt = (uint32_t*)arena_take(c, 4 * p.nb);
   uint32_t* d_off = (uint32_t*)arena_take(c, 4 * p.nb);
   uint32_t* d_cur = (uint32_t*)arena_take(c, 4 * p.nb);
