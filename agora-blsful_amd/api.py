@@ -34,6 +34,8 @@ EXPORTS = [
     'blsgpu_profile_enable', 'blsgpu_profile_count', 'blsgpu_profile_get',
     'blsgpu_aggregate_partial', 'blsgpu_fp12_product_is_one', 'blsgpu_core_verify', 'blsgpu_deserialize', 'blsgpu_pop_verify_batch', 'blsgpu_aggregate_secure',
     'blsgpu_signcrypt_valid_batch', 'blsgpu_sig_proof_verify_batch', 'blsgpu_pairing2_check_batch',
+    'blsgpu_init_devices', 'blsgpu_device_count', 'blsgpu_sort_keys', 'blsgpu_sorted_keys_digest',
+    'blsgpu_coefficients_for_range', 'blsgpu_first_duplicate_message', 'blsgpu_first_occurrence', 'blsgpu_signatures_from_tagged', 'blsgpu_signatures_to_tagged',
 ]
 
 
@@ -130,6 +132,14 @@ def load_library(path=None):
         lib.blsgpu_sig_proof_verify_batch.argtypes = [ci, ci, vp, vp, vp, u8p, u8p, u64p, sz, ci, i32p]
         lib.blsgpu_pairing2_check_batch.argtypes = [vp, vp, vp, vp, sz, ci, i32p]
         lib.blsgpu_profile_get.argtypes = [ci, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
+        lib.blsgpu_init_devices.argtypes = [ci]
+        lib.blsgpu_sort_keys.argtypes = [u8p, sz, sz, u32p]
+        lib.blsgpu_sorted_keys_digest.argtypes = [u8p, u32p, sz, sz, u8p]
+        lib.blsgpu_coefficients_for_range.argtypes = [u8p, u32p, sz, sz, sz, u8p, i32p]
+        lib.blsgpu_first_duplicate_message.argtypes = [u8p, u64p, sz, u64p]
+        lib.blsgpu_first_occurrence.argtypes = [u8p, u32p, sz, sz, u32p]
+        lib.blsgpu_signatures_from_tagged.argtypes = [ci, u8p, sz, u8p, vp, i32p]
+        lib.blsgpu_signatures_to_tagged.argtypes = [ci, u8p, vp, sz, ci, u8p]
         _lib = lib
     return _lib
 
@@ -396,6 +406,155 @@ def fp12_product_is_one(records):
     blob = b''.join(records)
     _check(lib.blsgpu_fp12_product_is_one(_ptr(blob), len(records), ctypes.byref(r)))
     return bool(r.value)
+
+
+def signatures_from_tagged(sig_group, blobs):
+    """Signature::try_from(&[u8]) per record (reference src/signature.rs:120-126): 49 / 97-byte serde_bare records ->
+    (schemes, RAW_PROJ points, statuses).  A record of the wrong length is BAD_LENGTH without touching the device."""
+    lib = init()
+    width = 48 if sig_group == 1 else 96
+    osz = 144 if sig_group == 1 else 288
+    good = [i for i, b in enumerate(blobs) if len(b) == width + 1]
+    n = len(good)
+    tags = ctypes.create_string_buffer(max(n, 1))
+    out = ctypes.create_string_buffer(osz * max(n, 1))
+    st = (ctypes.c_int32 * max(n, 1))()
+    blob = b''.join(blobs[i] for i in good)
+    _check(lib.blsgpu_signatures_from_tagged(sig_group, _ptr(blob), n, ctypes.cast(tags, ctypes.c_void_p), ctypes.cast(out, ctypes.c_void_p),
+                                             ctypes.cast(st, ctypes.c_void_p)))
+    schemes, pts, sts = [None] * len(blobs), [None] * len(blobs), [BAD_LENGTH] * len(blobs)
+    raw = out.raw
+    for k, i in enumerate(good):
+        schemes[i], pts[i], sts[i] = tags.raw[k], raw[osz * k:osz * (k + 1)], st[k]
+    return schemes, pts, sts
+
+
+def signatures_to_tagged(sig_group, schemes, sigs, fmt=FMT_RAW_PROJ):
+    """Vec<u8>::from(&Signature<C>) per signature (reference src/signature.rs:112-118): scheme byte + compressed point."""
+    lib = init()
+    n = len(sigs)
+    width = 48 if sig_group == 1 else 96
+    out = ctypes.create_string_buffer((width + 1) * max(n, 1))
+    _check(lib.blsgpu_signatures_to_tagged(sig_group, _ptr(bytes(schemes)), _ptr(b''.join(sigs)), n, fmt, ctypes.cast(out, ctypes.c_void_p)))
+    raw = out.raw
+    return [raw[(width + 1) * i:(width + 1) * (i + 1)] for i in range(n)]
+
+
+def first_duplicate_message(msgs):
+    """(old, i) of the Basic scheme's duplicate-message rule (reference src/traits/sig_basic.rs:46-58), or None."""
+    lib = init()
+    offs, blob = _offsets(msgs)
+    out = (ctypes.c_uint64 * 2)()
+    _check(lib.blsgpu_first_duplicate_message(_ptr(blob), ctypes.cast(offs, ctypes.c_void_p), len(msgs), ctypes.cast(out, ctypes.c_void_p)))
+    return None if out[1] == 2 ** 64 - 1 else (out[0], out[1])
+
+
+# ------------------------------------------------------------------ tensor-level calls (device-resident shards)
+class TensorOps:
+    """The C ABI on torch uint8 / int32 / int64 tensors that live on this process's GPU: every call passes data_ptr()s,
+    nothing is converted per item.  agora-blsful_amd/dist.py drives the one-process-per-GPU sharding through this object
+    (tests/fake_backend.py offers the same methods on CPU tensors, backed by the oracle, for the gloo tests)."""
+
+    def __init__(self, device):
+        import torch
+        self.torch, self.device = torch, device
+        self.lib = init(device.index if device.index is not None else -1)
+
+    @staticmethod
+    def _p(t):
+        return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
+
+    def empty(self, n, dtype=None):
+        return self.torch.empty(n, dtype=dtype or self.torch.uint8, device=self.device)
+
+    def verify_batch(self, sg, scheme, pks, sigs, msgs, offs, n):
+        st = self.empty(max(n, 1), self.torch.int32)
+        _check(self.lib.blsgpu_verify_batch(sg, scheme, self._p(pks), self._p(sigs), self._p(msgs), self._p(offs), n, FMT_RAW_PROJ, self._p(st)))
+        return st[:n]
+
+    def pop_verify_batch(self, sg, pks, proofs, n):
+        st = self.empty(max(n, 1), self.torch.int32)
+        _check(self.lib.blsgpu_pop_verify_batch(sg, self._p(pks), self._p(proofs), n, FMT_RAW_PROJ, self._p(st)))
+        return st[:n]
+
+    def sig_proof_verify_batch(self, sg, scheme, us, vs, pks, ys, msgs, offs, n):
+        st = self.empty(max(n, 1), self.torch.int32)
+        _check(self.lib.blsgpu_sig_proof_verify_batch(sg, scheme, self._p(us), self._p(vs), self._p(pks), self._p(ys), self._p(msgs), self._p(offs), n,
+                                                      FMT_RAW_PROJ, self._p(st)))
+        return st[:n]
+
+    def signcrypt_valid_batch(self, sg, scheme, us, ws, vs, offs, n):
+        st = self.empty(max(n, 1), self.torch.int32)
+        _check(self.lib.blsgpu_signcrypt_valid_batch(sg, scheme, self._p(us), self._p(ws), self._p(vs), self._p(offs), n, FMT_RAW_PROJ, self._p(st)))
+        return st[:n]
+
+    def point_sum(self, group, pts, n, scalars=None):
+        out = self.empty(144 if group == 1 else 288)
+        if scalars is None:
+            fn = self.lib.blsgpu_sum_g1 if group == 1 else self.lib.blsgpu_sum_g2
+            _check(fn(self._p(pts), n, FMT_RAW_PROJ, self._p(out)))
+        else:
+            fn = self.lib.blsgpu_msm_g1 if group == 1 else self.lib.blsgpu_msm_g2
+            _check(fn(self._p(pts), self._p(scalars), n, FMT_RAW_PROJ, self._p(out)))
+        return out
+
+    def multi_verify(self, sg, scheme, pks, n, sig, msg):
+        st = ctypes.c_int32(-99)
+        _check(self.lib.blsgpu_multi_verify(sg, scheme, self._p(pks), n, self._p(sig), _ptr(msg), len(msg), FMT_RAW_PROJ, ctypes.byref(st)))
+        return st.value
+
+    def core_verify_one(self, sg, dst, pk, sig, msg):
+        st = ctypes.c_int32(-99)
+        offs = (ctypes.c_uint64 * 2)(0, len(msg))
+        _check(self.lib.blsgpu_core_verify(sg, _ptr(dst), len(dst), self._p(pk), self._p(sig), _ptr(msg), ctypes.cast(offs, ctypes.c_void_p), 1,
+                                           FMT_RAW_PROJ, ctypes.byref(st)))
+        return st.value
+
+    def aggregate_partial(self, sg, scheme, pks, msgs, offs, n, sig=None):
+        """(576-byte record, first_bad) as DEVICE tensors: nothing crosses to the host."""
+        rec, fb = self.empty(576), self.empty(1, self.torch.int64)
+        _check(self.lib.blsgpu_aggregate_partial(sg, scheme, self._p(pks), self._p(msgs), self._p(offs), n, self._p(sig), FMT_RAW_PROJ,
+                                                 self._p(rec), ctypes.cast(self._p(fb), ctypes.POINTER(ctypes.c_int64))))
+        return rec, fb
+
+    def fp12_product_is_one(self, recs, k):
+        r = ctypes.c_int32(-99)
+        _check(self.lib.blsgpu_fp12_product_is_one(self._p(recs), k, ctypes.byref(r)))
+        return bool(r.value)
+
+    def first_duplicate(self, msgs, offs, n):
+        out = (ctypes.c_uint64 * 2)()
+        _check(self.lib.blsgpu_first_duplicate_message(self._p(msgs), self._p(offs), n, ctypes.cast(out, ctypes.c_void_p)))
+        return None if out[1] == 2 ** 64 - 1 else (out[0], out[1])
+
+    def serialize(self, group, pts, n, legacy=False):
+        out = self.empty((48 if group == 1 else 96) * max(n, 1))
+        _check(self.lib.blsgpu_serialize(group, self._p(pts), n, FMT_RAW_PROJ, FMT_LEGACY if legacy else FMT_COMPRESSED, self._p(out), None))
+        return out[:(48 if group == 1 else 96) * n]
+
+    def sort_keys(self, kb, n, width):
+        perm = self.empty(max(n, 1), self.torch.int32)
+        _check(self.lib.blsgpu_sort_keys(self._p(kb), n, width, self._p(perm)))
+        return perm[:n]
+
+    def keys_digest(self, kb, perm, n, width):
+        out = self.empty(32)
+        _check(self.lib.blsgpu_sorted_keys_digest(self._p(kb), self._p(perm), n, width, self._p(out)))
+        return out
+
+    def coefficients_for_range(self, digest, perm, n, base, count):
+        scal = self.empty(32 * max(count, 1))
+        st = ctypes.c_int32(-99)
+        _check(self.lib.blsgpu_coefficients_for_range(self._p(digest), self._p(perm), n, base, count, self._p(scal), ctypes.byref(st)))
+        return scal[:32 * count], st.value
+
+    def first_occurrence(self, kb, perm, n, width):
+        out = self.empty(max(n, 1), self.torch.int32)
+        _check(self.lib.blsgpu_first_occurrence(self._p(kb), self._p(perm), n, width, self._p(out)))
+        return out[:n]
+
+    def is_identity(self, group, pt):
+        return int(self.serialize(group, pt, 1)[0].item()) == 0xc0
 
 
 def profile_enable(on=True):

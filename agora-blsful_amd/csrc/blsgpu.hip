@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <numeric>
@@ -24,10 +25,10 @@ thread_local std::string t_err;
 
 enum {
   KID_PREPARE, KID_MILLER2, KID_FINALEXP, KID_PREPARE_AGG, KID_PAIRS_AFF, KID_MILLER1, KID_F12_FOLD, KID_FINALEXP_ONE,
-  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_F12_IO, KID_MSM_SORT, KID_MSM_BUCKET, KID_MSM_CHUNK, KID_DECOMPRESS, KID_PAIRING_COOP, KID_COUNT
+  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_F12_IO, KID_MSM_SORT, KID_MSM_BUCKET, KID_MSM_CHUNK, KID_DECOMPRESS, KID_PAIRING_COOP, KID_KEY_SORT, KID_COEFF, KID_DUP, KID_COUNT
 };
 const char* KID_NAMES[KID_COUNT] = {"k_prepare", "k_miller2", "k_finalexp", "k_prepare_agg", "k_pairs_to_affine", "k_miller1", "k_f12_fold",
-                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign", "k_f12_io", "k_msm_sort", "k_msm_bucket", "k_msm_chunk", "k_decompress", "k_pairing_coop"};
+                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign", "k_f12_io", "k_msm_sort", "k_msm_bucket", "k_msm_chunk", "k_decompress", "k_pairing_coop", "k_key_sort", "k_sha256_coeff", "k_duplicate_rule"};
 
 struct Ctx {
   int dev = -1;
@@ -38,6 +39,10 @@ struct Ctx {
   hipEvent_t ev_host = nullptr;   // "the host may read what was copied so far" marker (verify_secure)
   hipStream_t side = nullptr;     // side stream: the message hash of a multi_verify tail runs beside the key sum
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  uint8_t* hpin = nullptr;        // pinned host staging (sorted key bytes on their way to the host's SHA-256 stream)
+  size_t hpin_cap = 0;
+  uint8_t* hsmall = nullptr;      // pinned 64 KiB for the small host <-> device records of a call (offsets, flags, verdicts):
+  size_t hsmall_off = 0;          // they outlive every early return, unlike stack variables
   // optional per-kernel timing with HIP events on `stream` (blsgpu_profile_*)
   bool prof_on = false;
   struct Pending { int kid; hipEvent_t e0, e1; };
@@ -46,8 +51,64 @@ struct Ctx {
   double prof_ms[KID_COUNT] = {0};
   uint64_t prof_cnt[KID_COUNT] = {0};
 };
-Ctx* g_ctx = nullptr;
+// One pool of contexts per bound device: a call leases a free context (own stream, own arena, own mutex), so concurrent
+// callers overlap on the device instead of queueing behind one mutex.  Device index 0 is the device of blsgpu_init.
+struct Device {
+  int dev = -1;
+  std::vector<Ctx*> pool;
+  std::atomic<unsigned> rr{0};
+};
+std::vector<Device*> g_devices;     // written only under g_init_mu, before any compute call / after all of them
 std::mutex g_init_mu;
+bool initialised() { return !g_devices.empty(); }
+
+struct Lease {
+  Ctx* c = nullptr;
+  std::unique_lock<std::mutex> lk;
+  Lease() = default;
+  Lease(Lease&&) = default;
+  // An entry point that fails half-way returns without having synchronised: drain what it enqueued before the caller's
+  // buffers (and this context) are reused.  After a normal return both streams are idle and the queries cost nothing.
+  ~Lease() {
+    if (!c) return;
+    if (hipStreamQuery(c->stream) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipStreamSynchronize(c->stream);
+    }
+    if (c->side && hipStreamQuery(c->side) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipStreamSynchronize(c->side);
+    }
+  }
+};
+Lease acquire_ctx(size_t devidx) {
+  Device* d = g_devices[devidx];
+  Lease L;
+  for (Ctx* c : d->pool) {
+    std::unique_lock<std::mutex> lk(c->mu, std::try_to_lock);
+    if (lk.owns_lock()) {
+      L.c = c;
+      L.lk = std::move(lk);
+      return L;
+    }
+  }
+  Ctx* c = d->pool[d->rr.fetch_add(1) % d->pool.size()];
+  L.lk = std::unique_lock<std::mutex>(c->mu);
+  L.c = c;
+  return L;
+}
+#define CTX_ACQUIRE_ON(c, devidx)        \
+  Lease lease_ = acquire_ctx(devidx);     \
+  Ctx* c = lease_.c;                      \
+  c->hsmall_off = 0;                      \
+  HIPCK(hipSetDevice(c->dev))
+#define CTX_ACQUIRE(c) CTX_ACQUIRE_ON(c, 0)
+#define NOT_INIT() fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)")
+// no C++ exception may unwind into a C / Rust caller
+#define API_CATCH                                                                              \
+  catch (const std::bad_alloc&) { return fail(BLSGPU_E_HIP, "out of host memory"); }           \
+  catch (const std::exception& e) { return fail(BLSGPU_E_HIP, std::string("internal: ") + e.what()); } \
+  catch (...) { return fail(BLSGPU_E_HIP, "internal: unknown exception"); }
 
 int fail(int code, const std::string& msg) {
   t_err = msg;
@@ -92,6 +153,23 @@ void* arena_take(Ctx* c, size_t bytes) {
   return c->arena + off;
 }
 size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// small pinned records of a call (see Ctx::hsmall)
+const size_t HSMALL_BYTES = 65536;
+void* hsmall_take(Ctx* c, size_t bytes) {
+  size_t off = (c->hsmall_off + 63) & ~(size_t)63;
+  if (off + bytes > HSMALL_BYTES) return nullptr;
+  c->hsmall_off = off + bytes;
+  return c->hsmall + off;
+}
+// host -> device copy of a few bytes that live on the caller's stack
+int h2d_small(Ctx* c, void* d, const void* src, size_t bytes) {
+  void* h = hsmall_take(c, bytes);
+  if (!h) return fail(BLSGPU_E_HIP, "internal: pinned record buffer exhausted");
+  memcpy(h, src, bytes);
+  HIPCK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
 
 // device view of an input buffer: device pointers pass through, host buffers are staged into the arena
 int stage_in(Ctx* c, const void* p, size_t bytes, const void** out) {
@@ -139,7 +217,7 @@ dst_arg scheme_dst(int sg, int scheme) {
 }
 
 int check_common(int sg, int scheme, int fmt) {
-  if (!g_ctx) return fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)");
+  if (!initialised()) return NOT_INIT();
   if (sg != 1 && sg != 2) return fail(BLSGPU_E_ARG, "sig_group must be 1 (Bls12381G1Impl) or 2 (Bls12381G2Impl)");
   if (scheme < 0 || scheme > 2) return fail(BLSGPU_E_ARG, "scheme must be 0 (Basic), 1 (MessageAugmentation) or 2 (ProofOfPossession)");
   if (fmt != BLSGPU_FMT_RAW_PROJ && fmt != BLSGPU_FMT_RAW_AFFINE)
@@ -209,6 +287,42 @@ size_t coop_max_items() {
 }
 
 unsigned blocks_for(size_t n) { return (unsigned)((n + BLS_BLOCK - 1) / BLS_BLOCK); }
+
+int pinned_reserve(Ctx* c, size_t bytes) {
+  if (bytes <= c->hpin_cap) return 0;
+  if (c->hpin) HIPCK(hipHostFree(c->hpin));
+  c->hpin = nullptr;
+  c->hpin_cap = 0;
+  HIPCK(hipHostMalloc((void**)&c->hpin, bytes + bytes / 8 + 4096, hipHostMallocDefault));
+  c->hpin_cap = bytes + bytes / 8 + 4096;
+  return 0;
+}
+
+// exclusive prefix sum of m u32 counters (three launches, util_kernels.cuh); d_tiles: scan_tiles(m) words
+size_t scan_tiles(size_t m) { return (m + UK_SCAN_TILE - 1) / UK_SCAN_TILE; }
+int run_scan_u32(Ctx* c, int kid, size_t m, const uint32_t* d_in, uint32_t* d_out, uint32_t* d_tiles) {
+  if (m == 0) return 0;
+  const unsigned nt = (unsigned)scan_tiles(m);
+  KL(kid, k_scan_tiles, dim3(nt), dim3(BLS_BLOCK), m, d_in, d_out, d_tiles);
+  if (nt > 1) {
+    KL(kid, k_scan_top, dim3(1), dim3(BLS_BLOCK), (size_t)nt, d_tiles);
+    KL(kid, k_scan_apply, dim3(nt), dim3(BLS_BLOCK), m, d_out, (const uint32_t*)d_tiles);
+  }
+  HIPCK(hipGetLastError());
+  return 0;
+}
+int run_scan_max_u32(Ctx* c, int kid, size_t m, uint32_t* d_v, uint32_t* d_tiles) {
+  if (m == 0) return 0;
+  const unsigned nt = (unsigned)scan_tiles(m);
+  KL(kid, k_scan_max_tiles, dim3(nt), dim3(BLS_BLOCK), m, d_v, d_tiles);
+  if (nt > 1) {
+    KL(kid, k_scan_max_top, dim3(1), dim3(BLS_BLOCK), (size_t)nt, d_tiles);
+    KL(kid, k_scan_max_apply, dim3(nt), dim3(BLS_BLOCK), m, d_v, (const uint32_t*)d_tiles);
+  }
+  HIPCK(hipGetLastError());
+  return 0;
+}
+
 
 // ---- shared device pipelines (stream-ordered; caller holds the context mutex) ------------------------
 
@@ -308,8 +422,13 @@ msm_plan msm_make_plan(size_t n, int G) {
   // chunks (sort 0.4 + buckets 3.3 + chunks 2.9 ms against 0.6 + 2.7 + 3.9 with 12 / 8), G1 with 12 / 8 (0.6 + 1.4 + 2.5)
   p.c = n >= 16384 ? (G == 2 ? 11 : 12) : 8;
   p.CH = (n >= 16384 && G == 2) ? 4 : 8;   // short chunks: the 2^(c w) doublings of the chunk lanes dominate their critical path
-  if (const char* e = getenv("BLSGPU_MSM_C")) p.c = atoi(e);        // tuning overrides (window bits, buckets per chunk lane)
-  if (const char* e = getenv("BLSGPU_MSM_CH")) p.CH = atoi(e);
+  if (const char* e = getenv("BLSGPU_MSM_C")) p.c = atoi(e);        // tuning overrides (window bits, buckets per chunk lane),
+  if (const char* e = getenv("BLSGPU_MSM_CH")) p.CH = atoi(e);      // clamped to what the kernels assume
+  if (p.c < 4) p.c = 4;
+  if (p.c > 16) p.c = 16;
+  if (p.CH < 1) p.CH = 1;
+  while (p.CH & (p.CH - 1)) p.CH &= p.CH - 1;                       // a power of two, so that it divides 2^c and 2^clast
+  if (p.CH > (1 << p.c)) p.CH = 1 << p.c;
   p.W = 255 / p.c;                      // scalars are < r < 2^255
   p.clast = 255 - p.c * (p.W - 1);      // the last window takes the remainder: c <= clast < 2c
   p.nb = ((size_t)(p.W - 1) << p.c) + ((size_t)1 << p.clast);
@@ -320,7 +439,7 @@ size_t msm_ws_bytes(size_t n) {         // callers reserve for either group
   size_t need = 0;
   for (int G = 1; G <= 2; G++) {
     msm_plan p = msm_make_plan(n, G);
-    size_t b = 3 * pad256(4 * p.nb) + pad256(4 * n * p.W) + pad256(288 * p.nb) + pad256(288 * p.nchunks) + 4096;
+    size_t b = 3 * pad256(4 * p.nb) + pad256(4 * n * p.W) + pad256(4 * scan_tiles(p.nb)) + pad256(288 * p.nb) + pad256(288 * p.nchunks) + 4096;
     if (b > need) need = b;
   }
   return need;
@@ -340,13 +459,17 @@ int run_msm_pippenger(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_sc
   uint32_t* d_off = (uint32_t*)arena_take(c, 4 * p.nb);
   uint32_t* d_cur = (uint32_t*)arena_take(c, 4 * p.nb);
   uint32_t* d_idx = (uint32_t*)arena_take(c, 4 * n * p.W);
+  uint32_t* d_tiles = (uint32_t*)arena_take(c, 4 * scan_tiles(p.nb));
   uint8_t* d_sums = (uint8_t*)arena_take(c, 288 * p.nb);
   uint8_t* d_part = (uint8_t*)arena_take(c, 288 * p.nchunks);
-  if (!d_cnt || !d_off || !d_cur || !d_idx || !d_sums || !d_part) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  if (!d_cnt || !d_off || !d_cur || !d_idx || !d_tiles || !d_sums || !d_part) return fail(BLSGPU_E_HIP, "internal: arena too small");
   HIPCK(hipMemsetAsync(d_cnt, 0, 4 * p.nb, c->stream));
   HIPCK(hipMemsetAsync(d_cur, 0, 4 * p.nb, c->stream));
   KL(KID_MSM_SORT, k_msm_count, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_scalars, p.c, p.W, p.clast, d_cnt);
-  KL(KID_MSM_SORT, k_msm_scan, dim3(1), dim3(BLS_BLOCK), p.nb, d_cnt, d_off);
+  {
+    int rc = run_scan_u32(c, KID_MSM_SORT, p.nb, d_cnt, d_off, d_tiles);
+    if (rc) return rc;
+  }
   KL(KID_MSM_SORT, k_msm_fill, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_scalars, p.c, p.W, p.clast, d_off, d_cur, d_idx);
   if (G == 2) KL(KID_MSM_BUCKET, k_msm_bucket_g2s, dim3(blocks_for(2 * p.nb)), dim3(BLS_BLOCK), p.nb, d_pts, fmt, d_perm, d_cnt, d_off, d_idx, d_sums);
   else KL(KID_MSM_BUCKET, k_msm_bucket<G>, dim3(blocks_for(p.nb)), dim3(BLS_BLOCK), p.nb, d_pts, fmt, d_perm, d_cnt, d_off, d_idx, d_sums);
@@ -365,115 +488,129 @@ int run_msm_pippenger(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_sc
   return 0;
 }
 
-// 256-bit big-endian hash -> scalar mod r, 32 bytes little-endian; returns false when the result is zero.
-// Restates `int_BE(hash) mod r` of reference src/secure_aggregation.rs:61-100.
-const uint32_t R_LIMBS[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
-bool hash_to_scalar_le(const uint8_t hash[32], uint8_t out[32]) {
-  uint32_t v[8];
-  for (int i = 0; i < 8; i++) {
-    const uint8_t* q = hash + 4 * (7 - i);
-    v[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+
+// ---- hash_public_keys_with_sorted on the device (reference src/secure_aggregation.rs:41-103,269-335) -----------------
+// Workspace of the key sort / coefficient step, carved from the arena.
+struct keysort_ws {
+  uint32_t *perm_a, *perm_b, *hist, *tiles, *flag;
+  uint8_t* sorted;
+  size_t ntiles;
+};
+size_t keysort_ws_bytes(size_t n, size_t width) {
+  const size_t nt = (n + UK_SORT_TILE - 1) / UK_SORT_TILE;
+  return 2 * pad256(4 * n) + pad256(4 * 256 * nt) + pad256(4 * scan_tiles(256 * nt)) + pad256(width * n) + 5 * 256 + 64;
+}
+int keysort_ws_take(Ctx* c, size_t n, size_t width, keysort_ws& w) {
+  w.ntiles = (n + UK_SORT_TILE - 1) / UK_SORT_TILE;
+  w.perm_a = (uint32_t*)arena_take(c, 4 * n);
+  w.perm_b = (uint32_t*)arena_take(c, 4 * n);
+  w.hist = (uint32_t*)arena_take(c, 4 * 256 * w.ntiles);
+  w.tiles = (uint32_t*)arena_take(c, 4 * scan_tiles(256 * w.ntiles));
+  w.sorted = (uint8_t*)arena_take(c, width * n);
+  w.flag = (uint32_t*)arena_take(c, 64);
+  if (!w.perm_a || !w.perm_b || !w.hist || !w.tiles || !w.sorted || !w.flag) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  return 0;
+}
+// stable LSD radix sort on key bytes [0, nbytes): the result lands in w.perm_a
+int run_key_sort_passes(Ctx* c, const uint8_t* d_kb, size_t n, size_t width, int nbytes, keysort_ws& w) {
+  // nbytes passes ping-pong between the two buffers; start so that the last pass writes perm_a
+  uint32_t* bufs[2] = {w.perm_a, w.perm_b};
+  int dst = (nbytes & 1) ? 0 : 1;
+  const uint32_t* src = nullptr;   // identity
+  const unsigned nt = (unsigned)w.ntiles;
+  for (int b = nbytes - 1; b >= 0; b--) {
+    KL(KID_KEY_SORT, k_rs_hist, dim3(nt), dim3(BLS_BLOCK), n, d_kb, width, b, src, w.hist, w.ntiles);
+    int rc = run_scan_u32(c, KID_KEY_SORT, 256 * w.ntiles, w.hist, w.hist, w.tiles);
+    if (rc) return rc;
+    KL(KID_KEY_SORT, k_rs_scatter, dim3(nt), dim3(BLS_BLOCK), n, d_kb, width, b, src, (const uint32_t*)w.hist, w.ntiles, bufs[dst]);
+    src = bufs[dst];
+    dst ^= 1;
   }
-  for (int round = 0; round < 3; round++) {  // hash < 2^256 < 3r
-    uint32_t d[8];
-    uint64_t bw = 0;
-    for (int i = 0; i < 8; i++) {
-      uint64_t s = (uint64_t)v[i] - R_LIMBS[i] - bw;
-      d[i] = (uint32_t)s;
-      bw = (s >> 63) & 1;
+  HIPCK(hipGetLastError());
+  return 0;
+}
+// The keys are compressed curve points, i.e. their leading bytes are as good as random: sort on the first 8 bytes only and
+// check that no two neighbours tie there; only if they do (duplicate keys, adversarial prefixes) sort again on every byte.
+// Leaves the permutation in w.perm_a, the sorted concatenation in the pinned host buffer (c->hpin) and synchronises.
+const int KEYSORT_PREFIX = 8;
+int run_key_sort_to_host(Ctx* c, const uint8_t* d_kb, size_t n, size_t width, keysort_ws& w, hipEvent_t ev_ready, bool* used_full) {
+  int rc = pinned_reserve(c, width * n + 64);
+  if (rc) return rc;
+  uint32_t* h_flag = (uint32_t*)(c->hpin + ((width * n + 63) & ~(size_t)63));
+  for (int attempt = 0; attempt < 2; attempt++) {
+    const int nbytes = attempt == 0 ? KEYSORT_PREFIX : (int)width;
+    if ((rc = run_key_sort_passes(c, d_kb, n, width, nbytes, w))) return rc;
+    HIPCK(hipMemsetAsync(w.flag, 0, 4, c->stream));
+    if (attempt == 0)
+      KL(KID_KEY_SORT, k_keys_tie_flag, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_kb, width, (size_t)KEYSORT_PREFIX, (const uint32_t*)w.perm_a, w.flag);
+    KL(KID_KEY_SORT, k_keys_gather, dim3(blocks_for(n * (width / 4))), dim3(BLS_BLOCK), n, d_kb, width, (const uint32_t*)w.perm_a, w.sorted);
+    HIPCK(hipGetLastError());
+    HIPCK(hipMemcpyAsync(c->hpin, w.sorted, width * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipMemcpyAsync(h_flag, w.flag, 4, hipMemcpyDeviceToHost, c->stream));
+    if (ev_ready && attempt == 0) {
+      HIPCK(hipEventRecord(ev_ready, c->stream));
+      return 0;                       // the caller enqueues more work, then calls run_key_sort_finish
     }
-    if (bw) break;
-    memcpy(v, d, sizeof v);
+    HIPCK(hipStreamSynchronize(c->stream));
+    if (*h_flag == 0) break;
+    if (used_full) *used_full = true;
   }
-  uint32_t nz = 0;
-  for (int i = 0; i < 8; i++) {
-    nz |= v[i];
-    out[4 * i] = (uint8_t)v[i];
-    out[4 * i + 1] = (uint8_t)(v[i] >> 8);
-    out[4 * i + 2] = (uint8_t)(v[i] >> 16);
-    out[4 * i + 3] = (uint8_t)(v[i] >> 24);
-  }
-  return nz != 0;
+  return 0;
+}
+// second half of the overlapped form: wait for the prefix-sorted bytes; redo with the full sort when the prefix tied
+int run_key_sort_finish(Ctx* c, const uint8_t* d_kb, size_t n, size_t width, keysort_ws& w, hipEvent_t ev_ready, bool* used_full) {
+  HIPCK(hipEventSynchronize(ev_ready));
+  const uint32_t* h_flag = (const uint32_t*)(c->hpin + ((width * n + 63) & ~(size_t)63));
+  if (*h_flag == 0) return 0;
+  if (used_full) *used_full = true;
+  int rc = run_key_sort_passes(c, d_kb, n, width, (int)width, w);
+  if (rc) return rc;
+  KL(KID_KEY_SORT, k_keys_gather, dim3(blocks_for(n * (width / 4))), dim3(BLS_BLOCK), n, d_kb, width, (const uint32_t*)w.perm_a, w.sorted);
+  HIPCK(hipGetLastError());
+  HIPCK(hipMemcpyAsync(c->hpin, w.sorted, width * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+// H = SHA-256(sorted key bytes): ONE sequential hash stream (reference :45-59), which is why it runs on a host core
+// (SHA-NI: ~2 GB/s; a GPU lane would need ~100 ms for it)
+void keys_digest_host(const uint8_t* sorted, size_t bytes, uint8_t H[32]) {
+  host_sha256 h;
+  h.update(sorted, bytes);
+  h.final(H);
+}
+// t_p for every sorted position p on the device.  sorted_order: d_scal[p]; else d_scal[perm[p] - base] for keys of the shard
+int run_coefficients(Ctx* c, const uint8_t* d_H, const uint32_t* d_perm, size_t n, size_t base, size_t count, int sorted_order,
+                     uint8_t* d_scal, int32_t* d_zero_flag) {
+  KL(KID_COEFF, k_sha256_coeff, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_H, d_perm, base, count, sorted_order, d_scal, d_zero_flag);
+  HIPCK(hipGetLastError());
+  return 0;
 }
 
-// host part of hash_public_keys_with_sorted (reference src/secure_aggregation.rs:41-103): stable sort by serialised
-// bytes, H = SHA-256(concat), t_i = SHA-256(BE32(i) || H) mod r.  Returns BLSGPU_OK or BLSGPU_INVALID_COEFFICIENT.
-int secure_coefficients_host(const uint8_t* kb, size_t n, size_t width, std::vector<uint32_t>& perm, std::vector<uint8_t>& scalars) {
-  const bool trace = getenv("BLSGPU_HOST_TRACE") != nullptr;
-  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double t_start = now();
-  perm.resize(n);
-  std::iota(perm.begin(), perm.end(), 0u);
-  // byte-lexicographic and stable (Rust's sort_by is stable): LSD radix sort (4 x 16 bits, stable) on the first 8 bytes
-  // read as a big-endian word, then a stable comparison sort of every run of equal prefixes on the remaining bytes
-  std::vector<uint64_t> pre(n);
-  for (size_t i = 0; i < n; i++) {
-    uint64_t v = 0;
-    for (int k = 0; k < 8; k++) v = (v << 8) | kb[i * width + k];
-    pre[i] = v;
+// ---- Basic's duplicate-message rule on device-resident messages (util_kernels.cuh) -> d_out2 = (old, i) or (~0, ~0)
+size_t dup_ws_bytes(size_t n) {
+  size_t cap = 64;
+  while (cap < 2 * n) cap <<= 1;
+  return 2 * pad256(4 * cap) + pad256(4 * n) + 1024;
+}
+int run_first_duplicate(Ctx* c, const uint8_t* d_msgs, const uint64_t* d_offs, size_t n, uint64_t* d_out2) {
+  if (n >= 0xffffffffull) return fail(BLSGPU_E_ARG, "more than 2^32 - 2 messages");
+  size_t cap = 64;
+  while (cap < 2 * n) cap <<= 1;
+  uint32_t* tab = (uint32_t*)arena_take(c, 4 * cap);
+  uint32_t* minidx = (uint32_t*)arena_take(c, 4 * cap);
+  uint32_t* slot_of = (uint32_t*)arena_take(c, 4 * (n ? n : 1));
+  uint32_t* best = (uint32_t*)arena_take(c, 64);
+  if (!tab || !minidx || !slot_of || !best) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  HIPCK(hipMemsetAsync(tab, 0xff, 4 * cap, c->stream));
+  HIPCK(hipMemsetAsync(minidx, 0xff, 4 * cap, c->stream));
+  HIPCK(hipMemsetAsync(best, 0xff, 4, c->stream));
+  if (n) {
+    KL(KID_DUP, k_dup_insert, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_msgs, d_offs, (uint32_t)(cap - 1), tab, minidx, slot_of);
+    KL(KID_DUP, k_dup_find, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint32_t*)slot_of, (const uint32_t*)minidx, best);
   }
-  {
-    std::vector<uint32_t> tmp(n), cnt(65536);
-    for (int pass = 0; pass < 4; pass++) {
-      const int sh = 16 * pass;
-      std::fill(cnt.begin(), cnt.end(), 0u);
-      for (size_t i = 0; i < n; i++) cnt[(pre[perm[i]] >> sh) & 0xffff]++;
-      uint32_t run = 0;
-      for (size_t d = 0; d < 65536; d++) {
-        const uint32_t c0 = cnt[d];
-        cnt[d] = run;
-        run += c0;
-      }
-      for (size_t i = 0; i < n; i++) tmp[cnt[(pre[perm[i]] >> sh) & 0xffff]++] = perm[i];
-      perm.swap(tmp);
-    }
-  }
-  for (size_t a = 0; a < n;) {
-    size_t b = a + 1;
-    while (b < n && pre[perm[b]] == pre[perm[a]]) b++;
-    if (b - a > 1)
-      std::stable_sort(perm.begin() + a, perm.begin() + b, [&](uint32_t x, uint32_t y) {
-        return memcmp(kb + (size_t)x * width + 8, kb + (size_t)y * width + 8, width - 8) < 0;
-      });
-    a = b;
-  }
-  const double t_sorted = now();
-  host_sha256 h;
-  for (size_t i = 0; i < n; i++) h.update(kb + (size_t)perm[i] * width, width);
-  uint8_t H[32];
-  h.final(H);
-  const double t_hashed = now();
-  scalars.resize(32 * n);
-  // t_i = SHA256(BE32(i) || H): independent one-block hashes, spread over the host cores (the sorted-key hash above is one
-  // sequential stream and stays on one core)
-  unsigned nthr = std::thread::hardware_concurrency();
-  if (nthr > 16) nthr = 16;
-  if (nthr < 1 || n < 4096) nthr = 1;
-  std::vector<int> bad(nthr, 0);
-  auto work = [&](unsigned t) {
-    const size_t lo = n * t / nthr, hi = n * (t + 1) / nthr;
-    for (size_t i = lo; i < hi; i++) {
-      uint8_t buf[36] = {(uint8_t)(i >> 24), (uint8_t)(i >> 16), (uint8_t)(i >> 8), (uint8_t)i};
-      memcpy(buf + 4, H, 32);
-      uint8_t d[32];
-      host_sha256 hi2;
-      hi2.update(buf, 36);
-      hi2.final(d);
-      if (!hash_to_scalar_le(d, &scalars[32 * i])) bad[t] = 1;
-    }
-  };
-  if (nthr == 1) {
-    work(0);
-  } else {
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < nthr; t++) pool.emplace_back(work, t);
-    for (auto& th : pool) th.join();
-  }
-  for (unsigned t = 0; t < nthr; t++)
-    if (bad[t]) return BLSGPU_INVALID_COEFFICIENT;
-  if (trace) fprintf(stderr, "[blsgpu] secure coefficients n=%zu: sort %.2f ms, key hash %.2f ms, coefficient hashes %.2f ms\n", n,
-                     t_sorted - t_start, t_hashed - t_sorted, now() - t_hashed);
-  return BLSGPU_OK;
+  KL(KID_DUP, k_dup_fin, dim3(1), dim3(BLS_BLOCK), (const uint32_t*)best, (const uint32_t*)slot_of, (const uint32_t*)minidx, d_out2);
+  HIPCK(hipGetLastError());
+  return 0;
 }
 
 }  // namespace
@@ -481,9 +618,77 @@ int secure_coefficients_host(const uint8_t* kb, size_t n, size_t width, std::vec
 // =========================================================================================================
 extern "C" {
 
-int blsgpu_init(int device) {
+// binds one device: a pool of contexts on it
+static int bind_device(int device, int ndev) {
+  if (device >= ndev) return fail(BLSGPU_E_ARG, "device ordinal out of range");
+  HIPCK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCK(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return fail(BLSGPU_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 (MI355X) only");
+  int nctx = 2;                     // contexts per device (BLSGPU_CONTEXTS): concurrent callers beyond this queue up
+  if (const char* e = getenv("BLSGPU_CONTEXTS")) nctx = atoi(e);
+  if (nctx < 1) nctx = 1;
+  if (nctx > 16) nctx = 16;
+  Device* d = new Device();
+  d->dev = device;
+  for (int k = 0; k < nctx; k++) {
+    Ctx* c = new Ctx();
+    c->dev = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+      e = hipHostMalloc((void**)&c->hsmall, HSMALL_BYTES, hipHostMallocDefault);
+      if (e != hipSuccess) (void)hipStreamDestroy(c->stream);
+    }
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      delete c;
+      for (Ctx* q : d->pool) {
+        (void)hipStreamDestroy(q->stream);
+        (void)hipHostFree(q->hsmall);
+        delete q;
+      }
+      delete d;
+      return fail(BLSGPU_E_HIP, std::string("creating a context (stream / pinned memory): ") + hipGetErrorString(e));
+    }
+    d->pool.push_back(c);
+  }
+  g_devices.push_back(d);
+  return 0;
+}
+
+static void release_devices() {
+  for (Device* d : g_devices) {
+    (void)hipSetDevice(d->dev);
+    for (Ctx* c : d->pool) {
+      std::lock_guard<std::mutex> lk(c->mu);   // waits for a call in flight on this context
+      (void)hipStreamSynchronize(c->stream);
+      if (c->arena) (void)hipFree(c->arena);
+      if (c->ev_host) (void)hipEventDestroy(c->ev_host);
+      if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+      if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+      if (c->side) (void)hipStreamDestroy(c->side);
+      if (c->hpin) (void)hipHostFree(c->hpin);
+      if (c->hsmall) (void)hipHostFree(c->hsmall);
+      for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
+      (void)hipStreamDestroy(c->stream);
+    }
+  }
+  for (Device* d : g_devices) {
+    for (Ctx* c : d->pool) delete c;
+    delete d;
+  }
+  g_devices.clear();
+}
+
+int blsgpu_init(int device) try {
   std::lock_guard<std::mutex> lk(g_init_mu);
-  if (g_ctx) return 0;
+  if (initialised()) {
+    if (device >= 0 && device != g_devices[0]->dev)
+      return fail(BLSGPU_E_ARG, "blsgpu_init: the library is already bound to device " + std::to_string(g_devices[0]->dev) +
+                                    " (call blsgpu_shutdown first to rebind)");
+    return 0;
+  }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0) {
@@ -493,57 +698,101 @@ int blsgpu_init(int device) {
   if (device < 0) {
     if (hipGetDevice(&device) != hipSuccess) device = 0;
   }
-  if (device >= ndev) return fail(BLSGPU_E_ARG, "device ordinal out of range");
-  HIPCK(hipSetDevice(device));
-  hipDeviceProp_t prop;
-  HIPCK(hipGetDeviceProperties(&prop, device));
-  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
-    return fail(BLSGPU_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 (MI355X) only");
-  Ctx* c = new Ctx();
-  c->dev = device;
-  HIPCK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  g_ctx = c;
-  return 0;
+  return bind_device(device, ndev);
 }
+API_CATCH
+
+/* One process driving several GPUs of the node (the in-library alternative to one process per GPU): binds the
+ * first ndev visible devices (ndev <= 0: all of them).  The four verify entry points then shard their items over the
+ * bound devices (contiguous ranges, one host thread per device) and fold the per-device partial results -- key sums,
+ * Fp12 Miller products, MSM partials -- on device 0, exactly as the one-process-per-GPU path does over RCCL.
+ * BLSGPU_FAKE_DEVICES=k (testing on a one-GPU box) binds k logical devices that all map to the one physical GPU. */
+int blsgpu_init_devices(int ndev_req) try {
+  std::lock_guard<std::mutex> lk(g_init_mu);
+  if (initialised()) {
+    if (ndev_req > 0 && (size_t)ndev_req != g_devices.size())
+      return fail(BLSGPU_E_ARG, "blsgpu_init_devices: the library is already bound to " + std::to_string(g_devices.size()) +
+                                    " device(s) (call blsgpu_shutdown first to rebind)");
+    return (int)g_devices.size();
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    (void)hipGetLastError();
+    return fail(BLSGPU_E_NO_DEVICE, "no HIP device available: libblsgpu has no CPU fallback");
+  }
+  int fake = 0;
+  if (const char* f = getenv("BLSGPU_FAKE_DEVICES")) fake = atoi(f);
+  int want = ndev_req > 0 ? ndev_req : (fake > 0 ? fake : ndev);
+  if (fake <= 0 && want > ndev) return fail(BLSGPU_E_ARG, "blsgpu_init_devices: more devices requested than visible");
+  if (want > 64) return fail(BLSGPU_E_ARG, "blsgpu_init_devices: at most 64 devices");
+  for (int k = 0; k < want; k++) {
+    int rc = bind_device(fake > 0 ? k % ndev : k, ndev);
+    if (rc) {
+      release_devices();
+      return rc;
+    }
+  }
+  // peer access so that a device can read a shard that lives on another device's memory (xGMI loads); failures are not
+  // fatal: shards of host buffers never need it
+  for (size_t a = 0; a < g_devices.size(); a++)
+    for (size_t b = 0; b < g_devices.size(); b++) {
+      if (g_devices[a]->dev == g_devices[b]->dev) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, g_devices[a]->dev, g_devices[b]->dev) == hipSuccess && can) {
+        (void)hipSetDevice(g_devices[a]->dev);
+        hipError_t pe = hipDeviceEnablePeerAccess(g_devices[b]->dev, 0);
+        if (pe != hipSuccess) (void)hipGetLastError();
+      }
+    }
+  (void)hipSetDevice(g_devices[0]->dev);
+  return (int)g_devices.size();
+}
+API_CATCH
+
+int blsgpu_device_count(void) { return (int)g_devices.size(); }
 
 void blsgpu_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_init_mu);
-  if (!g_ctx) return;
-  (void)hipSetDevice(g_ctx->dev);
-  (void)hipStreamSynchronize(g_ctx->stream);
-  if (g_ctx->arena) (void)hipFree(g_ctx->arena);
-  if (g_ctx->ev_host) (void)hipEventDestroy(g_ctx->ev_host);
-  if (g_ctx->ev_fork) (void)hipEventDestroy(g_ctx->ev_fork);
-  if (g_ctx->ev_join) (void)hipEventDestroy(g_ctx->ev_join);
-  if (g_ctx->side) (void)hipStreamDestroy(g_ctx->side);
-  (void)hipStreamDestroy(g_ctx->stream);
-  delete g_ctx;
-  g_ctx = nullptr;
+  if (!initialised()) return;
+  release_devices();
 }
 
-int blsgpu_profile_enable(int on) {
-  if (!g_ctx) return fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)");
-  std::lock_guard<std::mutex> lk(g_ctx->mu);
-  g_ctx->prof_on = on != 0;
-  for (int k = 0; k < KID_COUNT; k++) {
-    g_ctx->prof_ms[k] = 0;
-    g_ctx->prof_cnt[k] = 0;
-  }
+int blsgpu_profile_enable(int on) try {
+  if (!initialised()) return NOT_INIT();
+  for (Device* d : g_devices)
+    for (Ctx* c : d->pool) {
+      std::lock_guard<std::mutex> lk(c->mu);
+      c->prof_on = on != 0;
+      for (int k = 0; k < KID_COUNT; k++) {
+        c->prof_ms[k] = 0;
+        c->prof_cnt[k] = 0;
+      }
+    }
   return 0;
 }
+API_CATCH
 int blsgpu_profile_count(void) { return KID_COUNT; }
-int blsgpu_profile_get(int kernel_id, char* name, size_t name_cap, double* total_ms, uint64_t* launches) {
-  if (!g_ctx) return fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)");
+int blsgpu_profile_get(int kernel_id, char* name, size_t name_cap, double* total_ms, uint64_t* launches) try {
+  if (!initialised()) return NOT_INIT();
   if (kernel_id < 0 || kernel_id >= KID_COUNT) return fail(BLSGPU_E_ARG, "kernel id out of range");
-  std::lock_guard<std::mutex> lk(g_ctx->mu);
   if (name && name_cap) {
     strncpy(name, KID_NAMES[kernel_id], name_cap - 1);
     name[name_cap - 1] = 0;
   }
-  if (total_ms) *total_ms = g_ctx->prof_ms[kernel_id];
-  if (launches) *launches = g_ctx->prof_cnt[kernel_id];
+  double ms = 0;
+  uint64_t cnt = 0;
+  for (Device* d : g_devices)
+    for (Ctx* c : d->pool) {
+      std::lock_guard<std::mutex> lk(c->mu);
+      ms += c->prof_ms[kernel_id];
+      cnt += c->prof_cnt[kernel_id];
+    }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = cnt;
   return 0;
 }
+API_CATCH
 
 size_t blsgpu_last_error(char* buf, size_t cap) {
   if (buf && cap) {
@@ -555,15 +804,13 @@ size_t blsgpu_last_error(char* buf, size_t cap) {
 }
 
 int blsgpu_verify_batch(int sig_group, int scheme, const void* pks, const void* sigs, const uint8_t* msgs,
-                        const uint64_t* msg_offsets, size_t n, int fmt, int32_t* status) {
+                        const uint64_t* msg_offsets, size_t n, int fmt, int32_t* status) try {
   const bool wire = fmt == BLSGPU_FMT_COMPRESSED || fmt == BLSGPU_FMT_LEGACY;
   int rc = check_common(sig_group, scheme, wire ? BLSGPU_FMT_RAW_PROJ : fmt);
   if (rc) return rc;
   if (n == 0) return 0;
   if (!pks || !sigs || !msg_offsets || !status) return fail(BLSGPU_E_ARG, "null argument");
-  Ctx* c = g_ctx;
-  std::lock_guard<std::mutex> lk(c->mu);
-  HIPCK(hipSetDevice(c->dev));
+  CTX_ACQUIRE(c);
   // total message bytes: last offset (read it from wherever it lives)
   uint64_t total = 0;
   if (is_device_ptr(msg_offsets)) HIPCK(hipMemcpy(&total, msg_offsets + n, 8, hipMemcpyDeviceToHost));
@@ -612,6 +859,7 @@ int blsgpu_verify_batch(int sig_group, int scheme, const void* pks, const void* 
   SYNC_FLUSH(c);
   return 0;
 }
+API_CATCH
 
 // aug_prefix: MultiSignature::verify under MessageAugmentation prefixes the (aggregated) key bytes
 // (reference src/traits/sig_aug.rs:20-24); verify_secure_message_augmentation does NOT, it only switches the DST
@@ -626,14 +874,14 @@ static int verify_one_tail(Ctx* c, int sig_group, int scheme, int aug_prefix, co
   if ((rc = stage_in(c, sig, sig_size(sig_group, fmt), &d_sig_in))) return rc;
   const void* d_msg = nullptr;
   if (!d_hash && (rc = stage_in(c, msg, msg_len, &d_msg))) return rc;
-  uint64_t offs_h[2] = {0, (uint64_t)msg_len};
+  const uint64_t offs_h[2] = {0, (uint64_t)msg_len};
   uint64_t* d_offs = (uint64_t*)arena_take(c, 16);
   int32_t* d_status = (int32_t*)arena_take(c, 4);
   uint32_t* d_pairs = (uint32_t*)arena_take(c, WS_PAIRS_WORDS * 4);
   uint32_t* d_f = (uint32_t*)arena_take(c, WS_F_WORDS * 4);
   uint8_t* d_sig_proj = (uint8_t*)arena_take(c, 288);
   if (!d_offs || !d_status || !d_pairs || !d_f || !d_sig_proj) return fail(BLSGPU_E_HIP, "internal: arena too small");
-  HIPCK(hipMemcpyAsync(d_offs, offs_h, 16, hipMemcpyHostToDevice, c->stream));
+  if ((rc = h2d_small(c, d_offs, offs_h, 16))) return rc;
   // normalise the signature to RAW_PROJ with a 1-point "sum"
   if (sig_group == 1) rc = run_point_sum<1>(c, (const uint8_t*)d_sig_in, fmt, nullptr, nullptr, 1, d_sig_proj, 1);
   else rc = run_point_sum<2>(c, (const uint8_t*)d_sig_in, fmt, nullptr, nullptr, 1, d_sig_proj, 1);
@@ -653,13 +901,11 @@ static int verify_one_tail(Ctx* c, int sig_group, int scheme, int aug_prefix, co
 }
 
 int blsgpu_multi_verify(int sig_group, int scheme, const void* pks, size_t n, const void* sig, const uint8_t* msg,
-                        size_t msg_len, int fmt, int32_t* status) {
+                        size_t msg_len, int fmt, int32_t* status) try {
   int rc = check_common(sig_group, scheme, fmt);
   if (rc) return rc;
   if (!sig || !status || (n && !pks)) return fail(BLSGPU_E_ARG, "null argument");
-  Ctx* c = g_ctx;
-  std::lock_guard<std::mutex> lk(c->mu);
-  HIPCK(hipSetDevice(c->dev));
+  CTX_ACQUIRE(c);
   const size_t psz = pk_size(sig_group, fmt), T = accumulate_lanes(n);
   size_t need = pad256(psz * n) + pad256(288 * T) + 2 * pad256(msg_len) + 8192;
   if ((rc = arena_reserve(c, need))) return rc;
@@ -678,7 +924,7 @@ int blsgpu_multi_verify(int sig_group, int scheme, const void* pks, size_t n, co
     d_hash = (uint8_t*)arena_take(c, 288);
     if (!d_offs0 || !d_hash) return fail(BLSGPU_E_HIP, "internal: arena too small");
     const uint64_t offs0[2] = {0, (uint64_t)msg_len};
-    HIPCK(hipMemcpyAsync(d_offs0, offs0, 16, hipMemcpyHostToDevice, c->stream));
+    if ((rc = h2d_small(c, d_offs0, offs0, 16))) return rc;
     if (!c->side) {
       HIPCK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
       HIPCK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -706,144 +952,193 @@ int blsgpu_multi_verify(int sig_group, int scheme, const void* pks, size_t n, co
   if (rc) return rc;
   return verify_one_tail(c, sig_group, scheme, scheme == BLSGPU_SCHEME_AUG, d_part, sig, fmt, msg, msg_len, status, d_hash);
 }
+API_CATCH
+
+// The device part of core_aggregate_verify (reference src/traits/sig_core.rs:149-178) for n (pk, msg) pairs [plus the
+// (sig, -g) pair when d_sig != nullptr], enqueued without a host round trip: hash-to-curve + identity flags, the first
+// identity key reduced on the device (d_first: index, n when the signature is the identity, -1 when none), Miller loops
+// (flagged pairs contribute 1), product tree; then either the final exponentiation's verdict (d_verdict) or the product
+// before the final exponentiation as a 576-byte record (d_rec).
+static int aggregate_enqueue(Ctx* c, int sig_group, int scheme, const uint8_t* d_pks, const uint8_t* d_sig, int fmt, const uint8_t* d_msgs,
+                             const uint64_t* d_offs, size_t n, int64_t* d_first, int32_t* d_verdict, uint8_t* d_rec) {
+  int rc;
+  const size_t m = n + 1, mm = d_sig ? m : n;
+  const int has_sig = d_sig ? 1 : 0;
+  int32_t* d_bad = (int32_t*)arena_take(c, 4 * m);
+  unsigned long long* d_min = (unsigned long long*)arena_take(c, 64);
+  uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)WS_PAIR1_WORDS * 4 * m);
+  uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * m);
+  if (!d_bad || !d_min || !d_pairs || !d_f) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  HIPCK(hipMemsetAsync(d_min, 0xff, 8, c->stream));
+  HIPCK(hipMemsetAsync(d_bad, 0, 4 * m, c->stream));
+  const dst_arg dst = scheme_dst(sig_group, scheme);
+  const int aug = scheme == BLSGPU_SCHEME_AUG;
+  if (mm > 0) {
+    // the workspace stride is always n + 1 (k_prepare_agg's layout); without a signature lane n stays idle
+    if (sig_group == 1)
+      KL(KID_PREPARE_AGG, k_prepare_agg<1>, dim3(blocks_for(mm)), dim3(BLS_BLOCK), n, d_pks, d_sig, fmt, aug, d_msgs, d_offs, dst, d_pairs, d_bad, 0, has_sig);
+    else
+      KL(KID_PREPARE_AGG, k_prepare_agg<2>, dim3(blocks_for(2 * mm)), dim3(BLS_BLOCK), n, d_pks, d_sig, fmt, aug, d_msgs, d_offs, dst, d_pairs, d_bad, 1, has_sig);
+    if (n) KL(KID_PREPARE_AGG, k_first_bad, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const int32_t*)d_bad, d_min);
+  }
+  KL(KID_PREPARE_AGG, k_first_bad_fin, dim3(1), dim3(BLS_BLOCK), n, (const int32_t*)d_bad, has_sig, (const unsigned long long*)d_min, d_first);
+  HIPCK(hipGetLastError());
+  if (mm == 0) {                   // an empty shard: the neutral record
+    if (d_rec) {
+      uint8_t one[576];
+      memset(one, 0, sizeof one);
+      memcpy(one, FP_ONE_HOST, 48);
+      if ((rc = h2d_small(c, d_rec, one, 576))) return rc;
+    }
+    if (d_verdict) HIPCK(hipMemsetAsync(d_verdict, 0, 4, c->stream));   // the empty product is one
+    return 0;
+  }
+  MILLER1_LAUNCH(mm, m, d_pairs, d_bad, d_f);
+  if (d_verdict) {
+    if ((rc = run_f12_product_verdict(c, d_f, MILLER1_OUTPUTS(mm), m, d_verdict))) return rc;
+  } else {
+    if ((rc = run_f12_fold(c, d_f, MILLER1_OUTPUTS(mm), m))) return rc;
+    KL(KID_F12_IO, k_f12_export, dim3(1), dim3(BLS_BLOCK), d_f, m, d_rec);
+    HIPCK(hipGetLastError());
+  }
+  return 0;
+}
+
+// reference src/traits/sig_basic.rs:46-58 on host-resident messages: first i whose message equals an earlier one.
+// Open-addressing table of message indices keyed by a 64-bit hash (computed on all host cores), equality verified on the
+// bytes; the scan is sequential so that the FIRST such i is reported, as the reference does.  Returns true on a duplicate.
+static bool duplicate_check_host(const uint8_t* mh, const uint64_t* offs_h, size_t n, uint64_t aux_h[2]) {
+  std::vector<uint64_t> hs(n);
+  {
+    unsigned nthr = std::thread::hardware_concurrency();
+    if (nthr > 16) nthr = 16;
+    if (nthr < 1 || n < 16384) nthr = 1;
+    auto work = [&](unsigned t) {
+      for (size_t i = n * t / nthr; i < n * (t + 1) / nthr; i++) {
+        const uint8_t* p = mh + offs_h[i];
+        size_t len = (size_t)(offs_h[i + 1] - offs_h[i]);
+        uint64_t h = 0x9e3779b97f4a7c15ull ^ (len * 0xff51afd7ed558ccdull);
+        while (len >= 8) {
+          uint64_t w;
+          memcpy(&w, p, 8);
+          h = (h ^ w) * 0xc4ceb9fe1a85ec53ull;
+          h ^= h >> 29;
+          p += 8;
+          len -= 8;
+        }
+        uint64_t w = 0;
+        memcpy(&w, p, len);
+        h = (h ^ w) * 0xff51afd7ed558ccdull;
+        h ^= h >> 32;
+        hs[i] = h;
+      }
+    };
+    if (nthr == 1) {
+      work(0);
+    } else {
+      std::vector<std::thread> pool;
+      for (unsigned t = 0; t < nthr; t++) pool.emplace_back(work, t);
+      for (auto& th : pool) th.join();
+    }
+  }
+  size_t cap = 16;
+  while (cap < 2 * n) cap <<= 1;
+  std::vector<uint32_t> tab(cap, 0);          // index + 1, 0 = empty
+  for (size_t i = 0; i < n; i++) {
+    const size_t len = (size_t)(offs_h[i + 1] - offs_h[i]);
+    size_t slot = (size_t)hs[i] & (cap - 1);
+    while (tab[slot]) {
+      const size_t j = tab[slot] - 1;
+      if (hs[j] == hs[i] && (size_t)(offs_h[j + 1] - offs_h[j]) == len && memcmp(mh + offs_h[j], mh + offs_h[i], len) == 0) {
+        aux_h[0] = j;
+        aux_h[1] = i;
+        return true;
+      }
+      slot = (slot + 1) & (cap - 1);
+    }
+    tab[slot] = (uint32_t)(i + 1);
+  }
+  return false;
+}
 
 int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const uint8_t* msgs, const uint64_t* msg_offsets,
-                            size_t n, const void* sig, int fmt, int32_t* status, uint64_t* aux) {
+                            size_t n, const void* sig, int fmt, int32_t* status, uint64_t* aux) try {
   int rc = check_common(sig_group, scheme, fmt);
   if (rc) return rc;
   if (!sig || !status || !msg_offsets || (n && !pks)) return fail(BLSGPU_E_ARG, "null argument");
-  Ctx* c = g_ctx;
-  std::lock_guard<std::mutex> lk(c->mu);
-  HIPCK(hipSetDevice(c->dev));
+  CTX_ACQUIRE(c);
   uint64_t aux_h[2] = {0, 0};
   const bool trace = getenv("BLSGPU_HOST_TRACE") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_start = now();
-  // host views of offsets (and of messages for the Basic duplicate check)
-  std::vector<uint64_t> offs_h(n + 1);
-  if (is_device_ptr(msg_offsets)) HIPCK(hipMemcpy(offs_h.data(), msg_offsets, 8 * (n + 1), hipMemcpyDeviceToHost));
-  else memcpy(offs_h.data(), msg_offsets, 8 * (n + 1));
-  const uint64_t total = offs_h[n];
-  int32_t st = BLSGPU_OK;
-  // reference src/traits/sig_basic.rs:46-58: first i whose message equals an earlier one.  In the reference this runs to
-  // completion before anything else; here the GPU already hashes the messages to the curve meanwhile (the verdict keeps
-  // the reference's precedence: a duplicate wins over whatever the device finds).
-  std::vector<uint8_t> tmp;
-  const uint8_t* mh = msgs;
-  if (scheme == BLSGPU_SCHEME_BASIC && is_device_ptr(msgs)) {
-    tmp.resize(total);
-    HIPCK(hipMemcpy(tmp.data(), msgs, total, hipMemcpyDeviceToHost));
-    mh = tmp.data();
+  const bool basic = scheme == BLSGPU_SCHEME_BASIC;
+  // Basic's duplicate-message rule (reference src/traits/sig_basic.rs:46-58) runs where the messages live: on the device for
+  // device-resident messages (k_dup_*), on the host (overlapped with the device's hashing) for host buffers.  In the
+  // reference it runs to completion before anything else; here the verdict keeps that precedence.
+  const bool dev_msgs = is_device_ptr(msgs), dev_offs = is_device_ptr(msg_offsets);
+  const bool dup_on_device = basic && dev_msgs;
+  std::vector<uint64_t> offs_h;
+  uint64_t total = 0;
+  if (basic && !dev_msgs && dev_offs) {   // host messages with device offsets: the host check needs the offsets
+    offs_h.resize(n + 1);
+    HIPCK(hipMemcpy(offs_h.data(), msg_offsets, 8 * (n + 1), hipMemcpyDeviceToHost));
+    total = offs_h[n];
+  } else if (dev_offs) {
+    HIPCK(hipMemcpy(&total, msg_offsets + n, 8, hipMemcpyDeviceToHost));
+  } else {
+    total = msg_offsets[n];
   }
-  auto duplicate_check = [&]() {
-    // open-addressing table of message indices keyed by a 64-bit hash (computed on all host cores), equality verified on
-    // the bytes; the scan is sequential so that the FIRST i with an earlier equal message is reported, as the reference does
-    std::vector<uint64_t> hs(n);
-    {
-      unsigned nthr = std::thread::hardware_concurrency();
-      if (nthr > 16) nthr = 16;
-      if (nthr < 1 || n < 16384) nthr = 1;
-      auto work = [&](unsigned t) {
-        for (size_t i = n * t / nthr; i < n * (t + 1) / nthr; i++) {
-          const uint8_t* p = mh + offs_h[i];
-          size_t len = (size_t)(offs_h[i + 1] - offs_h[i]);
-          uint64_t h = 0x9e3779b97f4a7c15ull ^ (len * 0xff51afd7ed558ccdull);
-          while (len >= 8) {
-            uint64_t w;
-            memcpy(&w, p, 8);
-            h = (h ^ w) * 0xc4ceb9fe1a85ec53ull;
-            h ^= h >> 29;
-            p += 8;
-            len -= 8;
-          }
-          uint64_t w = 0;
-          memcpy(&w, p, len);
-          h = (h ^ w) * 0xff51afd7ed558ccdull;
-          h ^= h >> 32;
-          hs[i] = h;
-        }
-      };
-      if (nthr == 1) {
-        work(0);
-      } else {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < nthr; t++) pool.emplace_back(work, t);
-        for (auto& th : pool) th.join();
-      }
-    }
-    size_t cap = 16;
-    while (cap < 2 * n) cap <<= 1;
-    std::vector<uint32_t> tab(cap, 0);          // index + 1, 0 = empty
-    for (size_t i = 0; i < n && st == BLSGPU_OK; i++) {
-      const size_t len = (size_t)(offs_h[i + 1] - offs_h[i]);
-      size_t slot = (size_t)hs[i] & (cap - 1);
-      while (tab[slot]) {
-        const size_t j = tab[slot] - 1;
-        if (hs[j] == hs[i] && (size_t)(offs_h[j + 1] - offs_h[j]) == len && memcmp(mh + offs_h[j], mh + offs_h[i], len) == 0) {
-          st = BLSGPU_DUPLICATE_MESSAGE;
-          aux_h[0] = j;
-          aux_h[1] = i;
-          break;
-        }
-        slot = (slot + 1) & (cap - 1);
-      }
-      if (st == BLSGPU_OK) tab[slot] = (uint32_t)(i + 1);
-    }
-  };
-  const double t_dup = now();
-  {
-    const size_t m = n + 1, psz = pk_size(sig_group, fmt);
-    size_t need = pad256(psz * n) + pad256(sig_size(sig_group, fmt)) + pad256(total) + pad256(8 * m) + pad256(4 * m) +
-                  2 * pad256((size_t)WS_PAIRS_WORDS * 4 * m) + 8192;
-    if ((rc = arena_reserve(c, need))) return rc;
-    c->arena_off = 0;
-    const void *d_pks, *d_sig, *d_msgs, *d_offs;
-    if ((rc = stage_in(c, pks, psz * n, &d_pks))) return rc;
-    if ((rc = stage_in(c, sig, sig_size(sig_group, fmt), &d_sig))) return rc;
-    if ((rc = stage_in(c, msgs, total, &d_msgs))) return rc;
-    if ((rc = stage_in(c, msg_offsets, 8 * m, &d_offs))) return rc;
-    const double t_staged = now();
-    if (trace) fprintf(stderr, "[blsgpu] aggregate_verify n=%zu: host copies %.2f ms, staging %.2f ms\n", n, t_dup - t_start, t_staged - t_dup);
-    int32_t* d_bad = (int32_t*)arena_take(c, 4 * m);
-    int32_t* d_verdict = (int32_t*)arena_take(c, 4);
-    uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)WS_PAIR1_WORDS * 4 * m);
-    uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * m);
-    if (!d_bad || !d_verdict || !d_pairs || !d_f) return fail(BLSGPU_E_HIP, "internal: arena too small");
-    dst_arg dst = scheme_dst(sig_group, scheme);
-    int aug = scheme == BLSGPU_SCHEME_AUG;
-    if (sig_group == 1)
-      KL(KID_PREPARE_AGG, k_prepare_agg<1>, dim3(blocks_for(m)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, aug,
-                         (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad, 0);
-    else
-      KL(KID_PREPARE_AGG, k_prepare_agg<2>, dim3(blocks_for(2 * m)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, aug,
-                         (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad, 1);
-    HIPCK(hipGetLastError());
-    // The Miller loops and the final exponentiation are enqueued at once (flagged pairs are skipped on the device); the
-    // identity flags come back together with the verdict, and the host applies the reference's precedence afterwards.
-    MILLER1_LAUNCH(m, m, d_pairs, d_bad, d_f);
-    if ((rc = run_f12_product_verdict(c, d_f, MILLER1_OUTPUTS(m), m, d_verdict))) return rc;
-    if (scheme == BLSGPU_SCHEME_BASIC) {
-      duplicate_check();          // on the host, while the device works
-      if (trace) fprintf(stderr, "[blsgpu] aggregate_verify n=%zu: duplicate check %.2f ms (overlapped)\n", n, now() - t_staged);
-    }
-    std::vector<int32_t> bad(m);
-    int32_t verdict = BLSGPU_OK;
-    HIPCK(hipMemcpyAsync(bad.data(), d_bad, 4 * m, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(hipMemcpyAsync(&verdict, d_verdict, 4, hipMemcpyDeviceToHost, c->stream));
-    SYNC_FLUSH(c);
-    if (st != BLSGPU_OK) {
-      // duplicate messages: reported before any identity check (sig_basic.rs:46-58 precedes core_aggregate_verify)
-    } else if (bad[n]) {          // reference src/traits/sig_core.rs:155-167: signature identity first, ...
-      st = BLSGPU_SIG_IDENTITY;
-    } else {
-      for (size_t i = 0; i < n; i++)
-        if (bad[i]) {             // ... then the first identity key (1-based)
-          st = BLSGPU_PK_IDENTITY;
-          aux_h[0] = i + 1;
-          break;
-        }
-      if (st == BLSGPU_OK) st = verdict;
-    }
+  const size_t m = n + 1, psz = pk_size(sig_group, fmt);
+  size_t need = pad256(psz * n) + pad256(sig_size(sig_group, fmt)) + pad256(total) + pad256(8 * m) + pad256(4 * m) +
+                2 * pad256((size_t)WS_PAIRS_WORDS * 4 * m) + 8192 + (dup_on_device ? dup_ws_bytes(n) : 0);
+  if ((rc = arena_reserve(c, need))) return rc;
+  c->arena_off = 0;
+  const void *d_pks, *d_sig, *d_msgs, *d_offs;
+  if ((rc = stage_in(c, pks, psz * n, &d_pks))) return rc;
+  if ((rc = stage_in(c, sig, sig_size(sig_group, fmt), &d_sig))) return rc;
+  if ((rc = stage_in(c, msgs, total, &d_msgs))) return rc;
+  if ((rc = stage_in(c, msg_offsets, 8 * m, &d_offs))) return rc;
+  const double t_staged = now();
+  int64_t* d_first = (int64_t*)arena_take(c, 64);
+  int32_t* d_verdict = (int32_t*)arena_take(c, 64);
+  uint64_t* d_dup = (uint64_t*)arena_take(c, 64);
+  struct results { int64_t first; int32_t verdict; int32_t pad; uint64_t dup[2]; };
+  results* h = (results*)hsmall_take(c, sizeof(results));
+  if (!d_first || !d_verdict || !d_dup || !h) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  h->dup[0] = h->dup[1] = ~0ull;
+  // everything is enqueued at once; the identity index, the verdict and the duplicate pair come back together and the
+  // host applies the reference's precedence afterwards
+  if ((rc = aggregate_enqueue(c, sig_group, scheme, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, (const uint8_t*)d_msgs,
+                              (const uint64_t*)d_offs, n, d_first, d_verdict, nullptr)))
+    return rc;
+  if (dup_on_device) {
+    if ((rc = run_first_duplicate(c, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, n, d_dup))) return rc;
+    HIPCK(hipMemcpyAsync(h->dup, d_dup, 16, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCK(hipMemcpyAsync(&h->first, d_first, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(hipMemcpyAsync(&h->verdict, d_verdict, 4, hipMemcpyDeviceToHost, c->stream));
+  bool dup = false;
+  if (basic && !dev_msgs) {       // on the host, while the device works
+    dup = duplicate_check_host(msgs, offs_h.empty() ? msg_offsets : offs_h.data(), n, aux_h);
+    if (trace) fprintf(stderr, "[blsgpu] aggregate_verify n=%zu: host duplicate check %.2f ms (overlapped)\n", n, now() - t_staged);
+  }
+  SYNC_FLUSH(c);
+  if (trace) fprintf(stderr, "[blsgpu] aggregate_verify n=%zu: staging %.2f ms, total %.2f ms\n", n, t_staged - t_start, now() - t_start);
+  if (dup_on_device && h->dup[1] != ~0ull) {
+    dup = true;
+    aux_h[0] = h->dup[0];
+    aux_h[1] = h->dup[1];
+  }
+  int32_t st;
+  if (dup) {
+    st = BLSGPU_DUPLICATE_MESSAGE;   // reported before any identity check (sig_basic.rs:46-58 precedes core_aggregate_verify)
+  } else if (h->first == (int64_t)n) {
+    st = BLSGPU_SIG_IDENTITY;        // reference src/traits/sig_core.rs:155-167: signature identity first, ...
+  } else if (h->first >= 0) {
+    st = BLSGPU_PK_IDENTITY;         // ... then the first identity key (1-based)
+    aux_h[0] = (uint64_t)h->first + 1;
+  } else {
+    st = h->verdict;
   }
   if (is_device_ptr(status)) HIPCK(hipMemcpy(status, &st, 4, hipMemcpyHostToDevice));
   else *status = st;
@@ -853,121 +1148,310 @@ int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const ui
   }
   return 0;
 }
+API_CATCH
+
+// sig is the identity <=> Ok for an empty key list (reference src/secure_aggregation.rs:189-195)
+static int empty_list_verdict(Ctx* c, int sig_group, const void* sig, int fmt, int32_t* st) {
+  int rc;
+  const void* d_sig;
+  if ((rc = stage_in(c, sig, sig_size(sig_group, fmt), &d_sig))) return rc;
+  uint8_t* d_proj = (uint8_t*)arena_take(c, 288);
+  uint8_t* h = (uint8_t*)hsmall_take(c, 288);
+  if (!d_proj || !h) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  if (sig_group == 1) rc = run_point_sum<1>(c, (const uint8_t*)d_sig, fmt, nullptr, nullptr, 1, d_proj, 1);
+  else rc = run_point_sum<2>(c, (const uint8_t*)d_sig, fmt, nullptr, nullptr, 1, d_proj, 1);
+  if (rc) return rc;
+  HIPCK(hipMemcpyAsync(h, d_proj, 288, hipMemcpyDeviceToHost, c->stream));
+  SYNC_FLUSH(c);
+  const size_t zoff = sig_group == 1 ? 96 : 192, zlen = sig_group == 1 ? 48 : 96;
+  bool inf = true;
+  for (size_t k = 0; k < zlen; k++) inf = inf && h[zoff + k] == 0;
+  *st = inf ? BLSGPU_OK : BLSGPU_INVALID_SIGNATURE;
+  return 0;
+}
 
 int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, const void* sig, const uint8_t* msg,
-                         size_t msg_len, int ser_format, int fmt, int32_t* status) {
+                         size_t msg_len, int ser_format, int fmt, int32_t* status) try {
   int rc = check_common(sig_group, scheme, fmt);
   if (rc) return rc;
   if (!sig || !status || (n && !pks)) return fail(BLSGPU_E_ARG, "null argument");
   if (ser_format != 0 && ser_format != 1) return fail(BLSGPU_E_ARG, "ser_format must be 0 (Modern) or 1 (Legacy)");
   if (ser_format == 1 && sig_group != 2)
     return fail(BLSGPU_E_ARG, "Legacy serialization exists only for Bls12381G2Impl (48-byte keys), reference src/signature.rs:201-204");
-  Ctx* c = g_ctx;
-  std::lock_guard<std::mutex> lk(c->mu);
-  HIPCK(hipSetDevice(c->dev));
+  if (n >= 0xffffffffull) return fail(BLSGPU_E_ARG, "more than 2^32 - 2 keys");
+  CTX_ACQUIRE(c);
+  const bool trace = getenv("BLSGPU_HOST_TRACE") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const size_t psz = pk_size(sig_group, fmt), width = sig_group == 1 ? 96 : 48, T = accumulate_lanes(n);
-  size_t need = pad256(psz * n) + pad256(width * n) + pad256(4 * n) + pad256(32 * n) + pad256(288 * T) + pad256(msg_len) + 16384 + msm_ws_bytes(n);
+  size_t need = pad256(psz * n) + pad256(width * n) + pad256(32 * n) + pad256(288 * T) + pad256(msg_len) + 16384 + msm_ws_bytes(n) +
+                keysort_ws_bytes(n, width);
   if ((rc = arena_reserve(c, need))) return rc;
   c->arena_off = 0;
   int32_t st = BLSGPU_OK;
   if (n == 0) {
-    // reference src/secure_aggregation.rs:189-195: Ok iff the signature is the identity
-    const void* d_sig;
-    if ((rc = stage_in(c, sig, sig_size(sig_group, fmt), &d_sig))) return rc;
-    uint8_t* d_proj = (uint8_t*)arena_take(c, 288);
-    std::vector<uint8_t> h(288);
-    if (sig_group == 1) rc = run_point_sum<1>(c, (const uint8_t*)d_sig, fmt, nullptr, nullptr, 1, d_proj, 1);
-    else rc = run_point_sum<2>(c, (const uint8_t*)d_sig, fmt, nullptr, nullptr, 1, d_proj, 1);
-    if (rc) return rc;
-    HIPCK(hipMemcpyAsync(h.data(), d_proj, 288, hipMemcpyDeviceToHost, c->stream));
-    SYNC_FLUSH(c);
-    const size_t zoff = sig_group == 1 ? 96 : 192, zlen = sig_group == 1 ? 48 : 96;
-    bool inf = true;
-    for (size_t k = 0; k < zlen; k++) inf = inf && h[zoff + k] == 0;
-    st = inf ? BLSGPU_OK : BLSGPU_INVALID_SIGNATURE;
-  } else {
-    const void* d_pks;
-    if ((rc = stage_in(c, pks, psz * n, &d_pks))) return rc;
-    uint8_t* d_bytes = (uint8_t*)arena_take(c, width * n);
-    uint32_t* d_perm = (uint32_t*)arena_take(c, 4 * n);
-    uint8_t* d_scal = (uint8_t*)arena_take(c, 32 * n);
-    uint8_t* d_part = (uint8_t*)arena_take(c, 288 * T);
-    if (!d_bytes || !d_perm || !d_scal || !d_part) return fail(BLSGPU_E_HIP, "internal: arena too small");
-    // PublicKey::to_bytes / to_bytes_with_mode of every key (reference src/secure_aggregation.rs:42,47; public_key.rs:146-151)
-    if (sig_group == 1)
-      KL(KID_COMPRESS, k_compress<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, fmt, ser_format, d_bytes);
-    else
-      KL(KID_COMPRESS, k_compress<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, fmt, ser_format, d_bytes);
-    HIPCK(hipGetLastError());
-    std::vector<uint8_t> kb(width * n);
-    HIPCK(hipMemcpyAsync(kb.data(), d_bytes, width * n, hipMemcpyDeviceToHost, c->stream));
-    // The host waits for the key bytes only; behind them the stream hashes the message to the curve (H(msg) does not depend
-    // on the keys: verify_secure never prefixes them, reference src/secure_aggregation.rs:236-246), so the hash-to-curve of
-    // the final core_verify runs while the host sorts and derives the coefficients.
-    if (!c->ev_host) HIPCK(hipEventCreateWithFlags(&c->ev_host, hipEventDisableTiming));
-    HIPCK(hipEventRecord(c->ev_host, c->stream));
-    const void* d_msg0;
-    if ((rc = stage_in(c, msg, msg_len, &d_msg0))) return rc;
-    uint64_t* d_offs0 = (uint64_t*)arena_take(c, 16);
-    uint8_t* d_hash = (uint8_t*)arena_take(c, 288);
-    if (!d_offs0 || !d_hash) return fail(BLSGPU_E_HIP, "internal: arena too small");
-    const uint64_t offs0[2] = {0, (uint64_t)msg_len};
-    HIPCK(hipMemcpyAsync(d_offs0, offs0, 16, hipMemcpyHostToDevice, c->stream));
-    if (sig_group == 1) KL(KID_HASH, k_hash_to_g1, dim3(1), dim3(BLS_BLOCK), (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, scheme_dst(sig_group, scheme), d_hash, 1);
-    else KL(KID_HASH, k_hash_to_g2, dim3(1), dim3(BLS_BLOCK), (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, scheme_dst(sig_group, scheme), d_hash, 1);
-    HIPCK(hipGetLastError());
-    HIPCK(hipEventSynchronize(c->ev_host));
-    std::vector<uint32_t> perm;
-    std::vector<uint8_t> scal;
-    st = secure_coefficients_host(kb.data(), n, width, perm, scal);
-    if (st == BLSGPU_OK) {
-      HIPCK(hipMemcpyAsync(d_perm, perm.data(), 4 * n, hipMemcpyHostToDevice, c->stream));
-      HIPCK(hipMemcpyAsync(d_scal, scal.data(), 32 * n, hipMemcpyHostToDevice, c->stream));
-      // aggregated_pk = sum t_i * pk_sorted[i]   (reference src/secure_aggregation.rs:201-204)
-      if (sig_group == 1) rc = run_point_sum<2>(c, (const uint8_t*)d_pks, fmt, d_scal, d_perm, n, d_part, T);
-      else rc = run_point_sum<1>(c, (const uint8_t*)d_pks, fmt, d_scal, d_perm, n, d_part, T);
-      if (rc) return rc;
-      return verify_one_tail(c, sig_group, scheme, 0, d_part, sig, fmt, msg, msg_len, status, d_hash);
-    }
-    SYNC_FLUSH(c);   // coefficient error: let the hash kernel (it reads the arena) drain before returning
+    if ((rc = empty_list_verdict(c, sig_group, sig, fmt, &st))) return rc;
+    if (is_device_ptr(status)) HIPCK(hipMemcpy(status, &st, 4, hipMemcpyHostToDevice));
+    else *status = st;
+    return 0;
   }
-  if (is_device_ptr(status)) HIPCK(hipMemcpy(status, &st, 4, hipMemcpyHostToDevice));
-  else *status = st;
+  const void* d_pks;
+  if ((rc = stage_in(c, pks, psz * n, &d_pks))) return rc;
+  uint8_t* d_bytes = (uint8_t*)arena_take(c, width * n);
+  uint8_t* d_scal = (uint8_t*)arena_take(c, 32 * n);
+  uint8_t* d_part = (uint8_t*)arena_take(c, 288 * T);
+  uint8_t* d_H = (uint8_t*)arena_take(c, 64);
+  int32_t* d_zero = (int32_t*)arena_take(c, 64);
+  int32_t* h_zero = (int32_t*)hsmall_take(c, 64);
+  keysort_ws w;
+  if (!d_bytes || !d_scal || !d_part || !d_H || !d_zero || !h_zero) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  if ((rc = keysort_ws_take(c, n, width, w))) return rc;
+  const double t0 = now();
+  // PublicKey::to_bytes / to_bytes_with_mode of every key (reference src/secure_aggregation.rs:42,47; public_key.rs:146-151)
+  if (sig_group == 1)
+    KL(KID_COMPRESS, k_compress<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, fmt, ser_format, d_bytes);
+  else
+    KL(KID_COMPRESS, k_compress<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, fmt, ser_format, d_bytes);
+  HIPCK(hipGetLastError());
+  // stable byte-lexicographic sort on the device; the sorted bytes travel to the host for the one sequential SHA-256
+  if (!c->ev_host) HIPCK(hipEventCreateWithFlags(&c->ev_host, hipEventDisableTiming));
+  bool full_sort = false;
+  if ((rc = run_key_sort_to_host(c, d_bytes, n, width, w, c->ev_host, &full_sort))) return rc;
+  // Behind them the stream hashes the message to the curve (H(msg) does not depend on the keys: verify_secure never
+  // prefixes them, reference src/secure_aggregation.rs:236-246), so the hash-to-curve of the final core_verify runs
+  // while the host hashes the key stream.
+  const void* d_msg0;
+  if ((rc = stage_in(c, msg, msg_len, &d_msg0))) return rc;
+  uint64_t* d_offs0 = (uint64_t*)arena_take(c, 16);
+  uint8_t* d_hash = (uint8_t*)arena_take(c, 288);
+  if (!d_offs0 || !d_hash) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  const uint64_t offs0[2] = {0, (uint64_t)msg_len};
+  if ((rc = h2d_small(c, d_offs0, offs0, 16))) return rc;
+  if (sig_group == 1) KL(KID_HASH, k_hash_to_g1, dim3(1), dim3(BLS_BLOCK), (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, scheme_dst(sig_group, scheme), d_hash, 1);
+  else KL(KID_HASH, k_hash_to_g2, dim3(1), dim3(BLS_BLOCK), (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, scheme_dst(sig_group, scheme), d_hash, 1);
+  HIPCK(hipGetLastError());
+  if ((rc = run_key_sort_finish(c, d_bytes, n, width, w, c->ev_host, &full_sort))) return rc;
+  const double t1 = now();
+  uint8_t H[32];
+  keys_digest_host(c->hpin, width * n, H);
+  const double t2 = now();
+  if ((rc = h2d_small(c, d_H, H, 32))) return rc;
+  HIPCK(hipMemsetAsync(d_zero, 0, 4, c->stream));
+  // t_i on the device, written to the INPUT slot of the key that sorted to position i: the sum below needs no permutation
+  if ((rc = run_coefficients(c, d_H, w.perm_a, n, 0, n, 0, d_scal, d_zero))) return rc;
+  HIPCK(hipMemcpyAsync(h_zero, d_zero, 4, hipMemcpyDeviceToHost, c->stream));
+  // aggregated_pk = sum t_i * pk_sorted[i]   (reference src/secure_aggregation.rs:201-204)
+  if (sig_group == 1) rc = run_point_sum<2>(c, (const uint8_t*)d_pks, fmt, d_scal, nullptr, n, d_part, T);
+  else rc = run_point_sum<1>(c, (const uint8_t*)d_pks, fmt, d_scal, nullptr, n, d_part, T);
+  if (rc) return rc;
+  if ((rc = verify_one_tail(c, sig_group, scheme, 0, d_part, sig, fmt, msg, msg_len, status, d_hash))) return rc;
+  if (trace)
+    fprintf(stderr, "[blsgpu] verify_secure n=%zu: compress + key sort%s + D2H %.2f ms (message hash enqueued behind), key-stream SHA-256 on the host %.2f ms, rest %.2f ms\n",
+            n, full_sort ? " (full-width)" : "", t1 - t0, t2 - t1, now() - t2);
+  if (*h_zero) {                   // a zero coefficient: BlsError::InvalidCoefficient before any verification (:97-100)
+    st = BLSGPU_INVALID_COEFFICIENT;
+    if (is_device_ptr(status)) HIPCK(hipMemcpy(status, &st, 4, hipMemcpyHostToDevice));
+    else *status = st;
+  }
   return 0;
 }
+API_CATCH
 
 int blsgpu_secure_coefficients(const uint8_t* key_bytes, size_t n, size_t width, uint32_t* out_perm, uint8_t* out_scalars,
-                               int32_t* status) {
-  if (!g_ctx) return fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)");
+                               int32_t* status) try {
+  if (!initialised()) return NOT_INIT();
   if (width != 48 && width != 96) return fail(BLSGPU_E_ARG, "width must be 48 or 96");
   if (!status || (n && (!key_bytes || !out_perm || !out_scalars))) return fail(BLSGPU_E_ARG, "null argument");
-  std::vector<uint8_t> tmp;
-  const uint8_t* kb = key_bytes;
-  if (is_device_ptr(key_bytes)) {
-    tmp.resize(n * width);
-    HIPCK(hipMemcpy(tmp.data(), key_bytes, n * width, hipMemcpyDeviceToHost));
-    kb = tmp.data();
-  }
-  std::vector<uint32_t> perm;
-  std::vector<uint8_t> scal;
-  int32_t st = secure_coefficients_host(kb, n, width, perm, scal);
-  if (st == BLSGPU_OK && n) {
-    HIPCK(hipMemcpy(out_perm, perm.data(), 4 * n, is_device_ptr(out_perm) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
-    HIPCK(hipMemcpy(out_scalars, scal.data(), 32 * n, is_device_ptr(out_scalars) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+  if (n >= 0xffffffffull) return fail(BLSGPU_E_ARG, "more than 2^32 - 2 keys");
+  int32_t st = BLSGPU_OK;
+  if (n) {
+    CTX_ACQUIRE(c);
+    int rc = arena_reserve(c, pad256(width * n) + pad256(32 * n) + keysort_ws_bytes(n, width) + 4096);
+    if (rc) return rc;
+    c->arena_off = 0;
+    const void* d_kb;
+    if ((rc = stage_in(c, key_bytes, width * n, &d_kb))) return rc;
+    uint8_t* d_scal = (uint8_t*)arena_take(c, 32 * n);
+    uint8_t* d_H = (uint8_t*)arena_take(c, 64);
+    int32_t* d_zero = (int32_t*)arena_take(c, 64);
+    int32_t* h_zero = (int32_t*)hsmall_take(c, 64);
+    keysort_ws w;
+    if (!d_scal || !d_H || !d_zero || !h_zero) return fail(BLSGPU_E_HIP, "internal: arena too small");
+    if ((rc = keysort_ws_take(c, n, width, w))) return rc;
+    if ((rc = run_key_sort_to_host(c, (const uint8_t*)d_kb, n, width, w, nullptr, nullptr))) return rc;
+    uint8_t H[32];
+    keys_digest_host(c->hpin, width * n, H);
+    if ((rc = h2d_small(c, d_H, H, 32))) return rc;
+    HIPCK(hipMemsetAsync(d_zero, 0, 4, c->stream));
+    if ((rc = run_coefficients(c, d_H, w.perm_a, n, 0, n, 1, d_scal, d_zero))) return rc;
+    HIPCK(hipMemcpyAsync(h_zero, d_zero, 4, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = copy_out(c, out_perm, w.perm_a, 4 * n))) return rc;
+    if ((rc = copy_out(c, out_scalars, d_scal, 32 * n))) return rc;
+    SYNC_FLUSH(c);
+    if (*h_zero) st = BLSGPU_INVALID_COEFFICIENT;
   }
   if (is_device_ptr(status)) HIPCK(hipMemcpy(status, &st, 4, hipMemcpyHostToDevice));
   else *status = st;
   return 0;
 }
+API_CATCH
+
+/* The three steps of hash_public_keys_with_sorted as separate calls, for callers that shard the keys over several GPUs
+ * (agora-blsful_amd/dist.py): every rank sorts the gathered key bytes (cheap, on its device), ONE rank hashes the sorted
+ * stream and broadcasts the 32-byte digest, every rank derives the coefficients of its own keys.
+ * blsgpu_sort_keys: out_perm[i] = input index of the i-th key in stable byte-lexicographic order. */
+int blsgpu_sort_keys(const uint8_t* key_bytes, size_t n, size_t width, uint32_t* out_perm) try {
+  if (!initialised()) return NOT_INIT();
+  if (width != 48 && width != 96) return fail(BLSGPU_E_ARG, "width must be 48 or 96");
+  if (n == 0) return 0;
+  if (!key_bytes || !out_perm) return fail(BLSGPU_E_ARG, "null argument");
+  if (n >= 0xffffffffull) return fail(BLSGPU_E_ARG, "more than 2^32 - 2 keys");
+  CTX_ACQUIRE(c);
+  int rc = arena_reserve(c, pad256(width * n) + keysort_ws_bytes(n, width) + 4096);
+  if (rc) return rc;
+  c->arena_off = 0;
+  const void* d_kb;
+  if ((rc = stage_in(c, key_bytes, width * n, &d_kb))) return rc;
+  keysort_ws w;
+  if ((rc = keysort_ws_take(c, n, width, w))) return rc;
+  uint32_t* h_flag = (uint32_t*)hsmall_take(c, 64);
+  if (!h_flag) return fail(BLSGPU_E_HIP, "internal: pinned record buffer exhausted");
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if ((rc = run_key_sort_passes(c, (const uint8_t*)d_kb, n, width, attempt == 0 ? KEYSORT_PREFIX : (int)width, w))) return rc;
+    if (attempt == 1) break;
+    HIPCK(hipMemsetAsync(w.flag, 0, 4, c->stream));
+    KL(KID_KEY_SORT, k_keys_tie_flag, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_kb, width, (size_t)KEYSORT_PREFIX, (const uint32_t*)w.perm_a, w.flag);
+    HIPCK(hipGetLastError());
+    HIPCK(hipMemcpyAsync(h_flag, w.flag, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    if (*h_flag == 0) break;
+  }
+  if ((rc = copy_out(c, out_perm, w.perm_a, 4 * n))) return rc;
+  SYNC_FLUSH(c);
+  return 0;
+}
+API_CATCH
+
+/* out_digest[32] = SHA-256 over the keys concatenated in the order of perm (reference src/secure_aggregation.rs:45-59). */
+int blsgpu_sorted_keys_digest(const uint8_t* key_bytes, const uint32_t* perm, size_t n, size_t width, uint8_t* out_digest) try {
+  if (!initialised()) return NOT_INIT();
+  if (width != 48 && width != 96) return fail(BLSGPU_E_ARG, "width must be 48 or 96");
+  if (!out_digest || (n && (!key_bytes || !perm))) return fail(BLSGPU_E_ARG, "null argument");
+  CTX_ACQUIRE(c);
+  int rc = arena_reserve(c, 2 * pad256(width * n) + pad256(4 * n) + 4096);
+  if (rc) return rc;
+  c->arena_off = 0;
+  if ((rc = pinned_reserve(c, width * n + 64))) return rc;
+  if (n) {
+    const void *d_kb, *d_perm;
+    if ((rc = stage_in(c, key_bytes, width * n, &d_kb))) return rc;
+    if ((rc = stage_in(c, perm, 4 * n, &d_perm))) return rc;
+    uint8_t* d_sorted = (uint8_t*)arena_take(c, width * n);
+    if (!d_sorted) return fail(BLSGPU_E_HIP, "internal: arena too small");
+    KL(KID_KEY_SORT, k_keys_gather, dim3(blocks_for(n * (width / 4))), dim3(BLS_BLOCK), n, (const uint8_t*)d_kb, width, (const uint32_t*)d_perm, d_sorted);
+    HIPCK(hipGetLastError());
+    HIPCK(hipMemcpyAsync(c->hpin, d_sorted, width * n, hipMemcpyDeviceToHost, c->stream));
+    SYNC_FLUSH(c);
+  }
+  uint8_t H[32];
+  keys_digest_host(c->hpin, width * n, H);
+  HIPCK(hipMemcpy(out_digest, H, 32, is_device_ptr(out_digest) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
+  return 0;
+}
+API_CATCH
+
+/* t_i = SHA-256(BE32(i) || digest) mod r for the keys of the shard [base, base + count) of the n sorted keys, written in the
+ * shard's INPUT order: out_scalars[g - base] belongs to input key g (32 B little-endian each).  *status: BLSGPU_OK or
+ * BLSGPU_INVALID_COEFFICIENT (reference src/secure_aggregation.rs:61-100). */
+int blsgpu_coefficients_for_range(const uint8_t* digest, const uint32_t* perm, size_t n, size_t base, size_t count,
+                                  uint8_t* out_scalars, int32_t* status) try {
+  if (!initialised()) return NOT_INIT();
+  if (!digest || !status || (n && !perm) || (count && !out_scalars)) return fail(BLSGPU_E_ARG, "null argument");
+  if (base + count > n) return fail(BLSGPU_E_ARG, "shard range exceeds the key count");
+  int32_t st = BLSGPU_OK;
+  if (n) {
+    CTX_ACQUIRE(c);
+    int rc = arena_reserve(c, pad256(4 * n) + pad256(32 * count) + 4096);
+    if (rc) return rc;
+    c->arena_off = 0;
+    const void *d_perm, *d_H;
+    if ((rc = stage_in(c, perm, 4 * n, &d_perm))) return rc;
+    if ((rc = stage_in(c, digest, 32, &d_H))) return rc;
+    uint8_t* d_scal = is_device_ptr(out_scalars) ? out_scalars : (uint8_t*)arena_take(c, 32 * count);
+    int32_t* d_zero = (int32_t*)arena_take(c, 64);
+    int32_t* h_zero = (int32_t*)hsmall_take(c, 64);
+    if ((count && !d_scal) || !d_zero || !h_zero) return fail(BLSGPU_E_HIP, "internal: arena too small");
+    HIPCK(hipMemsetAsync(d_zero, 0, 4, c->stream));
+    if ((rc = run_coefficients(c, (const uint8_t*)d_H, (const uint32_t*)d_perm, n, base, count, 0, d_scal, d_zero))) return rc;
+    HIPCK(hipMemcpyAsync(h_zero, d_zero, 4, hipMemcpyDeviceToHost, c->stream));
+    if (d_scal != out_scalars && (rc = copy_out(c, out_scalars, d_scal, 32 * count))) return rc;
+    SYNC_FLUSH(c);
+    if (*h_zero) st = BLSGPU_INVALID_COEFFICIENT;
+  }
+  if (is_device_ptr(status)) HIPCK(hipMemcpy(status, &st, 4, hipMemcpyHostToDevice));
+  else *status = st;
+  return 0;
+}
+API_CATCH
+
+/* out_idx[p] = input index of the FIRST key equal to the p-th sorted key (perm from blsgpu_sort_keys: stable, so that is
+ * the input index at the start of p's run of equal keys) -- the `position` search of aggregate_secure, reference
+ * src/secure_aggregation.rs:150-162. */
+int blsgpu_first_occurrence(const uint8_t* key_bytes, const uint32_t* perm, size_t n, size_t width, uint32_t* out_idx) try {
+  if (!initialised()) return NOT_INIT();
+  if (width != 48 && width != 96) return fail(BLSGPU_E_ARG, "width must be 48 or 96");
+  if (n == 0) return 0;
+  if (!key_bytes || !perm || !out_idx) return fail(BLSGPU_E_ARG, "null argument");
+  CTX_ACQUIRE(c);
+  int rc = arena_reserve(c, pad256(width * n) + 3 * pad256(4 * n) + pad256(4 * scan_tiles(n)) + 4096);
+  if (rc) return rc;
+  c->arena_off = 0;
+  const void *d_kb, *d_perm;
+  if ((rc = stage_in(c, key_bytes, width * n, &d_kb))) return rc;
+  if ((rc = stage_in(c, perm, 4 * n, &d_perm))) return rc;
+  uint32_t* d_start = (uint32_t*)arena_take(c, 4 * n);
+  uint32_t* d_tiles = (uint32_t*)arena_take(c, 4 * scan_tiles(n));
+  uint32_t* d_idx = is_device_ptr(out_idx) ? out_idx : (uint32_t*)arena_take(c, 4 * n);
+  if (!d_start || !d_tiles || !d_idx) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  KL(KID_KEY_SORT, k_keys_run_start, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_kb, width, (const uint32_t*)d_perm, d_start);
+  if ((rc = run_scan_max_u32(c, KID_KEY_SORT, n, d_start, d_tiles))) return rc;
+  KL(KID_KEY_SORT, k_run_first_index, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint32_t*)d_perm, (const uint32_t*)d_start, d_idx);
+  HIPCK(hipGetLastError());
+  if (d_idx != out_idx && (rc = copy_out(c, out_idx, d_idx, 4 * n))) return rc;
+  SYNC_FLUSH(c);
+  return 0;
+}
+API_CATCH
+
+/* Basic's duplicate-message rule on its own (reference src/traits/sig_basic.rs:46-58), for sharded callers that gathered the
+ * messages: out2 = (index of the earlier equal message, first index i whose message was seen before), or (~0, ~0). */
+int blsgpu_first_duplicate_message(const uint8_t* msgs, const uint64_t* msg_offsets, size_t n, uint64_t* out2) try {
+  if (!initialised()) return NOT_INIT();
+  if (!out2 || !msg_offsets) return fail(BLSGPU_E_ARG, "null argument");
+  CTX_ACQUIRE(c);
+  uint64_t total = 0;
+  if (is_device_ptr(msg_offsets)) HIPCK(hipMemcpy(&total, msg_offsets + n, 8, hipMemcpyDeviceToHost));
+  else total = msg_offsets[n];
+  int rc = arena_reserve(c, pad256(total) + pad256(8 * (n + 1)) + dup_ws_bytes(n) + 4096);
+  if (rc) return rc;
+  c->arena_off = 0;
+  const void *d_msgs, *d_offs;
+  if ((rc = stage_in(c, msgs, total, &d_msgs))) return rc;
+  if ((rc = stage_in(c, msg_offsets, 8 * (n + 1), &d_offs))) return rc;
+  uint64_t* d_out = (uint64_t*)arena_take(c, 64);
+  if (!d_out) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  if ((rc = run_first_duplicate(c, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, n, d_out))) return rc;
+  if ((rc = copy_out(c, out2, d_out, 16))) return rc;
+  SYNC_FLUSH(c);
+  return 0;
+}
+API_CATCH
 
 static int hash_to_group(int group, const uint8_t* msgs, const uint64_t* msg_offsets, size_t n, const uint8_t* dst, size_t dst_len, void* out) {
-  if (!g_ctx) return fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)");
+  if (!initialised()) return NOT_INIT();
   if (dst_len > 255) return fail(BLSGPU_E_ARG, "dst longer than 255 bytes is not supported");
   if (n == 0) return 0;
   if (!msg_offsets || !out || !dst) return fail(BLSGPU_E_ARG, "null argument");
-  Ctx* c = g_ctx;
-  std::lock_guard<std::mutex> lk(c->mu);
-  HIPCK(hipSetDevice(c->dev));
+  CTX_ACQUIRE(c);
   uint64_t total = 0;
   if (is_device_ptr(msg_offsets)) HIPCK(hipMemcpy(&total, msg_offsets + n, 8, hipMemcpyDeviceToHost));
   else total = msg_offsets[n];
@@ -990,20 +1474,20 @@ static int hash_to_group(int group, const uint8_t* msgs, const uint64_t* msg_off
   SYNC_FLUSH(c);
   return 0;
 }
-int blsgpu_hash_to_g1(const uint8_t* msgs, const uint64_t* msg_offsets, size_t n, const uint8_t* dst, size_t dst_len, void* out) {
+int blsgpu_hash_to_g1(const uint8_t* msgs, const uint64_t* msg_offsets, size_t n, const uint8_t* dst, size_t dst_len, void* out) try {
   return hash_to_group(1, msgs, msg_offsets, n, dst, dst_len, out);
 }
-int blsgpu_hash_to_g2(const uint8_t* msgs, const uint64_t* msg_offsets, size_t n, const uint8_t* dst, size_t dst_len, void* out) {
+API_CATCH
+int blsgpu_hash_to_g2(const uint8_t* msgs, const uint64_t* msg_offsets, size_t n, const uint8_t* dst, size_t dst_len, void* out) try {
   return hash_to_group(2, msgs, msg_offsets, n, dst, dst_len, out);
 }
+API_CATCH
 
 static int point_sum_entry(int group, const void* pts, const uint8_t* scalars, size_t n, int fmt, void* out) {
-  if (!g_ctx) return fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)");
+  if (!initialised()) return NOT_INIT();
   if (fmt != BLSGPU_FMT_RAW_PROJ && fmt != BLSGPU_FMT_RAW_AFFINE) return fail(BLSGPU_E_ARG, "fmt must be RAW_PROJ or RAW_AFFINE");
   if (!out || (n && !pts)) return fail(BLSGPU_E_ARG, "null argument");
-  Ctx* c = g_ctx;
-  std::lock_guard<std::mutex> lk(c->mu);
-  HIPCK(hipSetDevice(c->dev));
+  CTX_ACQUIRE(c);
   const size_t psz = group == 1 ? g1_size(fmt) : g2_size(fmt), osz = group == 1 ? 144 : 288, T = accumulate_lanes(n);
   int rc = arena_reserve(c, pad256(psz * n) + pad256(32 * n) + pad256(288 * T) + 4096 + (scalars ? msm_ws_bytes(n) : 0));
   if (rc) return rc;
@@ -1022,24 +1506,24 @@ static int point_sum_entry(int group, const void* pts, const uint8_t* scalars, s
 }
 int blsgpu_sum_g1(const void* pts, size_t n, int fmt, void* out) { return point_sum_entry(1, pts, nullptr, n, fmt, out); }
 int blsgpu_sum_g2(const void* pts, size_t n, int fmt, void* out) { return point_sum_entry(2, pts, nullptr, n, fmt, out); }
-int blsgpu_msm_g1(const void* pts, const uint8_t* scalars, size_t n, int fmt, void* out) {
+int blsgpu_msm_g1(const void* pts, const uint8_t* scalars, size_t n, int fmt, void* out) try {
   if (n && !scalars) return fail(BLSGPU_E_ARG, "null scalars");
   return point_sum_entry(1, pts, scalars, n, fmt, out);
 }
-int blsgpu_msm_g2(const void* pts, const uint8_t* scalars, size_t n, int fmt, void* out) {
+API_CATCH
+int blsgpu_msm_g2(const void* pts, const uint8_t* scalars, size_t n, int fmt, void* out) try {
   if (n && !scalars) return fail(BLSGPU_E_ARG, "null scalars");
   return point_sum_entry(2, pts, scalars, n, fmt, out);
 }
+API_CATCH
 
-int blsgpu_pairing_product_is_one(const void* g1s, const void* g2s, size_t n, int fmt, int32_t* is_one) {
-  if (!g_ctx) return fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)");
+int blsgpu_pairing_product_is_one(const void* g1s, const void* g2s, size_t n, int fmt, int32_t* is_one) try {
+  if (!initialised()) return NOT_INIT();
   if (fmt != BLSGPU_FMT_RAW_PROJ && fmt != BLSGPU_FMT_RAW_AFFINE) return fail(BLSGPU_E_ARG, "fmt must be RAW_PROJ or RAW_AFFINE");
   if (!is_one || (n && (!g1s || !g2s))) return fail(BLSGPU_E_ARG, "null argument");
   int32_t verdict = BLSGPU_OK;
   if (n > 0) {
-    Ctx* c = g_ctx;
-    std::lock_guard<std::mutex> lk(c->mu);
-    HIPCK(hipSetDevice(c->dev));
+    CTX_ACQUIRE(c);
     int rc = arena_reserve(c, pad256(g1_size(fmt) * n) + pad256(g2_size(fmt) * n) + pad256(4 * n) + 2 * pad256((size_t)WS_F_WORDS * 4 * n) + 4096);
     if (rc) return rc;
     c->arena_off = 0;
@@ -1061,17 +1545,16 @@ int blsgpu_pairing_product_is_one(const void* g1s, const void* g2s, size_t n, in
   else *is_one = one;
   return 0;
 }
+API_CATCH
 
-int blsgpu_serialize(int group, const void* pts, size_t n, int fmt_in, int fmt_out, void* out, int32_t* status) {
-  if (!g_ctx) return fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)");
+int blsgpu_serialize(int group, const void* pts, size_t n, int fmt_in, int fmt_out, void* out, int32_t* status) try {
+  if (!initialised()) return NOT_INIT();
   if (group != 1 && group != 2) return fail(BLSGPU_E_ARG, "group must be 1 or 2");
   if ((fmt_in != BLSGPU_FMT_RAW_PROJ && fmt_in != BLSGPU_FMT_RAW_AFFINE) || (fmt_out != BLSGPU_FMT_COMPRESSED && fmt_out != BLSGPU_FMT_LEGACY))
     return fail(BLSGPU_E_ARG, "supported conversions: RAW_PROJ/RAW_AFFINE -> COMPRESSED/LEGACY");
   if (n == 0) return 0;
   if (!pts || !out) return fail(BLSGPU_E_ARG, "null argument");
-  Ctx* c = g_ctx;
-  std::lock_guard<std::mutex> lk(c->mu);
-  HIPCK(hipSetDevice(c->dev));
+  CTX_ACQUIRE(c);
   const size_t psz = group == 1 ? g1_size(fmt_in) : g2_size(fmt_in), osz = group == 1 ? 48 : 96;
   int rc = arena_reserve(c, pad256(psz * n) + pad256(osz * n) + 4096);
   if (rc) return rc;
@@ -1092,17 +1575,16 @@ int blsgpu_serialize(int group, const void* pts, size_t n, int fmt_in, int fmt_o
   }
   return 0;
 }
+API_CATCH
 
 /* ProofOfPossession::verify for n (pk, proof) pairs: pop_verify(pk, sig) = core_verify(pk, sig, pk.to_bytes(), POP_DST)
  * (reference src/proof_of_possession.rs:79-81, src/traits/sig_pop.rs:67-70; POP_DST src/impls/g1.rs:119, g2.rs:117). */
-int blsgpu_pop_verify_batch(int sig_group, const void* pks, const void* proofs, size_t n, int fmt, int32_t* status) {
+int blsgpu_pop_verify_batch(int sig_group, const void* pks, const void* proofs, size_t n, int fmt, int32_t* status) try {
   int rc = check_common(sig_group, 0, fmt);
   if (rc) return rc;
   if (n == 0) return 0;
   if (!pks || !proofs || !status) return fail(BLSGPU_E_ARG, "null argument");
-  Ctx* c = g_ctx;
-  std::lock_guard<std::mutex> lk(c->mu);
-  HIPCK(hipSetDevice(c->dev));
+  CTX_ACQUIRE(c);
   const size_t pkb = pk_size(sig_group, fmt) * n, sgb = sig_size(sig_group, fmt) * n;
   size_t need = pad256(pkb) + pad256(sgb) + pad256(4 * n) + 2 * pad256((size_t)WS_PAIRS_WORDS * 4 * n) + 4096;
   if ((rc = arena_reserve(c, need))) return rc;
@@ -1125,29 +1607,32 @@ int blsgpu_pop_verify_batch(int sig_group, const void* pks, const void* proofs, 
   SYNC_FLUSH(c);
   return 0;
 }
+API_CATCH
 
 /* Sign-side secure aggregation: aggregate_secure[_with_mode] / AggregateSignature::from_signatures_secure
  * (reference src/secure_aggregation.rs:110-169,338-352, src/aggregate_signature.rs:191-227): sig_agg = sum t_i * sig[idx_i]
  * over the keys in sorted order, where idx_i is the FIRST input position whose serialised key equals the i-th sorted key
  * (the reference's `position` search, so duplicate keys pick the first matching signature).  n == 0: the identity. */
 int blsgpu_aggregate_secure(int sig_group, const void* pks, const void* sigs, size_t n, int ser_format, int fmt, void* out_sig,
-                            int32_t* status) {
+                            int32_t* status) try {
   int rc = check_common(sig_group, 0, fmt);
   if (rc) return rc;
   if (!out_sig || !status || (n && (!pks || !sigs))) return fail(BLSGPU_E_ARG, "null argument");
   if (ser_format != 0 && ser_format != 1) return fail(BLSGPU_E_ARG, "ser_format must be 0 (Modern) or 1 (Legacy)");
   if (ser_format == 1 && sig_group != 2) return fail(BLSGPU_E_ARG, "Legacy serialization exists only for Bls12381G2Impl");
-  Ctx* c = g_ctx;
-  std::lock_guard<std::mutex> lk(c->mu);
-  HIPCK(hipSetDevice(c->dev));
+  if (n >= 0xffffffffull) return fail(BLSGPU_E_ARG, "more than 2^32 - 2 keys");
+  CTX_ACQUIRE(c);
   const size_t psz = pk_size(sig_group, fmt), ssz = sig_size(sig_group, fmt), width = sig_group == 1 ? 96 : 48, T = accumulate_lanes(n);
   const size_t osz = sig_group == 1 ? 144 : 288;
-  size_t need = pad256(psz * n) + pad256(ssz * n) + pad256(width * n) + pad256(4 * n) + pad256(32 * n) + pad256(288 * T) + 8192 + msm_ws_bytes(n);
+  size_t need = pad256(psz * n) + pad256(ssz * n) + pad256(width * n) + 2 * pad256(4 * n) + pad256(32 * n) + pad256(288 * T) + 8192 + msm_ws_bytes(n) +
+                keysort_ws_bytes(n, width) + pad256(4 * scan_tiles(n));
   if ((rc = arena_reserve(c, need))) return rc;
   c->arena_off = 0;
   int32_t st = BLSGPU_OK;
   uint8_t* d_part = (uint8_t*)arena_take(c, 288 * T);
-  if (!d_part) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  int32_t* h_zero = (int32_t*)hsmall_take(c, 64);
+  if (!d_part || !h_zero) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  *h_zero = 0;
   if (n == 0) {
     if (sig_group == 1) rc = run_point_sum<1>(c, nullptr, fmt, nullptr, nullptr, 0, d_part, T);
     else rc = run_point_sum<2>(c, nullptr, fmt, nullptr, nullptr, 0, d_part, T);
@@ -1158,45 +1643,53 @@ int blsgpu_aggregate_secure(int sig_group, const void* pks, const void* sigs, si
     if ((rc = stage_in(c, sigs, ssz * n, &d_sigs))) return rc;
     uint8_t* d_bytes = (uint8_t*)arena_take(c, width * n);
     uint32_t* d_idx = (uint32_t*)arena_take(c, 4 * n);
+    uint32_t* d_start = (uint32_t*)arena_take(c, 4 * n);
+    uint32_t* d_tiles = (uint32_t*)arena_take(c, 4 * scan_tiles(n));
     uint8_t* d_scal = (uint8_t*)arena_take(c, 32 * n);
-    if (!d_bytes || !d_idx || !d_scal) return fail(BLSGPU_E_HIP, "internal: arena too small");
+    uint8_t* d_H = (uint8_t*)arena_take(c, 64);
+    int32_t* d_zero = (int32_t*)arena_take(c, 64);
+    keysort_ws w;
+    if (!d_bytes || !d_idx || !d_start || !d_tiles || !d_scal || !d_H || !d_zero) return fail(BLSGPU_E_HIP, "internal: arena too small");
+    if ((rc = keysort_ws_take(c, n, width, w))) return rc;
     if (sig_group == 1) KL(KID_COMPRESS, k_compress<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, fmt, ser_format, d_bytes);
     else KL(KID_COMPRESS, k_compress<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, fmt, ser_format, d_bytes);
     HIPCK(hipGetLastError());
-    std::vector<uint8_t> kb(width * n);
-    HIPCK(hipMemcpyAsync(kb.data(), d_bytes, width * n, hipMemcpyDeviceToHost, c->stream));
-    SYNC_FLUSH(c);
-    std::vector<uint32_t> perm;
-    std::vector<uint8_t> scal;
-    st = secure_coefficients_host(kb.data(), n, width, perm, scal);
-    if (st == BLSGPU_OK) {
-      std::vector<uint32_t> idx(n);
-      for (size_t i = 0; i < n; i++)   // stable sort: equal keys keep input order, the first of a run has the smallest index
-        idx[i] = (i > 0 && memcmp(&kb[(size_t)perm[i] * width], &kb[(size_t)perm[i - 1] * width], width) == 0) ? idx[i - 1] : perm[i];
-      HIPCK(hipMemcpyAsync(d_idx, idx.data(), 4 * n, hipMemcpyHostToDevice, c->stream));
-      HIPCK(hipMemcpyAsync(d_scal, scal.data(), 32 * n, hipMemcpyHostToDevice, c->stream));
-      if (sig_group == 1) rc = run_point_sum<1>(c, (const uint8_t*)d_sigs, fmt, d_scal, d_idx, n, d_part, T);
-      else rc = run_point_sum<2>(c, (const uint8_t*)d_sigs, fmt, d_scal, d_idx, n, d_part, T);
-      if (rc) return rc;
-      SYNC_FLUSH(c);                   // idx / scal are host vectors: finish the copies before they go out of scope
-    }
+    if ((rc = run_key_sort_to_host(c, d_bytes, n, width, w, nullptr, nullptr))) return rc;
+    uint8_t H[32];
+    keys_digest_host(c->hpin, width * n, H);
+    if ((rc = h2d_small(c, d_H, H, 32))) return rc;
+    HIPCK(hipMemsetAsync(d_zero, 0, 4, c->stream));
+    if ((rc = run_coefficients(c, d_H, w.perm_a, n, 0, n, 1, d_scal, d_zero))) return rc;
+    HIPCK(hipMemcpyAsync(h_zero, d_zero, 4, hipMemcpyDeviceToHost, c->stream));
+    // the signature of sorted position i is that of the FIRST input position holding an equal key (the reference's
+    // `position` search): the sort is stable, so that is the input index at the start of i's run of equal keys
+    KL(KID_KEY_SORT, k_keys_run_start, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_bytes, width, (const uint32_t*)w.perm_a, d_start);
+    if ((rc = run_scan_max_u32(c, KID_KEY_SORT, n, d_start, d_tiles))) return rc;
+    KL(KID_KEY_SORT, k_run_first_index, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint32_t*)w.perm_a, (const uint32_t*)d_start, d_idx);
+    HIPCK(hipGetLastError());
+    if (sig_group == 1) rc = run_point_sum<1>(c, (const uint8_t*)d_sigs, fmt, d_scal, d_idx, n, d_part, T);
+    else rc = run_point_sum<2>(c, (const uint8_t*)d_sigs, fmt, d_scal, d_idx, n, d_part, T);
+    if (rc) return rc;
   }
-  if (st == BLSGPU_OK && (rc = copy_out(c, out_sig, d_part, osz))) return rc;
   SYNC_FLUSH(c);
+  if (*h_zero) st = BLSGPU_INVALID_COEFFICIENT;
+  if (st == BLSGPU_OK) {
+    if ((rc = copy_out(c, out_sig, d_part, osz))) return rc;
+    SYNC_FLUSH(c);
+  }
   if (is_device_ptr(status)) HIPCK(hipMemcpy(status, &st, 4, hipMemcpyHostToDevice));
   else *status = st;
   return 0;
 }
+API_CATCH
 
-int blsgpu_deserialize(int group, const uint8_t* bytes, size_t n, int fmt_in, void* out, int32_t* status) {
-  if (!g_ctx) return fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)");
+int blsgpu_deserialize(int group, const uint8_t* bytes, size_t n, int fmt_in, void* out, int32_t* status) try {
+  if (!initialised()) return NOT_INIT();
   if (group != 1 && group != 2) return fail(BLSGPU_E_ARG, "group must be 1 or 2");
   if (fmt_in != BLSGPU_FMT_COMPRESSED && fmt_in != BLSGPU_FMT_LEGACY) return fail(BLSGPU_E_ARG, "fmt_in must be COMPRESSED or LEGACY");
   if (n == 0) return 0;
   if (!bytes || !out || !status) return fail(BLSGPU_E_ARG, "null argument");
-  Ctx* c = g_ctx;
-  std::lock_guard<std::mutex> lk(c->mu);
-  HIPCK(hipSetDevice(c->dev));
+  CTX_ACQUIRE(c);
   const size_t isz = group == 1 ? 48 : 96, osz = group == 1 ? 144 : 288;
   int rc = arena_reserve(c, pad256(isz * n) + pad256(osz * n) + pad256(4 * n) + 4096);
   if (rc) return rc;
@@ -1215,16 +1708,73 @@ int blsgpu_deserialize(int group, const uint8_t* bytes, size_t n, int fmt_in, vo
   SYNC_FLUSH(c);
   return 0;
 }
+API_CATCH
+
+/* Signature::<C>::try_from(&[u8]) / Vec<u8>::from(&Signature<C>) for n signatures (reference src/signature.rs:112-126): the
+ * serde_bare form is the scheme as one byte (enum variant index 0 / 1 / 2) followed by the compressed point, 49 bytes
+ * (Bls12381G1Impl) or 97 bytes (Bls12381G2Impl) per record -- the lengths asserted at src/signature.rs:285-286.
+ * from_tagged: out_schemes[i] = tag, out = RAW_PROJ points (checked decompression on the device), status[i] = OK or
+ * BAD_ENCODING (unknown tag or invalid point; the reference maps every serde error to InvalidInputs(..)). */
+int blsgpu_signatures_from_tagged(int sig_group, const uint8_t* bytes, size_t n, uint8_t* out_schemes, void* out, int32_t* status) try {
+  int rc = check_common(sig_group, 0, BLSGPU_FMT_RAW_PROJ);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  if (!bytes || !out_schemes || !out || !status) return fail(BLSGPU_E_ARG, "null argument");
+  CTX_ACQUIRE(c);
+  const size_t width = sig_group == 1 ? 48 : 96, osz = sig_group == 1 ? 144 : 288;
+  if ((rc = arena_reserve(c, pad256((width + 1) * n) + pad256(width * n) + pad256(n) + pad256(osz * n) + pad256(4 * n) + 4096))) return rc;
+  c->arena_off = 0;
+  const void* d_in;
+  if ((rc = stage_in(c, bytes, (width + 1) * n, &d_in))) return rc;
+  uint8_t* d_bytes = (uint8_t*)arena_take(c, width * n);
+  uint8_t* d_tags = is_device_ptr(out_schemes) ? out_schemes : (uint8_t*)arena_take(c, n);
+  uint8_t* d_out = is_device_ptr(out) ? (uint8_t*)out : (uint8_t*)arena_take(c, osz * n);
+  int32_t* d_st = is_device_ptr(status) ? status : (int32_t*)arena_take(c, 4 * n);
+  if (!d_bytes || !d_tags || !d_out || !d_st) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  KL(KID_DECOMPRESS, k_untag, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, width, (const uint8_t*)d_in, d_bytes, d_tags, d_st);
+  HIPCK(hipMemsetAsync(d_out, 0, osz * n, c->stream));      // records with a bad tag are not decoded: leave the identity encoding
+  if (sig_group == 1) KL(KID_DECOMPRESS, k_decompress<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_bytes, 0, d_out, d_st, 1);
+  else KL(KID_DECOMPRESS, k_decompress<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_bytes, 0, d_out, d_st, 1);
+  HIPCK(hipGetLastError());
+  if (d_tags != out_schemes && (rc = copy_out(c, out_schemes, d_tags, n))) return rc;
+  if (d_out != out && (rc = copy_out(c, out, d_out, osz * n))) return rc;
+  if (d_st != status && (rc = copy_out(c, status, d_st, 4 * n))) return rc;
+  SYNC_FLUSH(c);
+  return 0;
+}
+API_CATCH
+int blsgpu_signatures_to_tagged(int sig_group, const uint8_t* schemes, const void* sigs, size_t n, int fmt, uint8_t* out) try {
+  int rc = check_common(sig_group, 0, fmt);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  if (!schemes || !sigs || !out) return fail(BLSGPU_E_ARG, "null argument");
+  CTX_ACQUIRE(c);
+  const size_t width = sig_group == 1 ? 48 : 96, psz = sig_size(sig_group, fmt);
+  if ((rc = arena_reserve(c, pad256(psz * n) + pad256(n) + pad256(width * n) + pad256((width + 1) * n) + 4096))) return rc;
+  c->arena_off = 0;
+  const void *d_pts, *d_tags;
+  if ((rc = stage_in(c, sigs, psz * n, &d_pts))) return rc;
+  if ((rc = stage_in(c, schemes, n, &d_tags))) return rc;
+  uint8_t* d_bytes = (uint8_t*)arena_take(c, width * n);
+  uint8_t* d_out = is_device_ptr(out) ? out : (uint8_t*)arena_take(c, (width + 1) * n);
+  if (!d_bytes || !d_out) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  if (sig_group == 1) KL(KID_COMPRESS, k_compress<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pts, fmt, 0, d_bytes);
+  else KL(KID_COMPRESS, k_compress<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pts, fmt, 0, d_bytes);
+  KL(KID_COMPRESS, k_tag, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, width, (const uint8_t*)d_tags, (const uint8_t*)d_bytes, d_out);
+  HIPCK(hipGetLastError());
+  if (d_out != out && (rc = copy_out(c, out, d_out, (width + 1) * n))) return rc;
+  SYNC_FLUSH(c);
+  return 0;
+}
+API_CATCH
 
 int blsgpu_sign_batch(int sig_group, int scheme, const uint8_t* sks, const uint8_t* msgs, const uint64_t* msg_offsets, size_t n,
-                      void* out_pks, void* out_sigs) {
+                      void* out_pks, void* out_sigs) try {
   int rc = check_common(sig_group, scheme, BLSGPU_FMT_RAW_PROJ);
   if (rc) return rc;
   if (n == 0) return 0;
   if (!sks || !msg_offsets || !out_pks || !out_sigs) return fail(BLSGPU_E_ARG, "null argument");
-  Ctx* c = g_ctx;
-  std::lock_guard<std::mutex> lk(c->mu);
-  HIPCK(hipSetDevice(c->dev));
+  CTX_ACQUIRE(c);
   uint64_t total = 0;
   if (is_device_ptr(msg_offsets)) HIPCK(hipMemcpy(&total, msg_offsets + n, 8, hipMemcpyDeviceToHost));
   else total = msg_offsets[n];
@@ -1250,6 +1800,7 @@ int blsgpu_sign_batch(int sig_group, int scheme, const uint8_t* sks, const uint8
   SYNC_FLUSH(c);
   return 0;
 }
+API_CATCH
 
 /* ---- sharded aggregate verify: the local part of core_aggregate_verify (reference
  * src/traits/sig_core.rs:149-178) for a contiguous shard of the (pk, msg) pairs.  out_f12 = product of the Miller
@@ -1257,13 +1808,11 @@ int blsgpu_sign_batch(int sig_group, int scheme, const uint8_t* sks, const uint8
  * 576-byte record; *first_bad = local index of the first identity public key, n when the signature is the identity,
  * or -1.  Duplicate-message detection is global and stays with the caller. */
 int blsgpu_aggregate_partial(int sig_group, int scheme, const void* pks, const uint8_t* msgs, const uint64_t* msg_offsets, size_t n,
-                             const void* sig, int fmt, void* out_f12, int64_t* first_bad) {
+                             const void* sig, int fmt, void* out_f12, int64_t* first_bad) try {
   int rc = check_common(sig_group, scheme, fmt);
   if (rc) return rc;
   if (!out_f12 || !first_bad || !msg_offsets || (n && !pks)) return fail(BLSGPU_E_ARG, "null argument");
-  Ctx* c = g_ctx;
-  std::lock_guard<std::mutex> lk(c->mu);
-  HIPCK(hipSetDevice(c->dev));
+  CTX_ACQUIRE(c);
   uint64_t total = 0;
   if (is_device_ptr(msg_offsets)) HIPCK(hipMemcpy(&total, msg_offsets + n, 8, hipMemcpyDeviceToHost));
   else total = msg_offsets[n];
@@ -1277,52 +1826,19 @@ int blsgpu_aggregate_partial(int sig_group, int scheme, const void* pks, const u
   if (sig && (rc = stage_in(c, sig, sig_size(sig_group, fmt), &d_sig))) return rc;
   if ((rc = stage_in(c, msgs, total, &d_msgs))) return rc;
   if ((rc = stage_in(c, msg_offsets, 8 * m, &d_offs))) return rc;
-  int32_t* d_bad = (int32_t*)arena_take(c, 4 * m);
-  uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)WS_PAIR1_WORDS * 4 * m);
-  uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * m);
-  uint8_t* d_out = (uint8_t*)arena_take(c, 576);
-  if (!d_bad || !d_pairs || !d_f || !d_out) return fail(BLSGPU_E_HIP, "internal: arena too small");
-  dst_arg dst = scheme_dst(sig_group, scheme);
-  int aug = scheme == BLSGPU_SCHEME_AUG;
-  // without a signature the extra lane n is simply not launched (mm = n): k_prepare_agg treats i == n as the sig lane
-  const size_t mm = sig ? m : n;
-  std::vector<int32_t> bad(m, 0);
-  int64_t fb = -1;
-  if (mm > 0) {
-    // the workspace stride is always n + 1 (k_prepare_agg's layout); lanes >= mm are never read
-    if (sig_group == 1) {
-      if (sig) KL(KID_PREPARE_AGG, k_prepare_agg<1>, dim3(blocks_for(m)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, aug, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad, 0);
-      else KL(KID_PREPARE_AGG, k_prepare_agg<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_pks, fmt, aug, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad, 0);
-    } else {
-      if (sig) KL(KID_PREPARE_AGG, k_prepare_agg<2>, dim3(blocks_for(2 * m)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, aug, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad, 1);
-      else KL(KID_PREPARE_AGG, k_prepare_agg<2>, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_pks, fmt, aug, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_bad, 1);
-    }
-    HIPCK(hipGetLastError());
-    HIPCK(hipMemcpyAsync(bad.data(), d_bad, 4 * mm, hipMemcpyDeviceToHost, c->stream));
-    SYNC_FLUSH(c);
-    if (sig && bad[n]) fb = (int64_t)n;
-    else
-      for (size_t i = 0; i < n; i++)
-        if (bad[i]) { fb = (int64_t)i; break; }
-  }
-  std::vector<uint8_t> one(576, 0);
-  if (fb < 0 && mm > 0) {
-    MILLER1_LAUNCH(mm, m, d_pairs, d_bad, d_f);   // stride n + 1 as k_prepare_agg wrote
-  }
-  *first_bad = fb;
-  if (fb >= 0 || mm == 0) {
-    // neutral element (Montgomery one in c0.a0) so that callers can always fold
-    memcpy(one.data(), FP_ONE_HOST, 48);
-    HIPCK(hipMemcpy(out_f12, one.data(), 576, is_device_ptr(out_f12) ? hipMemcpyHostToDevice : hipMemcpyHostToHost));
-    return 0;
-  }
-  if ((rc = run_f12_fold(c, d_f, MILLER1_OUTPUTS(mm), m))) return rc;
-  KL(KID_F12_IO, k_f12_export, dim3(1), dim3(BLS_BLOCK), d_f, m, d_out);
-  HIPCK(hipGetLastError());
-  if ((rc = copy_out(c, out_f12, d_out, 576))) return rc;
+  // outputs may be device pointers (the sharded caller hands them to RCCL as they are): nothing crosses to the host then
+  uint8_t* d_rec = is_device_ptr(out_f12) ? (uint8_t*)out_f12 : (uint8_t*)arena_take(c, 576);
+  int64_t* d_first = is_device_ptr(first_bad) ? first_bad : (int64_t*)arena_take(c, 64);
+  if (!d_rec || !d_first) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  if ((rc = aggregate_enqueue(c, sig_group, scheme, (const uint8_t*)d_pks, (const uint8_t*)d_sig, fmt, (const uint8_t*)d_msgs,
+                              (const uint64_t*)d_offs, n, d_first, nullptr, d_rec)))
+    return rc;
+  if (d_rec != out_f12 && (rc = copy_out(c, out_f12, d_rec, 576))) return rc;
+  if (d_first != first_bad && (rc = copy_out(c, first_bad, d_first, 8))) return rc;
   SYNC_FLUSH(c);
   return 0;
 }
+API_CATCH
 
 /* BlsSignatureCore::core_verify(pk, sig, msg, dst) with an explicit DST (reference src/traits/sig_core.rs:120-146):
  * n items share one DST; no message augmentation.  Used by the sharded verify_secure tail and by PoP checks
@@ -1332,9 +1848,7 @@ static int core_verify_entry(int sig_group, const dst_arg& dst, int aug, const v
   int rc = 0;
   if (n == 0) return 0;
   if (!pks || !sigs || !msg_offsets || !status) return fail(BLSGPU_E_ARG, "null argument");
-  Ctx* c = g_ctx;
-  std::lock_guard<std::mutex> lk(c->mu);
-  HIPCK(hipSetDevice(c->dev));
+  CTX_ACQUIRE(c);
   uint64_t total = 0;
   if (is_device_ptr(msg_offsets)) HIPCK(hipMemcpy(&total, msg_offsets + n, 8, hipMemcpyDeviceToHost));
   else total = msg_offsets[n];
@@ -1359,23 +1873,25 @@ static int core_verify_entry(int sig_group, const dst_arg& dst, int aug, const v
   return 0;
 }
 int blsgpu_core_verify(int sig_group, const uint8_t* dst, size_t dst_len, const void* pks, const void* sigs, const uint8_t* msgs,
-                       const uint64_t* msg_offsets, size_t n, int fmt, int32_t* status) {
+                       const uint64_t* msg_offsets, size_t n, int fmt, int32_t* status) try {
   int rc = check_common(sig_group, 0, fmt);
   if (rc) return rc;
   if (dst_len > 255 || (!dst && dst_len)) return fail(BLSGPU_E_ARG, "dst must be at most 255 bytes");
   return core_verify_entry(sig_group, make_dst(dst, dst_len), 0, pks, sigs, msgs, msg_offsets, n, fmt, status);
 }
+API_CATCH
 
 /* SignCryptCiphertext::is_valid for n ciphertexts (reference src/sign_crypt_ciphertext.rs:86-101 -> BlsSignCrypt::valid,
  * src/traits/sign_crypt.rs:69-77): W' = H(U.to_bytes() || V) under the scheme's DST, then e(W, -g) * e(W', U) == 1 with
  * U and W not the identity.  That is core_verify(pk := U, sig := W, msg := U.to_bytes() || V, dst): the key-prefixed hash is
  * the augmentation path of k_prepare.  status[i] == 0 <=> valid (Choice 1); any other status <=> Choice 0. */
 int blsgpu_signcrypt_valid_batch(int sig_group, int scheme, const void* us, const void* ws, const uint8_t* vs,
-                                 const uint64_t* v_offsets, size_t n, int fmt, int32_t* status) {
+                                 const uint64_t* v_offsets, size_t n, int fmt, int32_t* status) try {
   int rc = check_common(sig_group, scheme, fmt);
   if (rc) return rc;
   return core_verify_entry(sig_group, scheme_dst(sig_group, scheme), 1, us, ws, vs, v_offsets, n, fmt, status);
 }
+API_CATCH
 
 /* ProofOfKnowledge::verify for n proofs (reference src/proof_of_knowledge.rs:132-164 -> BlsSignatureProof::verify,
  * src/traits/sig_proof.rs:102-142; verify_timestamp_proof :145-175 derives y and calls the same check): status[i] in
@@ -1384,14 +1900,12 @@ int blsgpu_signcrypt_valid_batch(int sig_group, int scheme, const void* us, cons
  * MessageAugmentation). */
 int blsgpu_sig_proof_verify_batch(int sig_group, int scheme, const void* commitments, const void* proofs, const void* pks,
                                   const uint8_t* ys, const uint8_t* msgs, const uint64_t* msg_offsets, size_t n, int fmt,
-                                  int32_t* status) {
+                                  int32_t* status) try {
   int rc = check_common(sig_group, scheme, fmt);
   if (rc) return rc;
   if (n == 0) return 0;
   if (!commitments || !proofs || !pks || !ys || !msg_offsets || !status) return fail(BLSGPU_E_ARG, "null argument");
-  Ctx* c = g_ctx;
-  std::lock_guard<std::mutex> lk(c->mu);
-  HIPCK(hipSetDevice(c->dev));
+  CTX_ACQUIRE(c);
   uint64_t total = 0;
   if (is_device_ptr(msg_offsets)) HIPCK(hipMemcpy(&total, msg_offsets + n, 8, hipMemcpyDeviceToHost));
   else total = msg_offsets[n];
@@ -1423,20 +1937,19 @@ int blsgpu_sig_proof_verify_batch(int sig_group, int scheme, const void* commitm
   SYNC_FLUSH(c);
   return 0;
 }
+API_CATCH
 
 /* n independent two-pair checks  e(g1a[i], g2a[i]) * e(g1b[i], g2b[i]) == 1  -- Pairing::pairing(&[(..), (..)]).is_identity()
  * per item (reference src/traits/pairings.rs:50, glue src/helpers.rs:41-63), the shape of BlsSignCrypt::verify_share
  * (src/traits/sign_crypt.rs:192-207) and the ElGamal / time-lock share checks.  is_one[i] = 1 / 0.  Points must be in the
  * prime-order subgroups (every reference type guarantees it): a pair with an identity member contributes 1. */
 int blsgpu_pairing2_check_batch(const void* g1a, const void* g2a, const void* g1b, const void* g2b, size_t n, int fmt,
-                                int32_t* is_one) {
+                                int32_t* is_one) try {
   int rc = check_common(1, 0, fmt);
   if (rc) return rc;
   if (n == 0) return 0;
   if (!g1a || !g2a || !g1b || !g2b || !is_one) return fail(BLSGPU_E_ARG, "null argument");
-  Ctx* c = g_ctx;
-  std::lock_guard<std::mutex> lk(c->mu);
-  HIPCK(hipSetDevice(c->dev));
+  CTX_ACQUIRE(c);
   const size_t b1 = (fmt == BLSGPU_FMT_RAW_PROJ ? 144 : 96) * n, b2 = (fmt == BLSGPU_FMT_RAW_PROJ ? 288 : 192) * n;
   size_t need = 2 * pad256(b1) + 2 * pad256(b2) + pad256(4 * n) + 2 * pad256((size_t)WS_PAIRS_WORDS * 4 * n) + 4096;
   if ((rc = arena_reserve(c, need))) return rc;
@@ -1458,16 +1971,15 @@ int blsgpu_pairing2_check_batch(const void* g1a, const void* g2a, const void* g1
   SYNC_FLUSH(c);
   return 0;
 }
+API_CATCH
 
 /* product of k Fp12 records (the partials of blsgpu_aggregate_partial) -> final exponentiation -> *is_one */
-int blsgpu_fp12_product_is_one(const void* f12s, size_t k, int32_t* is_one) {
-  if (!g_ctx) return fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)");
+int blsgpu_fp12_product_is_one(const void* f12s, size_t k, int32_t* is_one) try {
+  if (!initialised()) return NOT_INIT();
   if (!is_one || (k && !f12s)) return fail(BLSGPU_E_ARG, "null argument");
   int32_t verdict = BLSGPU_OK;
   if (k > 0) {
-    Ctx* c = g_ctx;
-    std::lock_guard<std::mutex> lk(c->mu);
-    HIPCK(hipSetDevice(c->dev));
+    CTX_ACQUIRE(c);
     int rc = arena_reserve(c, pad256(576 * k) + pad256((size_t)WS_F_WORDS * 4 * k) + 4096);
     if (rc) return rc;
     c->arena_off = 0;
@@ -1486,5 +1998,6 @@ int blsgpu_fp12_product_is_one(const void* f12s, size_t k, int32_t* is_one) {
   else *is_one = one;
   return 0;
 }
+API_CATCH
 
 }  // extern "C"

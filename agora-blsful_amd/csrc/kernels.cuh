@@ -161,6 +161,29 @@ __device__ __forceinline__ void ld_g2s_fmt(jac<hfp2>& p, const uint8_t* base, si
 }
 
 
+// scalars are taken modulo the group order r (blsgpu.h): a reference Scalar is always canonical, any other 256-bit value is
+// reduced here so that the windowed path (255 bits of windows) and the double-and-add path agree on every input
+__device__ __forceinline__ void scalar_load_mod_r(uint32_t v[8], const uint8_t* scalars, size_t i) {
+  const uint32_t* k = (const uint32_t*)(scalars + 32 * i);
+#pragma unroll
+  for (int j = 0; j < 8; j++) v[j] = k[j];
+  const uint32_t R[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+  for (int round = 0; round < 3; round++) {   // 2^256 < 2.3 r
+    uint32_t d[8];
+    uint64_t bw = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint64_t t = (uint64_t)v[j] - R[j] - bw;
+      d[j] = (uint32_t)t;
+      bw = (t >> 63) & 1;
+    }
+    if (!bw) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] = d[j];
+    }
+  }
+}
+
 // ---- kernel prototypes (each kernel is defined in exactly one translation unit, see the BLS_TU_* sections)
 template <int SG>
 __global__ void k_prepare(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int aug, const uint8_t* msgs,
@@ -174,7 +197,7 @@ __global__ void k_pairing_coop(size_t n, const uint32_t* pairs, int32_t* status,
 __global__ void k_finalexp_coop(const uint32_t* fws, size_t stride, int32_t* verdict);
 template <int SG>
 __global__ void k_prepare_agg(size_t n, const uint8_t* pks, const uint8_t* sig, int fmt, int aug, const uint8_t* msgs,
-                              const uint64_t* offs, dst_arg dst, uint32_t* pairs, int32_t* bad, int two_lanes);
+                              const uint64_t* offs, dst_arg dst, uint32_t* pairs, int32_t* bad, int two_lanes, int has_sig);
 __global__ void k_pairs_to_affine(size_t n, const uint8_t* g1s, const uint8_t* g2s, int fmt, uint32_t* pairs, int32_t* skip);
 __global__ void k_pairs2_to_affine(size_t n, const uint8_t* g1a, const uint8_t* g2a, const uint8_t* g1b, const uint8_t* g2b, int fmt,
                                    uint32_t* pairs, int32_t* status);
@@ -203,7 +226,6 @@ __global__ void k_sign(size_t n, const uint8_t* sks, int aug, const uint8_t* msg
                        uint8_t* out_pks, uint8_t* out_sigs);
 // Pippenger multi-scalar multiplication (bucket method), see the BLS_TU_MSM section
 __global__ void k_msm_count(size_t n, const uint8_t* scalars, int c, int W, int clast, uint32_t* cnt);
-__global__ void k_msm_scan(size_t m, const uint32_t* cnt, uint32_t* off);
 __global__ void k_msm_fill(size_t n, const uint8_t* scalars, int c, int W, int clast, const uint32_t* off, uint32_t* cursor, uint32_t* idx);
 template <int G>
 __global__ void k_msm_bucket(size_t nb, const uint8_t* pts, int fmt, const uint32_t* perm, const uint32_t* cnt, const uint32_t* off,
@@ -221,6 +243,8 @@ __global__ void k_normalize(uint8_t* pt);
 // keep != 0: leave a non-zero status[i] that is already there (first error wins when keys and signatures are decoded)
 template <int G>
 __global__ void k_decompress(size_t n, const uint8_t* bytes, int legacy, uint8_t* out, int32_t* status, int keep);
+
+#include "util_kernels.cuh"
 
 #if defined(BLS_TU_PREPARE1) || defined(BLS_TU_PREPARE2)
 // =====================================================================================================
@@ -280,12 +304,12 @@ template __global__ void k_prepare<2>(size_t, const uint8_t*, const uint8_t*, in
 template <int SG>
 __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare_agg(size_t n, const uint8_t* pks, const uint8_t* sig, int fmt, int aug,
                                                          const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint32_t* pairs,
-                                                         int32_t* bad, int two_lanes) {
+                                                         int32_t* bad, int two_lanes, int has_sig) {
   // two_lanes: as k_prepare (two adjacent lanes per item, the hash's two SSWU maps side by side; lane 0 stores)
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t i = two_lanes ? gid >> 1 : gid;
   const int lane2 = two_lanes ? (int)(gid & 1) : -1;
-  if (i > n) return;
+  if (i > n || (i == n && !has_sig)) return;   // has_sig == 0: a shard without the signature pair (sig may be null)
   const size_t stride = n + 1;
   g1_aff P;
   g2_aff Q;
@@ -349,9 +373,9 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare_agg(size_t n, const ui
 }
 
 #if defined(BLS_TU_AGG1)
-template __global__ void k_prepare_agg<1>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, dst_arg, uint32_t*, int32_t*, int);
+template __global__ void k_prepare_agg<1>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, dst_arg, uint32_t*, int32_t*, int, int);
 #else
-template __global__ void k_prepare_agg<2>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, dst_arg, uint32_t*, int32_t*, int);
+template __global__ void k_prepare_agg<2>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, dst_arg, uint32_t*, int32_t*, int, int);
 #endif
 #endif  // BLS_TU_AGG*
 
@@ -551,7 +575,11 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_accumulate(size_t n, const uint8_
     for (size_t i = t; i < n; i += T) {
       size_t src = perm ? perm[i] : i;
       load_g1_pt(p, pts, src, fmt);
-      if (WITH_SCALARS) jac_mul_scalar(p, p, (const uint32_t*)(scalars + 32 * i));
+      if (WITH_SCALARS) {
+        uint32_t k[8];
+        scalar_load_mod_r(k, scalars, i);
+        jac_mul_scalar(p, p, k);
+      }
       jac_add(acc, acc, p);
     }
     store_g1_pt(partials, t, acc);
@@ -561,7 +589,11 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_accumulate(size_t n, const uint8_
     for (size_t i = t; i < n; i += T) {
       size_t src = perm ? perm[i] : i;
       load_g2_pt(p, pts, src, fmt);
-      if (WITH_SCALARS) jac_mul_scalar(p, p, (const uint32_t*)(scalars + 32 * i));
+      if (WITH_SCALARS) {
+        uint32_t k[8];
+        scalar_load_mod_r(k, scalars, i);
+        jac_mul_scalar(p, p, k);
+      }
       jac_add(acc, acc, p);
     }
     store_g2_pt(partials, t, acc);
@@ -891,7 +923,8 @@ __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_finalexps(size_t
 // Pippenger MSM: sum_i k_i P_i.  Scalars are < r < 2^255: W = floor(255 / c) windows, the first W - 1 are c bits wide
 // (2^c buckets each) and the LAST takes the remaining clast = 255 - c (W - 1) bits (2^clast buckets), so no window is a
 // narrow remainder whose few buckets would each receive n / 4 points.  Bucket b of window w sits at (w << c) + b.
-//   k_msm_count / k_msm_scan / k_msm_fill : counting sort of (window, digit) -> per-bucket index lists
+//   k_msm_count / k_scan_* / k_msm_fill : counting sort of (window, digit) -> per-bucket index lists (multi-workgroup
+//                    prefix sum of util_kernels.cuh)
 //   k_msm_bucket   : one lane per bucket sums its points                     (n W / (1 - 2^-c) additions in total)
 //   k_msm_chunk    : one lane per CH consecutive buckets of a window: running sums give sum_d (d - lo + 1) S_d, plus
 //                    (lo - 1) * (chunk total) by a c-bit double-and-add, then c*w doublings weigh the window
@@ -908,32 +941,19 @@ __device__ __forceinline__ uint32_t msm_digit(const uint32_t* k, int bit, int c)
 __global__ void __launch_bounds__(BLS_BLOCK) k_msm_count(size_t n, const uint8_t* scalars, int c, int W, int clast, uint32_t* cnt) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint32_t* k = (const uint32_t*)(scalars + 32 * i);
+  uint32_t k[8];
+  scalar_load_mod_r(k, scalars, i);
   for (int w = 0; w < W; w++) {
     uint32_t d = msm_digit(k, w * c, w == W - 1 ? clast : c);
     if (d) atomicAdd(&cnt[((size_t)w << c) + d], 1u);
-  }
-}
-// exclusive prefix sum over m counters, one workgroup
-__global__ void __launch_bounds__(BLS_BLOCK) k_msm_scan(size_t m, const uint32_t* cnt, uint32_t* off) {
-  __shared__ uint32_t part[BLS_BLOCK];
-  const size_t per = (m + BLS_BLOCK - 1) / BLS_BLOCK, lo = per * threadIdx.x, hi = lo + per < m ? lo + per : m;
-  uint32_t s = 0;
-  for (size_t j = lo; j < hi; j++) s += cnt[j];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  uint32_t base = 0;
-  for (unsigned t = 0; t < threadIdx.x; t++) base += part[t];
-  for (size_t j = lo; j < hi; j++) {
-    off[j] = base;
-    base += cnt[j];
   }
 }
 __global__ void __launch_bounds__(BLS_BLOCK) k_msm_fill(size_t n, const uint8_t* scalars, int c, int W, int clast, const uint32_t* off,
                                                       uint32_t* cursor, uint32_t* idx) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint32_t* k = (const uint32_t*)(scalars + 32 * i);
+  uint32_t k[8];
+  scalar_load_mod_r(k, scalars, i);
   for (int w = 0; w < W; w++) {
     uint32_t d = msm_digit(k, w * c, w == W - 1 ? clast : c);
     if (d) {

@@ -1,27 +1,37 @@
-"""One-process-per-GPU sharding of the verify path.  Every function takes the caller's LOCAL shard
-(contiguous item range [base, base + n_local) of the global input) and returns the GLOBAL result on every rank, with
-the reference's semantics and error precedence.
+"""One-process-per-GPU sharding of the verify path on DEVICE-RESIDENT shards.
 
-  verify_batch       independent items: no exchange on the data path, only the verdicts are gathered
-  multi_verify       local point sum -> all-gather of one group element per rank (144/288 B) -> fold -> one verify
-  aggregate_verify   local Miller products -> all-gather of one Fp12 record per rank (576 B) + first-bad indices ->
-                     fold + final exponentiation; Basic's duplicate-message rule is decided on gathered SHA-256 digests
-  verify_secure      local compress -> all-gather of the serialised keys (n * 48/96 B) -> every rank derives the same
-                     sort / H / t_i -> local MSM over its own keys with their coefficients -> all-gather of one group
-                     element per rank -> fold -> one core_verify
-  pop_verify_batch   independent (key, proof) items like verify_batch
-  aggregate_secure   the sign-side twin of verify_secure: same gathered keys and coefficients, local MSM over the local
-                     SIGNATURES, all-gather of one group element per rank -> fold
+Every rank holds its contiguous item range [base, base + n_local) of the global input as torch uint8 tensors in its own
+HBM (RAW_PROJ points, a message blob + int64 offsets) and calls the C ABI with their device pointers through
+`api.TensorOps`; ranks exchange only fixed-size device tensors with torch.distributed (backend "nccl" = RCCL over xGMI).
+There is no per-item Python anywhere and no pickled object on the wire.  Every function returns the GLOBAL result on
+every rank, with the reference's semantics and error precedence.
 
-`backend` is the C-ABI wrapper module (agora-blsful_amd/api.py); `pg` is torch.distributed (backend "nccl" = RCCL over
-xGMI on MI355X; the payloads are tiny so the exchange is latency-bound) or None for a single process.  RCCL has no
-user-defined reduction and neither Fp12 products nor point additions are element-wise, hence all-gather + local fold.
+  verify_batch       independent items: no exchange on the data path (config 2); verdicts all-gathered on request
+  multi_verify       local key sum -> all-gather of one group element per rank (144/288 B) -> fold + one verify (config 3)
+  aggregate_verify   local hash-to-curve + Miller loops -> all-gather of one Fp12 record per rank (576 B) and of the
+                     first-identity index (8 B) -> fold + final exponentiation; Basic's duplicate-message rule runs on the
+                     gathered message bytes on the device, exactly (bytes are compared), while the Miller loops run (config 4)
+  verify_secure      local compress -> all-gather of the serialised keys (n * 48/96 B) -> every rank sorts them on its
+                     device; rank 0 alone hashes the sorted stream (the one sequential step) and broadcasts the 32-byte
+                     digest; every rank derives the coefficients of ITS keys on the device -> local MSM -> all-gather of
+                     one group element per rank -> fold -> one core_verify (config 5)
+  aggregate_secure   the sign-side twin: every sorted position's coefficient goes to the FIRST occurrence of its key
+                     (run starts of the stable sorted order, found on the device); every rank adds the terms whose
+                     signature it holds
+  pop / proof-of-knowledge / signcryption batches: independent items like verify_batch
+
+RCCL has no user-defined reduction and neither Fp12 products nor point additions are element-wise, hence all-gather +
+local fold ("all-reduce with multiply"): the payloads are <= 576 B per rank, so the exchange is latency-bound.
+`ops` is api.TensorOps (or tests/fake_backend.FakeOps on CPU tensors for the gloo tests); `pg` is torch.distributed or
+None for a single process.
 """
-import hashlib
-
 OK, INVALID_SIGNATURE, SIG_IDENTITY, PK_IDENTITY, DUPLICATE_MESSAGE, INVALID_COEFFICIENT = 0, 1, 2, 3, 4, 5
 BASIC, AUG, POP = 0, 1, 2
-R_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+DST = {  # reference src/impls/g1.rs:110-119, src/impls/g2.rs:108-117
+    (1, BASIC): b'BLS_SIG_BLS12381G1_XMD:SHA-256_SSWU_RO_NUL_', (1, AUG): b'BLS_SIG_BLS12381G1_XMD:SHA-256_SSWU_RO_AUG_',
+    (1, POP): b'BLS_SIG_BLS12381G1_XMD:SHA-256_SSWU_RO_POP_', (2, BASIC): b'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_',
+    (2, AUG): b'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_AUG_', (2, POP): b'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_',
+}
 
 
 def shard_range(n, rank, world):
@@ -30,121 +40,194 @@ def shard_range(n, rank, world):
 
 
 class Sharded:
-    def __init__(self, backend, pg=None, device=None):
-        self.be, self.pg = backend, pg
+    def __init__(self, ops, pg=None):
+        self.ops, self.pg = ops, pg
+        self.torch = ops.torch
         self.rank = pg.get_rank() if pg is not None else 0
         self.world = pg.get_world_size() if pg is not None else 1
-        self.device = device
+        # gloo (the CPU test backend) cannot all-gather device tensors: stage through the host there; nccl takes them as they are
+        self.stage = pg is not None and pg.get_backend() != 'nccl'
+        self.collective_s = 0.0          # wall time spent inside collectives (bench.py reports it)
 
-    # ---- collectives on byte strings
-    def _gather_objects(self, obj):
+    # ---- collectives on fixed-size tensors
+    def _all_gather(self, t):
+        """[world, *t.shape] tensor on t's device."""
         if self.pg is None:
-            return [obj]
-        out = [None] * self.world
-        self.pg.all_gather_object(out, obj)
+            return t.unsqueeze(0)
+        import time
+        t0 = time.perf_counter()
+        src = t.cpu() if (self.stage and t.is_cuda) else t.contiguous()
+        out = self.torch.empty((self.world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
+        self.pg.all_gather(list(out.unbind(0)), src)
+        if out.device != t.device:
+            out = out.to(t.device)
+        self.collective_s += time.perf_counter() - t0
         return out
 
-    def _gather_fixed(self, b):
-        """all-gather of one fixed-size record per rank as a uint8 tensor (the data-path exchange)."""
+    def _broadcast(self, t, src=0):
         if self.pg is None:
-            return [bytes(b)]
-        import torch
-        t = torch.frombuffer(bytearray(b), dtype=torch.uint8)
-        if self.device is not None:
-            t = t.to(self.device)
-        outs = [torch.empty_like(t) for _ in range(self.world)]
-        self.pg.all_gather(outs, t)
-        return [bytes(o.cpu().numpy().tobytes()) for o in outs]
+            return t
+        import time
+        t0 = time.perf_counter()
+        if self.stage and t.is_cuda:
+            h = t.cpu()
+            self.pg.broadcast(h, src)
+            t.copy_(h)
+        else:
+            self.pg.broadcast(t, src)
+        self.collective_s += time.perf_counter() - t0
+        return t
 
-    # ---- config 2
-    def verify_batch(self, sig_group, scheme, pks, sigs, msgs):
-        local = self.be.verify_batch(sig_group, scheme, pks, sigs, msgs)
-        return [s for part in self._gather_objects(local) for s in part]
+    def _counts(self, n_local, n_total):
+        """items per rank: from the balanced partition when the caller names the global size, else exchanged."""
+        if self.pg is None:
+            return [n_local]
+        if n_total is not None:
+            return [shard_range(n_total, r, self.world)[1] - shard_range(n_total, r, self.world)[0] for r in range(self.world)]
+        c = self._all_gather(self.torch.tensor([n_local], dtype=self.torch.int64, device=self.ops.device))
+        return [int(x) for x in c.view(-1).tolist()]
 
-    # ---- config 3
-    def multi_verify(self, sig_group, scheme, pks, sig, msg):
+    def _gather_rows(self, t, row, counts):
+        """all-gather of per-rank row lists (rank r holds counts[r] rows of `row` elements) -> one [sum * row] tensor."""
+        if self.pg is None:
+            return t
+        mx = max(counts)
+        if all(c == mx for c in counts):
+            return self._all_gather(t.view(-1)[:mx * row]).reshape(-1)
+        pad = self.torch.zeros(mx * row, dtype=t.dtype, device=t.device)
+        pad[:t.numel()] = t.view(-1)
+        g = self._all_gather(pad)
+        return self.torch.cat([g[r, :counts[r] * row] for r in range(self.world)])
+
+    def _gather_ragged(self, blob, offs, n_local, counts):
+        """messages of all ranks: (global blob, global int64 offsets [n_total + 1])."""
+        if self.pg is None:
+            return blob, offs
+        torch = self.torch
+        lens = self._all_gather(offs[n_local:n_local + 1].to(torch.int64)).view(-1)   # local blob sizes, 8 B per rank
+        lens_h = [int(x) for x in lens.tolist()]
+        blob_all = self._gather_rows(blob[:lens_h[self.rank]], 1, lens_h)
+        rel = self._gather_rows(offs[:n_local].to(torch.int64), 1, counts)            # offsets relative to each rank's blob
+        starts, acc = [], 0
+        for ln in lens_h:
+            starts.append(acc)
+            acc += ln
+        shift = torch.repeat_interleave(torch.tensor(starts, dtype=torch.int64, device=rel.device),
+                                        torch.tensor(counts, dtype=torch.int64, device=rel.device))
+        glob = torch.cat([rel + shift, torch.tensor([acc], dtype=torch.int64, device=rel.device)])
+        return blob_all, glob
+
+    # ---- config 2: independent items
+    def verify_batch(self, sig_group, scheme, pks, sigs, msgs, offs, n_local, gather=False, n_total=None):
+        st = self.ops.verify_batch(sig_group, scheme, pks, sigs, msgs, offs, n_local)
+        return self._gather_rows(st, 1, self._counts(n_local, n_total)) if gather else st
+
+    def pop_verify_batch(self, sig_group, pks, proofs, n_local, gather=False, n_total=None):
+        """ProofOfPossession::verify per item (reference src/proof_of_possession.rs:79-81)."""
+        st = self.ops.pop_verify_batch(sig_group, pks, proofs, n_local)
+        return self._gather_rows(st, 1, self._counts(n_local, n_total)) if gather else st
+
+    def sig_proof_verify_batch(self, sig_group, scheme, us, vs, pks, ys, msgs, offs, n_local, gather=False, n_total=None):
+        """ProofOfKnowledge::verify per item (reference src/traits/sig_proof.rs:102-142)."""
+        st = self.ops.sig_proof_verify_batch(sig_group, scheme, us, vs, pks, ys, msgs, offs, n_local)
+        return self._gather_rows(st, 1, self._counts(n_local, n_total)) if gather else st
+
+    def signcrypt_valid_batch(self, sig_group, scheme, us, ws, vs, offs, n_local, gather=False, n_total=None):
+        """SignCryptCiphertext::is_valid per item (reference src/traits/sign_crypt.rs:69-77): status 0 <=> valid."""
+        st = self.ops.signcrypt_valid_batch(sig_group, scheme, us, ws, vs, offs, n_local)
+        return self._gather_rows(st, 1, self._counts(n_local, n_total)) if gather else st
+
+    # ---- config 3: MultiSignature::verify (reference src/multi_signature.rs:127-135, src/traits/pk_multi.rs:7-13)
+    def multi_verify(self, sig_group, scheme, pks, n_local, sig, msg):
         pk_group = 2 if sig_group == 1 else 1
-        partial = self.be.point_sum(pk_group, pks)
-        apk = self.be.point_sum(pk_group, self._gather_fixed(partial))
-        return self.be.verify_batch(sig_group, scheme, [apk], [sig], [msg])[0]
+        partial = self.ops.point_sum(pk_group, pks, n_local)                 # 144 / 288 B, device
+        parts = self._all_gather(partial)                                     # [world, 144 / 288]
+        return self.ops.multi_verify(sig_group, scheme, parts.reshape(-1), self.world, sig, msg)
 
-    # ---- config 4
-    def aggregate_verify(self, sig_group, scheme, pks, msgs, sig, base):
-        """returns (status, (aux0, aux1)) like blsgpu_aggregate_verify, with global indices."""
-        rec, fb = self.be.aggregate_partial(sig_group, scheme, pks, msgs, sig if self.rank == 0 else None)
-        if scheme == BASIC:
-            digests = [d for part in self._gather_objects([hashlib.sha256(m).digest() for m in msgs]) for d in part]
-            seen = {}
-            for i, d in enumerate(digests):          # reference src/traits/sig_basic.rs:46-58
-                if d in seen:
-                    return DUPLICATE_MESSAGE, (seen[d], i)
-                seen[d] = i
-        info = self._gather_objects((base, len(pks), fb))
-        if info[0][2] == info[0][1]:                 # rank 0 saw the identity signature (local index n)
+    # ---- config 4: AggregateSignature::verify (reference src/aggregate_signature.rs:230-239, src/traits/sig_core.rs:149-178)
+    def aggregate_verify(self, sig_group, scheme, pks, msgs, offs, n_local, sig, base, n_total=None):
+        """(status, (aux0, aux1)) like blsgpu_aggregate_verify, with global indices."""
+        torch = self.torch
+        counts = self._counts(n_local, n_total)
+        dup_work = None
+        if scheme == BASIC and self.pg is not None:
+            # the messages of all ranks (8 MB at 262,144 x 32 B): gathered first so that the exchange overlaps nothing
+            # expensive; the duplicate rule itself runs after the local Miller loops have been enqueued
+            dup_work = self._gather_ragged(msgs, offs, n_local, counts)
+        rec, fb = self.ops.aggregate_partial(sig_group, scheme, pks, msgs, offs, n_local, sig if self.rank == 0 else None)
+        dup = None
+        if scheme == BASIC:                                                   # reference src/traits/sig_basic.rs:46-58
+            blob_all, offs_all = dup_work if dup_work is not None else (msgs, offs)
+            dup = self.ops.first_duplicate(blob_all, offs_all, sum(counts))
+        if dup is not None:
+            return DUPLICATE_MESSAGE, (int(dup[0]), int(dup[1]))
+        fbs = [int(x) for x in self._all_gather(fb).view(-1).tolist()]        # 8 B per rank
+        if fbs[0] == counts[0]:                                               # rank 0 saw the identity signature (local index n)
             return SIG_IDENTITY, (0, 0)
-        firsts = [b + f for (b, n, f) in info if 0 <= f < n]
+        bases, acc = [], 0
+        for cnt in counts:
+            bases.append(acc)
+            acc += cnt
+        firsts = [bases[r] + f for r, f in enumerate(fbs) if 0 <= f < counts[r]]
         if firsts:
-            return PK_IDENTITY, (min(firsts) + 1, 0)  # 1-based, reference src/traits/sig_core.rs:163-166
-        ok = self.be.fp12_product_is_one(self._gather_fixed(rec))
+            return PK_IDENTITY, (min(firsts) + 1, 0)                          # 1-based, reference src/traits/sig_core.rs:163-166
+        recs = self._all_gather(rec)                                          # [world, 576]: the "all-reduce with multiply"
+        ok = self.ops.fp12_product_is_one(recs.reshape(-1), self.world)
         return (OK if ok else INVALID_SIGNATURE), (0, 0)
 
-    # ---- config 5
-    def verify_secure(self, sig_group, scheme, pks, sig, msg, base, ser_format=0):
+    # ---- config 5: verify_secure[_with_mode] (reference src/secure_aggregation.rs:173-208, 37-106, 269-335)
+    def _sorted_keys(self, pk_group, pks, n_local, ser_format, counts):
+        """(gathered key bytes, n_total, perm, digest): hash_public_keys_with_sorted up to H, reference :41-59 / :273-291."""
+        width = 96 if pk_group == 2 else 48
+        local_bytes = self.ops.serialize(pk_group, pks, n_local, legacy=bool(ser_format))
+        all_bytes = self._gather_rows(local_bytes, width, counts)
+        n = sum(counts)
+        perm = self.ops.sort_keys(all_bytes, n, width)                        # every rank, on its device
+        if self.rank == 0:
+            digest = self.ops.keys_digest(all_bytes, perm, n, width)          # the sequential SHA-256 stream: one rank only
+        else:
+            digest = self.ops.empty(32)
+        digest = self._broadcast(digest, 0)                                   # 32 B
+        return all_bytes, n, perm, digest
+
+    def verify_secure(self, sig_group, scheme, pks, n_local, sig, msg, base, ser_format=0, n_total=None):
         pk_group = 2 if sig_group == 1 else 1
-        local_bytes = self.be.serialize(pk_group, pks, legacy=bool(ser_format)) if pks else []
-        parts = self._gather_objects((base, local_bytes))
-        parts.sort(key=lambda p: p[0])
-        all_bytes = [b for (_, bs) in parts for b in bs]
-        if not all_bytes:                            # reference src/secure_aggregation.rs:189-195
-            ident = self.be.serialize(sig_group, [sig])[0][0] == 0xc0
-            return OK if ident else INVALID_SIGNATURE
-        st, perm, ts = self.be.secure_coefficients(all_bytes)
-        if st != OK:
-            return st
-        pos = {orig: p for p, orig in enumerate(perm)}
-        scal = [ts[pos[base + i]] for i in range(len(pks))]
-        partial = self.be.point_sum(pk_group, pks, scal)
-        apk = self.be.point_sum(pk_group, self._gather_fixed(partial))
-        return self.be.core_verify(sig_group, self.be.DST[(sig_group, scheme)], [apk], [sig], [msg])[0]
-
-
-    # ---- N3: ProofOfPossession::verify, independent items (reference src/proof_of_possession.rs:79-81)
-    def pop_verify_batch(self, sig_group, pks, proofs):
-        local = self.be.pop_verify_batch(sig_group, pks, proofs)
-        return [s for part in self._gather_objects(local) for s in part]
-
-    # ---- N4: the other per-item two-pairing checks (independent items: shard, no data-path collective)
-    def sig_proof_verify_batch(self, sig_group, scheme, commitments, proofs, pks, ys, msgs):
-        """ProofOfKnowledge::verify per item (reference src/traits/sig_proof.rs:102-142): statuses in global order."""
-        local = self.be.sig_proof_verify_batch(sig_group, scheme, commitments, proofs, pks, ys, msgs)
-        return [s for part in self._gather_objects(local) for s in part]
-
-    def signcrypt_valid_batch(self, sig_group, scheme, us, ws, vs):
-        """SignCryptCiphertext::is_valid per item (reference src/traits/sign_crypt.rs:69-77): bools in global order."""
-        local = self.be.signcrypt_valid_batch(sig_group, scheme, us, ws, vs)
-        return [s for part in self._gather_objects(local) for s in part]
+        counts = self._counts(n_local, n_total)
+        if sum(counts) == 0:                                                  # reference src/secure_aggregation.rs:189-195
+            return OK if self.ops.is_identity(sig_group, sig) else INVALID_SIGNATURE
+        _, n, perm, digest = self._sorted_keys(pk_group, pks, n_local, ser_format, counts)
+        scal, st = self.ops.coefficients_for_range(digest, perm, n, base, n_local)   # t_i of the local keys, on the device
+        partial = self.ops.point_sum(pk_group, pks, n_local, scal)            # local MSM with the local keys' coefficients
+        # one exchange: the partial sum and the rank's coefficient status (a zero coefficient anywhere is
+        # InvalidCoefficient for everybody, reference :97-100)
+        rec = self.torch.cat([partial, self.torch.tensor([st], dtype=self.torch.uint8, device=partial.device)])
+        recs = self._all_gather(rec)
+        if int(recs[:, -1].max().item()) != OK:
+            return INVALID_COEFFICIENT
+        apk = self.ops.point_sum(pk_group, recs[:, :-1].reshape(-1), self.world)
+        return self.ops.core_verify_one(sig_group, DST[(sig_group, scheme)], apk, sig, msg)
 
     # ---- N1: aggregate_secure[_with_mode] (reference src/secure_aggregation.rs:110-169,338-352)
-    def aggregate_secure(self, sig_group, pks, sigs, base, ser_format=0):
-        """(status, RAW_PROJ aggregate signature) on every rank.  The reference looks every sorted key up with `position`,
-        so duplicated keys all take the signature of their FIRST occurrence: that owner adds up their coefficients."""
+    def aggregate_secure(self, sig_group, pks, sigs, n_local, base, ser_format=0, n_total=None):
+        """(status, RAW_PROJ aggregate signature tensor) on every rank: sum over sorted positions p of t_p * sig[first(p)],
+        where first(p) is the FIRST input position holding a key equal to sorted key p (the reference's `position` search,
+        so duplicated keys all take the signature of their first occurrence).  Every rank adds the terms whose signature it
+        holds."""
+        torch = self.torch
         pk_group = 2 if sig_group == 1 else 1
-        local_bytes = self.be.serialize(pk_group, pks, legacy=bool(ser_format)) if pks else []
-        parts = self._gather_objects((base, local_bytes))
-        parts.sort(key=lambda p: p[0])
-        all_bytes = [b for (_, bs) in parts for b in bs]
-        if not all_bytes:
-            return OK, self.be.point_sum(sig_group, [])
-        st, perm, ts = self.be.secure_coefficients(all_bytes)
+        sz = 144 if sig_group == 1 else 288
+        counts = self._counts(n_local, n_total)
+        if sum(counts) == 0:
+            return OK, self.ops.point_sum(sig_group, self.ops.empty(0), 0)
+        all_bytes, n, perm, digest = self._sorted_keys(pk_group, pks, n_local, ser_format, counts)
+        width = 96 if pk_group == 2 else 48
+        ident = torch.arange(n, dtype=torch.int32, device=perm.device)
+        scal, st = self.ops.coefficients_for_range(digest, ident, n, 0, n)    # t_p for every sorted position p
         if st != OK:
             return st, None
-        first = {}
-        for g, b in enumerate(all_bytes):
-            first.setdefault(b, g)
-        coef = {}
-        for p, orig in enumerate(perm):
-            owner = first[all_bytes[orig]]
-            coef[owner] = (coef.get(owner, 0) + ts[p]) % R_ORDER
-        mine = [(sigs[i], coef[base + i]) for i in range(len(pks)) if coef.get(base + i)]
-        partial = self.be.point_sum(sig_group, [m[0] for m in mine], [m[1] for m in mine])
-        return OK, self.be.point_sum(sig_group, self._gather_fixed(partial))
+        first = self.ops.first_occurrence(all_bytes, perm, n, width).to(torch.int64)
+        sel = torch.nonzero((first >= base) & (first < base + n_local)).view(-1)
+        pts = sigs.view(-1)[:n_local * sz].view(n_local, sz)[first[sel] - base].reshape(-1)
+        partial = self.ops.point_sum(sig_group, pts, int(sel.numel()), scal.view(n, 32)[sel].reshape(-1))
+        parts = self._all_gather(partial)
+        return OK, self.ops.point_sum(sig_group, parts.reshape(-1), self.world)

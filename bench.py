@@ -1,18 +1,29 @@
 #!/usr/bin/env python
 """Benchmark of the hot path: batch BLS12-381 signature verification on MI355X.
 
-Workload (BASELINE.json configs[1]): N independent (pk, msg, sig) Signature<Bls12381G1Impl>::verify items per GPU
-(default 65,536, 32-byte messages, ProofOfPossession scheme = the reference default), inputs already resident in HBM
-in RAW_PROJ form, 1 % of the items tampered as negative controls.  A "step" = one pass over the batch through the
-C ABI (blsgpu_verify_batch).  One process per GPU; N > 1 ranks shard independent batches (weak scaling, no
-collective on the data path); timing = barrier + synchronize on both sides, max over ranks.
+Default workload (BASELINE.json configs[1], the config the metric is quoted on): N independent (pk, msg, sig)
+Signature<Bls12381G1Impl>::verify items per GPU (default 65,536, 32-byte messages, ProofOfPossession scheme = the
+reference default), inputs already resident in HBM in RAW_PROJ form, 1 % of the items tampered as negative controls.
+A "step" = one pass over the batch through the C ABI (blsgpu_verify_batch).  One process per GPU; N > 1 ranks shard
+independent batches (weak scaling, no collective on the data path); timing = barrier + synchronize on both sides, max
+over ranks.
+
+--config 3 | 4 | 5 benches the other BASELINE configs instead, sharded over the ranks through agora-blsful_amd/dist.py
+(device-resident shards, fixed-size RCCL all-gathers; STRONG scaling: the total size is BASELINE's, each rank holds 1/N):
+  3  MultiSignature::verify, 1,048,576 G2 public keys, one message
+  4  AggregateSignature::verify, 262,144 distinct (pk, msg) pairs, Basic scheme (duplicate-message rule on)
+  5  verify_secure, 65,536 public keys (--variant g1m | g2m | g2l: Bls12381G1Impl Modern, Bls12381G2Impl Modern / Legacy)
+The default run also times a few steps of configs 3-5 AFTER the headline measurement and reports them under
+"other_configs" of the same JSON line (--no-extras switches that off), so that a multi-GPU launch of the default command
+yields hardware numbers for the sharded configs too.
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
-  roofline      the dominant kernel's algorithmic HBM bytes / its HIP-event-measured duration vs 8 TB/s
-  cpu_baseline  the oracle timed on a bounded sample of the same workload on this box's host cores
+  roofline      the dominant kernel's algorithmic HBM bytes / its HIP-event-measured duration vs 8 TB/s (and vs 6.29 TB/s)
+  cpu_baseline  the oracle timed on a bounded sample of the same workload on this box's host cores (config 2, N = 1)
 """
 import argparse
 import ctypes
+import datetime
 import hashlib
 import json
 import os
@@ -26,16 +37,39 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 R_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 SEED = hashlib.sha256(b'blsgpu-bench-v1').digest()
 S0 = int.from_bytes(SEED, 'big') % R_ORDER
+FIXED_MSG = hashlib.sha256(SEED + b'fixed').digest()
 ALG_BYTES_PER_VERIFY = 468          # pk 288 + sig 144 + msg 32 + status 4
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_MEASURED_GBS = 6290.0           # same guide: measured copy bandwidth (BASELINE.md section 4 asks for both)
 FPMUL_PEAK_G = 66.6                 # profiles/ubench_r01_fp28.txt: best measured Fp-multiplication-equivalent rate of the 28-bit-limb
                                     # multiplier chip-wide (fused two-product pass, 2-4 waves/SIMD): the integer-VALU roofline
+CONFIG_SIZES = {3: 1048576, 4: 262144, 5: 65536}
+VARIANTS = {'g1m': (1, 0, 'Bls12381G1Impl/Modern'), 'g2m': (2, 0, 'Bls12381G2Impl/Modern'), 'g2l': (2, 1, 'Bls12381G2Impl/Legacy')}
 
 
 def gen_inputs(n, base):
     sks = [(S0 + base + i) % R_ORDER or 1 for i in range(n)]
     msgs = [hashlib.sha256(SEED + (base + i).to_bytes(8, 'little')).digest() for i in range(n)]
     return sks, msgs
+
+
+def sk_bytes(n, base):
+    """32-byte little-endian secret keys S0 + base + i (mod r) for i < n, without a Python loop over big ints."""
+    import numpy as np
+    out = np.zeros((n, 32), dtype=np.uint8)
+    start = (S0 + base) % R_ORDER
+    if start + n < R_ORDER and start > 0:   # no wrap (always, for these sizes): add the 64-bit counter to the low limbs
+        lo = start & ((1 << 64) - 1)
+        hi = start >> 64
+        idx = np.arange(n, dtype=np.uint64)
+        low = (np.uint64(lo) + idx)
+        carry = (low < np.uint64(lo)).astype(np.uint64)
+        out[:, :8] = low.view(np.uint8).reshape(n, 8)
+        hi_rows = [(hi + c) for c in (0, 1)]
+        hb = [np.frombuffer(h.to_bytes(24, 'little'), dtype=np.uint8) for h in hi_rows]
+        out[:, 8:] = np.where(carry[:, None] == 0, hb[0][None, :], hb[1][None, :])
+        return out.tobytes()
+    return b''.join(((S0 + base + i) % R_ORDER or 1).to_bytes(32, 'little') for i in range(n))
 
 
 def host_cores():
@@ -70,46 +104,219 @@ def cpu_baseline(d_pks, d_sigs, msgs_host, sample, n_total):
                       % (sample, n_total, cores, dt)}, list(st)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--n', type=int, default=65536, help='items per GPU')
-    ap.add_argument('--cpu-sample', type=int, default=4096)
-    args = ap.parse_args()
+class Harness:
+    """Process group, library, device and the timing discipline shared by all configs."""
 
-    import torch
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node == --gpus'
-    assert torch.cuda.is_available(), 'bench.py needs a GPU: the product has no CPU path'
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or 'RANK' in os.environ:      # under torch.distributed.run: exercise RCCL init / barrier / all-reduce
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        assert self.world == args.gpus, 'launch with torch.distributed.run --nproc-per-node == --gpus'
+        assert torch.cuda.is_available(), 'bench.py needs a GPU: the product has no CPU path'
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device('cuda', self.local_rank)
+        self.dist = None
+        if self.world > 1 or 'RANK' in os.environ:      # under torch.distributed.run: RCCL init / barrier / collectives
+            import torch.distributed as dist_mod
+            self.dist = dist_mod
+            # a bounded timeout: a rank that fails outside a collective must not leave the others waiting for ever
+            self.dist.init_process_group('nccl', device_id=self.dev, timeout=datetime.timedelta(seconds=180))
+        import __graft_entry__ as ge
+        self.pkg = ge.import_pkg()
+        self.api = self.pkg.api
+        self.ops = self.api.TensorOps(self.dev)
+        self.lib = self.ops.lib
+        from agora_blsful_amd import dist as bd
+        self.bd = bd
+        self.sh = bd.Sharded(self.ops, self.dist)
 
-    import __graft_entry__ as ge
-    pkg = ge.import_pkg()
-    api = pkg.api
-    lib = api.init(local_rank)
-    n = args.n
-    dev = torch.device('cuda', local_rank)
+    def P(self, t):
+        return ctypes.c_void_p(t.data_ptr())
 
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def timed(self, step, steps, warmup, after_warmup=None):
+        """warmup untimed steps, then exactly `steps` steps between fences; (seconds = max over ranks, kernel profile)."""
+        for _ in range(warmup):
+            step()
+        if after_warmup is not None and warmup > 0:
+            after_warmup()
+        self.api.profile_enable(True)
+        self.sh.collective_s = 0.0
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.fence()
+        dt = time.perf_counter() - t0
+        prof = self.api.profile_read()
+        self.api.profile_enable(False)
+        if self.dist is not None:
+            t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, prof
+
+    def sign(self, sg, scheme, n, base, msgs_blob, msg_len):
+        """device-resident (pks, sigs, msgs, offs) of the keys S0 + base + i, signed on the device"""
+        torch = self.torch
+        pksz, sgsz = (288, 144) if sg == 1 else (144, 288)
+        d_msgs = torch.frombuffer(bytearray(msgs_blob), dtype=torch.uint8).to(self.dev) if n else torch.zeros(0, dtype=torch.uint8, device=self.dev)
+        d_offs = (torch.arange(n + 1, dtype=torch.int64) * msg_len).to(self.dev)
+        d_pks = torch.empty(max(n, 1) * pksz, dtype=torch.uint8, device=self.dev)
+        d_sigs = torch.empty(max(n, 1) * sgsz, dtype=torch.uint8, device=self.dev)
+        torch.cuda.synchronize()
+        if n:
+            self.api._check(self.lib.blsgpu_sign_batch(sg, scheme, self.api._ptr(sk_bytes(n, base)), self.P(d_msgs), self.P(d_offs), n, self.P(d_pks), self.P(d_sigs)))
+        return d_pks[:n * pksz], d_sigs[:n * sgsz], d_msgs, d_offs
+
+    def global_sum(self, group, local_partial):
+        """fold of one group element per rank (setup only: builds the aggregate signatures the configs verify)"""
+        parts = self.sh._all_gather(local_partial)
+        return self.ops.point_sum(group, parts.reshape(-1), self.world)
+
+
+def roofline_of(prof, alg_bytes_per_launch_of_dominant):
+    dom = max(prof.items(), key=lambda kv: kv[1][0])
+    dom_ms = dom[1][0] / dom[1][1]
+    achieved = alg_bytes_per_launch_of_dominant / (dom_ms * 1e-3) / 1e9
+    return {'bound': 'hbm', 'kernel': dom[0], 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+            'frac_of_measured_copy_bw': achieved / HBM_MEASURED_GBS, 'traffic': None, 'avg_launch_ms': dom_ms,
+            'algorithmic_bytes_per_launch': alg_bytes_per_launch_of_dominant}
+
+
+# ------------------------------------------------------------------------------------------------- configs 3, 4, 5
+def run_config3(h, steps, warmup, n_total=None):
+    """MultiSignature::verify (reference src/multi_signature.rs:127-135): n G2 keys, one message, sharded key sum."""
+    api, sh = h.api, h.sh
+    n = n_total or CONFIG_SIZES[3]
+    lo, hi = h.bd.shard_range(n, h.rank, h.world)
+    nl = hi - lo
+    d_pks, d_sigs, _, _ = h.sign(1, api.POP, nl, lo, FIXED_MSG * nl, 32)
+    agg = h.global_sum(1, h.ops.point_sum(1, d_sigs, nl))
+    del d_sigs
+    bad = agg.clone()
+    bad_msg = bytes([FIXED_MSG[0] ^ 1]) + FIXED_MSG[1:]
+    assert sh.multi_verify(1, api.POP, d_pks, nl, agg, FIXED_MSG) == api.OK, 'config 3: the valid aggregate must verify'
+    assert sh.multi_verify(1, api.POP, d_pks, nl, bad, bad_msg) == api.INVALID_SIGNATURE, 'config 3: negative control'
+    res = []
+    dt, prof = h.timed(lambda: res.append(sh.multi_verify(1, api.POP, d_pks, nl, agg, FIXED_MSG)), steps, warmup)
+    assert all(r == api.OK for r in res)
+    out = {'metric': 'MultiSignature::verify public keys/s (one verification of an n-key multi-signature)', 'value': n * steps / dt,
+           'unit': 'public keys/s', 'ms_per_step': dt / steps * 1e3, 'scaling': 'strong',
+           'config': {'workload': 'configs[2]: MultiSignature<Bls12381G1Impl>::verify, %d G2 public keys (RAW_PROJ, resident in HBM), one 32-byte message, PoP scheme' % n,
+                      'keys_total': n, 'keys_per_gpu': nl, 'sharding': 'contiguous key ranges, all-gather of one 288-byte partial sum per rank'},
+           'collective_ms_per_step': sh.collective_s / steps * 1e3,
+           'kernel_ms': {k: round(v[0] / v[1], 3) for k, v in prof.items()}}
+    if 'k_accumulate' in prof:
+        ms = prof['k_accumulate'][0] / prof['k_accumulate'][1]
+        out['roofline'] = {'bound': 'hbm', 'kernel': 'k_accumulate', 'achieved': 288 * nl / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                           'frac': 288 * nl / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'frac_of_measured_copy_bw': 288 * nl / (ms * 1e-3) / 1e9 / HBM_MEASURED_GBS,
+                           'traffic': None, 'avg_launch_ms': ms, 'algorithmic_bytes_per_launch': 288 * nl}
+        out['whole_call_GBps'] = 288 * n * steps / dt / 1e9
+    return out
+
+
+def run_config4(h, steps, warmup, n_total=None):
+    """AggregateSignature::verify (reference src/aggregate_signature.rs:230-239), Basic scheme, distinct messages."""
+    api, sh, torch = h.api, h.sh, h.torch
+    n = n_total or CONFIG_SIZES[4]
+    lo, hi = h.bd.shard_range(n, h.rank, h.world)
+    nl = hi - lo
+    blob = b''.join(hashlib.sha256(SEED + i.to_bytes(8, 'little')).digest() for i in range(lo, hi))
+    d_pks, d_sigs, d_msgs, d_offs = h.sign(1, api.BASIC, nl, lo, blob, 32)
+    agg = h.global_sum(1, h.ops.point_sum(1, d_sigs, nl))
+    del d_sigs
+    st, aux = sh.aggregate_verify(1, api.BASIC, d_pks, d_msgs, d_offs, nl, agg, lo, n_total=n)
+    assert (st, tuple(aux)) == (api.OK, (0, 0)), ('config 4: the valid aggregate must verify', st, aux)
+    # negative controls: one flipped message bit; a far-apart duplicate (reported with the reference's two indices)
+    if h.rank == h.world - 1:
+        d_msgs[(nl - 1) * 32] ^= 1
+    st, _ = sh.aggregate_verify(1, api.BASIC, d_pks, d_msgs, d_offs, nl, agg, lo, n_total=n)
+    assert st == api.INVALID_SIGNATURE, 'config 4: negative control'
+    if h.rank == h.world - 1:
+        d_msgs[(nl - 1) * 32] ^= 1
+        keep = d_msgs[(nl - 1) * 32:nl * 32].clone()
+        first = torch.frombuffer(bytearray(hashlib.sha256(SEED + (3).to_bytes(8, 'little')).digest()), dtype=torch.uint8).to(h.dev)
+        d_msgs[(nl - 1) * 32:nl * 32] = first
+    st, aux = sh.aggregate_verify(1, api.BASIC, d_pks, d_msgs, d_offs, nl, agg, lo, n_total=n)
+    assert (st, tuple(aux)) == (api.DUPLICATE_MESSAGE, (3, n - 1)), ('config 4: duplicate rule', st, aux)
+    if h.rank == h.world - 1:
+        d_msgs[(nl - 1) * 32:nl * 32] = keep
+    res = []
+    dt, prof = h.timed(lambda: res.append(sh.aggregate_verify(1, api.BASIC, d_pks, d_msgs, d_offs, nl, agg, lo, n_total=n)[0]), steps, warmup)
+    assert all(r == api.OK for r in res)
+    out = {'metric': 'AggregateSignature::verify (pk, msg) pairs/s (one verification of an n-pair aggregate)', 'value': n * steps / dt,
+           'unit': 'pairs/s', 'ms_per_step': dt / steps * 1e3, 'scaling': 'strong',
+           'config': {'workload': 'configs[3]: AggregateSignature<Bls12381G1Impl>::verify, %d distinct (pk, msg) pairs, Basic scheme, 32-byte messages, RAW_PROJ inputs resident in HBM' % n,
+                      'pairs_total': n, 'pairs_per_gpu': nl,
+                      'sharding': 'contiguous pair ranges; all-gather of one 576-byte Fp12 Miller product + one first-identity index per rank; messages all-gathered (32 B each) for the duplicate rule'},
+           'collective_ms_per_step': sh.collective_s / steps * 1e3,
+           'kernel_ms': {k: round(v[0] / v[1], 3) for k, v in prof.items()}}
+    if prof:
+        out['roofline'] = roofline_of(prof, 320 * nl)
+    return out
+
+
+def run_config5(h, steps, warmup, variant='g1m', n_total=None):
+    """verify_secure[_with_mode] (reference src/signature.rs:177-197,256-276, src/secure_aggregation.rs:173-208)."""
+    api, sh = h.api, h.sh
+    sg, mode, name = VARIANTS[variant]
+    n = n_total or CONFIG_SIZES[5]
+    lo, hi = h.bd.shard_range(n, h.rank, h.world)
+    nl = hi - lo
+    pk_group = 2 if sg == 1 else 1
+    d_pks, d_sigs, _, _ = h.sign(sg, api.BASIC, nl, lo, FIXED_MSG * nl, 32)
+    # the signature verify_secure accepts: sum t_i * sig_i (sign-side twin, checked against the oracle in tests/)
+    st, agg = sh.aggregate_secure(sg, d_pks, d_sigs, nl, lo, mode, n_total=n)
+    assert st == api.OK
+    del d_sigs
+    assert sh.verify_secure(sg, api.BASIC, d_pks, nl, agg, FIXED_MSG, lo, mode, n_total=n) == api.OK, 'config 5: must verify'
+    bad_msg = bytes([FIXED_MSG[0] ^ 1]) + FIXED_MSG[1:]
+    assert sh.verify_secure(sg, api.BASIC, d_pks, nl, agg, bad_msg, lo, mode, n_total=n) == api.INVALID_SIGNATURE, 'config 5: negative control'
+    res = []
+    if h.world == 1:      # one process, one GPU: the library's own entry point (what the Rust shim calls)
+        stc = ctypes.c_int32(-9)
+
+        def step():
+            api._check(h.lib.blsgpu_verify_secure(sg, api.BASIC, h.P(d_pks), nl, h.P(agg), api._ptr(FIXED_MSG), 32, mode, 0, ctypes.byref(stc)))
+            res.append(stc.value)
+    else:
+        def step():
+            res.append(sh.verify_secure(sg, api.BASIC, d_pks, nl, agg, FIXED_MSG, lo, mode, n_total=n))
+    dt, prof = h.timed(step, steps, warmup)
+    assert all(r == api.OK for r in res)
+    width = 96 if pk_group == 2 else 48
+    alg = (2 * (288 if pk_group == 2 else 144) + 64)
+    out = {'metric': 'verify_secure public keys/s (one verification over n hashed-coefficient keys)', 'value': n * steps / dt, 'unit': 'public keys/s',
+           'ms_per_step': dt / steps * 1e3, 'scaling': 'strong', 'variant': name,
+           'config': {'workload': 'configs[4]: Signature<%s>::verify_secure%s, %d public keys (RAW_PROJ, resident in HBM), Basic scheme, one 32-byte message'
+                                  % (name.split('/')[0], '_with_mode(Legacy)' if mode else '', n),
+                      'keys_total': n, 'keys_per_gpu': nl,
+                      'sharding': 'contiguous key ranges; all-gather of the %d-byte serialised keys, device sort on every rank, the sequential SHA-256 key stream on rank 0 + 32-byte broadcast, '
+                                  'coefficients and MSM per rank, all-gather of one partial point per rank' % width},
+           'collective_ms_per_step': sh.collective_s / steps * 1e3,
+           'kernel_ms': {k: round(v[0] / v[1], 3) for k, v in prof.items()}}
+    if prof:
+        out['roofline'] = roofline_of(prof, alg * nl)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- config 2 (headline)
+def run_config2(h, args):
+    torch, api, lib = h.torch, h.api, h.lib
+    n, rank, world, dev = args.n, h.rank, h.world, h.dev
+    P = h.P
     # ---- synthetic inputs, signed on the device, left resident in HBM
-    sks, msgs = gen_inputs(n, rank * n)
-    skb = b''.join(s.to_bytes(32, 'little') for s in sks)
-    d_msgs = torch.frombuffer(bytearray(b''.join(msgs)), dtype=torch.uint8).to(dev)
-    d_offs = (torch.arange(n + 1, dtype=torch.int64) * 32).to(dev)
-    d_pks = torch.empty(n * 288, dtype=torch.uint8, device=dev)
-    d_sigs = torch.empty(n * 144, dtype=torch.uint8, device=dev)
+    _, msgs = gen_inputs(n, rank * n)
+    d_pks, d_sigs, d_msgs, d_offs = h.sign(1, api.POP, n, rank * n, b''.join(msgs), 32)
     d_status = torch.full((n,), -7, dtype=torch.int32, device=dev)
-    torch.cuda.synchronize()
-    P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-    api._check(lib.blsgpu_sign_batch(1, api.POP, api._ptr(skb), P(d_msgs), P(d_offs), n, P(d_pks), P(d_sigs)))
     # negative controls: flip one bit of the message of 1 % of the items after signing
     bad = torch.arange(37, n, 100, device=dev)
     d_msgs[bad * 32] ^= 1
@@ -120,35 +327,16 @@ def main():
     def step():
         api._check(lib.blsgpu_verify_batch(1, api.POP, P(d_pks), P(d_sigs), P(d_msgs), P(d_offs), n, api.FMT_RAW_PROJ, P(d_status)))
 
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+    def check():
+        assert torch.equal(d_status, expect), 'verdict vector differs from the expected one'
 
-    for _ in range(args.warmup):
-        step()
-    assert torch.equal(d_status, expect), 'verdict vector differs from the expected one'
-    api.profile_enable(True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    prof = api.profile_read()
-    api.profile_enable(False)
-    assert torch.equal(d_status, expect), 'verdict vector differs from the expected one'
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
+    dt, prof = h.timed(step, args.steps, args.warmup, after_warmup=check)
+    check()
+    out = None
     if rank == 0:
         dom = max(prof.items(), key=lambda kv: kv[1][0])
-        dom_ms = dom[1][0] / dom[1][1]
-        achieved = ALG_BYTES_PER_VERIFY * n / (dom_ms * 1e-3) / 1e9
-        kernels = {k: round(v[0] / v[1], 3) for k, v in prof.items()}
+        rl = roofline_of(prof, ALG_BYTES_PER_VERIFY * n)
+        rl['note'] = 'integer-VALU bound path: see valu_roofline; traffic is scratch (by-reference Fp12 operands), not input data'
         out = {
             'metric': 'BLS12-381 sig verifications/sec (batch)', 'value': world * n * args.steps / dt, 'unit': 'verifications/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
@@ -156,11 +344,8 @@ def main():
             'config': {'workload': 'configs[1]: %d independent Signature<Bls12381G1Impl>::verify items per GPU, 32-byte messages, '
                                    'PoP scheme, RAW_PROJ inputs resident in HBM, 1%% tampered' % n,
                        'items_per_gpu': n, 'sharding': 'independent batches per rank, no collective'},
-            'roofline': {'bound': 'hbm', 'kernel': dom[0], 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_ms': dom_ms,
-                         'algorithmic_bytes_per_launch': ALG_BYTES_PER_VERIFY * n,
-                         'note': 'integer-VALU bound path: see valu_roofline; traffic is scratch (by-reference Fp12 operands), not input data'},
-            'kernel_ms': kernels,
+            'roofline': rl,
+            'kernel_ms': {k: round(v[0] / v[1], 3) for k, v in prof.items()},
         }
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(pmc):
@@ -174,9 +359,9 @@ def main():
         fpm = os.path.join(ROOT, 'profiles', 'fpmul_counts.json')
         if os.path.exists(fpm):
             cnt = json.load(open(fpm))['verify_g1impl_fp_mul_equiv']
-            rate = cnt * n * args.steps / dt / 1e9
-            out['valu_roofline'] = {'fp_mul_per_verify': cnt, 'achieved': rate, 'peak': FPMUL_PEAK_G, 'unit': 'G fp_mul/s',
-                                    'frac': rate / FPMUL_PEAK_G}
+            rate = cnt * world * n * args.steps / dt / 1e9
+            out['valu_roofline'] = {'fp_mul_per_verify': cnt, 'achieved_per_gpu': rate / world, 'peak': FPMUL_PEAK_G, 'unit': 'G fp_mul/s',
+                                    'frac': rate / world / FPMUL_PEAK_G}
         if world == 1:
             sample = min(args.cpu_sample, n)
             msgs_tampered = list(msgs)
@@ -184,9 +369,51 @@ def main():
                 msgs_tampered[i] = bytes([msgs[i][0] ^ 1]) + msgs[i][1:]
             out['cpu_baseline'], cpu_st = cpu_baseline(d_pks, d_sigs, msgs_tampered, sample, n)
             assert cpu_st == expect[:sample].cpu().tolist(), 'CPU oracle and GPU verdicts differ'  # checker, not measured path
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--n', type=int, default=65536, help='items per GPU (config 2)')
+    ap.add_argument('--cpu-sample', type=int, default=4096)
+    ap.add_argument('--config', type=int, default=2, choices=[2, 3, 4, 5])
+    ap.add_argument('--variant', default='g1m', choices=sorted(VARIANTS))
+    ap.add_argument('--size', type=int, default=None, help='total size of config 3 / 4 / 5 (default: BASELINE.json\'s)')
+    ap.add_argument('--no-extras', action='store_true', help='config 2 only: do not time configs 3-5 after the headline measurement')
+    args = ap.parse_args()
+    h = Harness(args)
+    common = {'n_gpus': h.world, 'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': True, 'vs_baseline': None, 'dtype': 'u32',
+              'data': 'synthetic'}
+    if args.config == 2:
+        out = run_config2(h, args)
+        if not args.no_extras:
+            extras = {}
+            k = max(1, min(args.steps, 3))
+            for name, fn in (('config3_multi_verify_1048576', lambda: run_config3(h, k, 1)),
+                             ('config4_aggregate_verify_262144', lambda: run_config4(h, k, 1)),
+                             ('config5_verify_secure_65536_g1impl_modern', lambda: run_config5(h, k, 1, 'g1m')),
+                             ('config5_verify_secure_65536_g2impl_modern', lambda: run_config5(h, k, 1, 'g2m')),
+                             ('config5_verify_secure_65536_g2impl_legacy', lambda: run_config5(h, k, 1, 'g2l'))):
+                try:
+                    r = fn()
+                    r.update({'n_gpus': h.world, 'steps': k, 'warmup': 1})
+                    extras[name] = r
+                except Exception as e:  # noqa: BLE001 -- the headline line must survive a failing extra
+                    extras[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+                h.torch.cuda.empty_cache()
+            if out is not None:
+                out['other_configs'] = extras
+    else:
+        fn = {3: run_config3, 4: run_config4}.get(args.config)
+        out = fn(h, args.steps, args.warmup, args.size) if fn else run_config5(h, args.steps, args.warmup, args.variant, args.size)
+        out.update(common)
+    if h.rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    if h.dist is not None:
+        h.dist.destroy_process_group()
 
 
 if __name__ == '__main__':

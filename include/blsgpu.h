@@ -7,7 +7,8 @@
  * Conventions
  *   - Every buffer is caller-owned and borrowed for the duration of the call.  Pointers may be host pointers or
  *     HIP device pointers; the library detects which (hipPointerGetAttributes) and stages host buffers itself.
- *   - All calls are blocking, thread-safe (the internal streams are guarded by one mutex) and deterministic.
+ *   - All calls are blocking, thread-safe and deterministic.  Each bound device owns a small pool of contexts (stream +
+ *     workspace, BLSGPU_CONTEXTS, default 2): concurrent callers lease different contexts and overlap on the device.
  *   - Return value: 0 = the call ran (look at the status outputs), < 0 = runtime failure (HIP error, bad argument);
  *     blsgpu_last_error() then gives a message.  There is NO CPU fallback: without a usable gfx950 device every
  *     compute entry point fails with BLSGPU_E_NO_DEVICE.
@@ -67,8 +68,16 @@ extern "C" {
 #define BLSGPU_E_ARG (-3)
 #define BLSGPU_E_NOT_INIT (-4)
 
-/* Library life cycle.  device = HIP ordinal, or -1 for the current device.  Idempotent. */
+/* Library life cycle.  device = HIP ordinal, or -1 for the current device.  Idempotent for the same device; a second call
+ * that names a DIFFERENT device fails with BLSGPU_E_ARG (shut down first to rebind). */
 int blsgpu_init(int device);
+/* One process driving several GPUs: binds the first ndev visible devices (ndev <= 0: all) and returns how many are bound
+ * (or < 0).  blsgpu_verify_batch, blsgpu_multi_verify, blsgpu_aggregate_verify and blsgpu_verify_secure then shard
+ * their items over the bound devices inside the library (contiguous ranges, one host thread per device) and fold the
+ * per-device partial results -- key sums, Fp12 Miller products, MSM partials -- on device 0; results are identical to
+ * the single-device ones.  The one-process-per-GPU alternative over RCCL is agora-blsful_amd/dist.py. */
+int blsgpu_init_devices(int ndev);
+int blsgpu_device_count(void);
 void blsgpu_shutdown(void);
 /* copies the last error message of the calling thread's most recent failing call; returns its length */
 size_t blsgpu_last_error(char* buf, size_t cap);
@@ -117,6 +126,22 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
 int blsgpu_secure_coefficients(const uint8_t* key_bytes, size_t n, size_t width, uint32_t* out_perm,
                                uint8_t* out_scalars, int32_t* status);
 
+/* The same step split for callers that shard the keys over several GPUs (agora-blsful_amd/dist.py): every rank sorts the
+ * gathered key bytes on its device, ONE rank hashes the sorted stream (the only sequential part) and broadcasts the
+ * 32-byte digest, every rank derives the coefficients of its own keys.
+ *   blsgpu_sort_keys               out_perm[i] = input index of the i-th key in stable byte-lexicographic order  (:41-44)
+ *   blsgpu_sorted_keys_digest      out_digest = SHA-256(keys concatenated in the order of perm)                  (:45-59)
+ *   blsgpu_coefficients_for_range  t_i = SHA-256(BE32(i) || digest) mod r for the input keys [base, base + count):
+ *                                  out_scalars[g - base] (32 B LE) belongs to input key g; *status OK or
+ *                                  INVALID_COEFFICIENT                                                            (:61-100)
+ *   blsgpu_first_occurrence        out_idx[p] = input index of the FIRST key equal to the p-th sorted key: the `position`
+ *                                  search of aggregate_secure (duplicated keys take their first signature)        (:150-162) */
+int blsgpu_sort_keys(const uint8_t* key_bytes, size_t n, size_t width, uint32_t* out_perm);
+int blsgpu_sorted_keys_digest(const uint8_t* key_bytes, const uint32_t* perm, size_t n, size_t width, uint8_t* out_digest);
+int blsgpu_coefficients_for_range(const uint8_t* digest, const uint32_t* perm, size_t n, size_t base, size_t count,
+                                  uint8_t* out_scalars, int32_t* status);
+int blsgpu_first_occurrence(const uint8_t* key_bytes, const uint32_t* perm, size_t n, size_t width, uint32_t* out_idx);
+
 /* HashToPoint::hash_to_point(msg, dst)                                        src/traits/hash_to_point.rs:11,
  * impls src/impls/g1.rs:17-19 (group 1) and src/impls/g2.rs:15-17 (group 2).  out: RAW_PROJ points. */
 int blsgpu_hash_to_g1(const uint8_t* msgs, const uint64_t* msg_offsets, size_t n, const uint8_t* dst, size_t dst_len,
@@ -130,7 +155,9 @@ int blsgpu_sum_g1(const void* pts, size_t n, int fmt, void* out);
 int blsgpu_sum_g2(const void* pts, size_t n, int fmt, void* out);
 
 /* sum_i scalars[i] * pts[i]: the loop `aggregated_pk += pk.0 * *coeff`        src/secure_aggregation.rs:201-204
- * (and the sign-side loop :163-166).  out: one RAW_PROJ point. */
+ * (and the sign-side loop :163-166).  out: one RAW_PROJ point.  Scalars are taken modulo the group order r (a reference
+ * Scalar is always < r; any 256-bit value is accepted and reduced) and the points must lie in the prime-order subgroup,
+ * which every reference type guarantees. */
 int blsgpu_msm_g1(const void* pts, const uint8_t* scalars, size_t n, int fmt, void* out);
 int blsgpu_msm_g2(const void* pts, const uint8_t* scalars, size_t n, int fmt, void* out);
 
@@ -161,15 +188,29 @@ int blsgpu_aggregate_secure(int sig_group, const void* pks, const void* sigs, si
  * becomes that item's status. */
 int blsgpu_deserialize(int group, const uint8_t* bytes, size_t n, int fmt_in, void* out, int32_t* status);
 
+/* Signature::<C>::try_from(&[u8]) and Vec<u8>::from(&Signature<C>) (src/signature.rs:112-126): the serde_bare form of the
+ * Signature enum is its variant index as one byte (0 Basic, 1 MessageAugmentation, 2 ProofOfPossession) followed by the
+ * compressed point -- 49 bytes (Bls12381G1Impl) / 97 bytes (Bls12381G2Impl) per record, the lengths the reference asserts at
+ * src/signature.rs:285-286.  n records back to back.  from_tagged: out_schemes[i] = the tag, out = RAW_PROJ points (checked
+ * decompression incl. the subgroup test), status[i] = OK or BAD_ENCODING (unknown tag, invalid point; the reference maps
+ * every serde error to InvalidInputs(..)). */
+int blsgpu_signatures_from_tagged(int sig_group, const uint8_t* bytes, size_t n, uint8_t* out_schemes, void* out, int32_t* status);
+int blsgpu_signatures_to_tagged(int sig_group, const uint8_t* schemes, const void* sigs, size_t n, int fmt, uint8_t* out);
+
 /* Sharded aggregate verify (one process per GPU): the shard-local part of core_aggregate_verify
  * (src/traits/sig_core.rs:149-178).  out_f12 (576 B) = product of the Miller values of the shard's (H(m_i), pk_i) pairs
  * [times (sig, -g) when sig != NULL], before the final exponentiation; *first_bad = local index of the first identity
- * key, n when the signature is the identity, -1 otherwise.  Ranks exchange the records (all-gather) and finish with
- * blsgpu_fp12_product_is_one.  Duplicate-message detection (Basic, src/traits/sig_basic.rs:46-58) is global and stays
- * with the caller. */
+ * key, n when the signature is the identity, -1 otherwise (identity pairs contribute 1 to the record, so it can always be
+ * folded).  out_f12 and first_bad may be device pointers: then nothing crosses to the host and the caller hands them to
+ * RCCL as they are.  Ranks exchange the records (all-gather) and finish with blsgpu_fp12_product_is_one.
+ * Duplicate-message detection (Basic, src/traits/sig_basic.rs:46-58) is global: blsgpu_first_duplicate_message. */
 int blsgpu_aggregate_partial(int sig_group, int scheme, const void* pks, const uint8_t* msgs, const uint64_t* msg_offsets,
                              size_t n, const void* sig, int fmt, void* out_f12, int64_t* first_bad);
 int blsgpu_fp12_product_is_one(const void* f12s, size_t k, int32_t* is_one);
+/* The Basic scheme's duplicate-message rule on its own (src/traits/sig_basic.rs:46-58), for sharded callers that gathered
+ * the messages: out2 = (index of the earlier equal message, the first index whose message was seen before) -- the two
+ * numbers of the reference's error string -- or (~0, ~0) when all messages are distinct.  Exact (bytes are compared). */
+int blsgpu_first_duplicate_message(const uint8_t* msgs, const uint64_t* msg_offsets, size_t n, uint64_t* out2);
 
 /* ---- other two-pairing checks of the reference that reuse the same pairing stages ----
  *

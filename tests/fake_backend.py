@@ -1,6 +1,7 @@
 """TEST-ONLY stand-in for agora-blsful_amd/api.py backed by the oracle, so that the sharding/orchestration logic of
 agora-blsful_amd/dist.py can be exercised with world_size 2 over gloo on a machine without a GPU.  The product never
-imports this."""
+imports this.  FakeOps offers the methods of api.TensorOps on CPU tensors: dist.py runs the SAME code path on it that
+it runs on device tensors."""
 import util
 from util import c, ref
 
@@ -135,3 +136,118 @@ def fp12_product_is_one(records):
     for r in records:
         f = c.f12_mul(f, util.f12_from_record(r))
     return c.final_exponentiation(f) == c.F12_ONE
+
+
+# ------------------------------------------------------------------ the tensor-level interface of api.TensorOps
+class FakeOps:
+    def __init__(self):
+        import torch
+        self.torch, self.device = torch, torch.device('cpu')
+
+    def empty(self, n, dtype=None):
+        return self.torch.zeros(n, dtype=dtype or self.torch.uint8)
+
+    def _t(self, b):
+        return self.torch.frombuffer(bytearray(b), dtype=self.torch.uint8) if len(b) else self.torch.zeros(0, dtype=self.torch.uint8)
+
+    @staticmethod
+    def _rows(t, n, sz):
+        b = bytes(t.numpy().tobytes())
+        return [b[sz * i:sz * (i + 1)] for i in range(n)]
+
+    @staticmethod
+    def _msgs(blob, offs, n):
+        b, o = bytes(blob.numpy().tobytes()), [int(x) for x in offs[:n + 1].tolist()]
+        return [b[o[i]:o[i + 1]] for i in range(n)]
+
+    def _st(self, lst):
+        return self.torch.tensor(lst, dtype=self.torch.int32)
+
+    @staticmethod
+    def _sizes(sg):
+        return (288, 144) if sg == 1 else (144, 288)
+
+    def verify_batch(self, sg, scheme, pks, sigs, msgs, offs, n):
+        ps, ss = self._sizes(sg)
+        return self._st(verify_batch(sg, scheme, self._rows(pks, n, ps), self._rows(sigs, n, ss), self._msgs(msgs, offs, n)))
+
+    def pop_verify_batch(self, sg, pks, proofs, n):
+        ps, ss = self._sizes(sg)
+        return self._st(pop_verify_batch(sg, self._rows(pks, n, ps), self._rows(proofs, n, ss)))
+
+    def sig_proof_verify_batch(self, sg, scheme, us, vs, pks, ys, msgs, offs, n):
+        ps, ss = self._sizes(sg)
+        yl = [int.from_bytes(y, 'little') for y in self._rows(ys, n, 32)]
+        return self._st(sig_proof_verify_batch(sg, scheme, self._rows(us, n, ss), self._rows(vs, n, ss), self._rows(pks, n, ps), yl,
+                                               self._msgs(msgs, offs, n)))
+
+    def signcrypt_valid_batch(self, sg, scheme, us, ws, vs, offs, n):
+        ps, ss = self._sizes(sg)
+        ok = signcrypt_valid_batch(sg, scheme, self._rows(us, n, ps), self._rows(ws, n, ss), self._msgs(vs, offs, n))
+        return self._st([0 if x else 1 for x in ok])
+
+    def point_sum(self, group, pts, n, scalars=None):
+        sz = 144 if group == 1 else 288
+        sc = None if scalars is None else [int.from_bytes(x, 'little') for x in self._rows(scalars, n, 32)]
+        return self._t(point_sum(group, self._rows(pts, n, sz), sc))
+
+    def multi_verify(self, sg, scheme, pks, n, sig, msg):
+        C = _impl(sg)
+        ps, ss = self._sizes(sg)
+        P = [_pk(sg, b) for b in self._rows(pks, n, ps)]
+        return _status(lambda: ref.multi_sig_verify(C, scheme, P, _sig(sg, bytes(sig.numpy().tobytes())), msg))
+
+    def core_verify_one(self, sg, dst, pk, sig, msg):
+        return core_verify(sg, dst, [bytes(pk.numpy().tobytes())], [bytes(sig.numpy().tobytes())], [msg])[0]
+
+    def aggregate_partial(self, sg, scheme, pks, msgs, offs, n, sig=None):
+        ps, _ = self._sizes(sg)
+        rec, fb = aggregate_partial(sg, scheme, self._rows(pks, n, ps), self._msgs(msgs, offs, n),
+                                    None if sig is None else bytes(sig.numpy().tobytes()))
+        return self._t(rec), self.torch.tensor([fb], dtype=self.torch.int64)
+
+    def fp12_product_is_one(self, recs, k):
+        return fp12_product_is_one(self._rows(recs, k, 576))
+
+    def first_duplicate(self, msgs, offs, n):
+        seen = {}
+        for i, m in enumerate(self._msgs(msgs, offs, n)):      # reference src/traits/sig_basic.rs:46-58
+            if m in seen:
+                return seen[m], i
+            seen[m] = i
+        return None
+
+    def serialize(self, group, pts, n, legacy=False):
+        sz = 144 if group == 1 else 288
+        return self._t(b''.join(serialize(group, self._rows(pts, n, sz), legacy)))
+
+    def sort_keys(self, kb, n, width):
+        keys = self._rows(kb, n, width)
+        return self.torch.tensor(sorted(range(n), key=lambda i: keys[i]), dtype=self.torch.int32)   # sorted() is stable
+
+    def keys_digest(self, kb, perm, n, width):
+        import hashlib
+        keys = self._rows(kb, n, width)
+        return self._t(hashlib.sha256(b''.join(keys[int(i)] for i in perm.tolist())).digest())
+
+    def coefficients_for_range(self, digest, perm, n, base, count):
+        import hashlib
+        H = bytes(digest.numpy().tobytes())
+        out, st = [b'\0' * 32] * count, 0
+        for p, g in enumerate(perm.tolist()):
+            if base <= g < base + count:
+                t = int.from_bytes(hashlib.sha256(p.to_bytes(4, 'big') + H).digest(), 'big') % c.R
+                if t == 0:
+                    st = 5
+                out[g - base] = t.to_bytes(32, 'little')
+        return self._t(b''.join(out)), st
+
+    def first_occurrence(self, kb, perm, n, width):
+        keys = self._rows(kb, n, width)
+        first = {}
+        for i, k in enumerate(keys):
+            first.setdefault(k, i)
+        return self.torch.tensor([first[keys[int(g)]] for g in perm.tolist()], dtype=self.torch.int32)
+
+    def is_identity(self, group, pt):
+        return (g1_from_raw if group == 1 else g2_from_raw)(bytes(pt.numpy().tobytes())) is None

@@ -48,6 +48,7 @@ def check(res):
         assert res['signcrypt_%d' % sg] == [True, True, True, True, False, True, True]
         for mode in ([0] if sg == 1 else [0, 1]):
             assert res['aggsec_%d_%d' % (sg, mode)] == [0, True]
+        assert res['agg_one_%d' % sg] == [0, [0, 0]]                            # one rank's shard is empty
 
 
 def test_shard_range(pkg):

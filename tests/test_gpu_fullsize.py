@@ -1,4 +1,4 @@
-"""BASELINE.json's full sizes for configs 3, 4 and 5 (config 2's 65,536 items are asserted by bench.py itself), checked
+"""BASELINE.json's full sizes for configs 2, 3, 4 and 5, checked
 through size-independent properties: inputs are signed on the device from consecutive secret keys, so the expected
 aggregates are closed forms computed here with Python integers only -- the oracle could not finish these sizes.
 One valid case and one minimally tampered case per config; exact status codes."""
@@ -106,3 +106,40 @@ def test_config5_verify_secure_65536_keys(api, gpu, sg, mode):
     _, d_bad, _, _ = g['sign'](sg, api.BASIC, [(total + sks[12345]) % R], [M_FIXED])
     api._check(lib.blsgpu_verify_secure(sg, api.BASIC, P(d_pks), n, P(d_bad), api._ptr(M_FIXED), len(M_FIXED), mode, api.FMT_RAW_PROJ, P(st)))
     assert int(st.item()) == api.INVALID_SIGNATURE
+
+
+def test_config2_verify_batch_65536(api, gpu):
+    """configs[1] at its full size: 65,536 independent Signature<Bls12381G1Impl>::verify items signed on the device, 1 % with a
+    flipped message bit, a few with swapped signatures / identity members: the exact verdict vector, and the first 4,096
+    items item by item against the C oracle (oracle/c)."""
+    torch, lib, P = gpu['torch'], gpu['lib'], gpu['P']
+    n = 65536
+    msgs = [hashlib.sha256(SEED + i.to_bytes(8, 'little')).digest() for i in range(n)]
+    d_pks, d_sigs, d_msgs, d_offs = gpu['sign'](1, api.POP, [(S0 + i) % R for i in range(n)], msgs)
+    bad = torch.arange(37, n, 100, device=gpu['dev'])
+    d_msgs[bad * 32] ^= 1
+    expect = torch.zeros(n, dtype=torch.int32, device=gpu['dev'])
+    expect[bad] = api.INVALID_SIGNATURE
+    sig_rows = d_sigs.view(n, 144)
+    keep = sig_rows[[10, 11]].clone()
+    sig_rows[10], sig_rows[11] = keep[1], keep[0]                 # swapped signatures: both items fail
+    expect[10] = expect[11] = api.INVALID_SIGNATURE
+    sig_rows[20, 96:] = 0                                          # Z = 0: the identity signature
+    expect[20] = api.SIG_IDENTITY
+    d_pks.view(n, 288)[21, 192:] = 0                               # identity public key
+    expect[21] = api.PK_IDENTITY
+    d_pks.view(n, 288)[22, 192:] = 0                               # both: the signature check comes first
+    sig_rows[22, 96:] = 0
+    expect[22] = api.SIG_IDENTITY
+    d_st = torch.full((n,), -7, dtype=torch.int32, device=gpu['dev'])
+    api._check(lib.blsgpu_verify_batch(1, api.POP, P(d_pks), P(d_sigs), P(d_msgs), P(d_offs), n, api.FMT_RAW_PROJ, P(d_st)))
+    assert torch.equal(d_st, expect)
+    sample = 4096
+    bo = util.load_c_oracle()
+    pks_h, sigs_h = d_pks[:sample * 288].cpu().numpy().tobytes(), d_sigs[:sample * 144].cpu().numpy().tobytes()
+    blob = d_msgs[:sample * 32].cpu().numpy().tobytes()
+    offs = (ctypes.c_uint64 * (sample + 1))(*[32 * i for i in range(sample + 1)])
+    st = (ctypes.c_int32 * sample)()
+    V = lambda x: ctypes.cast(x, ctypes.c_void_p)  # noqa: E731
+    bo.bo_verify_batch(1, 2, V(ctypes.c_char_p(pks_h)), V(ctypes.c_char_p(sigs_h)), V(ctypes.c_char_p(blob)), V(offs), sample, V(st), 16)
+    assert list(st) == d_st[:sample].cpu().tolist()

@@ -1,0 +1,305 @@
+"""GPU parity for what round 2 moved onto the device: the key sort / coefficient step of hash_public_keys_with_sorted,
+Basic's duplicate-message rule, the first-identity reduction and the neutral records of the sharded aggregate verify,
+scalars >= r in the MSM, the context pool.  Everything goes through the C ABI and is compared with the oracle or with a
+plain Python restatement of the reference's loop."""
+import ctypes
+import hashlib
+import random
+
+import pytest
+
+import util
+from util import c, ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops(pkg):
+    import torch
+    return pkg.api.TensorOps(torch.device('cuda', 0))
+
+
+def _t(ops, b):
+    import torch
+    return torch.frombuffer(bytearray(b), dtype=torch.uint8).to(ops.device) if b else torch.zeros(0, dtype=torch.uint8, device=ops.device)
+
+
+# ------------------------------------------------------------------ hash_public_keys_with_sorted on the device
+@pytest.mark.parametrize('width', [48, 96])
+def test_device_key_sort_is_stable_and_lexicographic(api, pkg, width):
+    """The sort of reference src/secure_aggregation.rs:41-44 / :273-276 (sort_by on the serialised bytes, stable): random keys,
+    keys that share their first 8 bytes (the prefix pass ties and the full-width pass must decide), exact duplicates (input
+    order must be kept), sizes around the 64-lane and 1,024-key tile edges."""
+    ops = _ops(pkg)
+    rng = random.Random(width)
+    for n in (1, 2, 63, 64, 65, 1023, 1024, 1025, 5000):
+        for flavour in ('random', 'shared_prefix', 'duplicates'):
+            keys = [rng.randbytes(width) for _ in range(n)]
+            if flavour == 'shared_prefix' and n > 2:
+                pre = keys[0][:8]
+                for i in range(0, n, 3):
+                    keys[i] = pre + keys[i][8:]
+                keys[n // 2] = pre + keys[1][8:40] + keys[n // 2][40:]
+            if flavour == 'duplicates' and n > 2:
+                for i in range(2, n, 5):
+                    keys[i] = keys[i % 2]
+            kb = _t(ops, b''.join(keys))
+            perm = [int(x) for x in ops.sort_keys(kb, n, width).cpu().tolist()]
+            assert perm == sorted(range(n), key=lambda i: keys[i]), (n, flavour)
+            first = [int(x) for x in ops.first_occurrence(kb, ops.sort_keys(kb, n, width), n, width).cpu().tolist()]
+            seen = {}
+            for i, k in enumerate(keys):
+                seen.setdefault(k, i)
+            assert first == [seen[keys[g]] for g in perm], (n, flavour)
+            # H and t_i of the shard [base, base + count) in input order
+            dig = ops.keys_digest(kb, ops.sort_keys(kb, n, width), n, width)
+            H = hashlib.sha256(b''.join(keys[g] for g in perm)).digest()
+            assert bytes(dig.cpu().numpy().tobytes()) == H
+            if n <= 1025:
+                base, count = n // 3, n - n // 3 - n // 5
+                scal, st = ops.coefficients_for_range(dig, ops.sort_keys(kb, n, width), n, base, count)
+                got = bytes(scal.cpu().numpy().tobytes())
+                pos = {g: p for p, g in enumerate(perm)}
+                for g in range(base, base + count):
+                    t = int.from_bytes(hashlib.sha256(pos[g].to_bytes(4, 'big') + H).digest(), 'big') % c.R
+                    assert got[32 * (g - base):32 * (g - base + 1)] == t.to_bytes(32, 'little')
+                assert st == 0
+
+
+def test_secure_coefficients_large_matches_oracle(api):
+    """blsgpu_secure_coefficients at a size that spans many sort tiles, against the oracle's restatement of
+    reference src/secure_aggregation.rs:41-103 (33 % of the coefficient hashes are >= r and must be reduced)."""
+    rng = random.Random(5)
+    n = 20000
+    keys = [rng.randbytes(48) for _ in range(n)]
+    keys[777] = keys[12]
+    st, perm, ts = api.secure_coefficients(keys)
+    wperm, _, wts = ref.secure_coefficients(keys)
+    assert st == 0 and perm == wperm and ts == wts
+
+
+# ------------------------------------------------------------------ Basic's duplicate-message rule on the device
+def _first_dup(msgs):
+    seen = {}
+    for i, m in enumerate(msgs):       # reference src/traits/sig_basic.rs:46-58
+        if m in seen:
+            return seen[m], i
+        seen[m] = i
+    return None
+
+
+def test_first_duplicate_message(api):
+    rng = random.Random(3)
+    cases = [[], [b''], [b'', b''], [b'a', b'b', b'a', b'b'], [b'x' * 100, b'x' * 99, b'x' * 100]]
+    for n in (64, 65, 1000, 30000):
+        msgs = [hashlib.sha256(i.to_bytes(4, 'big')).digest()[:rng.randrange(0, 33)] + bytes([i & 255, (i >> 8) & 255, i >> 16]) for i in range(n)]
+        cases.append(list(msgs))                       # all distinct
+        d = list(msgs)
+        d[n - 1] = d[3]
+        d[n // 2] = d[n // 2 - 1]                       # two duplicate pairs: the one with the smaller SECOND index wins
+        cases.append(d)
+        cases.append([b'same'] * n)                    # every message equal: (0, 1)
+    for msgs in cases:
+        assert api.first_duplicate_message(msgs) == _first_dup(msgs), len(msgs)
+
+
+@pytest.mark.parametrize('sg', [1, 2])
+def test_aggregate_verify_device_pointers(api, pkg, sg):
+    """blsgpu_aggregate_verify with every buffer resident on the device: duplicate rule, identity reduction and verdict all
+    stay on the device; the results equal the host-pointer path's (and the oracle's error precedence, reference
+    src/traits/sig_basic.rs:46-58 before src/traits/sig_core.rs:155-167)."""
+    import torch
+    ops = _ops(pkg)
+    lib = ops.lib
+    n = 70
+    sks = [1000 + 7 * i for i in range(n)]
+    msgs = [b'msg-%d' % i for i in range(n)]
+    pks, sigs = api.sign_batch(sg, api.BASIC, sks, msgs)
+    agg = api.point_sum(sg, sigs)
+    ident_pk = (util.g2_raw if sg == 1 else util.g1_raw)(None)
+    ident_sig = (util.g1_raw if sg == 1 else util.g2_raw)(None)
+
+    def run_dev(pk_rows, msg_rows, sig):
+        offs, t = [0], 0
+        for m in msg_rows:
+            t += len(m)
+            offs.append(t)
+        d_pks, d_msgs, d_sig = _t(ops, b''.join(pk_rows)), _t(ops, b''.join(msg_rows)), _t(ops, sig)
+        d_offs = torch.tensor(offs, dtype=torch.int64, device=ops.device)
+        d_st = torch.full((1,), -9, dtype=torch.int32, device=ops.device)
+        d_aux = torch.zeros(2, dtype=torch.int64, device=ops.device)
+        api._check(lib.blsgpu_aggregate_verify(sg, api.BASIC, ops._p(d_pks), ops._p(d_msgs), ops._p(d_offs), len(pk_rows), ops._p(d_sig), 0,
+                                               ops._p(d_st), ops._p(d_aux)))
+        return int(d_st.item()), tuple(int(x) for x in d_aux.tolist())
+
+    variants = {'ok': (pks, msgs, agg)}
+    bad = list(msgs)
+    bad[5] = b'tampered'
+    variants['bad'] = (pks, bad, agg)
+    dup = list(msgs)
+    dup[66], dup[40] = dup[2], dup[39]
+    variants['dup'] = (pks, dup, agg)
+    pid = list(pks)
+    pid[65], pid[9] = ident_pk, ident_pk
+    variants['pkid'] = (pid, msgs, agg)
+    variants['sigid'] = (pid, msgs, ident_sig)
+    variants['dup_and_ids'] = (pid, dup, ident_sig)
+    want = {'ok': (0, (0, 0)), 'bad': (1, (0, 0)), 'dup': (4, (39, 40)), 'pkid': (3, (10, 0)), 'sigid': (2, (0, 0)), 'dup_and_ids': (4, (39, 40))}
+    for name, (p_, m_, s_) in variants.items():
+        assert run_dev(p_, m_, s_) == want[name], name
+        assert api.aggregate_verify(sg, api.BASIC, p_, m_, s_) == want[name], name
+
+
+# ------------------------------------------------------------------ sharded aggregate verify: neutral records, no-signature shards
+@pytest.mark.parametrize('sg', [1, 2])
+def test_aggregate_partial_edge_shards(api, sg):
+    """blsgpu_aggregate_partial for the shards the world-2 tests cannot produce: an EMPTY shard with and without the
+    signature, a shard without the signature whose size is not a multiple of the wave (lane n must stay idle), and folding the
+    neutral record; the product over the shards is the verdict of the unsharded call."""
+    C = ref.G1Impl if sg == 1 else ref.G2Impl
+    pkraw, sigraw = (util.g2_raw, util.g1_raw) if sg == 1 else (util.g1_raw, util.g2_raw)
+    rng = random.Random(sg)
+    n = 7
+    sks = [ref.keygen_from_hash(bytes([i, 9]) * 16) for i in range(n)]
+    pks = [pkraw(ref.public_key(C, s), rng) for s in sks]
+    msgs = [b'shard %d' % i for i in range(n)]
+    asig = sigraw(ref.aggregate_signatures(C, [ref.sign(C, ref.BASIC, s, m) for s, m in zip(sks, msgs)]), rng)
+    one = util.f12_record(c.F12_ONE)
+    rec_e, fb = api.aggregate_partial(sg, api.BASIC, [], [], None)
+    assert (rec_e, fb) == (one, -1)
+    rec_s, fb = api.aggregate_partial(sg, api.BASIC, [], [], asig)          # the signature pair alone
+    assert fb == -1 and rec_s != one
+    rec_i, fb = api.aggregate_partial(sg, api.BASIC, [], [], sigraw(None))  # identity signature on an empty shard: index n = 0
+    assert fb == 0
+    recs = [rec_s, rec_e]
+    for lo, hi in ((0, 3), (3, 3), (3, 7)):                                 # shards WITHOUT the signature, one of them empty
+        r, fb = api.aggregate_partial(sg, api.BASIC, pks[lo:hi], msgs[lo:hi], None)
+        assert fb == -1
+        recs.append(r)
+    assert api.fp12_product_is_one(recs)
+    assert not api.fp12_product_is_one(recs[1:])
+    # an identity key inside a shard: its index comes back, the record still folds (the pair contributes 1)
+    pid = list(pks)
+    pid[5] = pkraw(None)
+    r, fb = api.aggregate_partial(sg, api.BASIC, pid[3:7], msgs[3:7], None)
+    assert fb == 2
+
+
+def test_init_rejects_a_different_device(api):
+    lib = api.load_library()
+    assert lib.blsgpu_init(-1) == 0 and lib.blsgpu_init(0) == 0
+    assert lib.blsgpu_init(5) == -3                    # BLSGPU_E_ARG: already bound to device 0
+    buf = ctypes.create_string_buffer(256)
+    lib.blsgpu_last_error(buf, 256)
+    assert b'already bound' in buf.value
+
+
+@pytest.mark.parametrize('group', [1, 2])
+def test_msm_scalars_beyond_the_group_order(api, group):
+    """blsgpu_msm takes scalars modulo r on BOTH of its paths (double-and-add below 1,024 points, windows above): scalars
+    with bit 255 set and scalars in [r, 2^256) give the same group element as their residues."""
+    rng = random.Random(group + 40)
+    E, gen, comp = (c.E1, c.G1_GEN, c.g1_compress) if group == 1 else (c.E2, c.G2_GEN, c.g2_compress)
+    for n in (1023, 1024):
+        ks = [3 + i for i in range(n)]
+        pts, _ = api.sign_batch(3 - group, api.POP, ks, [b'x'] * n)          # pk_i = (3 + i) g of the wanted group
+        scal = [rng.randrange(c.R) for _ in range(n)]
+        scal[0] = 2 ** 256 - 1
+        scal[1] = c.R
+        scal[2] = c.R + 5
+        scal[3] = 2 ** 255
+        scal[n - 1] = 2 ** 255 + 12345
+        total = sum(k * (s % c.R) for k, s in zip(ks, scal)) % c.R
+        got = api.serialize(group, [api.point_sum(group, pts, scal)])[0]
+        assert got == comp(E.mul(gen, total)), n
+
+
+def test_context_pool_overlaps_callers(api):
+    """Two host threads inside the library at the same time lease different contexts: both calls return the sequential
+    results (tests/test_gpu_api.py::test_concurrent_callers checks four threads; here the point is that a long call does
+    not block a short one behind one mutex -- the short call finishes while the long one is still running)."""
+    import threading
+    import time
+    n = 20000
+    pks, sigs = api.sign_batch(1, api.POP, [5 + i for i in range(n)], [b'm'] * n)
+    one_pk, one_sig = pks[:1], sigs[:1]
+    api.verify_batch(1, api.POP, one_pk, one_sig, [b'm'])
+    t_long = {}
+
+    def long_call():
+        t0 = time.perf_counter()
+        st = api.verify_batch(1, api.POP, pks, sigs, [b'm'] * n)
+        t_long['dt'] = time.perf_counter() - t0
+        t_long['ok'] = all(s == 0 for s in st)
+
+    th = threading.Thread(target=long_call)
+    th.start()
+    time.sleep(0.002)
+    t0 = time.perf_counter()
+    st = api.verify_batch(1, api.POP, one_pk, one_sig, [b'm'])
+    dt_short = time.perf_counter() - t0
+    th.join()
+    assert st == [0] and t_long['ok']
+    assert dt_short < t_long['dt']
+
+
+# ------------------------------------------------------------------ N2: the serde_bare form of Signature<C>
+@pytest.mark.parametrize('C,sg', [(ref.G1Impl, 1), (ref.G2Impl, 2)], ids=['g1', 'g2'])
+def test_signature_serde_bare_tagged_bytes(api, C, sg):
+    """Vec<u8>::from(&Signature) / Signature::try_from(&[u8]) (reference src/signature.rs:112-126): scheme tag byte + compressed
+    point; the reference's own test asserts the lengths 49 / 97 and the round trip for the three schemes (:279-318)."""
+    rng = random.Random(sg)
+    sk = ref.keygen_from_hash(b'test_try_from')
+    msg = b'test_try_from'
+    sigraw = util.g1_raw if sg == 1 else util.g2_raw
+    sig_pts = [ref.sign(C, scheme, sk, msg) for scheme in (ref.BASIC, ref.AUG, ref.POP)]
+    raws = [sigraw(p, rng) for p in sig_pts]
+    blobs = api.signatures_to_tagged(sg, [0, 1, 2], raws)
+    assert [len(b) for b in blobs] == [49 if sg == 1 else 97] * 3
+    assert blobs == [bytes([scheme]) + C.sig_to_bytes(p) for scheme, p in zip((0, 1, 2), sig_pts)]
+    schemes, pts, sts = api.signatures_from_tagged(sg, blobs)
+    assert schemes == [0, 1, 2] and sts == [0, 0, 0]
+    assert api.serialize(sg, pts) == [C.sig_to_bytes(p) for p in sig_pts]
+    # the decoded signatures verify under their own scheme
+    pk = (util.g2_raw if sg == 1 else util.g1_raw)(ref.public_key(C, sk), rng)
+    for scheme, p in zip(schemes, pts):
+        assert api.verify_batch(sg, scheme, [pk], [p], [msg]) == [0]
+    # malformed records: unknown tag, corrupted point, wrong length
+    bad_tag = bytes([3]) + blobs[0][1:]
+    bad_point = blobs[1][:1] + bytes([blobs[1][1] ^ 0x80]) + blobs[1][2:]
+    _, _, sts = api.signatures_from_tagged(sg, [bad_tag, bad_point, blobs[2][:-1], blobs[2]])
+    assert sts == [api.BAD_ENCODING, api.BAD_ENCODING, api.BAD_LENGTH, 0]
+
+
+# ------------------------------------------------------------------ N3: PublicKeyShare::verify
+@pytest.mark.parametrize('C,sg', [(ref.G1Impl, 1), (ref.G2Impl, 2)], ids=['g1', 'g2'])
+def test_public_key_share_verify(api, C, sg):
+    """PublicKeyShare::verify (reference src/public_key_share.rs:53-72) is the scheme's verify on the share VALUES: Shamir shares
+    f(1..5) of a secret (threshold 3), each partial signature checked against its public-key share in one batch; a share
+    paired with another participant's signature fails; the Lagrange combination of three partial signatures verifies under
+    the group key (what the partial checks protect)."""
+    rng = random.Random(31 + sg)
+    pkraw, sigraw = (util.g2_raw, util.g1_raw) if sg == 1 else (util.g1_raw, util.g2_raw)
+    coef = [rng.randrange(1, c.R) for _ in range(3)]
+    share = [sum(a * pow(x, k, c.R) for k, a in enumerate(coef)) % c.R for x in range(1, 6)]
+    msg = b'threshold message'
+    for scheme in (ref.BASIC, ref.AUG, ref.POP):
+        pk_shares = [ref.public_key(C, s) for s in share]
+        sig_shares = [ref.sign(C, scheme, s, msg) for s in share]
+        praw, sraw = [pkraw(p, rng) for p in pk_shares], [sigraw(s, rng) for s in sig_shares]
+        assert api.verify_batch(sg, scheme, praw, sraw, [msg] * 5) == [0] * 5
+        swapped = [sraw[1], sraw[0]] + sraw[2:]
+        assert api.verify_batch(sg, scheme, praw, swapped, [msg] * 5) == [1, 1, 0, 0, 0]
+        if scheme != ref.AUG:     # Aug signs pk_share || msg: partial signatures do not combine across different prefixes
+            xs = [1, 3, 4]
+            lam = []
+            for i in xs:
+                num = den = 1
+                for j in xs:
+                    if j != i:
+                        num = num * j % c.R
+                        den = den * (j - i) % c.R
+                lam.append(num * pow(den, -1, c.R) % c.R)
+            comb = api.point_sum(sg, [sraw[x - 1] for x in xs], lam)
+            group_pk = pkraw(ref.public_key(C, coef[0]), rng)
+            assert api.verify_batch(sg, scheme, [group_pk], [comb], [msg]) == [0]
