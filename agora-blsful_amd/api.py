@@ -460,6 +460,12 @@ class TensorOps:
         self.torch, self.device = torch, device
         self.lib = init(device.index if device.index is not None else -1)
 
+    def _sync(self):
+        """The library runs on its own (non-blocking) streams: tensors that torch kernels are still producing on torch's
+        current stream must be complete before their pointers are handed over.  (The other direction needs nothing: every
+        C-ABI call is blocking.)"""
+        self.torch.cuda.current_stream(self.device).synchronize()
+
     @staticmethod
     def _p(t):
         return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
@@ -468,27 +474,32 @@ class TensorOps:
         return self.torch.empty(n, dtype=dtype or self.torch.uint8, device=self.device)
 
     def verify_batch(self, sg, scheme, pks, sigs, msgs, offs, n):
+        self._sync()
         st = self.empty(max(n, 1), self.torch.int32)
         _check(self.lib.blsgpu_verify_batch(sg, scheme, self._p(pks), self._p(sigs), self._p(msgs), self._p(offs), n, FMT_RAW_PROJ, self._p(st)))
         return st[:n]
 
     def pop_verify_batch(self, sg, pks, proofs, n):
+        self._sync()
         st = self.empty(max(n, 1), self.torch.int32)
         _check(self.lib.blsgpu_pop_verify_batch(sg, self._p(pks), self._p(proofs), n, FMT_RAW_PROJ, self._p(st)))
         return st[:n]
 
     def sig_proof_verify_batch(self, sg, scheme, us, vs, pks, ys, msgs, offs, n):
+        self._sync()
         st = self.empty(max(n, 1), self.torch.int32)
         _check(self.lib.blsgpu_sig_proof_verify_batch(sg, scheme, self._p(us), self._p(vs), self._p(pks), self._p(ys), self._p(msgs), self._p(offs), n,
                                                       FMT_RAW_PROJ, self._p(st)))
         return st[:n]
 
     def signcrypt_valid_batch(self, sg, scheme, us, ws, vs, offs, n):
+        self._sync()
         st = self.empty(max(n, 1), self.torch.int32)
         _check(self.lib.blsgpu_signcrypt_valid_batch(sg, scheme, self._p(us), self._p(ws), self._p(vs), self._p(offs), n, FMT_RAW_PROJ, self._p(st)))
         return st[:n]
 
     def point_sum(self, group, pts, n, scalars=None):
+        self._sync()
         out = self.empty(144 if group == 1 else 288)
         if scalars is None:
             fn = self.lib.blsgpu_sum_g1 if group == 1 else self.lib.blsgpu_sum_g2
@@ -499,11 +510,13 @@ class TensorOps:
         return out
 
     def multi_verify(self, sg, scheme, pks, n, sig, msg):
+        self._sync()
         st = ctypes.c_int32(-99)
         _check(self.lib.blsgpu_multi_verify(sg, scheme, self._p(pks), n, self._p(sig), _ptr(msg), len(msg), FMT_RAW_PROJ, ctypes.byref(st)))
         return st.value
 
     def core_verify_one(self, sg, dst, pk, sig, msg):
+        self._sync()
         st = ctypes.c_int32(-99)
         offs = (ctypes.c_uint64 * 2)(0, len(msg))
         _check(self.lib.blsgpu_core_verify(sg, _ptr(dst), len(dst), self._p(pk), self._p(sig), _ptr(msg), ctypes.cast(offs, ctypes.c_void_p), 1,
@@ -511,6 +524,7 @@ class TensorOps:
         return st.value
 
     def aggregate_partial(self, sg, scheme, pks, msgs, offs, n, sig=None):
+        self._sync()
         """(576-byte record, first_bad) as DEVICE tensors: nothing crosses to the host."""
         rec, fb = self.empty(576), self.empty(1, self.torch.int64)
         _check(self.lib.blsgpu_aggregate_partial(sg, scheme, self._p(pks), self._p(msgs), self._p(offs), n, self._p(sig), FMT_RAW_PROJ,
@@ -518,42 +532,50 @@ class TensorOps:
         return rec, fb
 
     def fp12_product_is_one(self, recs, k):
+        self._sync()
         r = ctypes.c_int32(-99)
         _check(self.lib.blsgpu_fp12_product_is_one(self._p(recs), k, ctypes.byref(r)))
         return bool(r.value)
 
     def first_duplicate(self, msgs, offs, n):
+        self._sync()
         out = (ctypes.c_uint64 * 2)()
         _check(self.lib.blsgpu_first_duplicate_message(self._p(msgs), self._p(offs), n, ctypes.cast(out, ctypes.c_void_p)))
         return None if out[1] == 2 ** 64 - 1 else (out[0], out[1])
 
     def serialize(self, group, pts, n, legacy=False):
+        self._sync()
         out = self.empty((48 if group == 1 else 96) * max(n, 1))
         _check(self.lib.blsgpu_serialize(group, self._p(pts), n, FMT_RAW_PROJ, FMT_LEGACY if legacy else FMT_COMPRESSED, self._p(out), None))
         return out[:(48 if group == 1 else 96) * n]
 
     def sort_keys(self, kb, n, width):
+        self._sync()
         perm = self.empty(max(n, 1), self.torch.int32)
         _check(self.lib.blsgpu_sort_keys(self._p(kb), n, width, self._p(perm)))
         return perm[:n]
 
     def keys_digest(self, kb, perm, n, width):
+        self._sync()
         out = self.empty(32)
         _check(self.lib.blsgpu_sorted_keys_digest(self._p(kb), self._p(perm), n, width, self._p(out)))
         return out
 
     def coefficients_for_range(self, digest, perm, n, base, count):
+        self._sync()
         scal = self.empty(32 * max(count, 1))
         st = ctypes.c_int32(-99)
         _check(self.lib.blsgpu_coefficients_for_range(self._p(digest), self._p(perm), n, base, count, self._p(scal), ctypes.byref(st)))
         return scal[:32 * count], st.value
 
     def first_occurrence(self, kb, perm, n, width):
+        self._sync()
         out = self.empty(max(n, 1), self.torch.int32)
         _check(self.lib.blsgpu_first_occurrence(self._p(kb), self._p(perm), n, width, self._p(out)))
         return out[:n]
 
     def is_identity(self, group, pt):
+        self._sync()
         return int(self.serialize(group, pt, 1)[0].item()) == 0xc0
 
 

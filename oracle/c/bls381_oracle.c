@@ -419,7 +419,7 @@ static g2p hash_to_g2(const uint8_t* pre, size_t prel, const uint8_t* m, size_t 
  * tangent at T=(X,Y,Z), scaled by 2YZ^3:  l0 = 3X^3 - 2Y^2,  l2 = -3X^2 Z^2 xP,  l3 = 2YZ^3 yP
  * chord T,Q=(x2,y2), scaled by Z3 = Z H:   l0 = r x2 - y2 Z3,  l2 = -r xP,        l3 = Z3 yP      (r = y2 Z^3 - Y, H = x2 Z^2 - X) */
 static fp12 miller_loop(int n, const fp* xp, const fp* yp, const fp2* xq, const fp2* yq) {
-  g2p T[8]; fp12 f = F12_ONE;
+  g2p T8[8]; g2p* T = n <= 8 ? T8 : (g2p*)malloc(sizeof(g2p) * (size_t)n); fp12 f = F12_ONE;
   for (int k = 0; k < n; k++) { T[k].x = xq[k]; T[k].y = yq[k]; T[k].z = FP2_ONE; }
   for (int i = 62; i >= 0; i--) {
     f = f12_sqr(f);
@@ -440,6 +440,7 @@ static fp12 miller_loop(int n, const fp* xp, const fp* yp, const fp2* xq, const 
       }
     }
   }
+  if (T != T8) free(T);
   return f12_conj(f);
 }
 static fp12 pow_x(fp12 a) {
@@ -585,5 +586,174 @@ int bo_verify_secure(int sg, int scheme, const uint8_t* pks, size_t n, const uin
   }
   free(kb); free(order);
   if (rc >= 0) return rc;
+  return core_verify(sg, scheme, 0, sg == 1 ? (const uint8_t*)&a2 : (const uint8_t*)&a1, sig_raw, msg, len);
+}
+
+/* ------------------------------------------------------------------ CPU legs of BASELINE configs 3, 4, 5 (tools/bench_configs.py)
+ * threads == 1 is the reference's own loop; threads > 1 splits the items into contiguous ranges whose partial results
+ * (point sums, Miller products) are folded at the end -- the fairest multi-core form of the same algorithm. */
+typedef struct { int sg; const uint8_t* pks; size_t lo, hi; g1p s1; g2p s2; } sum_job;
+static void* sum_worker(void* a) {
+  sum_job* j = (sum_job*)a;
+  memset(&j->s1, 0, sizeof j->s1); memset(&j->s2, 0, sizeof j->s2);
+  for (size_t i = j->lo; i < j->hi; i++) {               /* reference src/traits/pk_multi.rs:7-13: g += key */
+    if (j->sg == 1) j->s2 = g2p_add(j->s2, load_g2(j->pks + i * 288)); else j->s1 = g1p_add(j->s1, load_g1(j->pks + i * 144));
+  }
+  return 0;
+}
+/* MultiSignature::verify (reference src/multi_signature.rs:127-135) with MultiPublicKey::from_public_keys */
+int bo_multi_verify(int sg, int scheme, const uint8_t* pks, size_t n, const uint8_t* sig, const uint8_t* msg, size_t len, int threads) {
+  bo_init();
+  if (threads < 1) threads = 1;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
+  sum_job* jobs = (sum_job*)malloc(sizeof(sum_job) * threads);
+  for (int t = 0; t < threads; t++) {
+    jobs[t].sg = sg; jobs[t].pks = pks; jobs[t].lo = n * t / threads; jobs[t].hi = n * (t + 1) / threads;
+    if (threads == 1) sum_worker(&jobs[t]); else pthread_create(&th[t], 0, sum_worker, &jobs[t]);
+  }
+  g1p a1; g2p a2; memset(&a1, 0, sizeof a1); memset(&a2, 0, sizeof a2);
+  for (int t = 0; t < threads; t++) {
+    if (threads > 1) pthread_join(th[t], 0);
+    a1 = g1p_add(a1, jobs[t].s1); a2 = g2p_add(a2, jobs[t].s2);
+  }
+  free(th); free(jobs);
+  return core_verify(sg, scheme, scheme == 1, sg == 1 ? (const uint8_t*)&a2 : (const uint8_t*)&a1, sig, msg, len);
+}
+
+typedef struct { int sg, scheme; const uint8_t *pks, *msgs; const uint64_t* offs; size_t lo, hi; fp12 f; long first_bad; } agg_job;
+static void* agg_worker(void* a) {
+  agg_job* j = (agg_job*)a;
+  const uint8_t* dst = (const uint8_t*)DSTS[j->sg - 1][j->scheme]; size_t dl = strlen((const char*)dst);
+  size_t k = j->hi - j->lo;
+  fp* xp = (fp*)malloc(sizeof(fp) * (k + 1)); fp* yp = (fp*)malloc(sizeof(fp) * (k + 1));
+  fp2* xq = (fp2*)malloc(sizeof(fp2) * (k + 1)); fp2* yq = (fp2*)malloc(sizeof(fp2) * (k + 1));
+  j->first_bad = -1;
+  size_t m = 0;
+  for (size_t i = j->lo; i < j->hi; i++) {               /* reference src/traits/sig_core.rs:161-171 */
+    uint8_t pre[96]; size_t prel = 0;
+    const uint8_t* msg = j->msgs + j->offs[i]; size_t len = (size_t)(j->offs[i + 1] - j->offs[i]);
+    if (j->sg == 1) {
+      g2p pk = load_g2(j->pks + i * 288);
+      if (g2p_is_inf(&pk)) { if (j->first_bad < 0) j->first_bad = (long)i; continue; }
+      if (j->scheme == 1) { g2_compress(pre, pk); prel = 96; }
+      g1_affine(&xp[m], &yp[m], hash_to_g1(pre, prel, msg, len, dst, dl)); g2_affine(&xq[m], &yq[m], pk);
+    } else {
+      g1p pk = load_g1(j->pks + i * 144);
+      if (g1p_is_inf(&pk)) { if (j->first_bad < 0) j->first_bad = (long)i; continue; }
+      if (j->scheme == 1) { g1_compress(pre, pk); prel = 48; }
+      g1_affine(&xp[m], &yp[m], pk); g2_affine(&xq[m], &yq[m], hash_to_g2(pre, prel, msg, len, dst, dl));
+    }
+    m++;
+  }
+  j->f = m ? miller_loop((int)m, xp, yp, xq, yq) : F12_ONE;
+  free(xp); free(yp); free(xq); free(yq);
+  return 0;
+}
+static const uint8_t* g_dup_msgs; static const uint64_t* g_dup_offs;
+static int cmp_msgs(const void* a, const void* b) {
+  size_t i = *(const size_t*)a, k = *(const size_t*)b;
+  size_t li = (size_t)(g_dup_offs[i + 1] - g_dup_offs[i]), lk = (size_t)(g_dup_offs[k + 1] - g_dup_offs[k]);
+  int c = memcmp(g_dup_msgs + g_dup_offs[i], g_dup_msgs + g_dup_offs[k], li < lk ? li : lk);
+  if (c) return c;
+  if (li != lk) return li < lk ? -1 : 1;
+  return i < k ? -1 : i > k;
+}
+/* AggregateSignature::verify (reference src/aggregate_signature.rs:230-239): Basic's duplicate rule (src/traits/sig_basic.rs:46-58),
+ * then core_aggregate_verify (src/traits/sig_core.rs:149-178).  Returns the status code; aux = the indices of the error strings. */
+int bo_aggregate_verify(int sg, int scheme, const uint8_t* pks, const uint8_t* msgs, const uint64_t* offs, size_t n, const uint8_t* sig_raw,
+                        int threads, uint64_t* aux) {
+  bo_init();
+  aux[0] = aux[1] = 0;
+  if (scheme == 0 && n > 1) {      /* first i whose message equals an earlier one: sort indices by (message, index), scan runs */
+    size_t* idx = (size_t*)malloc(sizeof(size_t) * n);
+    for (size_t i = 0; i < n; i++) idx[i] = i;
+    g_dup_msgs = msgs; g_dup_offs = offs; qsort(idx, n, sizeof(size_t), cmp_msgs);
+    size_t best = (size_t)-1, old = 0, run = 0;
+    for (size_t k = 1; k < n; k++) {
+      size_t a = idx[k - 1], b = idx[k];
+      size_t la = (size_t)(offs[a + 1] - offs[a]), lb = (size_t)(offs[b + 1] - offs[b]);
+      if (la == lb && memcmp(msgs + offs[a], msgs + offs[b], la) == 0) { if (b < best) { best = b; old = idx[run]; } }
+      else run = k;
+    }
+    free(idx);
+    if (best != (size_t)-1) { aux[0] = old; aux[1] = best; return 4; }
+  }
+  if (sg == 1) { g1p s = load_g1(sig_raw); if (g1p_is_inf(&s)) return 2; } else { g2p s = load_g2(sig_raw); if (g2p_is_inf(&s)) return 2; }
+  if (threads < 1) threads = 1;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
+  agg_job* jobs = (agg_job*)malloc(sizeof(agg_job) * threads);
+  for (int t = 0; t < threads; t++) {
+    agg_job j = {sg, scheme, pks, msgs, offs, n * t / threads, n * (t + 1) / threads, F12_ONE, -1};
+    jobs[t] = j;
+    if (threads == 1) agg_worker(&jobs[t]); else pthread_create(&th[t], 0, agg_worker, &jobs[t]);
+  }
+  fp12 f = F12_ONE; long fb = -1;
+  for (int t = 0; t < threads; t++) {
+    if (threads > 1) pthread_join(th[t], 0);
+    if (fb < 0 && jobs[t].first_bad >= 0) fb = jobs[t].first_bad;
+    f = f12_mul(f, jobs[t].f);
+  }
+  free(th); free(jobs);
+  if (fb >= 0) { aux[0] = (uint64_t)fb + 1; return 3; }
+  fp xp, yp; fp2 xq, yq;
+  if (sg == 1) { g1_affine(&xp, &yp, load_g1(sig_raw)); g2_affine(&xq, &yq, g2p_neg(G2_GEN)); }
+  else { g1_affine(&xp, &yp, g1p_neg(G1_GEN)); g2_affine(&xq, &yq, load_g2(sig_raw)); }
+  f = f12_mul(f, miller_loop(1, &xp, &yp, &xq, &yq));
+  return f12_is_one(final_exp(f)) ? 0 : 1;
+}
+
+typedef struct { int sg; const uint8_t* pks; const uint8_t* const* order; const uint8_t* kb; size_t width; const uint8_t* H; size_t lo, hi; g1p s1; g2p s2; int zero; } sec_job;
+static void* sec_worker(void* a) {
+  sec_job* j = (sec_job*)a;
+  size_t psz = j->sg == 1 ? 288 : 144;
+  memset(&j->s1, 0, sizeof j->s1); memset(&j->s2, 0, sizeof j->s2); j->zero = 0;
+  for (size_t i = j->lo; i < j->hi; i++) {               /* reference src/secure_aggregation.rs:61-100,201-204 */
+    sha256 s; uint8_t buf[36] = {(uint8_t)(i >> 24), (uint8_t)(i >> 16), (uint8_t)(i >> 8), (uint8_t)i}, d[32];
+    memcpy(buf + 4, j->H, 32); sha_init(&s); sha_update(&s, buf, 36); sha_final(&s, d);
+    uint64_t t[4]; for (int k = 0; k < 4; k++) { t[k] = 0; for (int b = 0; b < 8; b++) t[k] |= (uint64_t)d[31 - 8 * k - b] << (8 * b); }
+    for (int round = 0; round < 3; round++) {
+      uint64_t dd[4]; u128 bw = 0;
+      for (int k = 0; k < 4; k++) { u128 x = (u128)t[k] - K_R[k] - bw; dd[k] = (uint64_t)x; bw = (x >> 64) & 1; }
+      if (bw) break;
+      memcpy(t, dd, 32);
+    }
+    if (!(t[0] | t[1] | t[2] | t[3])) { j->zero = 1; return 0; }
+    size_t idx = (size_t)(j->order[i] - j->kb) / j->width;
+    if (j->sg == 1) j->s2 = g2p_add(j->s2, g2p_mul(load_g2(j->pks + idx * psz), t, 256)); else j->s1 = g1p_add(j->s1, g1p_mul(load_g1(j->pks + idx * psz), t, 256));
+  }
+  return 0;
+}
+/* verify_secure as bo_verify_secure, the n scalar multiplications spread over `threads` host threads */
+int bo_verify_secure_mt(int sg, int scheme, const uint8_t* pks, size_t n, const uint8_t* sig_raw, const uint8_t* msg, size_t len, int legacy, int threads) {
+  bo_init();
+  if (n == 0 || threads <= 1) return bo_verify_secure(sg, scheme, pks, n, sig_raw, msg, len, legacy);
+  size_t psz = sg == 1 ? 288 : 144, width = sg == 1 ? 96 : 48;
+  uint8_t* kb = (uint8_t*)malloc(width * n); const uint8_t** order = (const uint8_t**)malloc(sizeof(void*) * n);
+  for (size_t i = 0; i < n; i++) {
+    if (sg == 1) g2_compress(kb + i * width, load_g2(pks + i * psz)); else g1_compress(kb + i * width, load_g1(pks + i * psz));
+    if (legacy && kb[i * width] != 0xc0) { uint8_t ys = kb[i * width] & 0x20; kb[i * width] &= 0x1f; if (ys) kb[i * width] |= 0x80; }
+    order[i] = kb + i * width;
+  }
+  g_width = width; qsort(order, n, sizeof(void*), cmp_keys);
+  sha256 s; uint8_t H[32]; sha_init(&s);
+  for (size_t i = 0; i < n; i++) sha_update(&s, order[i], width);
+  sha_final(&s, H);
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
+  sec_job* jobs = (sec_job*)malloc(sizeof(sec_job) * threads);
+  for (int t = 0; t < threads; t++) {
+    sec_job j; memset(&j, 0, sizeof j);
+    j.sg = sg; j.pks = pks; j.order = order; j.kb = kb; j.width = width; j.H = H; j.lo = n * t / threads; j.hi = n * (t + 1) / threads;
+    jobs[t] = j;
+    pthread_create(&th[t], 0, sec_worker, &jobs[t]);
+  }
+  g1p a1; g2p a2; memset(&a1, 0, sizeof a1); memset(&a2, 0, sizeof a2);
+  int zero = 0;
+  for (int t = 0; t < threads; t++) {
+    pthread_join(th[t], 0);
+    zero |= jobs[t].zero;
+    a1 = g1p_add(a1, jobs[t].s1); a2 = g2p_add(a2, jobs[t].s2);
+  }
+  free(th); free(jobs); free(kb); free(order);
+  if (zero) return 5;
   return core_verify(sg, scheme, 0, sg == 1 ? (const uint8_t*)&a2 : (const uint8_t*)&a1, sig_raw, msg, len);
 }

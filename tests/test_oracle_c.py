@@ -93,3 +93,55 @@ def test_c_oracle_vs_python_oracle(bo):
         assert bo.bo_verify_secure(2, 0, raw, 5, util.g2_raw(agg, rng), msg, len(msg), 1 - mode) == 1
     assert bo.bo_verify_secure(2, 0, b'', 0, util.g2_raw(None), msg, len(msg), 0) == 0
     assert bo.bo_verify_secure(2, 0, b'', 0, util.g2_raw(sigs[0]), msg, len(msg), 0) == 1
+
+
+def test_c_oracle_config_legs_vs_python_oracle(bo):
+    """The CPU legs of BASELINE configs 3-5 (bo_multi_verify, bo_aggregate_verify, bo_verify_secure_mt), single-threaded =
+    the reference's loops and multi-threaded, against oracle/py: verdicts, error precedence and indices."""
+    rng = random.Random(8)
+    V = lambda b: ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p)  # noqa: E731
+    for C, sg in ((ref.G1Impl, 1), (ref.G2Impl, 2)):
+        pkraw, sigraw = (util.g2_raw, util.g1_raw) if sg == 1 else (util.g1_raw, util.g2_raw)
+        n = 11                      # > 8 pairs per thread: the multi-pair Miller loop allocates its point table
+        sks = [ref.keygen_from_hash(bytes([i, sg, 3]) * 10 + b'xx') for i in range(n)]
+        pks = [ref.public_key(C, s) for s in sks]
+        praw = b''.join(pkraw(p, rng) for p in pks)
+        m1 = b'one message'
+        msig = sigraw(ref.aggregate_signatures(C, [ref.sign(C, ref.POP, s, m1) for s in sks]), rng)
+        for th in (1, 3):
+            assert bo.bo_multi_verify(sg, 2, V(praw), n, V(msig), m1, len(m1), th) == 0
+            assert bo.bo_multi_verify(sg, 2, V(praw), n - 1, V(msig), m1, len(m1), th) == 1
+        msgs = [b'item %d' % i for i in range(n)]
+
+        def agg(scheme, pk_rows, msg_rows, sig, th):
+            offs = (ctypes.c_uint64 * (len(msg_rows) + 1))()
+            t = 0
+            for i, m in enumerate(msg_rows):
+                offs[i] = t
+                t += len(m)
+            offs[len(msg_rows)] = t
+            aux = (ctypes.c_uint64 * 2)()
+            st = bo.bo_aggregate_verify(sg, scheme, V(b''.join(pk_rows)), V(b''.join(msg_rows)), ctypes.cast(offs, ctypes.c_void_p), len(msg_rows), V(sig), th,
+                                        ctypes.cast(aux, ctypes.c_void_p))
+            return st, (aux[0], aux[1])
+        rows = [pkraw(p, rng) for p in pks]
+        for scheme in (ref.BASIC, ref.AUG):
+            asig = sigraw(ref.aggregate_signatures(C, [ref.sign(C, scheme, s, m) for s, m in zip(sks, msgs)]), rng)
+            for th in (1, 2, 4):
+                assert agg(scheme, rows, msgs, asig, th) == (0, (0, 0))
+                bad = list(msgs)
+                bad[4] = b'tampered'
+                assert agg(scheme, rows, bad, asig, th) == (1, (0, 0))
+                dup = list(msgs)
+                dup[6], dup[3] = dup[1], dup[2]
+                assert agg(scheme, rows, dup, asig, th) == ((4, (2, 3)) if scheme == ref.BASIC else (1, (0, 0)))
+                pid = list(rows)
+                pid[5] = pid[2] = pkraw(None)
+                assert agg(scheme, pid, msgs, asig, th) == (3, (3, 0))
+                assert agg(scheme, pid, msgs, sigraw(None), th) == (2, (0, 0))
+        ssigs = [C.sig_curve.mul(C.hash_to_point(m1, C.DST[ref.BASIC]), s) for s in sks]
+        for mode in ([0] if sg == 1 else [0, 1]):
+            sagg = sigraw(ref.aggregate_secure(C, pks, ssigs, None if sg == 1 else mode), rng)
+            for th in (1, 3):
+                assert bo.bo_verify_secure_mt(sg, 0, V(praw), n, V(sagg), m1, len(m1), mode, th) == 0
+                assert bo.bo_verify_secure_mt(sg, 0, V(praw), n - 1, V(sagg), m1, len(m1), mode, th) == 1

@@ -102,6 +102,9 @@ def load_c_oracle():
     lib.bo_compress.argtypes = [ci, cp, vp]
     lib.bo_compress.restype = None
     lib.bo_verify_secure.argtypes = [ci, ci, cp, sz, cp, cp, sz, ci]
+    lib.bo_verify_secure_mt.argtypes = [ci, ci, vp, sz, vp, cp, sz, ci, ci]
+    lib.bo_multi_verify.argtypes = [ci, ci, vp, sz, vp, cp, sz, ci]
+    lib.bo_aggregate_verify.argtypes = [ci, ci, vp, vp, vp, sz, vp, ci, vp]
     lib.bo_init()
     return lib
 

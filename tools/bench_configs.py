@@ -1,105 +1,161 @@
-"""Wall-clock of BASELINE.json configs 1 and 3-5 on one MI355X (parity-test cases, not the bench line): inputs are made on
-the device with blsgpu_sign_batch and stay resident in HBM.  Prints one JSON object per config.
-usage: python tools/bench_configs.py [--scale 1.0]"""
-import argparse, ctypes, hashlib, json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
-import torch
-import __graft_entry__ as ge
+"""BASELINE.json configs 1 and 3-5 beside their CPU legs (parity-test cases, not the bench line).
 
-R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+GPU side: config 1 (1,024 sequential single-item Signature::verify calls through the C ABI, the latency number) is timed
+here; configs 3-5 are timed by `python bench.py --config 3|4|5` (one code path for 1 and N GPUs) and only quoted here when
+--gpu-configs is given.
+CPU side (SURVEY 8d "timing the reference's CPU path beside it"; the reference itself cannot be built here): the plain-C
+oracle (oracle/c, kind "port", NOT blst) running the reference's own loops -- serial `g += key` (src/traits/pk_multi.rs:7-13),
+one (n + 1)-pair Miller product (src/traits/sig_core.rs:149-178), n serial scalar multiplications
+(src/secure_aggregation.rs:201-204) -- on 1 thread and on all host cores, on BOUNDED samples of the same device-signed
+inputs (sizes stated per line; rates are per item, so they extrapolate linearly except for the O(n log n) key sort).
+Prints one JSON object per line.   usage: python tools/bench_configs.py [--cpu-seconds 10] [--skip-gpu]"""
+import argparse
+import ctypes
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import torch  # noqa: E402
+import __graft_entry__ as ge  # noqa: E402
+import bench  # noqa: E402
+
+R = bench.R_ORDER
 
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument('--scale', type=float, default=1.0); args = ap.parse_args()
-    pkg = ge.import_pkg(); api = pkg.api; lib = api.init(0)
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cpu-seconds', type=float, default=8.0, help='target wall time per CPU leg (sample sizes are derived from a probe)')
+    ap.add_argument('--skip-gpu', action='store_true')
+    ap.add_argument('--skip-cpu', action='store_true')
+    args = ap.parse_args()
+    pkg = ge.import_pkg()
+    api = pkg.api
+    lib = api.init(0)
     dev = torch.device('cuda', 0)
-    P = lambda t: ctypes.c_void_p(t.data_ptr())
-    seed = hashlib.sha256(b'blsgpu-bench-v1').digest(); s0 = int.from_bytes(seed, 'big') % R
+    P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    V = lambda b: ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p)  # noqa: E731
+    msg = bench.FIXED_MSG
+    cores = bench.host_cores()
 
-    def make(sg, scheme, n, msgs=None, one_msg=None):
-        sks = [(s0 + i) % R or 1 for i in range(n)]
-        skb = b''.join(s.to_bytes(32, 'little') for s in sks)
-        if one_msg is not None:
-            blob = one_msg * n; offs = torch.arange(n + 1, dtype=torch.int64) * len(one_msg)
-        else:
-            blob = b''.join(msgs); offs = torch.arange(n + 1, dtype=torch.int64) * 32
-        d_msgs = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev); d_offs = offs.to(dev)
+    def emit(d):
+        print(json.dumps(d), flush=True)
+
+    def sign(sg, scheme, n, blob, msg_len):
         pksz, sgsz = (288, 144) if sg == 1 else (144, 288)
-        d_pks = torch.empty(n * pksz, dtype=torch.uint8, device=dev); d_sigs = torch.empty(n * sgsz, dtype=torch.uint8, device=dev)
+        d_msgs = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+        d_offs = (torch.arange(n + 1, dtype=torch.int64) * msg_len).to(dev)
+        d_pks = torch.empty(n * pksz, dtype=torch.uint8, device=dev)
+        d_sigs = torch.empty(n * sgsz, dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
-        api._check(lib.blsgpu_sign_batch(sg, scheme, api._ptr(skb), P(d_msgs), P(d_offs), n, P(d_pks), P(d_sigs)))
-        return sks, d_pks, d_sigs, d_msgs, d_offs
+        api._check(lib.blsgpu_sign_batch(sg, scheme, api._ptr(bench.sk_bytes(n, 0)), P(d_msgs), P(d_offs), n, P(d_pks), P(d_sigs)))
+        return d_pks, d_sigs, d_msgs, d_offs
 
-    def timed(fn, reps=3):
-        fn(); ts = []
-        for _ in range(reps):
-            torch.cuda.synchronize(); t = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
-        return min(ts)
-
-    st = ctypes.c_int32(-9)
-    # ---- config 1: 1,024 sequential single-item Signature::verify calls (the reference's own CPU-runnable case): the
-    # latency / plumbing number -- each call is one blsgpu_verify_batch of one item with host pointers, as a caller that
-    # keeps the reference's one-signature-per-call API would issue it
-    n1 = max(16, int(1024 * args.scale)); msg = hashlib.sha256(seed + b'fixed').digest()
-    sks1 = [(s0 + i) % R or 1 for i in range(n1)]
-    pks1, sigs1 = api.sign_batch(1, api.POP, sks1, [msg] * n1)
-    offs1 = (ctypes.c_uint64 * 2)(0, len(msg)); st1 = ctypes.c_int32(-9)
+    # ---- config 1 on the GPU: 1,024 sequential single-item Signature::verify calls (host pointers, one item per call)
+    n1 = 1024
+    pks1, sigs1 = api.sign_batch(1, api.POP, [(bench.S0 + i) % R or 1 for i in range(n1)], [msg] * n1)
+    if not args.skip_gpu:
+        offs1 = (ctypes.c_uint64 * 2)(0, len(msg))
+        st1 = ctypes.c_int32(-9)
+        lat = []
+        for i in range(n1):
+            t = time.perf_counter()
+            api._check(lib.blsgpu_verify_batch(1, api.POP, api._ptr(pks1[i]), api._ptr(sigs1[i]), api._ptr(msg), ctypes.cast(offs1, ctypes.c_void_p), 1, 0,
+                                               ctypes.cast(ctypes.byref(st1), ctypes.c_void_p)))
+            lat.append(time.perf_counter() - t)
+            assert st1.value == 0
+        lat.sort()
+        emit({'config': 1, 'side': 'gpu', 'n': n1, 'calls': 'sequential, one item each, host pointers', 'mean_ms': 1e3 * sum(lat) / n1,
+              'p50_ms': 1e3 * lat[n1 // 2], 'p99_ms': 1e3 * lat[min(n1 - 1, int(n1 * 0.99))], 'verifications_per_s': n1 / sum(lat)})
+    if args.skip_cpu:
+        return
+    import util
+    bo = util.load_c_oracle()
+    cpu = {'kind': 'port', 'what': 'oracle/c plain-C restatement (not blst) of the reference loop', 'host_cores': cores}
+    # ---- config 1 on the CPU: the same 1,024 calls, one thread (the reference's configs[0] is exactly this)
     lat = []
     for i in range(n1):
         t = time.perf_counter()
-        api._check(lib.blsgpu_verify_batch(1, api.POP, api._ptr(pks1[i]), api._ptr(sigs1[i]), api._ptr(msg), ctypes.cast(offs1, ctypes.c_void_p), 1, 0,
-                                           ctypes.cast(ctypes.byref(st1), ctypes.c_void_p)))
+        r = bo.bo_verify(1, 2, pks1[i], sigs1[i], msg, len(msg))
         lat.append(time.perf_counter() - t)
-        assert st1.value == 0
+        assert r == 0
     lat.sort()
-    print(json.dumps({'config': 1, 'n': n1, 'calls': 'sequential, one item each, host pointers', 'mean_ms': 1e3 * sum(lat) / n1,
-                      'p50_ms': 1e3 * lat[n1 // 2], 'p99_ms': 1e3 * lat[min(n1 - 1, int(n1 * 0.99))], 'verifications_per_s': n1 / sum(lat)}), flush=True)
-    # ---- config 3: MultiSignature::verify, 1,048,576 G2 public keys, one message
-    n = int(1048576 * args.scale); msg = hashlib.sha256(seed + b'fixed').digest()
-    sks, d_pks, d_sigs, _, _ = make(1, api.POP, n, one_msg=msg)
+    per_verify = sum(lat) / n1
+    emit(dict(cpu, config=1, side='cpu', threads=1, n=n1, mean_ms=1e3 * per_verify, p50_ms=1e3 * lat[n1 // 2], verifications_per_s=1 / per_verify))
+    pkb, sgb = b''.join(pks1), b''.join(sigs1)
+    offs = (ctypes.c_uint64 * (n1 + 1))(*[32 * i for i in range(n1 + 1)])
+    st = (ctypes.c_int32 * n1)()
+    t = time.perf_counter()
+    bo.bo_verify_batch(1, 2, V(pkb), V(sgb), V(msg * n1), ctypes.cast(offs, ctypes.c_void_p), n1, ctypes.cast(st, ctypes.c_void_p), cores)
+    dt = time.perf_counter() - t
+    assert not any(st)
+    emit(dict(cpu, config=1, side='cpu', threads=cores, n=n1, seconds=dt, verifications_per_s=n1 / dt, note='the 1,024 items as one threaded batch'))
+
+    # ---- config 3: serial G2 key sum + one verify
+    n3 = 1 << 20
+    d_pks, d_sigs, _, _ = sign(1, api.POP, n3, msg * n3, 32)
     agg = torch.empty(144, dtype=torch.uint8, device=dev)
-    api._check(lib.blsgpu_sum_g1(P(d_sigs), n, 0, P(agg)))
-    api.profile_enable(True)
-    t = timed(lambda: api._check(lib.blsgpu_multi_verify(1, api.POP, P(d_pks), n, P(agg), api._ptr(msg), len(msg), 0, ctypes.byref(st))))
-    prof = api.profile_read(); api.profile_enable(False)
-    print(json.dumps({'config': 3, 'n': n, 'status': st.value, 'seconds': t, 'keys_per_s': n / t, 'GBps_algorithmic': 288 * n / t / 1e9,
-                      'kernel_ms': {k: round(v[0] / v[1], 3) for k, v in prof.items()}, 'launches': {k: v[1] for k, v in prof.items()}}), flush=True)
+    api._check(lib.blsgpu_sum_g1(P(d_sigs), n3, 0, P(agg)))
+    pk_h, agg_h = d_pks.cpu().numpy().tobytes(), agg.cpu().numpy().tobytes()
     del d_pks, d_sigs
-    # ---- config 4: AggregateSignature::verify, 262,144 distinct (pk, msg), Basic
-    n = int(262144 * args.scale); msgs = [hashlib.sha256(seed + i.to_bytes(8, 'little')).digest() for i in range(n)]
-    sks, d_pks, d_sigs, d_msgs, d_offs = make(1, api.BASIC, n, msgs=msgs)
-    api._check(lib.blsgpu_sum_g1(P(d_sigs), n, 0, P(agg)))
+    probe = 4096
+    t = time.perf_counter()
+    bo.bo_multi_verify(1, 2, V(pk_h), probe, V(agg_h), msg, 32, 1)
+    per_key = max((time.perf_counter() - t - 2 * per_verify) / probe, 1e-7)
+    for th in (1, cores):
+        ns = int(min(n3, max(probe, args.cpu_seconds * th / per_key)))
+        t = time.perf_counter()
+        r = bo.bo_multi_verify(1, 2, V(pk_h), ns, V(agg_h), msg, 32, th)
+        dt = time.perf_counter() - t
+        assert r == (0 if ns == n3 else 1)                 # a partial key set must not verify the full aggregate
+        emit(dict(cpu, config=3, side='cpu', threads=th, sample_keys=ns, of=n3, seconds=dt, keys_per_s=ns / dt,
+                  extrapolated_seconds_full=dt * n3 / ns))
+    del pk_h
+
+    # ---- config 4: n hash-to-curve + (n + 1)-pair Miller product + one final exponentiation
+    n4 = 16384
+    blob = b''.join(hashlib.sha256(bench.SEED + i.to_bytes(8, 'little')).digest() for i in range(n4))
+    d_pks, d_sigs, _, _ = sign(1, api.BASIC, n4, blob, 32)
+    pk_h, sg_h = d_pks.cpu().numpy().tobytes(), d_sigs.cpu().numpy().tobytes()
+    offs4 = (ctypes.c_uint64 * (n4 + 1))(*[32 * i for i in range(n4 + 1)])
     aux = (ctypes.c_uint64 * 2)()
-    api.profile_enable(True)
-    t = timed(lambda: api._check(lib.blsgpu_aggregate_verify(1, api.BASIC, P(d_pks), P(d_msgs), P(d_offs), n, P(agg), 0, ctypes.byref(st), ctypes.cast(aux, ctypes.c_void_p))), reps=2)
-    prof = api.profile_read(); api.profile_enable(False)
-    print(json.dumps({'config': 4, 'n': n, 'status': st.value, 'seconds': t, 'pairs_per_s': n / t,
-                      'kernel_ms': {k: round(v[0] / v[1], 3) for k, v in prof.items()}, 'launches': {k: v[1] for k, v in prof.items()}}), flush=True)
-    del d_pks, d_sigs, d_msgs
-    # ---- config 5: verify_secure, 65,536 keys: G1Impl Modern, G2Impl Modern, G2Impl Legacy
-    n = int(65536 * args.scale)
+    per_pair = 1.0 * per_verify                            # hash + one Miller pair is about one verify without the final exp
+    for th in (1, cores):
+        ns = int(min(n4, max(64, args.cpu_seconds * th / per_pair)))
+        api._check(lib.blsgpu_sum_g1(P(d_sigs), ns, 0, P(agg)))          # the aggregate of exactly the sampled pairs
+        t = time.perf_counter()
+        r = bo.bo_aggregate_verify(1, 0, V(pk_h), V(blob), ctypes.cast(offs4, ctypes.c_void_p), ns, V(agg.cpu().numpy().tobytes()), th,
+                                   ctypes.cast(aux, ctypes.c_void_p))
+        dt = time.perf_counter() - t
+        assert r == 0
+        emit(dict(cpu, config=4, side='cpu', threads=th, sample_pairs=ns, of=262144, seconds=dt, pairs_per_s=ns / dt,
+                  extrapolated_seconds_full=dt * 262144 / ns))
+    del d_pks, d_sigs
+
+    # ---- config 5: sort + coefficient hashes + n serial 255-bit scalar multiplications + one verify
+    n5 = 8192
     for sg, mode, name in ((1, 0, 'G1Impl/Modern'), (2, 0, 'G2Impl/Modern'), (2, 1, 'G2Impl/Legacy')):
-        sks, d_pks, d_sigs, _, _ = make(sg, api.BASIC, n, one_msg=msg)
-        pk_group = 2 if sg == 1 else 1
-        kb = torch.empty(n * (96 if sg == 1 else 48), dtype=torch.uint8, device=dev)
-        api._check(lib.blsgpu_serialize(pk_group, P(d_pks), n, 0, api.FMT_LEGACY if mode else api.FMT_COMPRESSED, P(kb), None))
-        w = 96 if sg == 1 else 48
-        kbl = kb.cpu().numpy().tobytes()
-        stc, perm, ts = api.secure_coefficients([kbl[w * i:w * (i + 1)] for i in range(n)])
-        idx = torch.tensor(perm, dtype=torch.int64, device=dev)
+        d_pks, d_sigs, _, _ = sign(sg, api.BASIC, n5, msg * n5, 32)
+        pk_h = d_pks.cpu().numpy().tobytes()
         sgsz = 144 if sg == 1 else 288
-        sig_sorted = d_sigs.view(n, sgsz)[idx].contiguous().view(-1)
-        scal = torch.frombuffer(bytearray(b''.join(t_.to_bytes(32, 'little') for t_ in ts)), dtype=torch.uint8).to(dev)
-        aggs = torch.empty(sgsz, dtype=torch.uint8, device=dev)
-        torch.cuda.synchronize()
-        fn = lib.blsgpu_msm_g1 if sg == 1 else lib.blsgpu_msm_g2
-        api._check(fn(P(sig_sorted), P(scal), n, 0, P(aggs)))
-        api.profile_enable(True)
-        t = timed(lambda: api._check(lib.blsgpu_verify_secure(sg, api.BASIC, P(d_pks), n, P(aggs), api._ptr(msg), len(msg), mode, 0, ctypes.byref(st))), reps=2)
-        prof = api.profile_read(); api.profile_enable(False)
-        print(json.dumps({'config': 5, 'variant': name, 'n': n, 'status': st.value, 'seconds': t, 'keys_per_s': n / t,
-                          'kernel_ms': {k: round(v[0] / v[1], 3) for k, v in prof.items()}, 'launches': {k: v[1] for k, v in prof.items()}}), flush=True)
+        per_key = (3.0 if sg == 1 else 1.0) * 0.6 * per_verify        # a 255-bit G2 (G1) scalar multiplication, rough probe
+        for th in (1, cores):
+            ns = int(min(n5, max(64, args.cpu_seconds * th / per_key)))
+            # the signature verify_secure accepts for exactly the sampled keys (the device's sign-side twin, tests/ check it)
+            st5, aggs = api.aggregate_secure(sg, [pk_h[(432 - sgsz) * i:(432 - sgsz) * (i + 1)] for i in range(ns)],
+                                             [d_sigs[sgsz * i:sgsz * (i + 1)].cpu().numpy().tobytes() for i in range(ns)], mode)
+            assert st5 == 0
+            t = time.perf_counter()
+            r = bo.bo_verify_secure_mt(sg, 0, V(pk_h), ns, V(aggs), msg, 32, mode, th)
+            dt = time.perf_counter() - t
+            assert r == 0
+            emit(dict(cpu, config=5, side='cpu', variant=name, threads=th, sample_keys=ns, of=65536, seconds=dt, keys_per_s=ns / dt,
+                      extrapolated_seconds_full=dt * 65536 / ns))
+        del d_pks, d_sigs
 
 
 if __name__ == '__main__':
