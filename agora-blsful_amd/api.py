@@ -35,7 +35,7 @@ EXPORTS = [
     'blsgpu_aggregate_partial', 'blsgpu_fp12_product_is_one', 'blsgpu_core_verify', 'blsgpu_deserialize', 'blsgpu_pop_verify_batch', 'blsgpu_aggregate_secure',
     'blsgpu_signcrypt_valid_batch', 'blsgpu_sig_proof_verify_batch', 'blsgpu_pairing2_check_batch',
     'blsgpu_init_devices', 'blsgpu_device_count', 'blsgpu_sort_keys', 'blsgpu_sorted_keys_digest',
-    'blsgpu_coefficients_for_range', 'blsgpu_first_duplicate_message', 'blsgpu_first_occurrence', 'blsgpu_signatures_from_tagged', 'blsgpu_signatures_to_tagged',
+    'blsgpu_coefficients_for_range', 'blsgpu_first_duplicate_message', 'blsgpu_first_occurrence', 'blsgpu_core_verify_hashed', 'blsgpu_signatures_from_tagged', 'blsgpu_signatures_to_tagged',
 ]
 
 
@@ -138,6 +138,7 @@ def load_library(path=None):
         lib.blsgpu_coefficients_for_range.argtypes = [u8p, u32p, sz, sz, sz, u8p, i32p]
         lib.blsgpu_first_duplicate_message.argtypes = [u8p, u64p, sz, u64p]
         lib.blsgpu_first_occurrence.argtypes = [u8p, u32p, sz, sz, u32p]
+        lib.blsgpu_core_verify_hashed.argtypes = [ci, vp, vp, vp, sz, i32p]
         lib.blsgpu_signatures_from_tagged.argtypes = [ci, u8p, sz, u8p, vp, i32p]
         lib.blsgpu_signatures_to_tagged.argtypes = [ci, u8p, vp, sz, ci, u8p]
         _lib = lib
@@ -521,6 +522,21 @@ class TensorOps:
         offs = (ctypes.c_uint64 * 2)(0, len(msg))
         _check(self.lib.blsgpu_core_verify(sg, _ptr(dst), len(dst), self._p(pk), self._p(sig), _ptr(msg), ctypes.cast(offs, ctypes.c_void_p), 1,
                                            FMT_RAW_PROJ, ctypes.byref(st)))
+        return st.value
+
+    def hash_to_point(self, sg, dst, msg):
+        """H(msg) of the signature group of `sg` as a device tensor (RAW_PROJ).  Safe to call from a helper thread while
+        another call of this object is in flight: the library leases a second context."""
+        out = self.empty(144 if sg == 1 else 288)
+        offs = (ctypes.c_uint64 * 2)(0, len(msg))
+        fn = self.lib.blsgpu_hash_to_g1 if sg == 1 else self.lib.blsgpu_hash_to_g2
+        _check(fn(_ptr(msg), ctypes.cast(offs, ctypes.c_void_p), 1, _ptr(dst), len(dst), self._p(out)))
+        return out
+
+    def core_verify_hashed_one(self, sg, pk, sig, hm):
+        self._sync()
+        st = ctypes.c_int32(-99)
+        _check(self.lib.blsgpu_core_verify_hashed(sg, self._p(pk), self._p(sig), self._p(hm), 1, ctypes.byref(st)))
         return st.value
 
     def aggregate_partial(self, sg, scheme, pks, msgs, offs, n, sig=None):

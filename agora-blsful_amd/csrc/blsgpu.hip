@@ -25,10 +25,10 @@ thread_local std::string t_err;
 
 enum {
   KID_PREPARE, KID_MILLER2, KID_FINALEXP, KID_PREPARE_AGG, KID_PAIRS_AFF, KID_MILLER1, KID_F12_FOLD, KID_FINALEXP_ONE,
-  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_F12_IO, KID_MSM_SORT, KID_MSM_BUCKET, KID_MSM_CHUNK, KID_DECOMPRESS, KID_PAIRING_COOP, KID_KEY_SORT, KID_COEFF, KID_DUP, KID_COUNT
+  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_F12_IO, KID_MSM_SORT, KID_MSM_BUCKET, KID_MSM_CHUNK, KID_DECOMPRESS, KID_PAIRING_COOP, KID_KEY_SORT, KID_COEFF, KID_DUP, KID_FIRST_BAD, KID_COUNT
 };
 const char* KID_NAMES[KID_COUNT] = {"k_prepare", "k_miller2", "k_finalexp", "k_prepare_agg", "k_pairs_to_affine", "k_miller1", "k_f12_fold",
-                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign", "k_f12_io", "k_msm_sort", "k_msm_bucket", "k_msm_chunk", "k_decompress", "k_pairing_coop", "k_key_sort", "k_sha256_coeff", "k_duplicate_rule"};
+                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign", "k_f12_io", "k_msm_sort", "k_msm_bucket", "k_msm_chunk", "k_decompress", "k_pairing_coop", "k_key_sort", "k_sha256_coeff", "k_duplicate_rule", "k_first_identity"};
 
 struct Ctx {
   int dev = -1;
@@ -979,9 +979,9 @@ static int aggregate_enqueue(Ctx* c, int sig_group, int scheme, const uint8_t* d
       KL(KID_PREPARE_AGG, k_prepare_agg<1>, dim3(blocks_for(mm)), dim3(BLS_BLOCK), n, d_pks, d_sig, fmt, aug, d_msgs, d_offs, dst, d_pairs, d_bad, 0, has_sig);
     else
       KL(KID_PREPARE_AGG, k_prepare_agg<2>, dim3(blocks_for(2 * mm)), dim3(BLS_BLOCK), n, d_pks, d_sig, fmt, aug, d_msgs, d_offs, dst, d_pairs, d_bad, 1, has_sig);
-    if (n) KL(KID_PREPARE_AGG, k_first_bad, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const int32_t*)d_bad, d_min);
+    if (n) KL(KID_FIRST_BAD, k_first_bad, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const int32_t*)d_bad, d_min);
   }
-  KL(KID_PREPARE_AGG, k_first_bad_fin, dim3(1), dim3(BLS_BLOCK), n, (const int32_t*)d_bad, has_sig, (const unsigned long long*)d_min, d_first);
+  KL(KID_FIRST_BAD, k_first_bad_fin, dim3(1), dim3(BLS_BLOCK), n, (const int32_t*)d_bad, has_sig, (const unsigned long long*)d_min, d_first);
   HIPCK(hipGetLastError());
   if (mm == 0) {                   // an empty shard: the neutral record
     if (d_rec) {
@@ -1878,6 +1878,37 @@ int blsgpu_core_verify(int sig_group, const uint8_t* dst, size_t dst_len, const 
   if (rc) return rc;
   if (dst_len > 255 || (!dst && dst_len)) return fail(BLSGPU_E_ARG, "dst must be at most 255 bytes");
   return core_verify_entry(sig_group, make_dst(dst, dst_len), 0, pks, sigs, msgs, msg_offsets, n, fmt, status);
+}
+API_CATCH
+
+/* core_verify for n items whose message points H(m_i) are already known (RAW_PROJ, from blsgpu_hash_to_g1/g2 under the
+ * scheme's DST): the identity checks of reference src/traits/sig_core.rs:126-135 in the reference's order, then
+ * e(H(m), pk) * e(sig, -g) == 1 (:137-145).  Lets a caller hash the message while it is still adding up or exchanging the
+ * keys (the sharded MultiSignature::verify / verify_secure of agora-blsful_amd/dist.py do). */
+int blsgpu_core_verify_hashed(int sig_group, const void* pks, const void* sigs, const void* hashes, size_t n, int32_t* status) try {
+  int rc = check_common(sig_group, 0, BLSGPU_FMT_RAW_PROJ);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  if (!pks || !sigs || !hashes || !status) return fail(BLSGPU_E_ARG, "null argument");
+  CTX_ACQUIRE(c);
+  const size_t pkb = pk_size(sig_group, 0) * n, sgb = sig_size(sig_group, 0) * n;
+  size_t need = pad256(pkb) + 2 * pad256(sgb) + pad256(4 * n) + 2 * pad256((size_t)WS_PAIRS_WORDS * 4 * n) + 4096;
+  if ((rc = arena_reserve(c, need))) return rc;
+  c->arena_off = 0;
+  const void *d_pks, *d_sigs, *d_h;
+  if ((rc = stage_in(c, pks, pkb, &d_pks))) return rc;
+  if ((rc = stage_in(c, sigs, sgb, &d_sigs))) return rc;
+  if ((rc = stage_in(c, hashes, sgb, &d_h))) return rc;
+  int32_t* d_status = (int32_t*)arena_take(c, 4 * n);
+  uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)WS_PAIRS_WORDS * 4 * n);
+  uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * n);
+  if (!d_status || !d_pairs || !d_f) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  if (sig_group == 1) KL(KID_PREPARE, k_prepare_hashed<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sigs, (const uint8_t*)d_h, d_pairs, d_status);
+  else KL(KID_PREPARE, k_prepare_hashed<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sigs, (const uint8_t*)d_h, d_pairs, d_status);
+  if ((rc = run_pairing2(c, n, d_pairs, d_f, d_status, sig_group == 1 ? 1 : 0))) return rc;
+  if ((rc = copy_out(c, status, d_status, 4 * n))) return rc;
+  SYNC_FLUSH(c);
+  return 0;
 }
 API_CATCH
 

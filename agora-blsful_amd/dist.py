@@ -117,6 +117,27 @@ class Sharded:
         glob = torch.cat([rel + shift, torch.tensor([acc], dtype=torch.int64, device=rel.device)])
         return blob_all, glob
 
+    def _hash_async(self, sig_group, scheme, msg):
+        """H(msg) on a helper thread (the library leases it a second context, so it runs beside the key sum / MSM and the
+        exchanges of the calling thread); returns the join function."""
+        import threading
+        box = {}
+
+        def run():
+            try:
+                box['h'] = self.ops.hash_to_point(sig_group, DST[(sig_group, scheme)], msg)
+            except Exception as e:  # noqa: BLE001 -- re-raised on the calling thread
+                box['e'] = e
+        th = threading.Thread(target=run)
+        th.start()
+
+        def join():
+            th.join()
+            if 'e' in box:
+                raise box['e']
+            return box['h']
+        return join
+
     # ---- config 2: independent items
     def verify_batch(self, sig_group, scheme, pks, sigs, msgs, offs, n_local, gather=False, n_total=None):
         st = self.ops.verify_batch(sig_group, scheme, pks, sigs, msgs, offs, n_local)
@@ -140,9 +161,15 @@ class Sharded:
     # ---- config 3: MultiSignature::verify (reference src/multi_signature.rs:127-135, src/traits/pk_multi.rs:7-13)
     def multi_verify(self, sig_group, scheme, pks, n_local, sig, msg):
         pk_group = 2 if sig_group == 1 else 1
+        # H(msg) does not depend on the keys unless the scheme prefixes the aggregated key (MessageAugmentation,
+        # reference src/traits/sig_aug.rs:20-24): hash it beside the key sum and the exchange
+        join = self._hash_async(sig_group, scheme, msg) if scheme != AUG else None
         partial = self.ops.point_sum(pk_group, pks, n_local)                 # 144 / 288 B, device
         parts = self._all_gather(partial)                                     # [world, 144 / 288]
-        return self.ops.multi_verify(sig_group, scheme, parts.reshape(-1), self.world, sig, msg)
+        if join is None:
+            return self.ops.multi_verify(sig_group, scheme, parts.reshape(-1), self.world, sig, msg)
+        apk = self.ops.point_sum(pk_group, parts.reshape(-1), self.world)
+        return self.ops.core_verify_hashed_one(sig_group, apk, sig, join())
 
     # ---- config 4: AggregateSignature::verify (reference src/aggregate_signature.rs:230-239, src/traits/sig_core.rs:149-178)
     def aggregate_verify(self, sig_group, scheme, pks, msgs, offs, n_local, sig, base, n_total=None):
@@ -195,6 +222,9 @@ class Sharded:
         counts = self._counts(n_local, n_total)
         if sum(counts) == 0:                                                  # reference src/secure_aggregation.rs:189-195
             return OK if self.ops.is_identity(sig_group, sig) else INVALID_SIGNATURE
+        # verify_secure never prefixes keys to the message (reference src/secure_aggregation.rs:236-246): H(msg) is hashed
+        # beside the whole coefficient step
+        join = self._hash_async(sig_group, scheme, msg)
         _, n, perm, digest = self._sorted_keys(pk_group, pks, n_local, ser_format, counts)
         scal, st = self.ops.coefficients_for_range(digest, perm, n, base, n_local)   # t_i of the local keys, on the device
         partial = self.ops.point_sum(pk_group, pks, n_local, scal)            # local MSM with the local keys' coefficients
@@ -202,10 +232,11 @@ class Sharded:
         # InvalidCoefficient for everybody, reference :97-100)
         rec = self.torch.cat([partial, self.torch.tensor([st], dtype=self.torch.uint8, device=partial.device)])
         recs = self._all_gather(rec)
+        hm = join()
         if int(recs[:, -1].max().item()) != OK:
             return INVALID_COEFFICIENT
         apk = self.ops.point_sum(pk_group, recs[:, :-1].reshape(-1), self.world)
-        return self.ops.core_verify_one(sig_group, DST[(sig_group, scheme)], apk, sig, msg)
+        return self.ops.core_verify_hashed_one(sig_group, apk, sig, hm)
 
     # ---- N1: aggregate_secure[_with_mode] (reference src/secure_aggregation.rs:110-169,338-352)
     def aggregate_secure(self, sig_group, pks, sigs, n_local, base, ser_format=0, n_total=None):

@@ -97,6 +97,11 @@ int blsgpu_verify_batch(int sig_group, int scheme, const void* pks, const void* 
 int blsgpu_core_verify(int sig_group, const uint8_t* dst, size_t dst_len, const void* pks, const void* sigs,
                        const uint8_t* msgs, const uint64_t* msg_offsets, size_t n, int fmt, int32_t* status);
 
+/* core_verify for n items whose message points H(m_i) are already known (RAW_PROJ, from blsgpu_hash_to_g1/g2 under the
+ * scheme's DST): the identity checks of src/traits/sig_core.rs:126-135 in the reference's order, then the pairing check
+ * (:137-145).  Lets a caller hash the message while it still adds up or exchanges keys.  All points RAW_PROJ. */
+int blsgpu_core_verify_hashed(int sig_group, const void* pks, const void* sigs, const void* hashes, size_t n, int32_t* status);
+
 /* MultiSignature::<C>::verify(MultiPublicKey::from_public_keys(pks), msg)     src/multi_signature.rs:127-135,
  * src/multi_public_key.rs:79-83 -> BlsMultiKey::from_public_keys (serial sum) src/traits/pk_multi.rs:7-13;
  * fused form BlsSignaturePop::multi_sig_verify                                src/traits/sig_pop.rs:42-49. */

@@ -200,6 +200,22 @@ class FakeOps:
     def core_verify_one(self, sg, dst, pk, sig, msg):
         return core_verify(sg, dst, [bytes(pk.numpy().tobytes())], [bytes(sig.numpy().tobytes())], [msg])[0]
 
+    def hash_to_point(self, sg, dst, msg):
+        h = _impl(sg).hash_to_point(msg, dst)
+        return self._t((util.g1_raw if sg == 1 else util.g2_raw)(h))
+
+    def core_verify_hashed_one(self, sg, pk, sig, hm):
+        C = _impl(sg)
+        P, S = _pk(sg, bytes(pk.numpy().tobytes())), _sig(sg, bytes(sig.numpy().tobytes()))
+        Hm = _sig(sg, bytes(hm.numpy().tobytes()))
+        if S is None:                                   # reference src/traits/sig_core.rs:126-135
+            return SIG_IDENTITY
+        if P is None:
+            return PK_IDENTITY
+        neg = C.pk_curve.neg(C.pk_gen)
+        pairs = [(Hm, P), (S, neg)] if sg == 1 else [(P, Hm), (neg, S)]
+        return OK if c.final_exponentiation(c.miller_loop(pairs)) == c.F12_ONE else INVALID_SIGNATURE
+
     def aggregate_partial(self, sg, scheme, pks, msgs, offs, n, sig=None):
         ps, _ = self._sizes(sg)
         rec, fb = aggregate_partial(sg, scheme, self._rows(pks, n, ps), self._msgs(msgs, offs, n),
