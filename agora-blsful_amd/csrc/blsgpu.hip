@@ -25,10 +25,10 @@ thread_local std::string t_err;
 
 enum {
   KID_PREPARE, KID_MILLER2, KID_FINALEXP, KID_PREPARE_AGG, KID_PAIRS_AFF, KID_MILLER1, KID_F12_FOLD, KID_FINALEXP_ONE,
-  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_F12_IO, KID_MSM_SORT, KID_MSM_BUCKET, KID_MSM_CHUNK, KID_DECOMPRESS, KID_PAIRING_COOP, KID_KEY_SORT, KID_COEFF, KID_DUP, KID_FIRST_BAD, KID_COUNT
+  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_F12_IO, KID_MSM_SORT, KID_MSM_BUCKET, KID_MSM_CHUNK, KID_DECOMPRESS, KID_PAIRING_COOP, KID_KEY_SORT, KID_COEFF, KID_DUP, KID_FIRST_BAD, KID_MSM_PREP, KID_MSM_NORM, KID_MSM_MERGE, KID_COUNT
 };
 const char* KID_NAMES[KID_COUNT] = {"k_prepare", "k_miller2", "k_finalexp", "k_prepare_agg", "k_pairs_to_affine", "k_miller1", "k_f12_fold",
-                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign", "k_f12_io", "k_msm_sort", "k_msm_bucket", "k_msm_chunk", "k_decompress", "k_pairing_coop", "k_key_sort", "k_sha256_coeff", "k_duplicate_rule", "k_first_identity"};
+                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign", "k_f12_io", "k_msm_sort", "k_msm_bucket", "k_msm_chunk", "k_decompress", "k_pairing_coop", "k_key_sort", "k_sha256_coeff", "k_duplicate_rule", "k_first_identity", "k_msm_prep", "k_normalize", "k_msm_merge"};
 
 struct Ctx {
   int dev = -1;
@@ -385,6 +385,22 @@ size_t accumulate_lanes(size_t n) {
 }
 
 bool msm_use_pippenger(size_t n);
+bool msm_use_v1();
+struct msm2_plan {
+  int c, W, CH, Q, E;
+  size_t nb, nchunks;
+};
+struct msm2_ws {
+  msm2_plan p;
+  uint32_t *aff, *cnt, *off, *cur, *idx, *tiles;
+  uint64_t* subs;
+  uint8_t *inf, *sums, *part;
+};
+int msm2_ws_take(Ctx* c, size_t n, int G, msm2_ws& w);
+template <int G>
+int run_msm2_prep(Ctx* c, const uint8_t* d_pts, int fmt, const uint32_t* d_perm, size_t n, msm2_ws& w);
+template <int G>
+int run_msm2_rest(Ctx* c, const uint8_t* d_scalars, size_t n, msm2_ws& w, uint8_t* d_out, bool normalize = true);
 template <int G>
 int run_msm_pippenger(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_scalars, const uint32_t* d_perm, size_t n, uint8_t* d_out);
 
@@ -392,7 +408,14 @@ int run_msm_pippenger(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_sc
 template <int G>
 int run_point_sum(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_scalars, const uint32_t* d_perm, size_t n,
                   uint8_t* d_partials, size_t T) {
-  if (d_scalars && msm_use_pippenger(n)) return run_msm_pippenger<G>(c, d_pts, fmt, d_scalars, d_perm, n, d_partials);
+  if (d_scalars && msm_use_pippenger(n)) {
+    if (msm_use_v1()) return run_msm_pippenger<G>(c, d_pts, fmt, d_scalars, d_perm, n, d_partials);
+    msm2_ws w;
+    int rc = msm2_ws_take(c, n, G, w);
+    if (rc) return rc;
+    if ((rc = run_msm2_prep<G>(c, d_pts, fmt, d_perm, n, w))) return rc;
+    return run_msm2_rest<G>(c, d_scalars, n, w, d_partials);
+  }
   unsigned nb = blocks_for(T);
   if (d_scalars)
     KL(KID_ACCUM, (k_accumulate<G, 1>), dim3(nb), dim3(BLS_BLOCK), n, d_pts, fmt, d_scalars, d_perm, d_partials, T);
@@ -435,8 +458,9 @@ msm_plan msm_make_plan(size_t n, int G) {
   p.nchunks = p.nb / p.CH;
   return p;
 }
-size_t msm_ws_bytes(size_t n) {         // callers reserve for either group
-  size_t need = 0;
+size_t msm2_ws_bytes(size_t n);
+size_t msm_ws_bytes(size_t n) {         // callers reserve for either group and either generation
+  size_t need = msm2_ws_bytes(n);
   for (int G = 1; G <= 2; G++) {
     msm_plan p = msm_make_plan(n, G);
     size_t b = 3 * pad256(4 * p.nb) + pad256(4 * n * p.W) + pad256(4 * scan_tiles(p.nb)) + pad256(288 * p.nb) + pad256(288 * p.nchunks) + 4096;
@@ -444,6 +468,117 @@ size_t msm_ws_bytes(size_t n) {         // callers reserve for either group
   }
   return need;
 }
+// ---- second-generation MSM (csrc/msm2.cuh): endomorphism split, signed digits, mixed additions --------------------
+msm2_plan msm2_make_plan(size_t n, int G) {
+  msm2_plan p;
+  const int bits = G == 1 ? 128 : 64;     // width of the sub-scalars (k = a0 + a1 z^2 on G1, base-z digits on G2)
+  p.E = G == 1 ? 2 : 4;
+  int lg = 0;
+  while (((size_t)1 << (lg + 1)) <= n) lg++;
+  p.c = lg - 3;                           // target window width: 13 bits at 65,536 points (measured sweep, tools/dbg/msm.py)
+  if (p.c < 6) p.c = 6;
+  if (p.c > 14) p.c = 14;
+  p.CH = 4;                               // short chunks: the chunk lanes are a latency chain (4 / 8 / 16 measured: 1.1 / 1.4 / 2.1 ms)
+  if (const char* e = getenv("BLSGPU_MSM2_C")) p.c = atoi(e);      // tuning overrides, clamped to what the kernels assume
+  if (const char* e = getenv("BLSGPU_MSM2_CH")) p.CH = atoi(e);
+  if (p.c < 4) p.c = 4;
+  if (p.c > 16) p.c = 16;
+  // bits + 1 positions (one spare for the recoding carry) in W windows whose widths differ by at most one (msm2.cuh)
+  p.W = (bits + 1 + p.c / 2) / p.c;
+  if (p.W < 1) p.W = 1;
+  const int base = (bits + 1) / p.W, rem = (bits + 1) % p.W;
+  if (p.CH < 1) p.CH = 1;
+  while (p.CH & (p.CH - 1)) p.CH &= p.CH - 1;
+  if (p.CH > (1 << (base - 1))) p.CH = 1 << (base - 1);             // a chunk never straddles two windows
+  p.nb = ((size_t)rem << base) + ((size_t)(p.W - rem) << (base - 1));
+  p.nchunks = p.nb / p.CH;
+  // parts per bucket: about 130,000 (bucket, part) lanes keep every SIMD busy through the uneven bucket sizes (measured:
+  // 1 / 2 / 4 parts at 40,960 bucket lanes: 2.2 / 1.3 / 0.8 ms for G1); a fully parallel pass merges the parts afterwards
+  const size_t lanes = p.nb * (G == 1 ? 1 : 2);
+  p.Q = (int)((131072 + lanes - 1) / lanes);
+  if (const char* e = getenv("BLSGPU_MSM2_Q")) p.Q = atoi(e);
+  if (p.Q < 1) p.Q = 1;
+  if (p.Q > 8) p.Q = 8;
+  return p;
+}
+size_t msm2_ws_bytes(size_t n) {          // callers reserve for either group
+  size_t need = 0;
+  for (int G = 1; G <= 2; G++) {
+    const msm2_plan p = msm2_make_plan(n, G);
+    const size_t affw = (G == 1 ? 2 : 4) * FP_NL;
+    size_t b = pad256(4 * affw * p.E * n) + pad256(n) + pad256(32 * n) + 3 * pad256(4 * p.nb) + pad256(4 * n * p.E * p.W) + pad256(4 * scan_tiles(p.nb)) +
+               pad256(288 * p.nb * p.Q) + pad256(288 * p.nchunks) + 4096;
+    if (b > need) need = b;
+  }
+  return need;
+}
+int msm2_ws_take(Ctx* c, size_t n, int G, msm2_ws& w) {
+  w.p = msm2_make_plan(n, G);
+  const msm2_plan& p = w.p;
+  const size_t affw = (G == 1 ? 2 : 4) * FP_NL;
+  w.aff = (uint32_t*)arena_take(c, 4 * affw * p.E * n);
+  w.inf = (uint8_t*)arena_take(c, n);
+  w.subs = (uint64_t*)arena_take(c, 32 * n);
+  w.cnt = (uint32_t*)arena_take(c, 4 * p.nb);
+  w.off = (uint32_t*)arena_take(c, 4 * p.nb);
+  w.cur = (uint32_t*)arena_take(c, 4 * p.nb);
+  w.idx = (uint32_t*)arena_take(c, 4 * n * p.E * p.W);
+  w.tiles = (uint32_t*)arena_take(c, 4 * scan_tiles(p.nb));
+  w.sums = (uint8_t*)arena_take(c, 288 * p.nb * p.Q);
+  w.part = (uint8_t*)arena_take(c, 288 * p.nchunks);
+  if (!w.aff || !w.inf || !w.subs || !w.cnt || !w.off || !w.cur || !w.idx || !w.tiles || !w.sums || !w.part)
+    return fail(BLSGPU_E_HIP, "internal: arena too small");
+  return 0;
+}
+// the scalar-independent part: every point to affine, with its endomorphism images
+template <int G>
+int run_msm2_prep(Ctx* c, const uint8_t* d_pts, int fmt, const uint32_t* d_perm, size_t n, msm2_ws& w) {
+  KL(KID_MSM_PREP, k_msm2_prep<G>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_pts, fmt, d_perm, w.aff, w.inf);
+  HIPCK(hipGetLastError());
+  return 0;
+}
+// ... and the rest: digits, bucket lists, bucket sums, window weights, fold.  d_out[0] = the sum (RAW_PROJ, Z = 1)
+template <int G>
+int run_msm2_rest(Ctx* c, const uint8_t* d_scalars, size_t n, msm2_ws& w, uint8_t* d_out, bool normalize) {
+  const msm2_plan& p = w.p;
+  HIPCK(hipMemsetAsync(w.cnt, 0, 4 * p.nb, c->stream));
+  HIPCK(hipMemsetAsync(w.cur, 0, 4 * p.nb, c->stream));
+  KL(KID_MSM_SORT, k_msm2_count<G>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_scalars, (const uint8_t*)w.inf, p.W, w.cnt, w.subs);
+  int rc = run_scan_u32(c, KID_MSM_SORT, p.nb, w.cnt, w.off, w.tiles);
+  if (rc) return rc;
+  KL(KID_MSM_SORT, k_msm2_fill<G>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint64_t*)w.subs, (const uint8_t*)w.inf, p.W, (const uint32_t*)w.off, w.cur, w.idx);
+  const size_t nbq = p.nb * p.Q;
+  if (G == 2) KL(KID_MSM_BUCKET, k_msm2_bucket_g2s, dim3(blocks_for(2 * nbq)), dim3(BLS_BLOCK), p.nb, p.Q, (const uint32_t*)w.aff, (const uint32_t*)w.cnt, (const uint32_t*)w.off, (const uint32_t*)w.idx, w.sums);
+  else KL(KID_MSM_BUCKET, k_msm2_bucket_g1, dim3(blocks_for(nbq)), dim3(BLS_BLOCK), p.nb, p.Q, (const uint32_t*)w.aff, (const uint32_t*)w.cnt, (const uint32_t*)w.off, (const uint32_t*)w.idx, w.sums);
+  if (p.Q > 1) {
+    if (G == 2) KL(KID_MSM_MERGE, k_msm2_merge_g2s, dim3(blocks_for(2 * p.nb)), dim3(BLS_BLOCK), p.nb, p.Q, w.sums);
+    else KL(KID_MSM_MERGE, k_msm2_merge_g1, dim3(blocks_for(p.nb)), dim3(BLS_BLOCK), p.nb, p.Q, w.sums);
+  }
+  if (G == 2) KL(KID_MSM_CHUNK, k_msm2_chunk_g2q, dim3(blocks_for(4 * p.nchunks)), dim3(BLS_BLOCK), p.W, p.CH, p.Q, (const uint8_t*)w.sums, w.part);
+  else KL(KID_MSM_CHUNK, k_msm2_chunk_g1p, dim3(blocks_for(2 * p.nchunks)), dim3(BLS_BLOCK), p.W, p.CH, p.Q, (const uint8_t*)w.sums, w.part);
+  size_t cur = p.nchunks;
+  while (cur > 1) {
+    size_t half = (cur + 1) / 2;
+    if (G == 2) KL(KID_POINT_FOLD, k_point_fold_g2s, dim3(blocks_for(2 * half)), dim3(BLS_BLOCK), cur, half, w.part);
+    else KL(KID_POINT_FOLD, k_point_fold<G>, dim3(blocks_for(half)), dim3(BLS_BLOCK), cur, half, w.part);
+    cur = half;
+  }
+  // Z = 1 makes the output bytes independent of the (atomic) bucket fill order; a caller that only feeds the point to the
+  // pairing stages skips it
+  if (normalize) KL(KID_MSM_NORM, k_normalize<G>, dim3(1), dim3(BLS_BLOCK), w.part);
+  HIPCK(hipGetLastError());
+  HIPCK(hipMemcpyAsync(d_out, w.part, G == 1 ? 144 : 288, hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+bool msm_use_v1() {
+  static int v1 = -1;
+  if (v1 < 0) {
+    const char* e = getenv("BLSGPU_MSM_V1");     // A/B switch: the first-generation bucket method (unsigned digits, full additions)
+    v1 = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v1 != 0;
+}
+
 bool msm_use_pippenger(size_t n) {
   static int force_naive = -1;
   if (force_naive < 0) {
@@ -482,7 +617,7 @@ int run_msm_pippenger(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_sc
     else KL(KID_POINT_FOLD, k_point_fold<G>, dim3(blocks_for(half)), dim3(BLS_BLOCK), cur, half, d_part);
     cur = half;
   }
-  KL(KID_MSM_CHUNK, k_normalize<G>, dim3(1), dim3(BLS_BLOCK), d_part);
+  KL(KID_MSM_NORM, k_normalize<G>, dim3(1), dim3(BLS_BLOCK), d_part);
   HIPCK(hipGetLastError());
   HIPCK(hipMemcpyAsync(d_out, d_part, G == 1 ? 144 : 288, hipMemcpyDeviceToDevice, c->stream));
   return 0;
@@ -1229,6 +1364,15 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
   if (sig_group == 1) KL(KID_HASH, k_hash_to_g1, dim3(1), dim3(BLS_BLOCK), (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, scheme_dst(sig_group, scheme), d_hash, 1);
   else KL(KID_HASH, k_hash_to_g2, dim3(1), dim3(BLS_BLOCK), (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, scheme_dst(sig_group, scheme), d_hash, 1);
   HIPCK(hipGetLastError());
+  // ... and so does the scalar-independent part of the key sum (every key to affine, with its endomorphism images)
+  const bool msm2 = msm_use_pippenger(n) && !msm_use_v1();
+  msm2_ws mw;
+  if (msm2) {
+    if ((rc = msm2_ws_take(c, n, sig_group == 1 ? 2 : 1, mw))) return rc;
+    if (sig_group == 1) rc = run_msm2_prep<2>(c, (const uint8_t*)d_pks, fmt, nullptr, n, mw);
+    else rc = run_msm2_prep<1>(c, (const uint8_t*)d_pks, fmt, nullptr, n, mw);
+    if (rc) return rc;
+  }
   if ((rc = run_key_sort_finish(c, d_bytes, n, width, w, c->ev_host, &full_sort))) return rc;
   const double t1 = now();
   uint8_t H[32];
@@ -1240,8 +1384,13 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
   if ((rc = run_coefficients(c, d_H, w.perm_a, n, 0, n, 0, d_scal, d_zero))) return rc;
   HIPCK(hipMemcpyAsync(h_zero, d_zero, 4, hipMemcpyDeviceToHost, c->stream));
   // aggregated_pk = sum t_i * pk_sorted[i]   (reference src/secure_aggregation.rs:201-204)
-  if (sig_group == 1) rc = run_point_sum<2>(c, (const uint8_t*)d_pks, fmt, d_scal, nullptr, n, d_part, T);
-  else rc = run_point_sum<1>(c, (const uint8_t*)d_pks, fmt, d_scal, nullptr, n, d_part, T);
+  if (msm2) {
+    if (sig_group == 1) rc = run_msm2_rest<2>(c, d_scal, n, mw, d_part, false);
+    else rc = run_msm2_rest<1>(c, d_scal, n, mw, d_part, false);
+  } else {
+    if (sig_group == 1) rc = run_point_sum<2>(c, (const uint8_t*)d_pks, fmt, d_scal, nullptr, n, d_part, T);
+    else rc = run_point_sum<1>(c, (const uint8_t*)d_pks, fmt, d_scal, nullptr, n, d_part, T);
+  }
   if (rc) return rc;
   if ((rc = verify_one_tail(c, sig_group, scheme, 0, d_part, sig, fmt, msg, msg_len, status, d_hash))) return rc;
   if (trace)

@@ -239,6 +239,21 @@ __global__ void k_msm_bucket_g2s(size_t nb, const uint8_t* pts, int fmt, const u
                                  const uint32_t* idx, uint8_t* sums);
 template <int G>
 __global__ void k_normalize(uint8_t* pt);
+// second-generation MSM (msm2.cuh): endomorphism split, signed digits, mixed additions
+#define MSM2_E(G) ((G) == 1 ? 2 : 4)               // images per point
+#define MSM2_AFF_WORDS(G) ((G) == 1 ? 2 * FP_NL : 4 * FP_NL)   // words per affine entry of the workspace
+template <int G>
+__global__ void k_msm2_prep(size_t n, const uint8_t* pts, int fmt, const uint32_t* perm, uint32_t* affws, uint8_t* inf);
+template <int G>
+__global__ void k_msm2_count(size_t n, const uint8_t* scalars, const uint8_t* inf, int W, uint32_t* cnt, uint64_t* subs);
+template <int G>
+__global__ void k_msm2_fill(size_t n, const uint64_t* subs, const uint8_t* inf, int W, const uint32_t* off, uint32_t* cursor, uint32_t* idx);
+__global__ void k_msm2_merge_g1(size_t nb, int Q, uint8_t* sums);
+__global__ void k_msm2_merge_g2s(size_t nb, int Q, uint8_t* sums);
+__global__ void k_msm2_bucket_g1(size_t nb, int Q, const uint32_t* affws, const uint32_t* cnt, const uint32_t* off, const uint32_t* idx, uint8_t* sums);
+__global__ void k_msm2_bucket_g2s(size_t nb, int Q, const uint32_t* affws, const uint32_t* cnt, const uint32_t* off, const uint32_t* idx, uint8_t* sums);
+__global__ void k_msm2_chunk_g1p(int W, int CH, int stride, const uint8_t* sums, uint8_t* partials);
+__global__ void k_msm2_chunk_g2q(int W, int CH, int stride, const uint8_t* sums, uint8_t* partials);
 // wire bytes (48/96 B, modern or legacy header) -> RAW_PROJ with the checks of from_compressed; status[i] = 0 / 7 / 8.
 // keep != 0: leave a non-zero status[i] that is already there (first error wins when keys and signatures are decoded)
 template <int G>
@@ -919,6 +934,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_finalexps(size_t
 #endif
 
 #if defined(BLS_TU_MSM1) || defined(BLS_TU_MSM2)
+#include "msm2.cuh"
 // =====================================================================================================
 // Pippenger MSM: sum_i k_i P_i.  Scalars are < r < 2^255: W = floor(255 / c) windows, the first W - 1 are c bits wide
 // (2^c buckets each) and the LAST takes the remaining clast = 255 - c (W - 1) bits (2^clast buckets), so no window is a
@@ -1056,6 +1072,113 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_decompress(size_t n, const uint8_
   if (rc) jac_set_inf(p);
   msm_pt<G>::store(out, i, p);
   status[i] = rc;
+}
+
+// =====================================================================================================
+// MSM, second generation (msm2.cuh).  Workspace of affine images: array of structs, entry e = i * E + j holds Q_j(P_i) in
+// the internal limb form (G1: x, y = 28 words; G2: x.c0, x.c1, y.c0, y.c1 = 56 words): a bucket lane reads whole
+// entries at random indices, so the struct is what it should find contiguous.
+__device__ __forceinline__ void aff_st_fp(uint32_t* e, int w0, const fp& a) {
+#pragma unroll
+  for (int k = 0; k < FP_NL; k++) e[w0 + k] = (uint32_t)a.l[k];
+}
+__device__ __forceinline__ void aff_ld_fp(fp& r, const uint32_t* e, int w0) {
+#pragma unroll
+  for (int k = 0; k < FP_NL; k++) r.l[k] = (int32_t)e[w0 + k];
+}
+template <int G>
+__global__ void __launch_bounds__(BLS_BLOCK) k_msm2_prep(size_t n, const uint8_t* pts, int fmt, const uint32_t* perm, uint32_t* affws, uint8_t* inf) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t src = perm ? perm[i] : i;
+  typename msm_pt<G>::jac_t p;
+  msm_pt<G>::load(p, pts, src, fmt);
+  const bool isinf = jac_is_inf(p);
+  inf[i] = isinf ? 1 : 0;
+  if (isinf) return;
+  uint32_t* e = affws + i * MSM2_E(G) * MSM2_AFF_WORDS(G);
+  if (G == 1) {
+    g1_aff a;
+    jac_to_aff(a, *(g1_jac*)&p);
+    fp qx[2], qy[2];
+    msm2_images_g1(qx, qy, a);
+    for (int j = 0; j < 2; j++) {
+      aff_st_fp(e + j * 2 * FP_NL, 0, qx[j]);
+      aff_st_fp(e + j * 2 * FP_NL, FP_NL, qy[j]);
+    }
+  } else {
+    g2_aff a;
+    jac_to_aff(a, *(g2_jac*)&p);
+    fp2 qx[4], qy[4];
+    msm2_images_g2(qx, qy, a);
+    for (int j = 0; j < 4; j++) {
+      uint32_t* q = e + j * 4 * FP_NL;
+      aff_st_fp(q, 0, qx[j].c0);
+      aff_st_fp(q, FP_NL, qx[j].c1);
+      aff_st_fp(q, 2 * FP_NL, qy[j].c0);
+      aff_st_fp(q, 3 * FP_NL, qy[j].c1);
+    }
+  }
+}
+// scalar -> E sub-scalars (stored for k_msm2_fill) -> signed digits -> bucket sizes.  Bucket of digit magnitude m in
+// window w: msm2_bucket_base(w) + m - 1 (window layout in msm2.cuh).
+template <int G>
+__global__ void __launch_bounds__(BLS_BLOCK) k_msm2_count(size_t n, const uint8_t* scalars, const uint8_t* inf, int W, uint32_t* cnt, uint64_t* subs) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t a[4];
+  if (G == 1) msm2_decompose_g1(a, (const uint32_t*)(scalars + 32 * i));
+  else msm2_decompose_g2(a, (const uint32_t*)(scalars + 32 * i));
+#pragma unroll
+  for (int k = 0; k < 4; k++) subs[4 * i + k] = a[k];
+  if (inf[i]) return;
+  const int words = G == 1 ? 2 : 1;
+  const msm2_layout L = msm2_make_layout(64 * words, W);
+  for (int j = 0; j < MSM2_E(G); j++) {
+    uint32_t carry = 0;
+    for (int w = 0; w < W; w++) {
+      const int32_t d = msm2_digit(a + j * words, words, L, w, carry);
+      if (d) atomicAdd(&cnt[msm2_bucket_base(L, w) + (size_t)((d < 0 ? -d : d) - 1)], 1u);
+    }
+  }
+}
+// bucket lists: entry code = (i * E + j) << 1 | (digit negative)
+template <int G>
+__global__ void __launch_bounds__(BLS_BLOCK) k_msm2_fill(size_t n, const uint64_t* subs, const uint8_t* inf, int W, const uint32_t* off,
+                                                       uint32_t* cursor, uint32_t* idx) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || inf[i]) return;
+  uint64_t a[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) a[k] = subs[4 * i + k];
+  const int words = G == 1 ? 2 : 1;
+  const msm2_layout L = msm2_make_layout(64 * words, W);
+  for (int j = 0; j < MSM2_E(G); j++) {
+    uint32_t carry = 0;
+    for (int w = 0; w < W; w++) {
+      const int32_t d = msm2_digit(a + j * words, words, L, w, carry);
+      if (d) {
+        const size_t b = msm2_bucket_base(L, w) + (size_t)((d < 0 ? -d : d) - 1);
+        const uint32_t slot = atomicAdd(&cursor[b], 1u);
+        idx[off[b] + slot] = ((uint32_t)(i * MSM2_E(G) + j) << 1) | (d < 0 ? 1u : 0u);
+      }
+    }
+  }
+}
+// chunk t of the signed-digit layout -> (window, first bucket index inside the window)
+__device__ __forceinline__ bool msm2_chunk_of(const msm2_layout& L, int CH, size_t t, int& w, size_t& lo) {
+  const size_t cw_wide = ((size_t)1 << L.base) / CH, cw_narrow = ((size_t)1 << (L.base - 1)) / CH;
+  const size_t nwide = cw_wide * L.rem;
+  if (t < nwide) {
+    w = (int)(t / cw_wide);
+    lo = (t % cw_wide) * CH;
+    return true;
+  }
+  t -= nwide;
+  if (t >= cw_narrow * (L.W - L.rem)) return false;
+  w = L.rem + (int)(t / cw_narrow);
+  lo = (t % cw_narrow) * CH;
+  return true;
 }
 #if defined(BLS_TU_MSM2)
 // k_msm_chunk for G2 on TWO lanes per chunk (jac<hfp2>, tower_split.cuh): the 2^(c w) doublings are the critical path of
@@ -1225,11 +1348,146 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_msm_chunk_g1p(int c, int W, int c
   for (int k = 0; k < c * w; k++) jac_dbl_pair(acc, hi);   // weight 2^(c w)
   if (!hi) store_g1_pt(partials, t, acc);
 }
+
+// one lane per (bucket, part): part q of Q takes entries q, q + Q, ... of the bucket's list (Q > 1 fills the machine when
+// there are fewer buckets than lanes); mixed additions of affine images
+__global__ void __launch_bounds__(BLS_BLOCK) k_msm2_bucket_g1(size_t nb, int Q, const uint32_t* affws, const uint32_t* cnt, const uint32_t* off,
+                                                           const uint32_t* idx, uint8_t* sums) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nb * (size_t)Q) return;
+  const size_t b = t / Q;
+  const uint32_t q = (uint32_t)(t % Q);
+  g1_jac acc;
+  jac_set_inf(acc);
+  const uint32_t m = cnt[b], o = off[b];
+  for (uint32_t j = q; j < m; j += Q) {
+    const uint32_t code = idx[o + j];
+    const uint32_t* e = affws + (size_t)(code >> 1) * 2 * FP_NL;
+    fp x, y;
+    aff_ld_fp(x, e, 0);
+    aff_ld_fp(y, e, FP_NL);
+    if (code & 1u) fp_neg(y, y);
+    jac_madd(acc, acc, x, y);
+  }
+  store_g1_pt(sums, t, acc);
+}
+// the Q parts of every bucket added up in place (part 0 keeps the bucket's sum): one lane per bucket, fully parallel,
+// so that the latency-bound chunk lanes below read one sum per bucket
+__global__ void __launch_bounds__(BLS_BLOCK) k_msm2_merge_g1(size_t nb, int Q, uint8_t* sums) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  g1_jac acc, s;
+  load_g1_pt(acc, sums, b * Q, 0);
+  for (int q = 1; q < Q; q++) {
+    load_g1_pt(s, sums, b * Q + q, 0);
+    jac_add(acc, acc, s);
+  }
+  store_g1_pt(sums, b * Q, acc);
+}
+// chunk lanes as k_msm_chunk_g1p (two lanes per chunk sharing the doubling chains), for the signed-digit layout: bucket index
+// t of a window stands for digit t + 1 and window w weighs 2^start(w); bucket sums sit `stride` records apart
+__global__ void __launch_bounds__(BLS_BLOCK) k_msm2_chunk_g1p(int W, int CH, int stride, const uint8_t* sums, uint8_t* partials) {
+  const msm2_layout L = msm2_make_layout(128, W);
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, t = gid >> 1;
+  const bool hi = (gid & 1) != 0;
+  int w;
+  size_t lo;
+  if (!msm2_chunk_of(L, CH, t, w, lo)) return;
+  g1_jac run, acc, s;
+  jac_set_inf(run);
+  jac_set_inf(acc);
+  for (int d = CH - 1; d >= 0; d--) {
+    load_g1_pt(s, sums, (msm2_bucket_base(L, w) + lo + d) * stride, 0);
+    jac_add(run, run, s);
+    jac_add(acc, acc, run);   // acc = sum_d (d + 1) S_{lo + d}
+  }
+  if (lo != 0) {              // sum_d (lo + d + 1) S = acc + lo * run
+    jac_set_inf(s);
+    const uint32_t mlt = (uint32_t)lo;
+    for (int bit = msm2_width(L, w) - 2; bit >= 0; bit--) {
+      jac_dbl_pair(s, hi);
+      if ((mlt >> bit) & 1u) jac_add(s, s, run);
+    }
+    jac_add(acc, acc, s);
+  }
+  const int shift = msm2_start(L, w);
+  for (int k = 0; k < shift; k++) jac_dbl_pair(acc, hi);   // the window's weight
+  if (!hi) store_g1_pt(partials, t, acc);
+}
+template __global__ void k_msm2_prep<1>(size_t, const uint8_t*, int, const uint32_t*, uint32_t*, uint8_t*);
+template __global__ void k_msm2_count<1>(size_t, const uint8_t*, const uint8_t*, int, uint32_t*, uint64_t*);
+template __global__ void k_msm2_fill<1>(size_t, const uint64_t*, const uint8_t*, int, const uint32_t*, uint32_t*, uint32_t*);
 template __global__ void k_decompress<1>(size_t, const uint8_t*, int, uint8_t*, int32_t*, int);
 template __global__ void k_msm_bucket<1>(size_t, const uint8_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*);
 template __global__ void k_msm_chunk<1>(int, int, int, int, const uint8_t*, uint8_t*);
 template __global__ void k_normalize<1>(uint8_t*);
 #else
+
+// G2 buckets on two lanes per (bucket, part) (jac<hfp2>): each lane loads its own component of the affine entry
+__global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm2_bucket_g2s(size_t nb, int Q, const uint32_t* affws, const uint32_t* cnt, const uint32_t* off,
+                                                               const uint32_t* idx, uint8_t* sums) {
+  const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  if (t >= nb * (size_t)Q) return;
+  const size_t b = t / Q;
+  const uint32_t q = (uint32_t)(t % Q);
+  jac<hfp2> acc;
+  jac_set_inf(acc);
+  const uint32_t m = cnt[b], o = off[b];
+  const int half = lane_hi() ? FP_NL : 0;
+  for (uint32_t j = q; j < m; j += Q) {
+    const uint32_t code = idx[o + j];
+    const uint32_t* e = affws + (size_t)(code >> 1) * 4 * FP_NL;
+    hfp2 x, y;
+    aff_ld_fp(x.v, e, half);
+    aff_ld_fp(y.v, e, 2 * FP_NL + half);
+    if (code & 1u) fp_neg(y.v, y.v);
+    jac_madd(acc, acc, x, y);
+  }
+  st_g2s(sums, t, acc);
+}
+__global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm2_merge_g2s(size_t nb, int Q, uint8_t* sums) {
+  const size_t b = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  if (b >= nb) return;
+  jac<hfp2> acc, s;
+  ld_g2s(acc, sums, b * Q);
+  for (int q = 1; q < Q; q++) {
+    ld_g2s(s, sums, b * Q + q);
+    jac_add(acc, acc, s);
+  }
+  st_g2s(sums, b * Q, acc);
+}
+// chunk lanes as k_msm_chunk_g2q (four lanes per chunk: two lane pairs sharing the doubling chains), signed-digit layout
+__global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm2_chunk_g2q(int W, int CH, int stride, const uint8_t* sums, uint8_t* partials) {
+  const msm2_layout L = msm2_make_layout(64, W);
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, t = gid >> 2;
+  const bool hi2 = ((gid >> 1) & 1) != 0;
+  int w;
+  size_t lo;
+  if (!msm2_chunk_of(L, CH, t, w, lo)) return;
+  jac<hfp2> run, acc, s;
+  jac_set_inf(run);
+  jac_set_inf(acc);
+  for (int d = CH - 1; d >= 0; d--) {
+    ld_g2s(s, sums, (msm2_bucket_base(L, w) + lo + d) * stride);
+    jac_add(run, run, s);
+    jac_add(acc, acc, run);
+  }
+  if (lo != 0) {
+    jac_set_inf(s);
+    const uint32_t mlt = (uint32_t)lo;
+    for (int bit = msm2_width(L, w) - 2; bit >= 0; bit--) {
+      jac_dbl_quad(s, hi2);
+      if ((mlt >> bit) & 1u) jac_add(s, s, run);
+    }
+    jac_add(acc, acc, s);
+  }
+  const int shift = msm2_start(L, w);
+  for (int k = 0; k < shift; k++) jac_dbl_quad(acc, hi2);
+  if (!hi2) st_g2s(partials, t, acc);
+}
+template __global__ void k_msm2_prep<2>(size_t, const uint8_t*, int, const uint32_t*, uint32_t*, uint8_t*);
+template __global__ void k_msm2_count<2>(size_t, const uint8_t*, const uint8_t*, int, uint32_t*, uint64_t*);
+template __global__ void k_msm2_fill<2>(size_t, const uint64_t*, const uint8_t*, int, const uint32_t*, uint32_t*, uint32_t*);
 template __global__ void k_decompress<2>(size_t, const uint8_t*, int, uint8_t*, int32_t*, int);
 template __global__ void k_msm_bucket<2>(size_t, const uint8_t*, int, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*);
 template __global__ void k_msm_chunk<2>(int, int, int, int, const uint8_t*, uint8_t*);

@@ -4,6 +4,7 @@
 #include <string.h>
 #include "../../agora-blsful_amd/csrc/verify.cuh"
 #include "../../agora-blsful_amd/csrc/tower_split.cuh"
+#include "../../agora-blsful_amd/csrc/msm2.cuh"
 
 // callers pass blst-style Montgomery words (R = 2^384, 12 words per Fp) exactly like the RAW formats of the C ABI
 static void raw_fp2(fp2& r, const uint32_t* w) { fp_from_raw(r.c0, w); fp_from_raw(r.c1, w + 12); }
@@ -17,6 +18,39 @@ static void store_fp12_plain(uint32_t* out, const fp12& f) {
     store_plain(out + 24 * k, c[k]->c0);
     store_plain(out + 24 * k + 12, c[k]->c1);
   }
+}
+
+// sum_i k_i P_i by the signed-window bucket method with window width c (no shortcuts: buckets as plain arrays)
+template <class F, int E>
+static void msm2_eval(jac<F>& res, int n, const F* qx, const F* qy, const uint8_t* inf, const uint64_t* subs, int words, int W) {
+  const msm2_layout L = msm2_make_layout(64 * words, W);
+  const size_t nb = msm2_buckets(L);
+  jac<F>* bucket = new jac<F>[nb];
+  for (size_t t = 0; t < nb; t++) jac_set_inf(bucket[t]);
+  for (int i = 0; i < n; i++) {
+    if (inf[i]) continue;
+    for (int j = 0; j < E; j++) {
+      uint32_t carry = 0;
+      for (int w = 0; w < W; w++) {
+        const int32_t d = msm2_digit(subs + ((size_t)i * E + j) * words, words, L, w, carry);
+        if (!d) continue;
+        F y = qy[i * E + j];
+        if (d < 0) fe_neg(y, y);
+        jac<F>& b = bucket[msm2_bucket_base(L, w) + (size_t)((d < 0 ? -d : d) - 1)];
+        jac_madd(b, b, qx[i * E + j], y);
+      }
+    }
+  }
+  jac_set_inf(res);
+  for (int w = W - 1; w >= 0; w--) {
+    const int c = msm2_width(L, w);
+    for (int k = 0; k < c; k++) jac_dbl(res, res);          // Horner over the windows: res = res * 2^width(w) + window sum
+    jac<F> run, acc;
+    jac_set_inf(run); jac_set_inf(acc);
+    for (int t = (1 << (c - 1)) - 1; t >= 0; t--) { jac_add(run, run, bucket[msm2_bucket_base(L, w) + t]); jac_add(acc, acc, run); }
+    jac_add(res, res, acc);
+  }
+  delete[] bucket;
 }
 
 extern "C" {
@@ -226,5 +260,68 @@ int hs_verify(int sig_group, const uint32_t* pk, const uint32_t* sig, int aug, c
   const int v = pairing_verdict(f);
   const int vs = verdict_split(sig_group, P, Q);
   return v == vs ? v : -100 - vs;    // the two tower instantiations must agree
+}
+
+// ---- MSM second generation (msm2.cuh): scalar decomposition, point images, mixed addition, and a straightforward host
+// evaluation of the signed-window bucket method built from exactly the per-item functions the kernels use
+void hs_msm2_decompose(int group, const uint32_t* k, uint64_t* a) {
+  if (group == 1) msm2_decompose_g1(a, k); else msm2_decompose_g2(a, k);
+}
+// out: group 1: 2 x 48 bytes, group 2: 4 x 96 bytes (the compressed images Q_j)
+void hs_msm2_images(int group, const uint32_t* p, uint8_t* out) {
+  if (group == 1) {
+    g1_jac a; g1_aff f, q; load_g1_jac(a, p); jac_to_aff(f, a);
+    fp qx[2], qy[2]; msm2_images_g1(qx, qy, f);
+    for (int j = 0; j < 2; j++) { q.x = qx[j]; q.y = qy[j]; q.inf = false; g1_compress(out + 48 * j, q, false); }
+  } else {
+    g2_jac a; g2_aff f, q; load_g2_jac(a, p); jac_to_aff(f, a);
+    fp2 qx[4], qy[4]; msm2_images_g2(qx, qy, f);
+    for (int j = 0; j < 4; j++) { q.x = qx[j]; q.y = qy[j]; q.inf = false; g2_compress(out + 96 * j, q, false); }
+  }
+}
+// acc (raw Jacobian, may be the identity) + affine image of q; also through the lane-split tower for G2
+void hs_msm2_madd(int group, const uint32_t* acc, const uint32_t* q, int negate, uint8_t* out, uint8_t* out_split) {
+  if (group == 1) {
+    g1_jac a, b, r; g1_aff f; load_g1_jac(a, acc); load_g1_jac(b, q); jac_to_aff(f, b);
+    fp x, y; fp_reduce(x, f.x); fp_reduce(y, f.y);
+    if (negate) fp_neg(y, y);
+    jac_madd(r, a, x, y); jac_to_aff(f, r); g1_compress(out, f, false);
+  } else {
+    g2_jac a, b, r; g2_aff f; load_g2_jac(a, acc); load_g2_jac(b, q); jac_to_aff(f, b);
+    fp2 x, y; fp2_reduce(x, f.x); fp2_reduce(y, f.y);
+    if (negate) fp2_neg(y, y);
+    jac_madd(r, a, x, y);
+    g2_aff g; jac_to_aff(g, r); g2_compress(out, g, false);
+    jac<hfp2> sa, sr; split_jac(sa, a);
+    hfp2 sx, sy; sx.c[0] = x.c0; sx.c[1] = x.c1; sy.c[0] = y.c0; sy.c[1] = y.c1;
+    jac_madd(sr, sa, sx, sy); unsplit_jac(r, sr); jac_to_aff(g, r); g2_compress(out_split, g, false);
+  }
+}
+void hs_msm2_small(int group, int n, const uint32_t* pts, const uint32_t* scalars, int W, uint8_t* out) {
+  uint8_t* inf = new uint8_t[n];
+  if (group == 1) {
+    fp* qx = new fp[2 * n]; fp* qy = new fp[2 * n]; uint64_t* subs = new uint64_t[4 * n];
+    for (int i = 0; i < n; i++) {
+      g1_jac a; g1_aff f; load_g1_jac(a, pts + 36 * i);
+      inf[i] = jac_is_inf(a);
+      if (!inf[i]) { jac_to_aff(f, a); msm2_images_g1(qx + 2 * i, qy + 2 * i, f); }
+      msm2_decompose_g1(subs + 4 * i, scalars + 8 * i);
+    }
+    g1_jac r; msm2_eval<fp, 2>(r, n, qx, qy, inf, subs, 2, W);
+    g1_aff f; jac_to_aff(f, r); g1_compress(out, f, false);
+    delete[] qx; delete[] qy; delete[] subs;
+  } else {
+    fp2* qx = new fp2[4 * n]; fp2* qy = new fp2[4 * n]; uint64_t* subs = new uint64_t[4 * n];
+    for (int i = 0; i < n; i++) {
+      g2_jac a; g2_aff f; load_g2_jac(a, pts + 72 * i);
+      inf[i] = jac_is_inf(a);
+      if (!inf[i]) { jac_to_aff(f, a); msm2_images_g2(qx + 4 * i, qy + 4 * i, f); }
+      msm2_decompose_g2(subs + 4 * i, scalars + 8 * i);
+    }
+    g2_jac r; msm2_eval<fp2, 4>(r, n, qx, qy, inf, subs, 1, W);
+    g2_aff f; jac_to_aff(f, r); g2_compress(out, f, false);
+    delete[] qx; delete[] qy; delete[] subs;
+  }
+  delete[] inf;
 }
 }

@@ -252,3 +252,55 @@ def test_decompress(hs):
                 assert (rc == 0) == insub
                 seen.add('sub' if insub else 'nosub')
         assert {'off', 'nosub'} <= seen
+
+
+def test_msm2_per_item_functions(hs):
+    """csrc/msm2.cuh on the host with the bound tracker on: the base-z (G2) and base-z^2 (G1) scalar decompositions, the four
+    (two) endomorphism images with the decomposition's signs, the mixed addition incl. its exceptional cases on both towers,
+    and the whole signed-window bucket evaluation for several window widths -- against the oracle's plain sum of k_i P_i
+    (the loop of reference src/secure_aggregation.rs:201-204)."""
+    rng = random.Random(21)
+    z = 0xd201000000010000
+    a = (ctypes.c_uint64 * 4)()
+    ks = [0, 1, z - 1, z, z * z, z ** 3, c.R - 1, c.R, c.R + 7, 2 ** 255, 2 ** 256 - 1] + [rng.randrange(2 ** 256) for _ in range(40)]
+    for k in ks:
+        kb = k.to_bytes(32, 'little')
+        hs.hs_msm2_decompose(2, kb, a)
+        assert all(x < z for x in a) and sum(int(x) * z ** j for j, x in enumerate(a)) == k % c.R
+        hs.hs_msm2_decompose(1, kb, a)
+        a0, a1 = int(a[0]) | int(a[1]) << 64, int(a[2]) | int(a[3]) << 64
+        assert a0 < z * z and a0 + a1 * z * z == k % c.R
+    # images
+    P1, P2 = c.E1.mul(c.G1_GEN, rng.randrange(1, c.R)), c.E2.mul(c.G2_GEN, rng.randrange(1, c.R))
+    out = ctypes.create_string_buffer(4 * 96)
+    hs.hs_msm2_images(1, util.g1_raw(P1, rng), out)
+    assert out.raw[:48] == c.g1_compress(P1) and out.raw[48:96] == c.g1_compress(c.E1.mul(P1, z * z % c.R))   # -phi(P) = [z^2] P
+    hs.hs_msm2_images(2, util.g2_raw(P2, rng), out)
+    for j in range(4):
+        assert out.raw[96 * j:96 * (j + 1)] == c.g2_compress(c.E2.mul(P2, pow(z, j, c.R))), j                   # Q_j = [z^j] P
+    # mixed addition: generic, accumulator at infinity, equal points (doubling), opposite points (infinity)
+    o1, o2 = ctypes.create_string_buffer(96), ctypes.create_string_buffer(96)
+    for group, E, raw, comp, P in ((1, c.E1, util.g1_raw, c.g1_compress, P1), (2, c.E2, util.g2_raw, c.g2_compress, P2)):
+        Q = E.mul(P, 12345)
+        for acc, q, neg in ((P, Q, 0), (P, Q, 1), (None, Q, 0), (None, Q, 1), (Q, Q, 0), (Q, Q, 1), (E.neg(Q), Q, 0)):
+            hs.hs_msm2_madd(group, raw(acc, rng), raw(q, rng), neg, o1, o2)
+            want = comp(E.add(acc, E.neg(q) if neg else q))
+            assert o1.raw[:48 * group] == want, (group, neg)
+            if group == 2:
+                assert o2.raw == want
+    # whole evaluation
+    for group, E, gen, raw, comp in ((1, c.E1, c.G1_GEN, util.g1_raw, c.g1_compress), (2, c.E2, c.G2_GEN, util.g2_raw, c.g2_compress)):
+        n = 9
+        pts = [E.mul(gen, rng.randrange(1, c.R)) for _ in range(n)]
+        pts[3] = None
+        pts[5] = pts[1]
+        scal = [rng.randrange(c.R) for _ in range(n)]
+        scal[0], scal[2], scal[4] = 0, c.R - 1, 2 ** 256 - 1
+        want = None
+        for p, s in zip(pts, scal):
+            want = E.add(want, E.mul(p, s % c.R))
+        blob = b''.join(raw(p, rng) for p in pts)
+        sb = b''.join(s.to_bytes(32, 'little') for s in scal)
+        for W in (9, 10, 13, 22):           # window counts that divide the bits evenly and unevenly (widths differ by one)
+            hs.hs_msm2_small(group, n, blob, sb, W, o1)
+            assert o1.raw[:48 * group] == comp(want), (group, W)
