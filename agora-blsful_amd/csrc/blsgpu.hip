@@ -22,6 +22,8 @@ namespace {
 
 const uint32_t FP_ONE_HOST[12] = FP_RAW_ONE_WORDS;   // 1 as the C ABI's Fp12 records carry it
 thread_local std::string t_err;
+thread_local size_t t_devidx = 0;    // which bound device the calling thread's leases come from (the sharded entry points set it)
+thread_local bool t_nested = false;  // inside a sharded call: the per-device sub-calls must not shard again
 
 enum {
   KID_PREPARE, KID_MILLER2, KID_FINALEXP, KID_PREPARE_AGG, KID_PAIRS_AFF, KID_MILLER1, KID_F12_FOLD, KID_FINALEXP_ONE,
@@ -59,6 +61,7 @@ struct Device {
   std::atomic<unsigned> rr{0};
 };
 std::vector<Device*> g_devices;     // written only under g_init_mu, before any compute call / after all of them
+bool g_peer_ok = true;              // every bound device can read every other one's memory (needed to shard DEVICE buffers)
 std::mutex g_init_mu;
 bool initialised() { return !g_devices.empty(); }
 
@@ -102,7 +105,7 @@ Lease acquire_ctx(size_t devidx) {
   Ctx* c = lease_.c;                      \
   c->hsmall_off = 0;                      \
   HIPCK(hipSetDevice(c->dev))
-#define CTX_ACQUIRE(c) CTX_ACQUIRE_ON(c, 0)
+#define CTX_ACQUIRE(c) CTX_ACQUIRE_ON(c, t_devidx)
 #define NOT_INIT() fail(BLSGPU_E_NOT_INIT, "blsgpu_init has not been called (or found no gfx950 device)")
 // no C++ exception may unwind into a C / Rust caller
 #define API_CATCH                                                                              \
@@ -323,6 +326,64 @@ int run_scan_max_u32(Ctx* c, int kid, size_t m, uint32_t* d_v, uint32_t* d_tiles
   return 0;
 }
 
+
+
+// ---- one process, several GPUs (blsgpu_init_devices): the items of a call are cut into contiguous ranges, one per bound
+// device, each handled by a host thread whose leases come from that device's context pool
+size_t shard_min_items() {
+  static long v = -1;
+  if (v < 0) {
+    const char* e = getenv("BLSGPU_SHARD_MIN");   // below this many items a call stays on device 0
+    v = e ? atol(e) : 8192;
+    if (v < 1) v = 1;
+  }
+  return (size_t)v;
+}
+// how many devices a call over n items uses; device-resident inputs can only be sharded when the devices see each other
+size_t shard_devices(size_t n, std::initializer_list<const void*> inputs) {
+  if (t_nested || g_devices.size() < 2 || n < shard_min_items()) return 1;
+  if (!g_peer_ok)
+    for (const void* p : inputs)
+      if (is_device_ptr(p)) return 1;
+  size_t d = g_devices.size();
+  while (d > 1 && n / d < shard_min_items() / 4) d--;
+  return d;
+}
+// fn(d) for d < k on k host threads (thread d leases from device d); the first failure wins and its message is kept
+template <class F>
+int run_on_devices(size_t k, F&& fn) {
+  std::vector<int> rcs(k, 0);
+  std::vector<std::string> errs(k);
+  std::vector<std::thread> th;
+  auto body = [&](size_t d) {
+    t_devidx = d;
+    t_nested = true;
+    try {
+      rcs[d] = fn(d);
+    } catch (const std::exception& e) {
+      rcs[d] = fail(BLSGPU_E_HIP, std::string("internal: ") + e.what());
+    }
+    errs[d] = t_err;
+  };
+  for (size_t d = 1; d < k; d++) th.emplace_back(body, d);
+  const size_t keep_dev = t_devidx;
+  const bool keep_nested = t_nested;
+  body(0);
+  t_devidx = keep_dev;
+  t_nested = keep_nested;
+  for (auto& t : th) t.join();
+  for (size_t d = 0; d < k; d++)
+    if (rcs[d]) {
+      t_err = errs[d];
+      return rcs[d];
+    }
+  return 0;
+}
+struct NestedScope {     // the calling thread's own follow-up calls (fold, final verify) stay on device 0 and do not shard again
+  bool keep;
+  NestedScope() : keep(t_nested) { t_nested = true; }
+  ~NestedScope() { t_nested = keep; }
+};
 
 // ---- shared device pipelines (stream-ordered; caller holds the context mutex) ------------------------
 
@@ -870,6 +931,7 @@ int blsgpu_init_devices(int ndev_req) try {
   }
   // peer access so that a device can read a shard that lives on another device's memory (xGMI loads); failures are not
   // fatal: shards of host buffers never need it
+  g_peer_ok = true;
   for (size_t a = 0; a < g_devices.size(); a++)
     for (size_t b = 0; b < g_devices.size(); b++) {
       if (g_devices[a]->dev == g_devices[b]->dev) continue;
@@ -877,7 +939,10 @@ int blsgpu_init_devices(int ndev_req) try {
       if (hipDeviceCanAccessPeer(&can, g_devices[a]->dev, g_devices[b]->dev) == hipSuccess && can) {
         (void)hipSetDevice(g_devices[a]->dev);
         hipError_t pe = hipDeviceEnablePeerAccess(g_devices[b]->dev, 0);
+        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) g_peer_ok = false;
         if (pe != hipSuccess) (void)hipGetLastError();
+      } else {
+        g_peer_ok = false;
       }
     }
   (void)hipSetDevice(g_devices[0]->dev);
@@ -945,6 +1010,16 @@ int blsgpu_verify_batch(int sig_group, int scheme, const void* pks, const void* 
   if (rc) return rc;
   if (n == 0) return 0;
   if (!pks || !sigs || !msg_offsets || !status) return fail(BLSGPU_E_ARG, "null argument");
+  if (const size_t D = shard_devices(n, {pks, sigs, msgs, msg_offsets, status}); D > 1) {
+    // independent items: contiguous ranges per device, no exchange at all (message offsets are absolute, so every shard
+    // passes the whole blob and its own window of the offsets)
+    const size_t psz = pk_size(sig_group, fmt), ssz = sig_size(sig_group, fmt);
+    return run_on_devices(D, [&](size_t d) {
+      const size_t lo = n * d / D, hi = n * (d + 1) / D;
+      return blsgpu_verify_batch(sig_group, scheme, (const uint8_t*)pks + lo * psz, (const uint8_t*)sigs + lo * ssz, msgs, msg_offsets + lo, hi - lo,
+                                 fmt, status + lo);
+    });
+  }
   CTX_ACQUIRE(c);
   // total message bytes: last offset (read it from wherever it lives)
   uint64_t total = 0;
@@ -1040,6 +1115,20 @@ int blsgpu_multi_verify(int sig_group, int scheme, const void* pks, size_t n, co
   int rc = check_common(sig_group, scheme, fmt);
   if (rc) return rc;
   if (!sig || !status || (n && !pks)) return fail(BLSGPU_E_ARG, "null argument");
+  if (const size_t D = shard_devices(n, {pks, sig}); D > 1) {
+    // per-device partial key sums (reference src/traits/pk_multi.rs:7-13 cut into ranges), then the fold and the one
+    // verification on device 0: MultiSignature::verify over the D partial sums
+    const size_t psz = pk_size(sig_group, fmt), osz = sig_group == 1 ? 288 : 144;
+    std::vector<uint8_t> parts(osz * D), sig_proj(288);
+    if ((rc = run_on_devices(D, [&](size_t d) {
+          const size_t lo = n * d / D, hi = n * (d + 1) / D;
+          return (sig_group == 1 ? blsgpu_sum_g2 : blsgpu_sum_g1)((const uint8_t*)pks + lo * psz, hi - lo, fmt, parts.data() + osz * d);
+        })))
+      return rc;
+    NestedScope ns;
+    if ((rc = (sig_group == 1 ? blsgpu_sum_g1 : blsgpu_sum_g2)(sig, 1, fmt, sig_proj.data()))) return rc;   // the signature as RAW_PROJ
+    return blsgpu_multi_verify(sig_group, scheme, parts.data(), D, sig_proj.data(), msg, msg_len, BLSGPU_FMT_RAW_PROJ, status);
+  }
   CTX_ACQUIRE(c);
   const size_t psz = pk_size(sig_group, fmt), T = accumulate_lanes(n);
   size_t need = pad256(psz * n) + pad256(288 * T) + 2 * pad256(msg_len) + 8192;
@@ -1201,6 +1290,78 @@ int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const ui
   int rc = check_common(sig_group, scheme, fmt);
   if (rc) return rc;
   if (!sig || !status || !msg_offsets || (n && !pks)) return fail(BLSGPU_E_ARG, "null argument");
+  if (const size_t D = shard_devices(n, {pks, msgs, msg_offsets, sig}); D > 1) {
+    // every device: hash-to-curve + Miller loops of its range -> one Fp12 record (blsgpu_aggregate_partial; device 0 also
+    // takes the signature pair); meanwhile this thread applies Basic's duplicate rule to the whole list; then the D records
+    // are multiplied and exponentiated once on device 0 -- the exchange that the one-process-per-GPU path does over RCCL
+    const size_t psz = pk_size(sig_group, fmt);
+    std::vector<uint8_t> recs(576 * D);
+    std::vector<int64_t> fbs(D, -1);
+    uint64_t dup[2] = {~0ull, ~0ull};
+    int dup_rc = 0;
+    std::string dup_err;
+    std::thread dup_thread;
+    if (scheme == BLSGPU_SCHEME_BASIC)
+      dup_thread = std::thread([&] {
+        t_nested = true;
+        if (is_device_ptr(msgs)) {
+          dup_rc = blsgpu_first_duplicate_message(msgs, msg_offsets, n, dup);
+        } else {
+          std::vector<uint64_t> oh;
+          const uint64_t* offs = msg_offsets;
+          if (is_device_ptr(msg_offsets)) {
+            oh.resize(n + 1);
+            if (hipMemcpy(oh.data(), msg_offsets, 8 * (n + 1), hipMemcpyDeviceToHost) != hipSuccess) dup_rc = fail(BLSGPU_E_HIP, "copying the message offsets");
+            offs = oh.data();
+          }
+          uint64_t a2[2] = {0, 0};
+          if (!dup_rc && duplicate_check_host(msgs, offs, n, a2)) {
+            dup[0] = a2[0];
+            dup[1] = a2[1];
+          }
+        }
+        dup_err = t_err;
+      });
+    rc = run_on_devices(D, [&](size_t d) {
+      const size_t lo = n * d / D, hi = n * (d + 1) / D;
+      return blsgpu_aggregate_partial(sig_group, scheme, (const uint8_t*)pks + lo * psz, msgs, msg_offsets + lo, hi - lo, d == 0 ? sig : nullptr, fmt,
+                                      recs.data() + 576 * d, &fbs[d]);
+    });
+    if (dup_thread.joinable()) dup_thread.join();
+    if (rc) return rc;
+    if (dup_rc) {
+      t_err = dup_err;
+      return dup_rc;
+    }
+    int32_t st = BLSGPU_OK;
+    uint64_t aux_h[2] = {0, 0};
+    if (dup[1] != ~0ull) {
+      st = BLSGPU_DUPLICATE_MESSAGE;
+      aux_h[0] = dup[0];
+      aux_h[1] = dup[1];
+    } else if (fbs[0] == (int64_t)(n * 1 / D)) {          // device 0 saw the identity signature (its local index n)
+      st = BLSGPU_SIG_IDENTITY;
+    } else {
+      for (size_t d = 0; d < D && st == BLSGPU_OK; d++)
+        if (fbs[d] >= 0) {
+          st = BLSGPU_PK_IDENTITY;
+          aux_h[0] = n * d / D + (uint64_t)fbs[d] + 1;
+        }
+      if (st == BLSGPU_OK) {
+        NestedScope ns;
+        int32_t one = 0;
+        if ((rc = blsgpu_fp12_product_is_one(recs.data(), D, &one))) return rc;
+        st = one ? BLSGPU_OK : BLSGPU_INVALID_SIGNATURE;
+      }
+    }
+    if (is_device_ptr(status)) HIPCK(hipMemcpy(status, &st, 4, hipMemcpyHostToDevice));
+    else *status = st;
+    if (aux) {
+      if (is_device_ptr(aux)) HIPCK(hipMemcpy(aux, aux_h, 16, hipMemcpyHostToDevice));
+      else memcpy(aux, aux_h, 16);
+    }
+    return 0;
+  }
   CTX_ACQUIRE(c);
   uint64_t aux_h[2] = {0, 0};
   const bool trace = getenv("BLSGPU_HOST_TRACE") != nullptr;
@@ -1314,6 +1475,61 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
   if (ser_format == 1 && sig_group != 2)
     return fail(BLSGPU_E_ARG, "Legacy serialization exists only for Bls12381G2Impl (48-byte keys), reference src/signature.rs:201-204");
   if (n >= 0xffffffffull) return fail(BLSGPU_E_ARG, "more than 2^32 - 2 keys");
+  if (const size_t D = shard_devices(n, {pks, sig}); D > 1) {
+    // every device serialises its range of the keys; device 0 sorts all of them and a host core hashes the sorted stream
+    // (the one sequential step, reference src/secure_aggregation.rs:45-59); every device derives the coefficients of its
+    // own keys and adds up its share of sum t_i pk_i; device 0 folds the D partial sums and runs the one verification
+    const int pk_group = sig_group == 1 ? 2 : 1;
+    const size_t psz = pk_size(sig_group, fmt), width = sig_group == 1 ? 96 : 48, osz = sig_group == 1 ? 288 : 144;
+    std::vector<uint8_t> kb(width * n), parts(osz * D), apk(288), sig_proj(288), hm(288), digest(32);
+    std::vector<uint32_t> perm(n);
+    std::vector<int32_t> sts(D, 0);
+    const char* dsts = DST_TABLE[sig_group - 1][scheme];
+    const uint64_t offs1[2] = {0, (uint64_t)msg_len};
+    int hash_rc = 0;
+    std::string hash_err;
+    std::thread hash_thread([&] {           // H(msg) beside everything else (a second context of device 0)
+      t_nested = true;
+      hash_rc = (sig_group == 1 ? blsgpu_hash_to_g1 : blsgpu_hash_to_g2)(msg, offs1, 1, (const uint8_t*)dsts, strlen(dsts), hm.data());
+      hash_err = t_err;
+    });
+    rc = run_on_devices(D, [&](size_t d) {
+      const size_t lo = n * d / D, hi = n * (d + 1) / D;
+      return blsgpu_serialize(pk_group, (const uint8_t*)pks + lo * psz, hi - lo, fmt, ser_format ? BLSGPU_FMT_LEGACY : BLSGPU_FMT_COMPRESSED,
+                              kb.data() + width * lo, nullptr);
+    });
+    if (!rc) {
+      NestedScope ns;
+      rc = blsgpu_sort_keys(kb.data(), n, width, perm.data());
+      if (!rc) rc = blsgpu_sorted_keys_digest(kb.data(), perm.data(), n, width, digest.data());
+    }
+    if (!rc)
+      rc = run_on_devices(D, [&](size_t d) {
+        const size_t lo = n * d / D, hi = n * (d + 1) / D;
+        std::vector<uint8_t> scal(32 * (hi - lo));
+        int r2 = blsgpu_coefficients_for_range(digest.data(), perm.data(), n, lo, hi - lo, scal.data(), &sts[d]);
+        if (r2) return r2;
+        return (pk_group == 1 ? blsgpu_msm_g1 : blsgpu_msm_g2)((const uint8_t*)pks + lo * psz, scal.data(), hi - lo, fmt, parts.data() + osz * d);
+      });
+    hash_thread.join();
+    if (rc) return rc;
+    if (hash_rc) {
+      t_err = hash_err;
+      return hash_rc;
+    }
+    int32_t st = BLSGPU_OK;
+    for (size_t d = 0; d < D; d++)
+      if (sts[d] != BLSGPU_OK) st = BLSGPU_INVALID_COEFFICIENT;
+    if (st == BLSGPU_OK) {
+      NestedScope ns;
+      if ((rc = (pk_group == 1 ? blsgpu_sum_g1 : blsgpu_sum_g2)(parts.data(), D, BLSGPU_FMT_RAW_PROJ, apk.data()))) return rc;
+      if ((rc = (sig_group == 1 ? blsgpu_sum_g1 : blsgpu_sum_g2)(sig, 1, fmt, sig_proj.data()))) return rc;
+      if ((rc = blsgpu_core_verify_hashed(sig_group, apk.data(), sig_proj.data(), hm.data(), 1, &st))) return rc;
+    }
+    if (is_device_ptr(status)) HIPCK(hipMemcpy(status, &st, 4, hipMemcpyHostToDevice));
+    else *status = st;
+    return 0;
+  }
   CTX_ACQUIRE(c);
   const bool trace = getenv("BLSGPU_HOST_TRACE") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1351,9 +1567,9 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
   if (!c->ev_host) HIPCK(hipEventCreateWithFlags(&c->ev_host, hipEventDisableTiming));
   bool full_sort = false;
   if ((rc = run_key_sort_to_host(c, d_bytes, n, width, w, c->ev_host, &full_sort))) return rc;
-  // Behind them the stream hashes the message to the curve (H(msg) does not depend on the keys: verify_secure never
-  // prefixes them, reference src/secure_aggregation.rs:236-246), so the hash-to-curve of the final core_verify runs
-  // while the host hashes the key stream.
+  // H(msg) does not depend on the keys (verify_secure never prefixes them, reference src/secure_aggregation.rs:236-246): the
+  // hash-to-curve of the final core_verify -- one wave, 1.6 ms for G1 and 4 ms for G2 of pure latency -- runs on the side
+  // stream beside everything up to the pairing: the key sort, the host's hash of the key stream and the whole key sum.
   const void* d_msg0;
   if ((rc = stage_in(c, msg, msg_len, &d_msg0))) return rc;
   uint64_t* d_offs0 = (uint64_t*)arena_take(c, 16);
@@ -1361,9 +1577,21 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
   if (!d_offs0 || !d_hash) return fail(BLSGPU_E_HIP, "internal: arena too small");
   const uint64_t offs0[2] = {0, (uint64_t)msg_len};
   if ((rc = h2d_small(c, d_offs0, offs0, 16))) return rc;
-  if (sig_group == 1) KL(KID_HASH, k_hash_to_g1, dim3(1), dim3(BLS_BLOCK), (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, scheme_dst(sig_group, scheme), d_hash, 1);
-  else KL(KID_HASH, k_hash_to_g2, dim3(1), dim3(BLS_BLOCK), (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, scheme_dst(sig_group, scheme), d_hash, 1);
+  if (!c->side) {
+    HIPCK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    HIPCK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  }
+  HIPCK(hipEventRecord(c->ev_fork, c->stream));
+  HIPCK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+  if (sig_group == 1)
+    hipLaunchKernelGGL(k_hash_to_g1, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0,
+                       scheme_dst(sig_group, scheme), d_hash, 1);
+  else
+    hipLaunchKernelGGL(k_hash_to_g2, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0,
+                       scheme_dst(sig_group, scheme), d_hash, 1);
   HIPCK(hipGetLastError());
+  HIPCK(hipEventRecord(c->ev_join, c->side));
   // ... and so does the scalar-independent part of the key sum (every key to affine, with its endomorphism images)
   const bool msm2 = msm_use_pippenger(n) && !msm_use_v1();
   msm2_ws mw;
@@ -1392,9 +1620,10 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
     else rc = run_point_sum<1>(c, (const uint8_t*)d_pks, fmt, d_scal, nullptr, n, d_part, T);
   }
   if (rc) return rc;
+  HIPCK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
   if ((rc = verify_one_tail(c, sig_group, scheme, 0, d_part, sig, fmt, msg, msg_len, status, d_hash))) return rc;
   if (trace)
-    fprintf(stderr, "[blsgpu] verify_secure n=%zu: compress + key sort%s + D2H %.2f ms (message hash enqueued behind), key-stream SHA-256 on the host %.2f ms, rest %.2f ms\n",
+    fprintf(stderr, "[blsgpu] verify_secure n=%zu: compress + key sort%s + D2H %.2f ms (message hash on the side stream), key-stream SHA-256 on the host %.2f ms, rest %.2f ms\n",
             n, full_sort ? " (full-width)" : "", t1 - t0, t2 - t1, now() - t2);
   if (*h_zero) {                   // a zero coefficient: BlsError::InvalidCoefficient before any verification (:97-100)
     st = BLSGPU_INVALID_COEFFICIENT;

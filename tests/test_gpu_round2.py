@@ -303,3 +303,28 @@ def test_public_key_share_verify(api, C, sg):
             comb = api.point_sum(sg, [sraw[x - 1] for x in xs], lam)
             group_pk = pkraw(ref.public_key(C, coef[0]), rng)
             assert api.verify_batch(sg, scheme, [group_pk], [comb], [msg]) == [0]
+
+
+def test_in_library_multi_device(tmp_path):
+    """blsgpu_init_devices: one process driving several devices (here three logical devices on the one GPU of the box,
+    BLSGPU_FAKE_DEVICES) shards the four verify entry points inside the library -- contiguous ranges, one host thread per
+    device, partial key sums / Fp12 Miller products / MSM partials folded on device 0 -- and must return exactly what the
+    single-device library returns: verdict vectors, error precedence and indices, for host and for device-resident inputs."""
+    import json
+    import os
+    import subprocess
+    import sys
+    out = str(tmp_path / 'multidev.json')
+    env = dict(os.environ)
+    env.pop('BLSGPU_FAKE_DEVICES', None)
+    subprocess.check_call([sys.executable, os.path.join(util.ROOT, 'tests', 'multidev_worker.py'), out], env=env, timeout=600)
+    res = json.load(open(out))
+    assert res['equal'], {k: (res['single'][k], res['multi'][k]) for k in res['single'] if res['single'][k] != res['multi'][k]}
+    s = res['single']
+    for sg in (1, 2):
+        assert [i for i, v in enumerate(s['vb_%d' % sg]) if v] == [5, 60, 150] and s['vb_dev_%d' % sg] == s['vb_%d' % sg]
+        assert s['mv_%d' % sg] == [0, 1, 1]
+        assert s['av_%d' % sg] == [[0, [0, 0]], [1, [0, 0]], [4, [7, 180]], [1, [0, 0]], [3, [34, 0]], [2, [0, 0]]]
+        assert s['av_dev_%d' % sg] == [1, [0, 0]]
+        for mode in ([0] if sg == 1 else [0, 1]):
+            assert s['vs_%d_%d' % (sg, mode)] == [0, 0, 1, 1]
