@@ -8,7 +8,7 @@
 //   BlsError / BlsResult                           src/error.rs:5-58
 //   SecretKey<C> (test inputs only)                src/secret_key.rs:255-265,342-344
 //   PublicKey<C>                                   src/public_key.rs:5-11,58-74,146-171
-//   Signature<C>                                   src/signature.rs:25-44,130-138,177-197,231-276
+//   Signature<C>                                   src/signature.rs:25-44,112-126,130-138,177-197,231-276
 //   MultiPublicKey<C>, MultiSignature<C>           src/multi_public_key.rs:79-83, src/multi_signature.rs:127-135
 //   AggregateSignature<C>                          src/aggregate_signature.rs:191-239
 //   ProofOfPossession<C>                           src/proof_of_possession.rs:79-81
@@ -189,6 +189,28 @@ struct Signature {
     return Signature{scheme, r.unwrap()};
   }
   Bytes to_bytes_with_mode(SerializationFormat f) const { return detail::encode(C::SIG_GROUP, raw, C::SIG_BYTES, f); }
+
+  // Vec<u8>::from(&Signature) / Signature::try_from(&[u8]), src/signature.rs:112-126: the serde_bare form -- the enum's variant
+  // index as one byte followed by the compressed point, 49 / 97 bytes (the lengths asserted at src/signature.rs:285-286)
+  BlsResult<Bytes> to_bytes() const {
+    if (int rc = detail::ensure_init()) return detail::runtime_error(rc);
+    Bytes out(C::SIG_BYTES + 1);
+    const uint8_t tag = (uint8_t)scheme;
+    if (int rc = blsgpu_signatures_to_tagged(C::SIG_GROUP, &tag, raw.data(), 1, BLSGPU_FMT_RAW_PROJ, out.data())) return detail::runtime_error(rc);
+    return out;
+  }
+  static BlsResult<Signature> try_from(const Bytes& b) {
+    if (int rc = detail::ensure_init()) return detail::runtime_error(rc);
+    // serde_bare reports a short buffer or an unknown variant as an error; the reference maps every one to InvalidInputs(..)
+    if (b.size() != C::SIG_BYTES + 1) return BlsError{BlsError::Kind::InvalidInputs, "unexpected end of input"};
+    Signature s{SignatureSchemes::Basic, {}};
+    uint8_t tag = 0;
+    int32_t st = 0;
+    if (int rc = blsgpu_signatures_from_tagged(C::SIG_GROUP, b.data(), 1, &tag, s.raw.data(), &st)) return detail::runtime_error(rc);
+    if (st != BLSGPU_OK) return BlsError{BlsError::Kind::InvalidInputs, tag > 2 ? "invalid variant index" : "invalid point encoding"};
+    s.scheme = (SignatureSchemes)tag;
+    return s;
+  }
 
   // Signature::verify(&pk, msg), src/signature.rs:130-138: a batch of one
   BlsResult<Unit> verify(const PublicKey<C>& pk, const Bytes& msg) const {

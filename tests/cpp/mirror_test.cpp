@@ -137,6 +137,18 @@ static void test_schemes(uint8_t tag) {
     // wire round trip (to_bytes / try_from) keeps the key and the verdict
     auto pk2 = PublicKey<C>::try_from(pks[0].to_bytes()).unwrap();
     CHECK(pk2 == pks[0] && sig.verify(pk2, msg).is_ok());
+    // Signature <-> Vec<u8> (serde_bare: scheme tag + compressed point), the reference's try_from test (src/signature.rs:279-318):
+    // 49 / 97 bytes, round trip for every scheme, and the decoded signature keeps its scheme and verdict
+    {
+      const Bytes sb = sig.to_bytes().unwrap();
+      CHECK(sb.size() == C::SIG_BYTES + 1 && sb[0] == (uint8_t)scheme);
+      auto back = Signature<C>::try_from(sb);
+      CHECK(back.is_ok() && back.unwrap().scheme == scheme && back.unwrap().verify(pks[0], msg).is_ok());
+      Bytes bad = sb;
+      bad[0] = 3;
+      CHECK(Signature<C>::try_from(bad).unwrap_err().kind == BlsError::Kind::InvalidInputs);
+      CHECK(Signature<C>::try_from(Bytes(sb.begin(), sb.end() - 1)).unwrap_err().kind == BlsError::Kind::InvalidInputs);
+    }
     // identity key / identity signature: the reference's check order and strings (src/traits/sig_core.rs:126-135)
     PublicKey<C> inf_pk{};
     Signature<C> inf_sig{scheme, {}};
