@@ -35,7 +35,7 @@ EXPORTS = [
     'blsgpu_aggregate_partial', 'blsgpu_fp12_product_is_one', 'blsgpu_core_verify', 'blsgpu_deserialize', 'blsgpu_pop_verify_batch', 'blsgpu_aggregate_secure',
     'blsgpu_signcrypt_valid_batch', 'blsgpu_sig_proof_verify_batch', 'blsgpu_pairing2_check_batch',
     'blsgpu_init_devices', 'blsgpu_device_count', 'blsgpu_sort_keys', 'blsgpu_sorted_keys_digest',
-    'blsgpu_coefficients_for_range', 'blsgpu_first_duplicate_message', 'blsgpu_first_occurrence', 'blsgpu_core_verify_hashed', 'blsgpu_signatures_from_tagged', 'blsgpu_signatures_to_tagged',
+    'blsgpu_coefficients_for_range', 'blsgpu_first_duplicate_message', 'blsgpu_first_occurrence', 'blsgpu_core_verify_hashed', 'blsgpu_debug_wide_mul', 'blsgpu_signatures_from_tagged', 'blsgpu_signatures_to_tagged',
 ]
 
 
@@ -139,6 +139,7 @@ def load_library(path=None):
         lib.blsgpu_first_duplicate_message.argtypes = [u8p, u64p, sz, u64p]
         lib.blsgpu_first_occurrence.argtypes = [u8p, u32p, sz, sz, u32p]
         lib.blsgpu_core_verify_hashed.argtypes = [ci, vp, vp, vp, sz, i32p]
+        lib.blsgpu_debug_wide_mul.argtypes = [u8p, u8p, sz, ci, u8p]
         lib.blsgpu_signatures_from_tagged.argtypes = [ci, u8p, sz, u8p, vp, i32p]
         lib.blsgpu_signatures_to_tagged.argtypes = [ci, u8p, vp, sz, ci, u8p]
         _lib = lib
@@ -439,6 +440,15 @@ def signatures_to_tagged(sig_group, schemes, sigs, fmt=FMT_RAW_PROJ):
     _check(lib.blsgpu_signatures_to_tagged(sig_group, _ptr(bytes(schemes)), _ptr(b''.join(sigs)), n, fmt, ctypes.cast(out, ctypes.c_void_p)))
     raw = out.raw
     return [raw[(width + 1) * i:(width + 1) * (i + 1)] for i in range(n)]
+
+
+def debug_wide_mul(a_list, b_list, reps=1):
+    """[a * b^reps in Fp] through the row-wide multiplier; elements as 48-byte Montgomery words."""
+    lib = init()
+    n = len(a_list)
+    out = ctypes.create_string_buffer(48 * max(n, 1))
+    _check(lib.blsgpu_debug_wide_mul(_ptr(b''.join(a_list)), _ptr(b''.join(b_list)), n, reps, ctypes.cast(out, ctypes.c_void_p)))
+    return [out.raw[48 * i:48 * (i + 1)] for i in range(n)]
 
 
 def first_duplicate_message(msgs):

@@ -27,10 +27,10 @@ thread_local bool t_nested = false;  // inside a sharded call: the per-device su
 
 enum {
   KID_PREPARE, KID_MILLER2, KID_FINALEXP, KID_PREPARE_AGG, KID_PAIRS_AFF, KID_MILLER1, KID_F12_FOLD, KID_FINALEXP_ONE,
-  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_F12_IO, KID_MSM_SORT, KID_MSM_BUCKET, KID_MSM_CHUNK, KID_DECOMPRESS, KID_PAIRING_COOP, KID_KEY_SORT, KID_COEFF, KID_DUP, KID_FIRST_BAD, KID_MSM_PREP, KID_MSM_NORM, KID_MSM_MERGE, KID_COUNT
+  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_F12_IO, KID_MSM_SORT, KID_MSM_BUCKET, KID_MSM_CHUNK, KID_DECOMPRESS, KID_PAIRING_COOP, KID_KEY_SORT, KID_COEFF, KID_DUP, KID_FIRST_BAD, KID_MSM_PREP, KID_MSM_NORM, KID_MSM_MERGE, KID_WIDE, KID_COUNT
 };
 const char* KID_NAMES[KID_COUNT] = {"k_prepare", "k_miller2", "k_finalexp", "k_prepare_agg", "k_pairs_to_affine", "k_miller1", "k_f12_fold",
-                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign", "k_f12_io", "k_msm_sort", "k_msm_bucket", "k_msm_chunk", "k_decompress", "k_pairing_coop", "k_key_sort", "k_sha256_coeff", "k_duplicate_rule", "k_first_identity", "k_msm_prep", "k_normalize", "k_msm_merge"};
+                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign", "k_f12_io", "k_msm_sort", "k_msm_bucket", "k_msm_chunk", "k_decompress", "k_pairing_coop", "k_key_sort", "k_sha256_coeff", "k_duplicate_rule", "k_first_identity", "k_msm_prep", "k_normalize", "k_msm_merge", "k_wide"};
 
 struct Ctx {
   int dev = -1;
@@ -139,6 +139,7 @@ bool is_device_ptr(const void* p) {
 
 // ---- bump arena in device memory, reset per call
 int arena_reserve(Ctx* c, size_t bytes) {
+  bytes += 1u << 20;               // headroom that every call may rely on (the row-wide engine's per-item records, run_pairing2)
   if (bytes <= c->arena_cap) return 0;
   HIPCK(hipStreamSynchronize(c->stream));
   if (c->arena) HIPCK(hipFree(c->arena));
@@ -289,6 +290,19 @@ size_t coop_max_items() {
   return (size_t)v;
 }
 
+// batches up to this size finish on the row-wide engine (one 256-thread workgroup per item; csrc/wide_engine.cuh):
+// BLSGPU_WIDE_MAX overrides (0 = never).  One workgroup occupies the four SIMDs of a CU, so 256 items run side by side.
+size_t wide_max_items() {
+  static long v = -1;
+  if (v < 0) {
+    const char* e = getenv("BLSGPU_WIDE_MAX");
+    v = e ? atol(e) : 256;
+    if (v < 0) v = 0;
+    if (v > 4096) v = 4096;
+  }
+  return (size_t)v;
+}
+
 unsigned blocks_for(size_t n) { return (unsigned)((n + BLS_BLOCK - 1) / BLS_BLOCK); }
 
 int pinned_reserve(Ctx* c, size_t bytes) {
@@ -390,7 +404,14 @@ struct NestedScope {     // the calling thread's own follow-up calls (fold, fina
 // the two-pair pairing check of every item whose status is still BLS_OK: status <- OK / INVALID_SIGNATURE.
 // fixed_g2: the second pair's G2 member is -g2 (precomputed lines)
 int run_pairing2(Ctx* c, size_t n, uint32_t* d_pairs, uint32_t* d_f, int32_t* d_status, int fixed_g2) {
-  if (n <= coop_max_items()) {  // small batches and single-item tails: one wave per item
+  if (n <= wide_max_items() && n <= coop_max_items()) {
+    // single verifications and the one-verdict tails: Miller loop + easy part on one wave per item, the hard part of the
+    // final exponentiation on the row-wide engine (arena_reserve keeps 1 MiB of headroom: 768 B per item here)
+    uint32_t* d_easy = (uint32_t*)arena_take(c, (size_t)WIDE_EASY_WORDS * 4 * n);
+    if (!d_easy) return fail(BLSGPU_E_HIP, "internal: arena too small");
+    KL(KID_PAIRING_COOP, k_pairing_coop_easy, dim3((unsigned)n), dim3(BLS_BLOCK), n, (const uint32_t*)d_pairs, (const int32_t*)d_status, fixed_g2, d_easy);
+    KL(KID_WIDE, k_finalexp_wide, dim3((unsigned)n), dim3(WIDE_BLOCK), n, (const uint32_t*)d_easy, d_status);
+  } else if (n <= coop_max_items()) {  // small batches: one wave per item
     KL(KID_PAIRING_COOP, k_pairing_coop, dim3((unsigned)n), dim3(BLS_BLOCK), n, d_pairs, d_status, fixed_g2);
   } else {                      // two lanes per item (tower_split.cuh)
     KL(KID_MILLER2, k_miller2s, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_pairs, d_status, d_f, fixed_g2);
@@ -2141,6 +2162,32 @@ int blsgpu_signatures_to_tagged(int sig_group, const uint8_t* schemes, const voi
   KL(KID_COMPRESS, k_tag, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, width, (const uint8_t*)d_tags, (const uint8_t*)d_bytes, d_out);
   HIPCK(hipGetLastError());
   if (d_out != out && (rc = copy_out(c, out, d_out, (width + 1) * n))) return rc;
+  SYNC_FLUSH(c);
+  return 0;
+}
+API_CATCH
+
+/* Self-test / measurement hook of the row-wide Fp multiplier (csrc/wide.cuh): out[i] = a[i] * b[i]^reps in Fp, 48-byte Montgomery
+ * words per element (the Fp coordinate format of RAW_PROJ).  reps > 1 chains the multiplications: with n <= 4 (one wave) the
+ * call's device time / reps is the latency of one multiplication of a dependent chain. */
+int blsgpu_debug_wide_mul(const uint8_t* a, const uint8_t* b, size_t n, int reps, uint8_t* out) try {
+  if (!initialised()) return NOT_INIT();
+  if (n == 0) return 0;
+  if (!a || !b || !out || reps < 1) return fail(BLSGPU_E_ARG, "bad argument");
+  CTX_ACQUIRE(c);
+  int rc = arena_reserve(c, 3 * pad256(48 * n) + 4096);
+  if (rc) return rc;
+  c->arena_off = 0;
+  const void *d_a, *d_b;
+  if ((rc = stage_in(c, a, 48 * n, &d_a))) return rc;
+  if ((rc = stage_in(c, b, 48 * n, &d_b))) return rc;
+  uint8_t* d_out = is_device_ptr(out) ? out : (uint8_t*)arena_take(c, 48 * n);
+  if (!d_out) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  // BLSGPU_WIDE_TEST_BLOCK=256: sixteen items per 256-thread workgroup (the engine's shape) instead of four per wave
+  const unsigned tb = (getenv("BLSGPU_WIDE_TEST_BLOCK") && atoi(getenv("BLSGPU_WIDE_TEST_BLOCK")) == 256) ? 256 : 64, per = tb / 16;
+  KL(KID_WIDE, k_wide_mul_test, dim3((unsigned)((n + per - 1) / per)), dim3(tb), n, (const uint8_t*)d_a, (const uint8_t*)d_b, d_out, reps);
+  HIPCK(hipGetLastError());
+  if (d_out != out && (rc = copy_out(c, out, d_out, 48 * n))) return rc;
   SYNC_FLUSH(c);
   return 0;
 }

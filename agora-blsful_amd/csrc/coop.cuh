@@ -494,9 +494,8 @@ __device__ __noinline__ void coop_miller2(coop_shared& S, const g1_aff* P, const
   coop_conj(S.f, S.f);
 }
 
-// final exponentiation of S.f (as pairing.cuh final_exponentiation) and comparison with 1; returns the status code
-__device__ __noinline__ int coop_final_verdict(coop_shared& S) {
-  // easy part: f^((p^6 - 1)(p^2 + 1))
+// easy part of the final exponentiation: S.f <- S.f^((p^6 - 1)(p^2 + 1))
+__device__ __noinline__ void coop_final_easy(coop_shared& S) {
   if (coop_pair() == 0) {
     fp12_t<hfp2> a, b;
     coop_to_tower(a, S.f);
@@ -508,6 +507,10 @@ __device__ __noinline__ int coop_final_verdict(coop_shared& S) {
   coop_mul(S, S.f, S.u, S.t);
   coop_frob<2>(S.t, S.f);
   coop_mul(S, S.f, S.t, S.f);
+}
+// final exponentiation of S.f (as pairing.cuh final_exponentiation) and comparison with 1; returns the status code
+__device__ __noinline__ int coop_final_verdict(coop_shared& S) {
+  coop_final_easy(S);
   // hard part: t = f^((x-1)^2 (x+p) (x^2+p^2-1)) * f^3
   coop_pow_x(S, S.t, S.f);
   coop_conj(S.u, S.f);

@@ -260,6 +260,12 @@ template <int G>
 __global__ void k_decompress(size_t n, const uint8_t* bytes, int legacy, uint8_t* out, int32_t* status, int keep);
 
 #include "util_kernels.cuh"
+__global__ void k_wide_mul_test(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, int reps);
+// single-verification latency path: Miller loop + easy part per item on one wave (coop.cuh), hard part on the row-wide engine
+#define WIDE_BLOCK 256
+#define WIDE_EASY_WORDS (12 * 16)     // f^((p^6-1)(p^2+1)) of one item in the engine's value layout
+__global__ void k_pairing_coop_easy(size_t n, const uint32_t* pairs, const int32_t* status, int fixed_g2, uint32_t* easy);
+__global__ void k_finalexp_wide(size_t n, const uint32_t* easy, int32_t* status);
 
 #if defined(BLS_TU_PREPARE1) || defined(BLS_TU_PREPARE2)
 // =====================================================================================================
@@ -1536,4 +1542,93 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_finalexp_coop(const uint32_t* 
   int st = coop_final_verdict(S);
   if (threadIdx.x == 0) *verdict = st;
 }
+// Miller loop of the item's two pairs and the EASY part of the final exponentiation, f^((p^6 - 1)(p^2 + 1)), exported in the
+// value layout of the row-wide engine (coefficient k of the basis w^0..w^5, real then imaginary part, sixteen words each):
+// the hard part follows in k_finalexp_wide
+__global__ void __launch_bounds__(BLS_BLOCK, 2) k_pairing_coop_easy(size_t n, const uint32_t* pairs, const int32_t* status, int fixed_g2, uint32_t* easy) {
+  __shared__ coop_shared S;
+  const size_t i = blockIdx.x;
+  if (i >= n) return;
+  if (status[i] != BLS_OK) return;
+  g1_aff P[2];
+  aff<hfp2> Q[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int w0 = k * 3 * W2;
+    ws_ld_fp(P[k].x, pairs, n, i, w0);
+    ws_ld_fp(P[k].y, pairs, n, i, w0 + W1);
+    ws_ld_fp(Q[k].x.v, pairs, n, i, w0 + W2 + (lane_hi() ? W1 : 0));
+    ws_ld_fp(Q[k].y.v, pairs, n, i, w0 + 2 * W2 + (lane_hi() ? W1 : 0));
+    P[k].inf = false;
+    Q[k].inf = false;
+  }
+  coop_miller2(S, P, Q, fixed_g2);
+  coop_final_easy(S);
+  uint32_t* e = easy + i * WIDE_EASY_WORDS;
+  for (int t = threadIdx.x; t < WIDE_EASY_WORDS; t += BLS_BLOCK) {
+    const int v = t >> 4, l = t & 15;                  // value v = 2 k + component
+    e[t] = l < FP_NL ? S.f.c[v >> 1][(v & 1) * FP_NL + l] : 0u;
+  }
+}
 #endif
+
+#if defined(BLS_TU_WIDE)
+// =====================================================================================================
+#include "wide.cuh"
+// self-test of the row-wide multiplier: item i = a_i * b_i (caller format: 48-byte Montgomery words), `reps` chained
+// multiplications by b (reps = 1: the plain product), four items per wave
+__global__ void __launch_bounds__(WIDE_BLOCK) k_wide_mul_test(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, int reps) {
+  __shared__ uint32_t sh[WIDE_BLOCK / 16][3][16];
+  const int row = threadIdx.x >> 4, l = threadIdx.x & 15;
+  const size_t i = (size_t)blockIdx.x * (blockDim.x >> 4) + row;
+  wide_consts K;
+  wide_init(K);
+  if (l == 0 && i < n) {
+    fp x, y;
+    fp_from_raw(x, (const uint32_t*)(a + 48 * i));
+    fp_from_raw(y, (const uint32_t*)(b + 48 * i));
+    w_store_local(sh[row][0], x);
+    w_store_local(sh[row][1], y);
+  }
+  __syncthreads();
+  wfp wa = i < n ? (wfp)sh[row][0][l] : 0, wb = i < n ? (wfp)sh[row][1][l] : 0;
+  for (int r = 0; r < reps; r++) wa = w_mul(wa, wb, K);
+  sh[row][2][l] = (uint32_t)wa;
+  __syncthreads();
+  if (l == 0 && i < n) {
+    fp z;
+    w_load_local(z, sh[row][2]);
+    fp_to_raw((uint32_t*)(out + 48 * i), z);
+  }
+}
+#include "wide_engine.cuh"
+// the hard part of the final exponentiation and the comparison with one, one 256-thread workgroup per item
+__global__ void __launch_bounds__(WIDE_BLOCK) k_finalexp_wide(size_t n, const uint32_t* easy, int32_t* status) {
+  __shared__ wide_lds S;
+  const size_t item = blockIdx.x;
+  if (item >= n) return;
+  if (status[item] != BLS_OK) return;                   // uniform over the workgroup
+  wide_consts K;
+  wide_init(K);
+  wide_stage(S, WIDE_PROG_FINAL_HARD, WIDE_PROG_FINAL_HARD_LEN);
+  for (int t = threadIdx.x; t < WIDE_EASY_WORDS; t += WIDE_BLOCK) S.V[WV_F + (t >> 4)][t & 15] = easy[item * WIDE_EASY_WORDS + t];
+  if (threadIdx.x == 0) S.flag = 1;
+  __syncthreads();
+  wide_exec(S, WIDE_PROG_FINAL_HARD_LEN, K);
+  // == 1 ?  (lane-local canonical comparison of the twelve components)
+  if (threadIdx.x < 12) {
+    fp x, one;
+    w_load_local(x, S.V[WV_T + threadIdx.x]);
+    bool ok;
+    if (threadIdx.x == 0) {
+      fp_one(one);
+      ok = fp_eq(x, one);
+    } else {
+      ok = fp_is_zero(x);
+    }
+    if (!ok) S.flag = 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) status[item] = S.flag ? BLS_OK : BLS_ERR_INVALID_SIGNATURE;
+}
+#endif  // BLS_TU_WIDE

@@ -250,6 +250,10 @@ int blsgpu_profile_enable(int on);
 int blsgpu_profile_count(void);
 int blsgpu_profile_get(int kernel_id, char* name, size_t name_cap, double* total_ms, uint64_t* launches);
 
+/* Self-test / measurement hook of the row-wide Fp multiplier behind the single-verification latency path (csrc/wide.cuh):
+ * out[i] = a[i] * b[i]^reps in Fp, elements as 48-byte Montgomery words (the coordinate format of RAW_PROJ). */
+int blsgpu_debug_wide_mul(const uint8_t* a, const uint8_t* b, size_t n, int reps, uint8_t* out);
+
 /* Sign side, provided so that benchmarks and tests can build inputs on the device:
  * pk[i] = sk[i] * g (SecretKey::public_key, src/secret_key.rs:342-344) and
  * sig[i] = sk[i] * H(msg[i]) (BlsSignatureCore::core_sign, src/traits/sig_core.rs:108-117; the Aug scheme prefixes
