@@ -138,9 +138,10 @@ BLS_FN void fp_from_be64(fp& r, const uint8_t* b) {
 }
 
 // ------------------------------------------------------------------ G1: simplified SWU (RFC 9380 F.2, straight line)
-// returns x = xn/xd and y on E'1
-BLS_NOINLINE void sswu_g1(fp& xn, fp& xd, fp& y, const fp& u) {
-  fp A, B, Z, tv1, tv2, tv3, tv4, tv5, tv6, x, y1, t;
+// returns x = xn/xd and y on E'1.  F = fp (one lane) or wf (one DPP row, csrc/wide.cuh: the single-item latency path)
+template <class F>
+BLS_NOINLINE void sswu_g1(F& xn, F& xd, F& y, const F& u) {
+  F A, B, Z, tv1, tv2, tv3, tv4, tv5, tv6, x, y1, t;
   fp_load(A, SSWU1_A);
   fp_load(B, SSWU1_B);
   fp_load(Z, SSWU1_Z);
@@ -164,7 +165,7 @@ BLS_NOINLINE void sswu_g1(fp& xn, fp& xd, fp& y, const fp& u) {
   fp_add(tv2, tv2, tv5);
   fp_mul(x, tv1, tv3);
   // sqrt_ratio_3mod4(tv2, tv6)
-  fp s1, s2, s3, y2, c2;
+  F s1, s2, s3, y2, c2;
   fp_sqr(s1, tv6);
   fp_mul(s2, tv2, tv6);
   fp_mul(s1, s1, s2);
@@ -180,7 +181,7 @@ BLS_NOINLINE void sswu_g1(fp& xn, fp& xd, fp& y, const fp& u) {
   fp_mul(y, y, y2);
   fp_cmov(x, tv3, is_qr);
   fp_cmov(y, y1, is_qr);
-  fp ny;
+  F ny;
   fp_neg(ny, y);
   fp_cmov(y, ny, fp_parity(u) != fp_parity(y));
   xn = x;

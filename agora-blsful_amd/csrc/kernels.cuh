@@ -203,7 +203,7 @@ __global__ void k_pairs2_to_affine(size_t n, const uint8_t* g1a, const uint8_t* 
                                    uint32_t* pairs, int32_t* status);
 __global__ void k_status_to_flag(size_t n, int32_t* status);
 template <int SG>
-__global__ void k_prepare_hashed(size_t n, const uint8_t* pks, const uint8_t* sigs, const uint8_t* hashes, uint32_t* pairs, int32_t* status);
+__global__ void k_prepare_hashed(size_t n, const uint8_t* pks, const uint8_t* sigs, const uint8_t* hashes, uint32_t* pairs, int32_t* status, int fmt);
 template <int SG>
 __global__ void k_prepare_proof(size_t n, const uint8_t* commitments, const uint8_t* proofs, const uint8_t* pks, const uint8_t* ys,
                                 int fmt, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint32_t* pairs, int32_t* status);
@@ -266,6 +266,8 @@ __global__ void k_wide_mul_test(size_t n, const uint8_t* a, const uint8_t* b, ui
 #define WIDE_EASY_WORDS (12 * 16)     // f^((p^6-1)(p^2+1)) of one item in the engine's value layout
 __global__ void k_pairing_coop_easy(size_t n, const uint32_t* pairs, const int32_t* status, int fixed_g2, uint32_t* easy);
 __global__ void k_finalexp_wide(size_t n, const uint32_t* easy, int32_t* status);
+__global__ void k_pairing_wide(size_t n, const uint32_t* pairs, int32_t* status, int fixed_g2);
+__global__ void k_hash_to_g1_wide(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst, uint8_t* out);
 
 #if defined(BLS_TU_PREPARE1) || defined(BLS_TU_PREPARE2)
 // =====================================================================================================
@@ -461,7 +463,7 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_pairs2_to_affine(size_t n, const 
 // reference src/traits/sig_core.rs:126-135) and the shared-inversion conversion to affine pairs are left.
 template <int SG>
 __global__ void __launch_bounds__(BLS_BLOCK) k_prepare_hashed(size_t n, const uint8_t* pks, const uint8_t* sigs, const uint8_t* hashes,
-                                                            uint32_t* pairs, int32_t* status) {
+                                                            uint32_t* pairs, int32_t* status, int fmt) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   g1_aff P[2];
@@ -470,8 +472,8 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_prepare_hashed(size_t n, const ui
   if (SG == 1) {
     g2_jac pk;
     g1_jac sig, h;
-    load_g2_pt(pk, pks, i, 0);
-    load_g1_pt(sig, sigs, i, 0);
+    load_g2_pt(pk, pks, i, fmt);
+    load_g1_pt(sig, sigs, i, fmt);
     load_g1_pt(h, hashes, i, 0);
     if (jac_is_inf(sig)) st = BLS_ERR_SIG_IDENTITY;
     else if (jac_is_inf(pk)) st = BLS_ERR_PK_IDENTITY;
@@ -490,8 +492,8 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_prepare_hashed(size_t n, const ui
   } else {
     g1_jac pk;
     g2_jac sig, h;
-    load_g1_pt(pk, pks, i, 0);
-    load_g2_pt(sig, sigs, i, 0);
+    load_g1_pt(pk, pks, i, fmt);
+    load_g2_pt(sig, sigs, i, fmt);
     load_g2_pt(h, hashes, i, 0);
     if (jac_is_inf(sig)) st = BLS_ERR_SIG_IDENTITY;
     else if (jac_is_inf(pk)) st = BLS_ERR_PK_IDENTITY;
@@ -514,8 +516,8 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_prepare_hashed(size_t n, const ui
   ws_st_pair(pairs, n, i, 0, P[0], Q[0]);
   ws_st_pair(pairs, n, i, 1, P[1], Q[1]);
 }
-template __global__ void k_prepare_hashed<1>(size_t, const uint8_t*, const uint8_t*, const uint8_t*, uint32_t*, int32_t*);
-template __global__ void k_prepare_hashed<2>(size_t, const uint8_t*, const uint8_t*, const uint8_t*, uint32_t*, int32_t*);
+template __global__ void k_prepare_hashed<1>(size_t, const uint8_t*, const uint8_t*, const uint8_t*, uint32_t*, int32_t*, int);
+template __global__ void k_prepare_hashed<2>(size_t, const uint8_t*, const uint8_t*, const uint8_t*, uint32_t*, int32_t*, int);
 
 // status (0 = product is one) -> is_one flag (1 / 0)
 __global__ void __launch_bounds__(BLS_BLOCK) k_status_to_flag(size_t n, int32_t* status) {
@@ -1630,5 +1632,155 @@ __global__ void __launch_bounds__(WIDE_BLOCK) k_finalexp_wide(size_t n, const ui
   }
   __syncthreads();
   if (threadIdx.x == 0) status[item] = S.flag ? BLS_OK : BLS_ERR_INVALID_SIGNATURE;
+}
+
+// The whole two-pair pairing check of one item on the row-wide engine: the line coefficients of the variable G2 arguments,
+// the Miller loop, the final exponentiation and the comparison with one (program PAIR_FIXED when pair 1's G2 argument is
+// the constant -g2, whose lines come from the table G2NEG_LINES; PAIR_GENERAL otherwise).  pairs: the affine workspace that
+// the prepare stage writes (word-major: word k of item i at pairs[k n + i]).
+__global__ void __launch_bounds__(WIDE_BLOCK) k_pairing_wide(size_t n, const uint32_t* pairs, int32_t* status, int fixed_g2) {
+  __shared__ wide_lds S;
+  const size_t item = blockIdx.x;
+  if (item >= n) return;
+  if (status[item] != BLS_OK) return;                   // uniform over the workgroup
+  wide_consts K;
+  wide_init(K);
+  if (fixed_g2) wide_stage(S, WIDE_PROG_PAIR_FIXED, WIDE_PROG_PAIR_FIXED_LEN);
+  else wide_stage(S, WIDE_PROG_PAIR_GENERAL, WIDE_PROG_PAIR_GENERAL_LEN);
+  const int row = (int)(threadIdx.x >> 4), l = (int)(threadIdx.x & 15u);
+  auto ws_word = [&](int w) -> uint32_t { return l < FP_NL ? pairs[(size_t)(w + l) * n + item] : 0u; };
+  // per pair k: P = (x, y) at words w0, w0 + W1; Q = (x.c0, x.c1, y.c0, y.c1) at w0 + W2 ...
+  if (row < 2) {
+    const int w0 = row * 3 * W2;
+    S.V[WV_P + 2 * row][l] = ws_word(w0);
+    S.V[WV_P + 2 * row + 1][l] = ws_word(w0 + W1);
+    const uint32_t pt = row == 0 ? WV_PT0 : WV_PT1;
+    for (int c4 = 0; c4 < 4; c4++) {
+      const uint32_t q = ws_word(w0 + W2 + c4 * W1);
+      S.V[pt + c4][l] = q;          // T = Q
+      S.V[pt + 6 + c4][l] = q;      // Q
+    }
+    S.V[pt + 4][l] = l < FP_NL ? FP_ONE[l] : 0u;   // Z = 1
+    S.V[pt + 5][l] = 0u;
+  }
+  if (row == 2) {
+    S.V[WV_F][l] = l < FP_NL ? FP_ONE[l] : 0u;     // f = 1
+    for (int v = 1; v < 12; v++) S.V[WV_F + v][l] = 0u;
+  }
+  if (fixed_g2)                                      // pair 1's unscaled lines: the precomputed table of -g2
+    for (int t = threadIdx.x; t < WIDE_STEPS * 6 * 16; t += WIDE_BLOCK) {
+      const int st = t / 96, v = (t % 96) >> 4, ll = t & 15;
+      S.V[WV_L + 12 * st + 6 + v][ll] = ll < FP_NL ? G2NEG_LINES[st][v * FP_NL + ll] : 0u;
+    }
+  if (threadIdx.x == 0) S.flag = 1;
+  __syncthreads();
+  wide_exec(S, fixed_g2 ? WIDE_PROG_PAIR_FIXED_LEN : WIDE_PROG_PAIR_GENERAL_LEN, K);
+  if (threadIdx.x < 12) {
+    fp x, one;
+    w_load_local(x, S.V[WV_T + threadIdx.x]);
+    bool ok;
+    if (threadIdx.x == 0) {
+      fp_one(one);
+      ok = fp_eq(x, one);
+    } else {
+      ok = fp_is_zero(x);
+    }
+    if (!ok) S.flag = 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) status[item] = S.flag ? BLS_OK : BLS_ERR_INVALID_SIGNATURE;
+}
+
+// ---- hash_to_curve to G1 for single items: ONE wave per message, the two SSWU maps on rows 0 and 1 of the wave in the
+// row-wide field type `wf` (csrc/wide.cuh), then both rows add the two points and clear the cofactor redundantly.
+// A dependent multiplication costs ~0.45 us here against ~1.2 us lane-local, and this hash is ~1,000 of them in a row
+// (two square-root exponentiations side by side, the 11-isogeny, 64 doublings).  out: RAW_PROJ points.
+__device__ __forceinline__ void iso1_poly_wide(wf& r, const uint32_t (*k)[FP_NL], int deg, const wf& xn) {
+  const uint32_t (*zp)[16] = g_wf.tab[wf_row()];           // zp[j] = xd^j, staged by the caller
+  const int l = wf_lane();
+  wf acc, c, t, z;
+  fp_load(acc, k[deg]);
+  for (int i = deg - 1; i >= 0; i--) {
+    fp_mul(acc, acc, xn);
+    fp_load(c, k[i]);
+    z.v = (wfp)zp[deg - i][l];
+    fp_mul(t, c, z);
+    fp_add(acc, acc, t);
+  }
+  r = acc;
+}
+__device__ __noinline__ void iso_map_g1_wide(jac<wf>& r, const wf& xn, const wf& xd, const wf& y) {
+  uint32_t (*zp)[16] = g_wf.tab[wf_row()];
+  const int l = wf_lane();
+  wf t, XN, XD, YN, YD, zx, yd2;
+  fp_one(t);
+  zp[0][l] = (uint32_t)t.v;
+  zp[1][l] = (uint32_t)xd.v;
+  t = xd;
+  for (int i = 2; i < 16; i++) {
+    fp_mul(t, t, xd);
+    zp[i][l] = (uint32_t)t.v;
+  }
+  iso1_poly_wide(XN, ISO1_XNUM, 11, xn);
+  iso1_poly_wide(XD, ISO1_XDEN, 10, xn);
+  iso1_poly_wide(YN, ISO1_YNUM, 15, xn);
+  iso1_poly_wide(YD, ISO1_YDEN, 15, xn);
+  fp_mul(zx, XD, xd);     // x_out = XN / zx,  y_out = y YN / YD
+  fp_mul(r.z, zx, YD);    // Z = zx YD
+  fp_sqr(yd2, YD);
+  fp_mul(t, XN, zx);
+  fp_mul(r.x, t, yd2);    // X = XN zx YD^2
+  fp_sqr(t, zx);
+  fp_mul(t, t, zx);
+  fp_mul(t, t, yd2);
+  fp_mul(t, t, YN);
+  fp_mul(r.y, t, y);      // Y = y YN zx^3 YD^2
+}
+__global__ void __launch_bounds__(WIDE_BLOCK) k_hash_to_g1_wide(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst, uint8_t* out) {
+  __shared__ uint32_t pts[4][2][3][16];     // per wave: the Jacobian points of the two maps
+  const int wave = threadIdx.x >> 6, row = (threadIdx.x >> 4) & 3, l = threadIdx.x & 15;
+  const size_t i = (size_t)blockIdx.x * (blockDim.x >> 6) + wave;
+  wf_setup();
+  __syncthreads();
+  if (i >= n) return;
+  if (row >= 2) return;                       // rows 2 and 3 of the wave stay idle: the hash has two independent maps
+  const size_t mi = single_msg ? 0 : i;
+  uint8_t ub[128];
+  expand_message_xmd<128>(ub, nullptr, 0, msgs + offs[mi], (uint32_t)(offs[mi + 1] - offs[mi]), dst.b, dst.len);
+  fp ul;
+  fp_from_be64(ul, ub + 64 * row);            // u0 on row 0, u1 on row 1 (every lane of the row computes the same value)
+  wf u, xn, xd, y;
+  wf_from_local(u, ul);
+  sswu_g1(xn, xd, y, u);
+  jac<wf> mine, q0, q1, acc;
+  iso_map_g1_wide(mine, xn, xd, y);
+  // both rows take both points and continue with identical operands
+  pts[wave][row][0][l] = (uint32_t)mine.x.v;
+  pts[wave][row][1][l] = (uint32_t)mine.y.v;
+  pts[wave][row][2][l] = (uint32_t)mine.z.v;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  q0.x.v = (wfp)pts[wave][0][0][l];
+  q0.y.v = (wfp)pts[wave][0][1][l];
+  q0.z.v = (wfp)pts[wave][0][2][l];
+  q1.x.v = (wfp)pts[wave][1][0][l];
+  q1.y.v = (wfp)pts[wave][1][1][l];
+  q1.z.v = (wfp)pts[wave][1][2][l];
+  jac_add(q0, q0, q1);
+  jac_mul_u64(q1, q0, BLS_X_ABS);             // clear cofactor: h_eff = 1 - x = 1 + |x|
+  jac_add(acc, q1, q0);
+  if (row == 0) {
+    fp X, Y, Z;
+    wf_to_local(X, acc.x);
+    wf_to_local(Y, acc.y);
+    wf_to_local(Z, acc.z);
+    if (l == 0) {
+      g1_jac h;
+      h.x = X;
+      h.y = Y;
+      h.z = Z;
+      store_g1_pt(out, i, h);
+    }
+  }
 }
 #endif  // BLS_TU_WIDE

@@ -135,3 +135,165 @@ __device__ __forceinline__ void w_load_local(fp& r, const uint32_t* slot) {
 #pragma unroll
   for (int i = 0; i < FP_NL; i++) r.l[i] = (int32_t)slot[i];
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// `wf`: the wide element as a field type with the interface of `fp` (fp_mul, fp_add, ..., the fe_* names of curve.cuh), so
+// that the templated curve code (jac<F>: additions, doublings, the cofactor multiplication) and the SSWU map run on rows
+// unchanged: every row of a wave is an independent instance, all rows execute the same instruction stream.  Predicates
+// that need the canonical form (is-zero, parity) send the element through LDS to one lane's lane-local code: they are
+// rare (a few dozen per hash), multiplications are not.
+// Per-workgroup LDS of the wide field layer (WIDE_ROWS rows): the reduction's per-lane constants, a scratch slot per row,
+// the window table of an exponentiation per row.
+#ifndef WIDE_ROWS
+#define WIDE_ROWS 16
+#endif
+struct wide_field_lds {
+  int32_t k_plo[FP_NL][16], k_phi[FP_NL][16];
+  uint32_t slot[WIDE_ROWS][16];
+  int32_t pred[WIDE_ROWS];
+  uint32_t tab[WIDE_ROWS][16][16];
+};
+__shared__ wide_field_lds g_wf;
+
+struct wf {
+  wfp v;
+};
+__device__ __forceinline__ int wf_lane() { return (int)(threadIdx.x & 15u); }
+__device__ __forceinline__ int wf_row() { return (int)(threadIdx.x >> 4); }
+// call once per kernel from all threads (then a barrier) before any wf arithmetic
+__device__ __forceinline__ void wf_setup() {
+  for (unsigned t = threadIdx.x; t < FP_NL * 16; t += blockDim.x) {
+    const int s = t >> 4, l = t & 15, a = l - s, b = l + 16 - s;
+    g_wf.k_plo[s][l] = (a >= 0 && a < FP_NL) ? (int32_t)FP_P[a] : 0;
+    g_wf.k_phi[s][l] = (b >= 0 && b < FP_NL) ? (int32_t)FP_P[b] : 0;
+  }
+}
+__device__ __forceinline__ void wf_consts(wide_consts& K) {
+  const int l = wf_lane();
+  K.lane = l;
+#pragma unroll
+  for (int s = 0; s < FP_NL; s++) {
+    K.plo[s] = g_wf.k_plo[s][l];
+    K.phi[s] = g_wf.k_phi[s][l];
+  }
+  K.keep = l < FP_NL - 1 ? (int32_t)FP_MASK : (l == FP_NL - 1 ? -1 : 0);
+  K.pass = l < FP_NL - 1 ? -1 : 0;
+}
+// the one out-of-line multiplier of the wide field layer (~270 instructions with the constant loads)
+__device__ __noinline__ wfp wf_mul_leaf(wfp a, wfp b) {
+  wide_consts K;
+  wf_consts(K);
+  return w_mul(a, b, K);
+}
+__device__ __forceinline__ int32_t wf_keep() { const int l = wf_lane(); return l < FP_NL - 1 ? (int32_t)FP_MASK : (l == FP_NL - 1 ? -1 : 0); }
+__device__ __forceinline__ int32_t wf_pass() { return wf_lane() < FP_NL - 1 ? -1 : 0; }
+__device__ __forceinline__ wfp wf_norm1(wfp v) {
+  const int32_t c = (v >> FP_LB) & wf_pass();
+  return (v & wf_keep()) + w_shr<1>(c);
+}
+__device__ __forceinline__ void fp_zero(wf& r) { r.v = 0; }
+__device__ __forceinline__ void fp_load(wf& r, const uint32_t* c) { const int l = wf_lane(); r.v = l < FP_NL ? (int32_t)c[l] : 0; }
+__device__ __forceinline__ void fp_one(wf& r) { fp_load(r, FP_ONE); }
+__device__ __forceinline__ void fp_add(wf& r, const wf& a, const wf& b) { r.v = a.v + b.v; }
+__device__ __forceinline__ void fp_sub(wf& r, const wf& a, const wf& b) { r.v = a.v - b.v; }
+__device__ __forceinline__ void fp_neg(wf& r, const wf& a) { r.v = -a.v; }
+__device__ __forceinline__ void fp_dbl(wf& r, const wf& a) { r.v = a.v + a.v; }
+__device__ __forceinline__ void fp_norm(wf& r, const wf& a) { r.v = wf_norm1(a.v); }
+__device__ __forceinline__ void fp_cmov(wf& r, const wf& a, bool c) { r.v = c ? a.v : r.v; }
+// value brought back to (-0.6 p, 0.6 p) (nearest multiple of p estimated from the top limb), limbs normalised; the input may
+// carry limbs up to 2^31 in magnitude and a value of a few dozen p
+__device__ __forceinline__ void fp_reduce(wf& r, const wf& a) {
+  const wfp v1 = wf_norm1(a.v);
+  const int32_t top = w_bcast<13>(v1);
+  const int32_t k = __float2int_rn((float)top * (1.0f / 106513.57f));
+  const int l = wf_lane();
+  const int32_t pl = l < FP_NL ? (int32_t)FP_P[l] : 0;
+  const int64_t t = (int64_t)v1 - (int64_t)k * pl;
+  const int32_t c2 = (int32_t)(t >> FP_LB) & wf_pass();
+  const int64_t keep64 = l < FP_NL - 1 ? (int64_t)FP_MASK : (l == FP_NL - 1 ? (int64_t)-1 : (int64_t)0);
+  r.v = wf_norm1((int32_t)(t & keep64) + w_shr<1>(c2));
+}
+// operands of a product must have limbs below ~2^29.5: sums of up to two normalised values qualify, longer sums are
+// normalised first (one carry pass)
+__device__ __forceinline__ void fp_mul(wf& r, const wf& a, const wf& b) { r.v = wf_mul_leaf(a.v, b.v); }
+__device__ __forceinline__ void fp_sqr(wf& r, const wf& a) { r.v = wf_mul_leaf(a.v, a.v); }
+
+// element of this row -> lane-local fp on every lane of the row (through the row's LDS slot)
+__device__ __forceinline__ void wf_to_local(fp& r, const wf& a) {
+  uint32_t* s = g_wf.slot[wf_row()];
+  s[wf_lane()] = (uint32_t)a.v;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  w_load_local(r, s);
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void wf_from_local(wf& r, const fp& a) {   // every lane of the row holds the same lane-local value
+  const int l = wf_lane();
+  int32_t v = 0;
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) v = (l == i) ? a.l[i] : v;
+  r.v = v;
+}
+__device__ __noinline__ bool wf_is_zero_leaf(wfp v) {
+  fp t;
+  wf a;
+  a.v = v;
+  wf_to_local(t, a);
+  return fp_is_zero(t);
+}
+__device__ __noinline__ uint32_t wf_parity_leaf(wfp v) {
+  fp t;
+  wf a;
+  a.v = v;
+  wf_to_local(t, a);
+  return fp_parity(t);
+}
+__device__ __forceinline__ bool fp_is_zero(const wf& a) { return wf_is_zero_leaf(a.v); }
+__device__ __forceinline__ bool fp_eq(const wf& a, const wf& b) { return wf_is_zero_leaf(a.v - b.v); }
+__device__ __forceinline__ uint32_t fp_parity(const wf& a) { return wf_parity_leaf(a.v); }
+
+// a^e for a public exponent (4-bit windows; the table lives in the row's LDS block, the accumulator in a register)
+__device__ __noinline__ void fp_pow(wf& r, const wf& a, const uint32_t* e, int nbits) {
+  uint32_t (*tab)[16] = g_wf.tab[wf_row()];
+  const int l = wf_lane();
+  wf t, one, a1;
+  fp_one(one);
+  fp_norm(a1, a);
+  tab[0][l] = (uint32_t)one.v;
+  tab[1][l] = (uint32_t)a1.v;
+  t = a1;
+  for (int i = 2; i < 16; i++) {
+    fp_mul(t, t, a1);
+    tab[i][l] = (uint32_t)t.v;
+  }
+  wide_consts K;
+  wf_consts(K);
+  wfp acc = one.v;
+  const int ndig = (nbits + 3) / 4;
+  for (int d = ndig - 1; d >= 0; d--) {
+    if (d != ndig - 1) {
+      acc = w_mul(acc, acc, K);
+      acc = w_mul(acc, acc, K);
+      acc = w_mul(acc, acc, K);
+      acc = w_mul(acc, acc, K);
+    }
+    const uint32_t dig = (e[d >> 3] >> ((d & 7) * 4)) & 15u;
+    if (dig) acc = w_mul(acc, (wfp)tab[dig][l], K);
+  }
+  r.v = acc;
+}
+
+// the fe_* names of curve.cuh
+__device__ __forceinline__ void fe_add(wf& r, const wf& a, const wf& b) { fp_add(r, a, b); }
+__device__ __forceinline__ void fe_sub(wf& r, const wf& a, const wf& b) { fp_sub(r, a, b); }
+__device__ __forceinline__ void fe_mul(wf& r, const wf& a, const wf& b) { fp_mul(r, a, b); }
+__device__ __forceinline__ void fe_sqr(wf& r, const wf& a) { fp_sqr(r, a); }
+__device__ __forceinline__ void fe_neg(wf& r, const wf& a) { fp_neg(r, a); }
+__device__ __forceinline__ void fe_dbl(wf& r, const wf& a) { fp_dbl(r, a); }
+__device__ __forceinline__ bool fe_is_zero(const wf& a) { return fp_is_zero(a); }
+__device__ __forceinline__ bool fe_eq(const wf& a, const wf& b) { return fp_eq(a, b); }
+__device__ __forceinline__ void fe_zero(wf& r) { fp_zero(r); }
+__device__ __forceinline__ void fe_one(wf& r) { fp_one(r); }
+__device__ __forceinline__ void fe_cmov(wf& r, const wf& a, bool c) { fp_cmov(r, a, c); }
+__device__ __forceinline__ void fe_norm(wf& r, const wf& a) { fp_norm(r, a); }
+__device__ __forceinline__ void fe_reduce(wf& r, const wf& a) { fp_reduce(r, a); }

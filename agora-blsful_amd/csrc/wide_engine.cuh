@@ -1,31 +1,27 @@
-// The row-wide engine: Fp12 arithmetic of ONE item on a 256-thread workgroup (four waves, one per SIMD of a CU, sixteen
-// DPP rows), every Fp value living in LDS as sixteen words (limb j at word j, csrc/wide.cuh).  An operation is a table
-// (csrc/wide_tables.cuh, generated and oracle-checked by tools/gen_wide_tables.py): product sub-rounds in which every row
-// multiplies two short sums of values, then one linear phase in which up to sixteen rows combine products (and old values)
-// into the new coefficients and reduce them.  A program -- e.g. the hard part of the final exponentiation, 363 steps -- is
-// a table of (operation, destination array, operand arrays) words that one inlined interpreter loop walks, so the
-// multiplier's per-lane constants stay in registers and every access is a plain LDS access.  Additions cost one
-// instruction here and a product ~240, against ~500 plus a few hundred instructions of carries and selections per product
-// round of the lane-pair form (coop.cuh) -- and on a lone wave time is instruction count.
+// The row-wide engine: Fp12 / twist-point arithmetic of ONE item on a 256-thread workgroup (four waves, one per SIMD of a
+// CU, sixteen DPP rows), every Fp value living in LDS as sixteen words (limb j at word j, csrc/wide.cuh).  An operation is
+// a table (csrc/wide_tables.cuh, generated and oracle-checked by tools/gen_wide_tables.py): product sub-rounds in which
+// every row multiplies two short sums of values, then one linear phase in which rows combine products (and old values) into
+// new values and reduce them.  A program -- the key's line coefficients, the Miller loop, the final exponentiation: ~850
+// steps for one core_verify -- is a table of (operation, destination array, operand arrays) words that one inlined
+// interpreter loop walks, so the multiplier's per-lane constants stay in registers and every access is a plain LDS access.
+// Additions cost one instruction here and a product ~240, against ~500 plus a few hundred instructions of carries and
+// selections per product round of the lane-pair form (coop.cuh) -- and on a lone wave time is instruction count.
 #pragma once
+#include "tower_split.cuh"
 #include "wide.cuh"
 #include "wide_tables.cuh"
 
-// value store (indices of 16-word values): the named arrays WV_F.. of wide_tables.cuh, then product scratch, then constants
-#define WV_TMP 60
-#define WV_CONST (WV_TMP + WIDE_MAX_TMP)
-#define WV_COUNT (WV_CONST + 24)
 #define WIDE_NPROD (sizeof(WIDE_PROD) / sizeof(wide_prod))
 #define WIDE_NLIN (sizeof(WIDE_LIN) / sizeof(wide_lin))
 #define WIDE_NOPS (sizeof(WIDE_OPS) / sizeof(wide_op))
-#define WIDE_PROG_MAX 512
 
 struct wide_lds {
   uint32_t V[WV_COUNT][16];
   wide_prod prod[WIDE_NPROD];     // the tables and the program are staged in LDS: an interpreter on a lone wave cannot
   wide_lin lin[WIDE_NLIN];        // afford a global-memory round trip per step
   wide_op ops[WIDE_NOPS];
-  uint32_t prog[WIDE_PROG_MAX];
+  uint32_t prog[2 * WIDE_PROG_MAX];
   int flag;
 };
 
@@ -35,7 +31,7 @@ __device__ __forceinline__ void wide_stage(wide_lds& S, const uint32_t* prog, in
   for (unsigned t = threadIdx.x; t < sizeof(WIDE_PROD) / 4; t += blockDim.x) dp[t] = sp[t];
   for (unsigned t = threadIdx.x; t < sizeof(WIDE_LIN) / 4; t += blockDim.x) dl[t] = sl[t];
   for (unsigned t = threadIdx.x; t < sizeof(WIDE_OPS) / 4; t += blockDim.x) dq[t] = so[t];
-  for (int t = threadIdx.x; t < prog_len; t += blockDim.x) S.prog[t] = prog[t];
+  for (int t = threadIdx.x; t < 2 * prog_len; t += blockDim.x) S.prog[t] = prog[t];
   for (int t = threadIdx.x; t < 24 * 16; t += blockDim.x) {    // Frobenius constants xi^(k (p^j - 1) / 6): value 12 (j - 1) + 2 k + component
     const int v = t >> 4, l = t & 15, j = v / 12, k = (v % 12) >> 1, comp = v & 1;
     S.V[WV_CONST + v][l] = l < FP_NL ? (j == 0 ? FROB1[k][comp * FP_NL + l] : FROB2[k][comp * FP_NL + l]) : 0u;
@@ -59,38 +55,51 @@ __device__ __forceinline__ wfp w_finish(int64_t acc, const wide_consts& K) {
   return w_norm(v2, K);
 }
 
+// T <- F^-1 on lane pair 0 of the workgroup with the lane-split tower code (tower_split.cuh): the one operation of a
+// pairing that is neither a product table nor linear (one safegcd inversion inside)
+__device__ __noinline__ void wide_inv_f(wide_lds& S) {
+  if (threadIdx.x < 2) {
+    const int hi = (int)threadIdx.x;
+    fp12_t<hfp2> a, b;
+    hfp2* ca[6] = {&a.c0.a0, &a.c1.a0, &a.c0.a1, &a.c1.a1, &a.c0.a2, &a.c1.a2};   // coefficient k of w^k in tower order
+    hfp2* cb[6] = {&b.c0.a0, &b.c1.a0, &b.c0.a1, &b.c1.a1, &b.c0.a2, &b.c1.a2};
+#pragma unroll
+    for (int k = 0; k < 6; k++) w_load_local(ca[k]->v, S.V[WV_F + 2 * k + hi]);
+    fp12_inv(b, a);
+#pragma unroll
+    for (int k = 0; k < 6; k++) w_store_local(S.V[WV_T + 2 * k + hi], cb[k]->v);
+  }
+}
+
 // runs S.prog[0 .. prog_len): every step is dst = op(a, b) on value arrays (dst may alias an operand: products are staged in
 // the scratch values and a linear row reads nothing that another row writes).  Call from all 256 threads.
 __device__ __forceinline__ void wide_exec(wide_lds& S, int prog_len, const wide_consts& K) {
   const int row = (int)(threadIdx.x >> 4), lane = (int)(threadIdx.x & 15u);
   for (int pc = 0; pc < prog_len; pc++) {
-    const uint32_t w = S.prog[pc];
-    const wide_op op = S.ops[w & 0xffu];
-    const uint32_t bd = (w >> 8) & 0xffu, ba = (w >> 16) & 0xffu, bb = op.b_is_const ? (uint32_t)WV_CONST : (op.b_is_a ? ba : (w >> 24));
+    const uint32_t w0 = S.prog[2 * pc], w1 = S.prog[2 * pc + 1];
+    const uint32_t opid = w0 & 0xffu;
+    if (opid == WOP_INV) {
+      wide_inv_f(S);
+      __syncthreads();
+      continue;
+    }
+    const wide_op op = S.ops[opid];
+    const uint32_t bd = w0 >> 16, ba = w1 & 0xffffu, bb = op.b_is_const ? (uint32_t)WV_CONST : (op.b_is_a ? ba : (w1 >> 16));
     if (op.nsub) {
-      // software pipeline: the operands of sub-round t + 1 (and the table entry of t + 2) are fetched before the product of
-      // sub-round t runs -- products read only operand arrays and constants, never the scratch values they write
       wide_prod e = S.prod[op.prod_off + row];
-      wfp a0 = (wfp)S.V[ba + e.a[0]][lane], a1 = (wfp)S.V[ba + e.a[1]][lane];
-      wfp b0 = (wfp)S.V[bb + e.b[0]][lane], b1 = (wfp)S.V[bb + e.b[1]][lane];
       for (int t = 0; t < op.nsub; t++) {
+        const wfp a0 = (wfp)S.V[ba + e.a[0]][lane], a1 = (wfp)S.V[ba + e.a[1]][lane];
+        const wfp b0 = (wfp)S.V[bb + e.b[0]][lane], b1 = (wfp)S.V[bb + e.b[1]][lane];
         const wfp A = a0 * (int32_t)e.ca[0] + a1 * (int32_t)e.ca[1];
         const wfp B = b0 * (int32_t)e.cb[0] + b1 * (int32_t)e.cb[1];
         const uint32_t out = WV_TMP + e.out;
-        if (t + 1 < op.nsub) {
-          e = S.prod[op.prod_off + 16 * (t + 1) + row];
-          a0 = (wfp)S.V[ba + e.a[0]][lane];
-          a1 = (wfp)S.V[ba + e.a[1]][lane];
-          b0 = (wfp)S.V[bb + e.b[0]][lane];
-          b1 = (wfp)S.V[bb + e.b[1]][lane];
-        }
-        const wfp p = w_mul(A, B, K);
-        S.V[out][lane] = (uint32_t)p;
+        if (t + 1 < op.nsub) e = S.prod[op.prod_off + 16 * (t + 1) + row];     // the next entry travels while this product runs
+        S.V[out][lane] = (uint32_t)w_mul(A, B, K);
       }
       __syncthreads();
     }
-    if (row < op.nlin) {
-      const wide_lin* L = &S.lin[op.lin_off + row];
+    for (int r = row; r < op.nlin; r += 16) {
+      const wide_lin* L = &S.lin[op.lin_off + r];
       const int n = L->n;
       int64_t acc = 0;
       // six terms per step: their value loads are issued together (the unused ones carry coefficient zero)
