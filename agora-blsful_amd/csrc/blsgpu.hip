@@ -417,9 +417,9 @@ int run_pairing2(Ctx* c, size_t n, uint32_t* d_pairs, uint32_t* d_f, int32_t* d_
       uint32_t* d_easy = (uint32_t*)arena_take(c, (size_t)WIDE_EASY_WORDS * 4 * n);   // arena_reserve keeps 1 MiB of headroom: 768 B per item
       if (!d_easy) return fail(BLSGPU_E_HIP, "internal: arena too small");
       KL(KID_PAIRING_COOP, k_pairing_coop_easy, dim3((unsigned)n), dim3(BLS_BLOCK), n, (const uint32_t*)d_pairs, (const int32_t*)d_status, fixed_g2, d_easy);
-      KL(KID_WIDE, k_finalexp_wide, dim3((unsigned)n), dim3(WIDE_BLOCK), n, (const uint32_t*)d_easy, d_status);
+      KL(KID_WIDE, k_finalexp_wide, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), n, (const uint32_t*)d_easy, d_status);
     } else {
-      KL(KID_WIDE, k_pairing_wide, dim3((unsigned)n), dim3(WIDE_BLOCK), n, (const uint32_t*)d_pairs, d_status, fixed_g2);
+      KL(KID_WIDE, k_pairing_wide, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), n, (const uint32_t*)d_pairs, d_status, fixed_g2);
     }
   } else if (n <= coop_max_items()) {  // small batches: one wave per item
     KL(KID_PAIRING_COOP, k_pairing_coop, dim3((unsigned)n), dim3(BLS_BLOCK), n, d_pairs, d_status, fixed_g2);

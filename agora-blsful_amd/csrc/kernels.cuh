@@ -262,7 +262,9 @@ __global__ void k_decompress(size_t n, const uint8_t* bytes, int legacy, uint8_t
 #include "util_kernels.cuh"
 __global__ void k_wide_mul_test(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, int reps);
 // single-verification latency path: Miller loop + easy part per item on one wave (coop.cuh), hard part on the row-wide engine
-#define WIDE_BLOCK 256
+#include "wide_rows.cuh"
+#define WIDE_BLOCK 256            // threads of the wide field layer's kernels (hash, multiplier self-test)
+#define WIDE_ENGINE_BLOCK (16 * WIDE_TABLE_ROWS)   // threads of the engine kernels: one DPP row per product of a sub-round
 #define WIDE_EASY_WORDS (12 * 16)     // f^((p^6-1)(p^2+1)) of one item in the engine's value layout
 __global__ void k_pairing_coop_easy(size_t n, const uint32_t* pairs, const int32_t* status, int fixed_g2, uint32_t* easy);
 __global__ void k_finalexp_wide(size_t n, const uint32_t* easy, int32_t* status);
@@ -1605,7 +1607,7 @@ __global__ void __launch_bounds__(WIDE_BLOCK) k_wide_mul_test(size_t n, const ui
 }
 #include "wide_engine.cuh"
 // the hard part of the final exponentiation and the comparison with one, one 256-thread workgroup per item
-__global__ void __launch_bounds__(WIDE_BLOCK) k_finalexp_wide(size_t n, const uint32_t* easy, int32_t* status) {
+__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_finalexp_wide(size_t n, const uint32_t* easy, int32_t* status) {
   __shared__ wide_lds S;
   const size_t item = blockIdx.x;
   if (item >= n) return;
@@ -1613,7 +1615,7 @@ __global__ void __launch_bounds__(WIDE_BLOCK) k_finalexp_wide(size_t n, const ui
   wide_consts K;
   wide_init(K);
   wide_stage(S, WIDE_PROG_FINAL_HARD, WIDE_PROG_FINAL_HARD_LEN);
-  for (int t = threadIdx.x; t < WIDE_EASY_WORDS; t += WIDE_BLOCK) S.V[WV_F + (t >> 4)][t & 15] = easy[item * WIDE_EASY_WORDS + t];
+  for (int t = threadIdx.x; t < WIDE_EASY_WORDS; t += WIDE_ENGINE_BLOCK) S.V[WV_F + (t >> 4)][t & 15] = easy[item * WIDE_EASY_WORDS + t];
   if (threadIdx.x == 0) S.flag = 1;
   __syncthreads();
   wide_exec(S, WIDE_PROG_FINAL_HARD_LEN, K);
@@ -1638,7 +1640,7 @@ __global__ void __launch_bounds__(WIDE_BLOCK) k_finalexp_wide(size_t n, const ui
 // the Miller loop, the final exponentiation and the comparison with one (program PAIR_FIXED when pair 1's G2 argument is
 // the constant -g2, whose lines come from the table G2NEG_LINES; PAIR_GENERAL otherwise).  pairs: the affine workspace that
 // the prepare stage writes (word-major: word k of item i at pairs[k n + i]).
-__global__ void __launch_bounds__(WIDE_BLOCK) k_pairing_wide(size_t n, const uint32_t* pairs, int32_t* status, int fixed_g2) {
+__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_wide(size_t n, const uint32_t* pairs, int32_t* status, int fixed_g2) {
   __shared__ wide_lds S;
   const size_t item = blockIdx.x;
   if (item >= n) return;
@@ -1668,7 +1670,7 @@ __global__ void __launch_bounds__(WIDE_BLOCK) k_pairing_wide(size_t n, const uin
     for (int v = 1; v < 12; v++) S.V[WV_F + v][l] = 0u;
   }
   if (fixed_g2)                                      // pair 1's unscaled lines: the precomputed table of -g2
-    for (int t = threadIdx.x; t < WIDE_STEPS * 6 * 16; t += WIDE_BLOCK) {
+    for (int t = threadIdx.x; t < WIDE_STEPS * 6 * 16; t += WIDE_ENGINE_BLOCK) {
       const int st = t / 96, v = (t % 96) >> 4, ll = t & 15;
       S.V[WV_L + 12 * st + 6 + v][ll] = ll < FP_NL ? G2NEG_LINES[st][v * FP_NL + ll] : 0u;
     }

@@ -22,6 +22,7 @@ from oracle.py import bls381 as c  # noqa: E402
 P = c.P
 DST, SA, SB, TMP, CONST = 0, 1, 2, 3, 4
 MAXLIN = 18
+ROWS = int(os.environ.get('WIDE_ROWS', '16'))     # DPP rows of the workgroup = products per sub-round (16: four waves, one per SIMD)
 
 
 def idx(slot, off):
@@ -565,7 +566,7 @@ def check_programs():
 def emit(path, lay):
     out = []
     out.append('// GENERATED by tools/gen_wide_tables.py -- do not edit.  Operation tables and programs of the row-wide engine')
-    out.append('// (wide_engine.cuh).  Every table and program was checked against the oracle\'s Fp12 arithmetic and pairing by the generator.')
+    out.append('// (wide_engine.cuh).  Every table and program was checked against the oracle (Fp12 arithmetic, whole pairing checks) by the generator.')
     out.append('#pragma once')
     out.append('// product row: out = (ca0 V[A + a0] + ca1 V[A + a1]) * (cb0 V[B + b0] + cb1 V[B + b1]) -> V[TMP + out]; A, B: the step\'s operand arrays')
     out.append('struct wide_prod { uint8_t a[2], b[2]; int8_t ca[2], cb[2]; uint8_t out, pad[3]; };')
@@ -574,13 +575,13 @@ def emit(path, lay):
     out.append('struct wide_op { uint16_t prod_off, lin_off; uint8_t nsub, nlin, b_is_const, b_is_a; };')
     prods, lins, ops = [], [], []
     for op in OPS:
-        nsub = (len(op.prods) + 15) // 16
+        nsub = (len(op.prods) + ROWS - 1) // ROWS
         assert len(op.lins) <= 32 and op.ntmp < 127
         bslots = {i >> 12 for _, b, _ in op.prods for _, i in b}
         aslots = {i >> 12 for a, _, _ in op.prods for _, i in a}
         assert aslots <= {SA} and len(bslots) <= 1 and bslots <= {SA, SB, CONST}, (op.name, aslots, bslots)
         ops.append((op.name, len(prods), len(lins), nsub, len(op.lins), 1 if bslots == {CONST} else 0, 1 if bslots == {SA} else 0, len(op.prods)))
-        rows = list(op.prods) + [None] * (nsub * 16 - len(op.prods))
+        rows = list(op.prods) + [None] * (nsub * ROWS - len(op.prods))
         for r in rows:
             if r is None:      # an idle row multiplies zero by zero into a scratch value that nothing reads
                 prods.append('{{0, 0}, {0, 0}, {0, 0}, {0, 0}, %d, {0, 0, 0}}' % op.ntmp)
@@ -622,6 +623,7 @@ def emit(path, lay):
         out.append('#define WV_%s %d' % (k, v))
     out.append('#define WV_COUNT %d' % lay.count)
     out.append('#define WIDE_STEPS %d' % NSTEPS)
+    out.append('#include "wide_rows.cuh"')
     out.append('// programs: two words per step: op | dst << 16,  a | b << 16  (value-store indices of the arrays)')
     for pname, st in PROGRAMS:
         words = []
@@ -635,6 +637,9 @@ def emit(path, lay):
         out.append('};')
     out.append('#define WIDE_PROG_MAX %d' % max(len(st) for _, st in PROGRAMS))
     open(path, 'w').write('\n'.join(out) + '\n')
+    open(os.path.join(os.path.dirname(path), 'wide_rows.cuh'), 'w').write(
+        '// GENERATED by tools/gen_wide_tables.py -- do not edit.\n#pragma once\n'
+        '#define WIDE_TABLE_ROWS %d   // DPP rows per product sub-round the engine tables are laid out for (workgroup = 16 x this many threads)\n' % ROWS)
 
 
 if __name__ == '__main__':
