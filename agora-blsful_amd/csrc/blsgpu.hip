@@ -1197,9 +1197,9 @@ int blsgpu_multi_verify(int sig_group, int scheme, const void* pks, size_t n, co
     }
     HIPCK(hipEventRecord(c->ev_fork, c->stream));
     HIPCK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-    if (sig_group == 1)
-      hipLaunchKernelGGL(k_hash_to_g1, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0,
-                         scheme_dst(sig_group, scheme), d_hash, 1);
+    if (sig_group == 1)   // one wave, the two SSWU maps on two DPP rows in the row-wide field type (csrc/wide.cuh)
+      hipLaunchKernelGGL(k_hash_to_g1_wide, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, 1,
+                         scheme_dst(sig_group, scheme), d_hash);
     else
       hipLaunchKernelGGL(k_hash_to_g2, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0,
                          scheme_dst(sig_group, scheme), d_hash, 1);
@@ -1626,8 +1626,8 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
   HIPCK(hipEventRecord(c->ev_fork, c->stream));
   HIPCK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
   if (sig_group == 1)
-    hipLaunchKernelGGL(k_hash_to_g1, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0,
-                       scheme_dst(sig_group, scheme), d_hash, 1);
+    hipLaunchKernelGGL(k_hash_to_g1_wide, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, 1,
+                       scheme_dst(sig_group, scheme), d_hash);
   else
     hipLaunchKernelGGL(k_hash_to_g2, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0,
                        scheme_dst(sig_group, scheme), d_hash, 1);

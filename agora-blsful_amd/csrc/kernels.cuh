@@ -1738,6 +1738,61 @@ __device__ __noinline__ void iso_map_g1_wide(jac<wf>& r, const wf& xn, const wf&
   fp_mul(t, t, YN);
   fp_mul(r.y, t, y);      // Y = y YN zx^3 YD^2
 }
+// One G1 doubling by TWO rows that hold the same point (the schedule of h2c.cuh's jac_dbl_pair one level up): the seven
+// field products of dbl-2009-l as FOUR steps -- row 0: A = X^2, F = (3A)^2, YZ, E (D - X3); row 1: B = Y^2, C = B^2,
+// (X + B)^2 -- the rows exchange single registers (an element is one VGPR per lane here).  Same operation order and
+// reductions as jac_dbl_body.
+__device__ __forceinline__ void wf_row_swap(wf& r, const wf& a) { r.v = __shfl_xor(a.v, 16, 64); }
+__device__ __forceinline__ void wf_sel(wf& r, bool c, const wf& a, const wf& b) { r.v = c ? a.v : b.v; }
+__device__ __forceinline__ void jac_dbl_rows(jac<wf>& p, bool hi) {
+  wf s1, s2, s3, in, a, b, o2, o3, D, E, t, x3, y3, z3, c8;
+  wf_sel(in, hi, p.y, p.x);
+  fp_sqr(s1, in);                 // row 0: A = X^2           row 1: B = Y^2
+  fp_dbl(E, s1);
+  fp_add(E, E, s1);
+  fp_reduce(E, E);                // row 0: E = 3A
+  wf_sel(in, hi, s1, E);
+  fp_sqr(s2, in);                 // row 0: F = E^2           row 1: C = B^2
+  fp_add(t, p.x, s1);             //                          row 1: X + B
+  wf_sel(a, hi, t, p.y);
+  wf_sel(b, hi, t, p.z);
+  fp_mul(s3, a, b);               // row 0: Y Z               row 1: (X + B)^2
+  wf_row_swap(o2, s2);            // row 0: C
+  wf_row_swap(o3, s3);            // row 0: (X + B)^2
+  fp_sub(t, o3, s1);
+  fp_sub(t, t, o2);
+  fp_dbl(D, t);
+  fp_reduce(D, D);                // D = 2((X + B)^2 - A - C)
+  fp_dbl(t, D);
+  fp_sub(t, s2, t);
+  fp_reduce(x3, t);               // X3 = F - 2D
+  fp_sub(t, D, x3);
+  fp_mul(t, E, t);                // E (D - X3)
+  fp_dbl(c8, o2);
+  fp_dbl(c8, c8);
+  fp_reduce(c8, c8);
+  fp_dbl(c8, c8);                 // 8C
+  fp_sub(t, t, c8);
+  fp_reduce(y3, t);
+  fp_dbl(z3, s3);
+  fp_reduce(z3, z3);              // Z3 = 2YZ
+  wf_row_swap(a, x3);
+  wf_row_swap(b, y3);
+  wf_row_swap(t, z3);
+  wf_sel(p.x, hi, a, x3);
+  wf_sel(p.y, hi, b, y3);
+  wf_sel(p.z, hi, t, z3);
+}
+// [k] P (left to right), the doublings shared by the two rows; both rows hold the same P and end with the same result
+__device__ __noinline__ void jac_mul_u64_rows(jac<wf>& r, const jac<wf>& p, uint64_t k, bool hi) {
+  jac<wf> acc;
+  jac_set_inf(acc);
+  for (int i = 63; i >= 0; i--) {
+    jac_dbl_rows(acc, hi);                        // the identity (Z = 0) stays the identity: Z3 = 2 Y Z
+    if ((k >> i) & 1) jac_add(acc, acc, p);
+  }
+  r = acc;
+}
 __global__ void __launch_bounds__(WIDE_BLOCK) k_hash_to_g1_wide(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst, uint8_t* out) {
   __shared__ uint32_t pts[4][2][3][16];     // per wave: the Jacobian points of the two maps
   const int wave = threadIdx.x >> 6, row = (threadIdx.x >> 4) & 3, l = threadIdx.x & 15;
@@ -1769,7 +1824,7 @@ __global__ void __launch_bounds__(WIDE_BLOCK) k_hash_to_g1_wide(size_t n, const 
   q1.y.v = (wfp)pts[wave][1][1][l];
   q1.z.v = (wfp)pts[wave][1][2][l];
   jac_add(q0, q0, q1);
-  jac_mul_u64(q1, q0, BLS_X_ABS);             // clear cofactor: h_eff = 1 - x = 1 + |x|
+  jac_mul_u64_rows(q1, q0, BLS_X_ABS, row == 1);   // clear cofactor: h_eff = 1 - x = 1 + |x|
   jac_add(acc, q1, q0);
   if (row == 0) {
     fp X, Y, Z;
