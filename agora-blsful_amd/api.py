@@ -35,7 +35,7 @@ EXPORTS = [
     'blsgpu_aggregate_partial', 'blsgpu_fp12_product_is_one', 'blsgpu_core_verify', 'blsgpu_deserialize', 'blsgpu_pop_verify_batch', 'blsgpu_aggregate_secure',
     'blsgpu_signcrypt_valid_batch', 'blsgpu_sig_proof_verify_batch', 'blsgpu_pairing2_check_batch',
     'blsgpu_init_devices', 'blsgpu_device_count', 'blsgpu_sort_keys', 'blsgpu_sorted_keys_digest',
-    'blsgpu_coefficients_for_range', 'blsgpu_first_duplicate_message', 'blsgpu_first_occurrence', 'blsgpu_core_verify_hashed', 'blsgpu_debug_wide_mul', 'blsgpu_signatures_from_tagged', 'blsgpu_signatures_to_tagged',
+    'blsgpu_coefficients_for_range', 'blsgpu_first_duplicate_message', 'blsgpu_first_occurrence', 'blsgpu_core_verify_hashed', 'blsgpu_debug_wide_mul', 'blsgpu_debug_wide_program', 'blsgpu_signatures_from_tagged', 'blsgpu_signatures_to_tagged',
 ]
 
 
@@ -140,6 +140,7 @@ def load_library(path=None):
         lib.blsgpu_first_occurrence.argtypes = [u8p, u32p, sz, sz, u32p]
         lib.blsgpu_core_verify_hashed.argtypes = [ci, vp, vp, vp, sz, i32p]
         lib.blsgpu_debug_wide_mul.argtypes = [u8p, u8p, sz, ci, u8p]
+        lib.blsgpu_debug_wide_program.argtypes = [vp, sz, ci, u8p, u8p]
         lib.blsgpu_signatures_from_tagged.argtypes = [ci, u8p, sz, u8p, vp, i32p]
         lib.blsgpu_signatures_to_tagged.argtypes = [ci, u8p, vp, sz, ci, u8p]
         _lib = lib
@@ -449,6 +450,33 @@ def debug_wide_mul(a_list, b_list, reps=1):
     out = ctypes.create_string_buffer(48 * max(n, 1))
     _check(lib.blsgpu_debug_wide_mul(_ptr(b''.join(a_list)), _ptr(b''.join(b_list)), n, reps, ctypes.cast(out, ctypes.c_void_p)))
     return [out.raw[48 * i:48 * (i + 1)] for i in range(n)]
+
+
+_wide_defs = None
+
+
+def wide_defs():
+    """{name: value} of the engine's operation ids (WOP_*) and value arrays (WV_*), read from csrc/wide_tables.cuh"""
+    global _wide_defs
+    if _wide_defs is None:
+        import re
+        text = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'wide_tables.cuh')).read()
+        _wide_defs = {m.group(1): int(m.group(2)) for m in re.finditer(r'^#define (W(?:OP|V)_\w+) (\d+)', text, re.M)}
+    return _wide_defs
+
+
+def debug_wide_program(steps, f_raw, reps=1):
+    """steps: [(op, dst, a, b)] by name (e.g. ('MUL', 'T', 'F', 'U')); f_raw: twelve 48-byte Montgomery elements.  Returns
+    the twelve elements of T after `reps` runs of the program on the row-wide engine."""
+    lib = init()
+    d = wide_defs()
+    words = []
+    for op, dst, a, b in steps:
+        words += [d['WOP_' + op] | d['WV_' + dst] << 16, d['WV_' + a] | d['WV_' + b] << 16]
+    arr = (ctypes.c_uint32 * len(words))(*words)
+    out = ctypes.create_string_buffer(576)
+    _check(lib.blsgpu_debug_wide_program(ctypes.cast(arr, ctypes.c_void_p), len(steps), reps, _ptr(b''.join(f_raw)), ctypes.cast(out, ctypes.c_void_p)))
+    return [out.raw[48 * i:48 * (i + 1)] for i in range(12)]
 
 
 def first_duplicate_message(msgs):

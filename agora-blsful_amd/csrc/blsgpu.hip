@@ -2213,6 +2213,31 @@ int blsgpu_debug_wide_mul(const uint8_t* a, const uint8_t* b, size_t n, int reps
 }
 API_CATCH
 
+/* Self-test / measurement hook of the row-wide engine (csrc/wide_engine.cuh): runs a caller-supplied program (two words per
+ * step, the format of csrc/wide_tables.cuh) `reps` times on one workgroup with F = U = W = ACC = the Fp12 at f_in (twelve
+ * 48-byte Montgomery elements, coefficient order of the tables) and T = 0, and returns T.  Steps may only name the Fp12
+ * arrays F, T, U, W, ACC. */
+int blsgpu_debug_wide_program(const uint32_t* prog, size_t len, int reps, const uint8_t* f_in, uint8_t* t_out) try {
+  if (!initialised()) return NOT_INIT();
+  if (!prog || !f_in || !t_out || reps < 1 || len < 1 || is_device_ptr(prog)) return fail(BLSGPU_E_ARG, "bad argument");
+  if (!wide_prog_is_fp12(prog, len)) return fail(BLSGPU_E_ARG, "program: too long, or a step is not an Fp12 operation on F, T, U, W, ACC");
+  CTX_ACQUIRE(c);
+  int rc = arena_reserve(c, pad256(8 * len) + 2 * pad256(576) + 4096);
+  if (rc) return rc;
+  c->arena_off = 0;
+  const void *d_prog, *d_in;
+  if ((rc = stage_in(c, prog, 8 * len, &d_prog))) return rc;
+  if ((rc = stage_in(c, f_in, 576, &d_in))) return rc;
+  uint8_t* d_out = is_device_ptr(t_out) ? t_out : (uint8_t*)arena_take(c, 576);
+  if (!d_out) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  KL(KID_WIDE, k_wide_prog_test, dim3(1), dim3(WIDE_ENGINE_BLOCK), (const uint32_t*)d_prog, (int)len, reps, (const uint8_t*)d_in, d_out);
+  HIPCK(hipGetLastError());
+  if (d_out != t_out && (rc = copy_out(c, t_out, d_out, 576))) return rc;
+  SYNC_FLUSH(c);
+  return 0;
+}
+API_CATCH
+
 int blsgpu_sign_batch(int sig_group, int scheme, const uint8_t* sks, const uint8_t* msgs, const uint64_t* msg_offsets, size_t n,
                       void* out_pks, void* out_sigs) try {
   int rc = check_common(sig_group, scheme, BLSGPU_FMT_RAW_PROJ);

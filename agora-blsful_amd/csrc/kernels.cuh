@@ -268,6 +268,8 @@ __global__ void k_wide_mul_test(size_t n, const uint8_t* a, const uint8_t* b, ui
 #define WIDE_EASY_WORDS (12 * 16)     // f^((p^6-1)(p^2+1)) of one item in the engine's value layout
 __global__ void k_pairing_coop_easy(size_t n, const uint32_t* pairs, const int32_t* status, int fixed_g2, uint32_t* easy);
 __global__ void k_finalexp_wide(size_t n, const uint32_t* easy, int32_t* status);
+__global__ void k_wide_prog_test(const uint32_t* prog, int len, int reps, const uint8_t* fin, uint8_t* tout);
+bool wide_prog_is_fp12(const uint32_t* prog, size_t len);   // host: what k_wide_prog_test may be given
 __global__ void k_pairing_wide(size_t n, const uint32_t* pairs, int32_t* status, int fixed_g2);
 __global__ void k_hash_to_g1_wide(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst, uint8_t* out);
 
@@ -1606,9 +1608,45 @@ __global__ void __launch_bounds__(WIDE_BLOCK) k_wide_mul_test(size_t n, const ui
   }
 }
 #include "wide_engine.cuh"
+bool wide_prog_is_fp12(const uint32_t* prog, size_t len) {
+  if (len > WIDE_PROG_MAX) return false;
+  for (size_t k = 0; k < len; k++) {
+    const uint32_t w0 = prog[2 * k], w1 = prog[2 * k + 1], op = w0 & 0xffffu;
+    const uint32_t refs[3] = {w0 >> 16, w1 & 0xffffu, w1 >> 16};
+    if (op >= WOP_PDBL1 && op != WOP_MUL_LINE) return false;
+    for (uint32_t r : refs)
+      if (r != WV_F && r != WV_T && r != WV_U && r != WV_W && r != WV_ACC) return false;
+  }
+  return true;
+}
+// self-test / measurement: a caller-supplied program on one workgroup.  F, U, W, ACC <- the Fp12 at fin (twelve 48-byte
+// Montgomery elements), T <- 0; the program runs `reps` times; tout <- T.  (The host entry validates the program words.)
+__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_wide_prog_test(const uint32_t* prog, int len, int reps, const uint8_t* fin, uint8_t* tout) {
+  __shared__ wide_lds_t<wide_tb_f12> S;
+  wide_consts K;
+  wide_init(K);
+  wide_stage(S, prog, len);
+  if (threadIdx.x < 12) {
+    fp x;
+    fp_from_raw(x, (const uint32_t*)(fin + 48 * threadIdx.x));
+    w_store_local(S.V[WV_F + threadIdx.x], x);
+    w_store_local(S.V[WV_U + threadIdx.x], x);
+    w_store_local(S.V[WV_W + threadIdx.x], x);
+    w_store_local(S.V[WV_ACC + threadIdx.x], x);
+    fp_zero(x);
+    w_store_local(S.V[WV_T + threadIdx.x], x);
+  }
+  __syncthreads();
+  for (int r = 0; r < reps; r++) wide_exec(S, len, K, WV_F, WV_T);
+  if (threadIdx.x < 12) {
+    fp x;
+    w_load_local(x, S.V[WV_T + threadIdx.x]);
+    fp_to_raw((uint32_t*)(tout + 48 * threadIdx.x), x);
+  }
+}
 // the hard part of the final exponentiation and the comparison with one, one 256-thread workgroup per item
 __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_finalexp_wide(size_t n, const uint32_t* easy, int32_t* status) {
-  __shared__ wide_lds S;
+  __shared__ wide_lds_t<wide_tb_f12> S;
   const size_t item = blockIdx.x;
   if (item >= n) return;
   if (status[item] != BLS_OK) return;                   // uniform over the workgroup
@@ -1618,7 +1656,7 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_finalexp_wide(size_t n, c
   for (int t = threadIdx.x; t < WIDE_EASY_WORDS; t += WIDE_ENGINE_BLOCK) S.V[WV_F + (t >> 4)][t & 15] = easy[item * WIDE_EASY_WORDS + t];
   if (threadIdx.x == 0) S.flag = 1;
   __syncthreads();
-  wide_exec(S, WIDE_PROG_FINAL_HARD_LEN, K);
+  wide_exec(S, WIDE_PROG_FINAL_HARD_LEN, K, WV_F, WV_T);
   // == 1 ?  (lane-local canonical comparison of the twelve components)
   if (threadIdx.x < 12) {
     fp x, one;
@@ -1641,7 +1679,7 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_finalexp_wide(size_t n, c
 // the constant -g2, whose lines come from the table G2NEG_LINES; PAIR_GENERAL otherwise).  pairs: the affine workspace that
 // the prepare stage writes (word-major: word k of item i at pairs[k n + i]).
 __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_wide(size_t n, const uint32_t* pairs, int32_t* status, int fixed_g2) {
-  __shared__ wide_lds S;
+  __shared__ wide_lds_t<wide_tb_f12> S;
   const size_t item = blockIdx.x;
   if (item >= n) return;
   if (status[item] != BLS_OK) return;                   // uniform over the workgroup
@@ -1676,7 +1714,7 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_wide(size_t n, co
     }
   if (threadIdx.x == 0) S.flag = 1;
   __syncthreads();
-  wide_exec(S, fixed_g2 ? WIDE_PROG_PAIR_FIXED_LEN : WIDE_PROG_PAIR_GENERAL_LEN, K);
+  wide_exec(S, fixed_g2 ? WIDE_PROG_PAIR_FIXED_LEN : WIDE_PROG_PAIR_GENERAL_LEN, K, WV_F, WV_T);
   if (threadIdx.x < 12) {
     fp x, one;
     w_load_local(x, S.V[WV_T + threadIdx.x]);

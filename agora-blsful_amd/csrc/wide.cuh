@@ -123,6 +123,60 @@ __device__ __forceinline__ wfp w_mul(wfp a, wfp b, const wide_consts& K) {
   return ((int32_t)v1 & K.keep) + w_shr<1>(c2);
 }
 __device__ __forceinline__ wfp w_sqr(wfp a, const wide_consts& K) { return w_mul(a, a, K); }
+// ---- the two halves of a multiplication on their own, for sums of products that are reduced ONCE (wide_engine.cuh):
+// w_mul_cols: the 27 columns of a * b, not reduced, carried once so that every column fits a signed 32-bit word (below
+// 2^29.6): lane k holds column k in clo and column 16 + k in chi.  ~80 instructions.
+__device__ __forceinline__ void w_mul_cols(int32_t& clo, int32_t& chi, wfp a, wfp b, const wide_consts& K) {
+  int64_t lo = 0, hi = 0;
+  w_mul_prod_step<0>(lo, hi, a, b);
+  w_mul_prod_step<1>(lo, hi, a, b);
+  w_mul_prod_step<2>(lo, hi, a, b);
+  w_mul_prod_step<3>(lo, hi, a, b);
+  w_mul_prod_step<4>(lo, hi, a, b);
+  w_mul_prod_step<5>(lo, hi, a, b);
+  w_mul_prod_step<6>(lo, hi, a, b);
+  w_mul_prod_step<7>(lo, hi, a, b);
+  w_mul_prod_step<8>(lo, hi, a, b);
+  w_mul_prod_step<9>(lo, hi, a, b);
+  w_mul_prod_step<10>(lo, hi, a, b);
+  w_mul_prod_step<11>(lo, hi, a, b);
+  w_mul_prod_step<12>(lo, hi, a, b);
+  w_mul_prod_step<13>(lo, hi, a, b);
+  // a column c (below 2^63 in magnitude) = f0 + f1 2^28 + f2 2^56 with f0, f1 28-bit fields and f2 the signed rest: f1 moves
+  // one column up, f2 two.  Column 26 (chi of lane 10, the single product a13 b13, below 2^36) hands its whole signed rest to
+  // column 27; nothing sits above it.
+  const int32_t l0 = (int32_t)(uint32_t)lo, l1 = (int32_t)(lo >> 32), h0 = (int32_t)(uint32_t)hi, h1 = (int32_t)(hi >> 32);
+  const int32_t lf0 = l0 & (int32_t)FP_MASK, lf1 = (int32_t)__builtin_amdgcn_alignbit((uint32_t)l1, (uint32_t)l0, FP_LB) & (int32_t)FP_MASK, lf2 = l1 >> 24;
+  const int32_t hr = (int32_t)__builtin_amdgcn_alignbit((uint32_t)h1, (uint32_t)h0, FP_LB);
+  const int32_t hf0 = h0 & (int32_t)FP_MASK, hf1 = K.lane < 10 ? (hr & (int32_t)FP_MASK) : (K.lane == 10 ? hr : 0), hf2 = K.lane < 10 ? (h1 >> 24) : 0;
+  clo = lf0 + w_shr<1>(lf1) + w_shr<2>(lf2);
+  chi = hf0 + w_shr<1>(hf1) + w_shr<2>(hf2) + w_shl<15>(lf1) + w_shl<14>(lf2);   // columns 15 -> 16, 14 -> 16, 15 -> 17
+}
+// w_redc_cols: Montgomery reduction of 28 columns (lane k: column k in lo, column 16 + k in hi; magnitudes below 2^62) to
+// the 64-bit limb sums of T / R mod p (lane j: limb j, below 2^40), ready for w_finish / a carry pass
+__device__ __forceinline__ int64_t w_redc_cols(int64_t lo, int64_t hi, const wide_consts& K) {
+  int64_t cy = 0;
+  w_mul_redc_step<0>(lo, hi, cy, K);
+  w_mul_redc_step<1>(lo, hi, cy, K);
+  w_mul_redc_step<2>(lo, hi, cy, K);
+  w_mul_redc_step<3>(lo, hi, cy, K);
+  w_mul_redc_step<4>(lo, hi, cy, K);
+  w_mul_redc_step<5>(lo, hi, cy, K);
+  w_mul_redc_step<6>(lo, hi, cy, K);
+  w_mul_redc_step<7>(lo, hi, cy, K);
+  w_mul_redc_step<8>(lo, hi, cy, K);
+  w_mul_redc_step<9>(lo, hi, cy, K);
+  w_mul_redc_step<10>(lo, hi, cy, K);
+  w_mul_redc_step<11>(lo, hi, cy, K);
+  w_mul_redc_step<12>(lo, hi, cy, K);
+  w_mul_redc_step<13>(lo, hi, cy, K);
+  const uint32_t r0 = (uint32_t)w_shl<14>((int32_t)(uint32_t)lo) | (uint32_t)w_shr<2>((int32_t)(uint32_t)hi);
+  const int32_t r1 = w_shl<14>((int32_t)(lo >> 32)) | w_shr<2>((int32_t)(hi >> 32));
+  int64_t v = (int64_t)(((uint64_t)(uint32_t)r1 << 32) | r0);
+  if (K.lane == 0) v += cy;
+  return v;
+}
+
 
 // lane-local fp <-> wide through LDS: `slot` points at 16 words owned by the row
 __device__ __forceinline__ void w_store_local(uint32_t* slot, const fp& a) {   // one lane writes all 14 limbs (and the two zeros)

@@ -253,6 +253,10 @@ int blsgpu_profile_get(int kernel_id, char* name, size_t name_cap, double* total
 /* Self-test / measurement hook of the row-wide Fp multiplier behind the single-verification latency path (csrc/wide.cuh):
  * out[i] = a[i] * b[i]^reps in Fp, elements as 48-byte Montgomery words (the coordinate format of RAW_PROJ). */
 int blsgpu_debug_wide_mul(const uint8_t* a, const uint8_t* b, size_t n, int reps, uint8_t* out);
+/* The same for the table-driven engine on top of it (csrc/wide_engine.cuh): runs `prog` (len steps of two words, the
+ * format of csrc/wide_tables.cuh, Fp12 operations on the arrays F, T, U, W, ACC only) `reps` times on one workgroup with
+ * F = U = W = ACC = the Fp12 at f_in (twelve 48-byte Montgomery elements) and T = 0; t_out <- T.  prog: host memory. */
+int blsgpu_debug_wide_program(const uint32_t* prog, size_t len, int reps, const uint8_t* f_in, uint8_t* t_out);
 
 /* Sign side, provided so that benchmarks and tests can build inputs on the device:
  * pk[i] = sk[i] * g (SecretKey::public_key, src/secret_key.rs:342-344) and

@@ -24,3 +24,54 @@ def test_wide_multiplier_matches_integers(api):
         got = api.debug_wide_mul([util.fp_raw(x) for x in a[:40]], [util.fp_raw(y) for y in b[:40]], reps)
         for x, y, g in zip(a, b, got):
             assert util.fp_from_raw(g) == x * pow(y, reps, P) % P
+
+
+def _f12_raw(f):
+    return [util.fp_raw(x) for co in f for x in co]
+
+
+def _f12_from(raws):
+    v = [util.fp_from_raw(r) for r in raws]
+    return tuple((v[2 * k], v[2 * k + 1]) for k in range(6))
+
+
+def test_engine_operations_match_the_oracle(api):
+    """every Fp12 operation table of the row-wide engine (csrc/wide_tables.cuh) on the device, one step at a time and in
+    chains (unreduced product columns summed, one Montgomery reduction per output value), against the oracle's tower arithmetic.
+    blsgpu_debug_wide_program starts with F = U = W = ACC = the input and returns T."""
+    from oracle.py import bls381 as c
+    rng = random.Random(5)
+    for trial in range(3):
+        a = tuple((rng.randrange(P), rng.randrange(P)) for _ in range(6))
+        if trial == 2:
+            a = ((P - 1, P - 1),) * 6                                  # the largest canonical components
+        ra = _f12_raw(a)
+        run = lambda steps, reps=1: _f12_from(api.debug_wide_program(steps, ra, reps))  # noqa: E731
+        assert run([('MUL', 'T', 'F', 'U')]) == c.f12_mul(a, a)
+        assert run([('SQR', 'T', 'F', 'F')]) == c.f12_sqr(a)
+        assert run([('FROB1', 'T', 'F', 'F')]) == c.f12_frob(a, 1)
+        assert run([('FROB2', 'T', 'F', 'F')]) == c.f12_frob(a, 2)
+        assert run([('CONJ', 'T', 'F', 'F')]) == c.f12_conj(a)
+        assert run([('COPY', 'T', 'F', 'F')]) == a
+        line = ((a[0], (0, 0), a[1], a[2], (0, 0), (0, 0)))           # U's first three coefficients as l0, l2 w^2, l3 w^3
+        assert run([('MUL_LINE', 'T', 'F', 'U')]) == c.f12_mul(a, line)
+        # aliased destination and a chain: ACC <- ACC^2 * F, four times
+        want = a
+        for _ in range(4):
+            want = c.f12_mul(c.f12_sqr(want), a)
+        assert run([('SQR', 'ACC', 'ACC', 'ACC'), ('MUL', 'ACC', 'ACC', 'F')] * 4 + [('COPY', 'T', 'ACC', 'ACC')]) == want
+        # the cyclotomic squaring on an element of the cyclotomic subgroup: g = a^((p^6 - 1)(p^2 + 1)) built on the device
+        t = c.f12_mul(c.f12_conj(a), c.f12_inv(a))
+        g = c.f12_mul(c.f12_frob(t, 2), t)
+        rg = _f12_raw(g)
+        got = _f12_from(api.debug_wide_program([('CYC_SQR', 'ACC', 'ACC', 'ACC')] * 5 + [('COPY', 'T', 'ACC', 'ACC')], rg))
+        want = g
+        for _ in range(5):
+            want = c.f12_sqr(want)
+        assert got == want
+    # the same program run repeatedly on its own output (reps): T <- T * F after T <- F
+    a = tuple((rng.randrange(P), rng.randrange(P)) for _ in range(6))
+    got = _f12_from(api.debug_wide_program([('MUL', 'W', 'W', 'F'), ('COPY', 'T', 'W', 'W')], _f12_raw(a), 6))
+    assert got == c.f12_pow(a, 7)
+    with pytest.raises(api.BlsGpuRuntimeError):
+        api.debug_wide_program([('PDBL1', 'T', 'F', 'F')], _f12_raw(a))   # not an Fp12 operation: refused on the host

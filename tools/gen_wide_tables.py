@@ -230,16 +230,15 @@ def op_pdbl1():
     lin2(op, add2(B, F), PT_M + 4)
     lin2(op, E, PT_M + 6)
     lin2(op, B, PT_M + 8)
-    lin2(op, H, PT_M + 10)
     lin2(op, sub2(B, E), PT_L + 0)                        # l0 = Y^2 - 3b'Z^2
     lin2(op, S, PT_L + 2, -3)                             # c2 = -3 X^2
-    lin2(op, H, PT_L + 4)                                 # c3 = 2YZ
+    lin2(op, H, PT_L + 4)                                 # c3 = 2YZ = H: PDBL2 reads it from the line (sixteen rows here, one round)
     return op
 
 
 def op_pdbl2():
     op = Op('PDBL2')
-    M = [f2(SA, PT_M + 2 * k) for k in range(6)]
+    M = [f2(SA, PT_M + 2 * k) for k in range(5)] + [f2(SA, PT_L + 4)]
     X3 = op.fp2_mul(M[0], M[1])                           # A (B - F)
     Y3 = op.fp2_sqr(M[2])                                 # (B + F)^2
     EE = op.fp2_sqr(M[3])
@@ -345,6 +344,183 @@ def op_mul_line():
 OPS += [op_pdbl1(), op_pdbl2(), op_padd1(), op_padd2(), op_padd3(), op_padd4(), op_copy6(), op_lscale(), op_mul_line()]
 
 
+
+# ------------------------------------------------------------------ point sums on the engine (table set PT)
+# Complete addition on y^2 = x^3 + b in homogeneous projective coordinates (Renes, Costello, Batina 2016, algorithm 7 for a = 0).
+# E(Fp) and E'(Fp2) have odd order, so the formulas have NO exceptional inputs: doubling, opposite points and the identity
+# (0 : 1 : 0) go through the same twelve products -- which is what a table-driven engine without branches needs.  Two levels
+# of six Fp2 (Fp) products each:
+#   t0 = X1 X2, t1 = Y1 Y2, t2 = Z1 Z2, t3 = X1 Y2 + X2 Y1, t4 = Y1 Z2 + Y2 Z1, t5 = X1 Z2 + X2 Z1
+#   m0 = 3 t0, m1 = t1 - 3b t2, m2 = t1 + 3b t2, m3 = t3, m4 = t4, m5 = 3b t5
+#   X3 = m3 m1 - m4 m5,  Y3 = m1 m2 + m5 m0,  Z3 = m2 m4 + m0 m3
+# A PAIR SLOT holds the two operands and the m values: G2 [P1 (6) | P2 (6) | m (12)] = 24 values, G1 [3 | 3 | 6] = 12.  The
+# X<k> variants run k additions of consecutive slots in one step (so that the sixteen rows of a sub-round stay busy); the
+# second level writes sum j to operand j % 2 of slot j // 2 of the destination array: the next level of the tree.
+# Jacobian <-> homogeneous at the ends: (X, Y, Z) -> (X Z : Y : Z^3) and (X : Y : Z) -> (X Z, Y Z^2, Z).
+G2S, G1S = 24, 12
+
+
+def fp2_mul_sum(op, x1, x2, y1, y2):
+    """(x1 + x2)(y1 + y2) on single-term Fp2 components: schoolbook over two-term operand sums (four products)"""
+    rr = op.prod([x1[0], x2[0]], [y1[0], y2[0]])
+    ii = op.prod([x1[1], x2[1]], [y1[1], y2[1]])
+    ri = op.prod([x1[0], x2[0]], [y1[1], y2[1]])
+    ir = op.prod([x1[1], x2[1]], [y1[0], y2[0]])
+    return ([(1, rr), (-1, ii)], [(1, ri), (1, ir)])
+
+
+def b3_g2(v):
+    x = mul_xi(*v)                                          # 3 b' = 12 (1 + u)
+    return (scale(x[0], 12), scale(x[1], 12))
+
+
+def op_c2add1(m):
+    op = Op('C2ADD1X%d' % m)
+    for k in range(m):
+        o = G2S * k
+        X1, Y1, Z1, X2, Y2, Z2 = (f2(SA, o + 2 * j) for j in range(6))
+        t0, t1, t2 = op.fp2_mul(X1, X2), op.fp2_mul(Y1, Y2), op.fp2_mul(Z1, Z2)
+        t3 = sub2(sub2(fp2_mul_sum(op, X1, Y1, X2, Y2), t0), t1)
+        t4 = sub2(sub2(fp2_mul_sum(op, Y1, Z1, Y2, Z2), t1), t2)
+        t5 = sub2(sub2(fp2_mul_sum(op, X1, Z1, X2, Z2), t0), t2)
+        bt2 = b3_g2(t2)
+        lin2(op, t0, o + 12, 3)
+        lin2(op, sub2(t1, bt2), o + 14)
+        lin2(op, add2(t1, bt2), o + 16)
+        lin2(op, t3, o + 18)
+        lin2(op, t4, o + 20)
+        lin2(op, b3_g2(t5), o + 22)
+    return op
+
+
+def op_c2add2(m):
+    op = Op('C2ADD2X%d' % m)
+    for k in range(m):
+        o = G2S * k + 12
+        m0, m1, m2, m3, m4, m5 = (f2(SA, o + 2 * j) for j in range(6))
+        d = G2S * (k // 2) + 6 * (k % 2)
+        lin2(op, sub2(op.fp2_mul(m3, m1), op.fp2_mul(m4, m5)), d)
+        lin2(op, add2(op.fp2_mul(m1, m2), op.fp2_mul(m5, m0)), d + 2)
+        lin2(op, add2(op.fp2_mul(m2, m4), op.fp2_mul(m0, m3)), d + 4)
+    return op
+
+
+def g2_point_off(i):
+    return G2S * (i // 2) + 6 * (i % 2)
+
+
+def op_c2j2h(stage, m):
+    """Jacobian -> homogeneous for the m points of m / 2 consecutive slots: A: ZZ = Z^2 (into the slot's m area), X <- X Z;  B: Z <- Z ZZ"""
+    op = Op('C2J2H%sX%d' % (stage, m))
+    for i in range(m):
+        o, zz = g2_point_off(i), G2S * (i // 2) + 12 + 2 * (i % 2)
+        if stage == 'A':
+            lin2(op, op.fp2_sqr(f2(SA, o + 4)), zz)
+            lin2(op, op.fp2_mul(f2(SA, o), f2(SA, o + 4)), o)
+        else:
+            lin2(op, op.fp2_mul(f2(SA, o + 4), f2(SA, zz)), o + 4)
+    return op
+
+
+def op_c2h2j(stage):
+    """homogeneous -> Jacobian of the point at operand 0 of a slot: A: ZZ = Z^2, X <- X Z;  B: Y <- Y ZZ"""
+    op = Op('C2H2J%s' % stage)
+    if stage == 'A':
+        lin2(op, op.fp2_sqr(f2(SA, 4)), 12)
+        lin2(op, op.fp2_mul(f2(SA, 0), f2(SA, 4)), 0)
+    else:
+        lin2(op, op.fp2_mul(f2(SA, 2), f2(SA, 12)), 2)
+    return op
+
+
+def v1(off):
+    return (1, idx(SA, off))
+
+
+def op_c1add1(m):
+    op = Op('C1ADD1X%d' % m)
+    for k in range(m):
+        o = G1S * k
+        X1, Y1, Z1, X2, Y2, Z2 = (v1(o + j) for j in range(6))
+        t0, t1, t2 = op.prod([X1], [X2]), op.prod([Y1], [Y2]), op.prod([Z1], [Z2])
+        T3, T4, T5 = op.prod([X1, Y1], [X2, Y2]), op.prod([Y1, Z1], [Y2, Z2]), op.prod([X1, Z1], [X2, Z2])
+        op.lin([(3, t0)], idx(DST, o + 6))
+        op.lin([(1, t1), (-12, t2)], idx(DST, o + 7))
+        op.lin([(1, t1), (12, t2)], idx(DST, o + 8))
+        op.lin([(1, T3), (-1, t0), (-1, t1)], idx(DST, o + 9))
+        op.lin([(1, T4), (-1, t1), (-1, t2)], idx(DST, o + 10))
+        op.lin([(12, T5), (-12, t0), (-12, t2)], idx(DST, o + 11))
+    return op
+
+
+def op_c1add2(m):
+    op = Op('C1ADD2X%d' % m)
+    for k in range(m):
+        o = G1S * k + 6
+        m0, m1, m2, m3, m4, m5 = (v1(o + j) for j in range(6))
+        d = G1S * (k // 2) + 3 * (k % 2)
+        op.lin([(1, op.prod([m3], [m1])), (-1, op.prod([m4], [m5]))], idx(DST, d))
+        op.lin([(1, op.prod([m1], [m2])), (1, op.prod([m5], [m0]))], idx(DST, d + 1))
+        op.lin([(1, op.prod([m2], [m4])), (1, op.prod([m0], [m3]))], idx(DST, d + 2))
+    return op
+
+
+def g1_point_off(i):
+    return G1S * (i // 2) + 3 * (i % 2)
+
+
+def op_c1j2h(stage, m):
+    op = Op('C1J2H%sX%d' % (stage, m))
+    for i in range(m):
+        o, zz = g1_point_off(i), G1S * (i // 2) + 6 + (i % 2)
+        if stage == 'A':
+            op.lin([(1, op.prod([v1(o + 2)], [v1(o + 2)]))], idx(DST, zz))
+            op.lin([(1, op.prod([v1(o)], [v1(o + 2)]))], idx(DST, o))
+        else:
+            op.lin([(1, op.prod([v1(o + 2)], [v1(zz)]))], idx(DST, o + 2))
+    return op
+
+
+def op_c1h2j(stage):
+    op = Op('C1H2J%s' % stage)
+    if stage == 'A':
+        op.lin([(1, op.prod([v1(2)], [v1(2)]))], idx(DST, 6))
+        op.lin([(1, op.prod([v1(0)], [v1(2)]))], idx(DST, 0))
+    else:
+        op.lin([(1, op.prod([v1(1)], [v1(6)]))], idx(DST, 1))
+    return op
+
+
+OPS_PT = ([op_c2add1(m) for m in (4, 2, 1)] + [op_c2add2(m) for m in (4, 2, 1)] + [op_c2j2h('A', 8), op_c2j2h('B', 8), op_c2h2j('A'), op_c2h2j('B')] +
+          [op_c1add1(m) for m in (8, 4, 2, 1)] + [op_c1add2(m) for m in (8, 4, 2, 1)] + [op_c1j2h('A', 8), op_c1j2h('B', 8), op_c1h2j('A'), op_c1h2j('B')])
+PT_POINTS = 16                     # points per workgroup: a tree of four levels
+
+
+def prog_point_tree(g, jac_in, jac_out):
+    """the sum of sixteen points of group g (1: G1, 2: G2): L0 (eight pair slots) -> L1 -> L2 -> L3 -> operand 0 of L4"""
+    S = G2S if g == 2 else G1S
+    c = 'C%d' % g
+    st = []
+    if jac_in:
+        for grp in range(2):
+            a = ('L0', 4 * S * grp)
+            st += [(c + 'J2HAX8', a, a, a), (c + 'J2HBX8', a, a, a)]
+    if g == 2:
+        for grp in range(2):
+            a = ('L0', 4 * S * grp)
+            st += [(c + 'ADD1X4', a, a, a), (c + 'ADD2X4', ('L1', 2 * S * grp), a, a)]
+        st += [(c + 'ADD1X4', 'L1', 'L1', 'L1'), (c + 'ADD2X4', 'L2', 'L1', 'L1')]
+    else:
+        st += [(c + 'ADD1X8', 'L0', 'L0', 'L0'), (c + 'ADD2X8', 'L1', 'L0', 'L0'), (c + 'ADD1X4', 'L1', 'L1', 'L1'), (c + 'ADD2X4', 'L2', 'L1', 'L1')]
+    st += [(c + 'ADD1X2', 'L2', 'L2', 'L2'), (c + 'ADD2X2', 'L3', 'L2', 'L2'), (c + 'ADD1X1', 'L3', 'L3', 'L3'), (c + 'ADD2X1', 'L4', 'L3', 'L3')]
+    if jac_out:
+        st += [(c + 'H2JA', 'L4', 'L4', 'L4'), (c + 'H2JB', 'L4', 'L4', 'L4')]
+    return st
+
+
+PROGRAMS_PT = [('G%d_%s%s' % (g, 'J' if ji else 'H', 'J' if jo else 'H'), prog_point_tree(g, ji, jo)) for g in (1, 2) for ji in (1, 0) for jo in (1, 0)]
+
+
 # ------------------------------------------------------------------ simulation of the engine on integers
 def consts24():
     out = []
@@ -416,12 +592,11 @@ NSTEPS = 68                      # Miller steps: 63 doublings interleaved with 5
 
 
 class Layout:
-    """value-store indices (16-word values)"""
-    def __init__(self, ntmp):
+    """value-store indices (16-word values): named arrays in order, the product scratch 'TMP' among them"""
+    def __init__(self, arrays):
         self.base = {}
         off = 0
-        for name, n in (('F', 12), ('T', 12), ('U', 12), ('W', 12), ('ACC', 12), ('TMP', ntmp), ('CONST', 24), ('P', 4), ('PT0', 32), ('PT1', 32),
-                        ('L', 12 * NSTEPS)):
+        for name, n in arrays:
             self.base[name] = off
             off += n
         self.count = off
@@ -498,33 +673,33 @@ PROGRAMS = [('FINAL_HARD', prog_final_hard()),
             ('PAIR_GENERAL', prog_key_lines(0) + prog_key_lines(1) + prog_miller() + prog_easy() + prog_final_hard())]
 
 
-def sim_program(steps, store):
-    by = {o.name: o for o in OPS}
+def layout_f12():
+    return Layout([('F', 12), ('T', 12), ('U', 12), ('W', 12), ('ACC', 12), ('TMP', 2 * (max(o.ntmp for o in OPS) + 1)), ('CONST', 24), ('P', 4),
+                   ('PT0', 32), ('PT1', 32), ('L', 12 * NSTEPS)])
 
-    def arr(r):
-        if isinstance(r, tuple):
-            return store[r[0]], r[1]
-        return store[r], 0
 
-    class View(list):
-        pass
+def layout_pt():
+    return Layout([('L0', 8 * G2S), ('L1', 4 * G2S), ('L2', 2 * G2S), ('L3', G2S), ('L4', G2S), ('TMP', 2 * (max(o.ntmp for o in OPS_PT) + 1))])
+
+
+def sim_program(ops, lay, steps, V):
+    """the device's semantics on a flat integer value store: every step reads its operand arrays at their base index"""
+    by = {o.name: o for o in ops}
+    cb = lay.base.get('CONST')
+    if cb is not None:
+        V[cb:cb + 24] = consts24()
     for name, d, x, y in steps:
         if name == 'INV':
-            store['T'][:] = flat(c.f12_inv(unflat(store['F'])))
+            fb, tb = lay.base['F'], lay.base['T']
+            V[tb:tb + 12] = flat(c.f12_inv(unflat(V[fb:fb + 12])))
             continue
-        # views with offsets: copy in, run, copy out
-        (da, do), (xa, xo), (ya, yo) = arr(d), arr(x), arr(y)
         op = by[name]
-        span = 32
-        dv, xv, yv = da[do:do + span], xa[xo:xo + span], ya[yo:yo + span]
-        if da is xa and do == xo:
-            xv = dv
-        if da is ya and do == yo:
-            yv = dv
-        elif xa is ya and xo == yo:
-            yv = xv
-        exec_op(op, dv, xv, yv)
-        da[do:do + len(dv)] = dv
+        base = {DST: lay.ref(d), SA: lay.ref(x), SB: lay.ref(y), TMP: lay.base['TMP'], CONST: cb}
+        at = lambda i: V[base[i >> 12] + (i & 0xfff)]  # noqa: E731
+        for xa, ya, out in op.prods:
+            V[base[TMP] + (out & 0xfff)] = (sum(k * at(i) for k, i in xa) % P) * (sum(k * at(i) for k, i in ya) % P) % P
+        for terms, out in op.lins:
+            V[base[DST] + (out & 0xfff)] = sum(k * at(i) for k, i in terms) % P
 
 
 def check_programs():
@@ -533,12 +708,13 @@ def check_programs():
     a = tuple((rng.randrange(P), rng.randrange(P)) for _ in range(6))
     t = c.f12_mul(c.f12_conj(a), c.f12_inv(a))
     easy = c.f12_mul(c.f12_frob(t, 2), t)
-    lay = Layout(max(o.ntmp for o in OPS) + 1)
-    store = {k: [0] * 12 for k in ('F', 'T', 'U', 'W', 'ACC')}
-    store['F'] = flat(easy)
-    sim_program(prog_final_hard(), store)
-    assert unflat(store['T']) == c.final_exponentiation(a), 'hard part program'
-    # whole pairing: e(P0, Q0) e(P1, Q1) with the general program, and with pair 1's lines from the fixed-argument model
+    lay = layout_f12()
+    B = lay.base
+    V = [0] * lay.count
+    V[B['F']:B['F'] + 12] = flat(easy)
+    sim_program(OPS, lay, prog_final_hard(), V)
+    assert unflat(V[B['T']:B['T'] + 12]) == c.final_exponentiation(a), 'hard part program'
+    # whole pairing: e(P0, Q0) e(P1, Q1) with the general program
     sk, h = rng.randrange(1, c.R), rng.randrange(1, c.R)
     Hm = c.E1.mul(c.G1_GEN, h)
     pk = c.E2.mul(c.G2_GEN, sk)
@@ -546,86 +722,154 @@ def check_programs():
     negg2 = c.E2.neg(c.G2_GEN)
     for sgn, want_one in ((sig, True), (c.E1.mul(sig, 2), False)):
         pairs = [(Hm, pk), (sgn, negg2)]
-        store = {k: [0] * 12 for k in ('F', 'T', 'U', 'W', 'ACC')}
-        store['F'] = flat(c.F12_ONE)
-        store['P'] = [Hm[0], Hm[1], sgn[0], sgn[1]]
-        store['L'] = [0] * (12 * NSTEPS)
+        V = [0] * lay.count
+        V[B['F']:B['F'] + 12] = flat(c.F12_ONE)
+        V[B['P']:B['P'] + 4] = [Hm[0], Hm[1], sgn[0], sgn[1]]
         for pr, (_, q) in enumerate(pairs):
             pt = [0] * 32
             pt[0:6] = [q[0][0], q[0][1], q[1][0], q[1][1], 1, 0]
             pt[6:10] = [q[0][0], q[0][1], q[1][0], q[1][1]]
-            store['PT%d' % pr] = pt
-        sim_program(PROGRAMS[2][1], store)
+            V[B['PT%d' % pr]:B['PT%d' % pr] + 32] = pt
+        sim_program(OPS, lay, PROGRAMS[2][1], V)
         want = c.final_exponentiation(c.miller_loop(pairs))
-        assert unflat(store['T']) == want, 'pairing program'
-        assert (unflat(store['T']) == c.F12_ONE) == want_one
+        assert unflat(V[B['T']:B['T'] + 12]) == want, 'pairing program'
+        assert (unflat(V[B['T']:B['T'] + 12]) == c.F12_ONE) == want_one
+    return lay
+
+
+def check_point_programs():
+    """the point-sum programs against the oracle's affine additions: random points, repeated points, opposite points, identities,
+    random projective scalings of the inputs, every input / output coordinate combination"""
+    rng = random.Random(3)
+    lay = layout_pt()
+    for g in (1, 2):
+        E, gen, S = (c.E1, c.G1_GEN, G1S) if g == 1 else (c.E2, c.G2_GEN, G2S)
+        w = 1 if g == 1 else 2                      # values per coordinate
+        fmul = (lambda x, y: x * y % P) if g == 1 else c.f2_mul
+        vals = (lambda x: [x]) if g == 1 else (lambda x: list(x))
+        one, zero = (1, 0) if g == 1 else (c.F2_ONE, c.F2_ZERO)
+        for case in range(4):
+            pts = [E.mul(gen, rng.randrange(1, c.R)) for _ in range(PT_POINTS)]
+            if case == 1:
+                pts[1] = pts[0]                     # a doubling
+                pts[3] = E.neg(pts[2])              # a cancellation
+                pts[5] = None                       # identities on either side and against each other
+                pts[6] = None
+                pts[7] = None
+                pts[8:12] = [pts[8]] * 4
+            if case == 2:
+                pts = [None] * PT_POINTS
+            if case == 3:
+                pts = [pts[0], E.neg(pts[0])] * (PT_POINTS // 2)
+            want = None
+            for q in pts:
+                want = E.add(want, q)
+            for jin in (1, 0):
+                for jout in (1, 0):
+                    V = [0] * lay.count
+                    for i, q in enumerate(pts):
+                        lam = rng.randrange(1, P) if g == 1 else (rng.randrange(1, P), rng.randrange(P))
+                        if q is None:
+                            X, Y, Z = (lam, one, zero) if jin else (zero, lam, zero)
+                            if jin:
+                                X = zero           # the loader's normal form of a Jacobian identity: (0, 1, 0)
+                        elif jin:                   # Jacobian (x l^2, y l^3, l)
+                            l2 = fmul(lam, lam)
+                            X, Y, Z = fmul(q[0], l2), fmul(q[1], fmul(l2, lam)), lam
+                        else:                       # homogeneous (x l, y l, l)
+                            X, Y, Z = fmul(q[0], lam), fmul(q[1], lam), lam
+                        o = lay.base['L0'] + (g2_point_off(i) if g == 2 else g1_point_off(i))
+                        V[o:o + 3 * w] = vals(X) + vals(Y) + vals(Z)
+                    name = 'G%d_%s%s' % (g, 'J' if jin else 'H', 'J' if jout else 'H')
+                    sim_program(OPS_PT, lay, dict(PROGRAMS_PT)[name], V)
+                    o = lay.base['L4']
+                    if g == 1:
+                        X, Y, Z = V[o], V[o + 1], V[o + 2]
+                        inv, is0 = c.fp_inv, (lambda z: z == 0)
+                    else:
+                        X, Y, Z = (V[o], V[o + 1]), (V[o + 2], V[o + 3]), (V[o + 4], V[o + 5])
+                        inv, is0 = c.f2_inv, (lambda z: z == (0, 0))
+                    if is0(Z):
+                        got = None
+                    elif jout:
+                        zi = inv(Z)
+                        zi2 = fmul(zi, zi)
+                        got = (fmul(X, zi2), fmul(Y, fmul(zi2, zi)))
+                    else:
+                        zi = inv(Z)
+                        got = (fmul(X, zi), fmul(Y, zi))
+                    assert got == want, (name, case)
     return lay
 
 
 # ------------------------------------------------------------------ emission
-def emit(path, lay):
-    out = []
-    out.append('// GENERATED by tools/gen_wide_tables.py -- do not edit.  Operation tables and programs of the row-wide engine')
-    out.append('// (wide_engine.cuh).  Every table and program was checked against the oracle (Fp12 arithmetic, whole pairing checks) by the generator.')
-    out.append('#pragma once')
-    out.append('// product row: out = (ca0 V[A + a0] + ca1 V[A + a1]) * (cb0 V[B + b0] + cb1 V[B + b1]) -> V[TMP + out]; A, B: the step\'s operand arrays')
-    out.append('struct wide_prod { uint8_t a[2], b[2]; int8_t ca[2], cb[2]; uint8_t out, pad[3]; };')
-    out.append('// linear row: V[DST + out] = reduce(sum c_i V[idx_i]); idx bit 7 set: operand array A, clear: product scratch')
-    out.append('struct wide_lin { uint8_t n, out; uint8_t idx[%d]; int8_t c[%d]; uint8_t pad[2]; };' % (MAXLIN, MAXLIN))
-    out.append('struct wide_op { uint16_t prod_off, lin_off; uint8_t nsub, nlin, b_is_const, b_is_a; };')
-    prods, lins, ops = [], [], []
-    for op in OPS:
+def emit_set(out, ops, lay, programs, prefix, vprefix, trait, has_inv):
+    """one table set in the interpreter's format (csrc/wide_engine.cuh): byte offsets into the value store, pre-resolved"""
+    tmp_base = lay.base['TMP']
+    prods, lin_words, oprows = [], [], []
+    for op in ops:
         nsub = (len(op.prods) + ROWS - 1) // ROWS
-        assert len(op.lins) <= 32 and op.ntmp < 127
         bslots = {i >> 12 for _, b, _ in op.prods for _, i in b}
         aslots = {i >> 12 for a, _, _ in op.prods for _, i in a}
         assert aslots <= {SA} and len(bslots) <= 1 and bslots <= {SA, SB, CONST}, (op.name, aslots, bslots)
-        ops.append((op.name, len(prods), len(lins), nsub, len(op.lins), 1 if bslots == {CONST} else 0, 1 if bslots == {SA} else 0, len(op.prods)))
-        rows = list(op.prods) + [None] * (nsub * ROWS - len(op.prods))
-        for r in rows:
-            if r is None:      # an idle row multiplies zero by zero into a scratch value that nothing reads
-                prods.append('{{0, 0}, {0, 0}, {0, 0}, {0, 0}, %d, {0, 0, 0}}' % op.ntmp)
+        bsel = 1 if bslots == {CONST} else (2 if bslots == {SA} else 0)
+        maxt = max(sum(1 for _, i in t if (i >> 12) == TMP) for t, _ in op.lins)
+        stride = (3 + maxt + 3) // 4                       # 16-byte chunks per linear row: header, two plain-value slots, product terms
+        assert stride <= 7
+        assert len(prods) < 65536 and len(lin_words) // 4 < 65536 and len(op.lins) < 256 and nsub < 256
+        oprows.append((op.name, len(prods), len(lin_words) // 4, nsub, len(op.lins), stride, bsel, len(op.prods)))
+        idle = (tmp_base + 2 * op.ntmp) * 64               # an idle row multiplies zero by zero into a scratch entry nothing reads
+        assert idle < 65536
+        for r in list(op.prods) + [None] * (nsub * ROWS - len(op.prods)):
+            if r is None:
+                prods.append((0, 0, 0, idle))
                 continue
             a, b, o = r
             assert (o >> 12) == TMP
             a = a + [(0, 0)] * (2 - len(a))
             b = b + [(0, 0)] * (2 - len(b))
-            prods.append('{{%d, %d}, {%d, %d}, {%d, %d}, {%d, %d}, %d, {0, 0, 0}}' % (a[0][1] & 0xfff, a[1][1] & 0xfff, b[0][1] & 0xfff, b[1][1] & 0xfff,
-                                                                                   a[0][0], a[1][0], b[0][0], b[1][0], o & 0xfff))
+            for k, _ in a + b:
+                assert -128 <= k < 128
+            offs = [(i & 0xfff) * 64 for _, i in a + b]
+            assert max(offs) < 65536
+            cw = sum((k & 0xff) << (8 * j) for j, (k, _) in enumerate(a + b))
+            prods.append((offs[0] | offs[1] << 16, offs[2] | offs[3] << 16, cw, (tmp_base + 2 * (o & 0xfff)) * 64))
         for terms, o in op.lins:
-            assert (o >> 12) == DST
-            ii, cc = [], []
-            for k, i in terms:
-                assert (i >> 12) in (TMP, SA) and (i & 0xfff) < 128 and -128 < k < 128
-                ii.append((0x80 if (i >> 12) == SA else 0) | (i & 0xfff))
-                cc.append(k)
-            ii += [0] * (MAXLIN - len(ii))
-            cc += [0] * (MAXLIN - len(cc))
-            lins.append('{%d, %d, {%s}, {%s}, {0, 0}}' % (len(terms), o & 0xfff, ', '.join(map(str, ii)), ', '.join(map(str, cc))))
-    out.append('BLS_CONST wide_prod WIDE_PROD[%d] = {' % len(prods))
-    out += ['    %s,' % p for p in prods]
+            assert (o >> 12) == DST and (o & 0xfff) * 64 < 65536
+            rel = [(k, i) for k, i in terms if (i >> 12) == SA]
+            ab = [(k, i) for k, i in terms if (i >> 12) == TMP]
+            assert len(rel) + len(ab) == len(terms) and len(rel) <= 2, op.name
+            row = [len(ab) | ((o & 0xfff) * 64) << 16]
+            for k, i in rel + [(0, idx(SA, 0))] * (2 - len(rel)) + ab:
+                assert -32768 <= k < 32768
+                off = ((i & 0xfff) if (i >> 12) == SA else tmp_base + 2 * (i & 0xfff)) * 64
+                assert off < 65536
+                row.append(off | (k & 0xffff) << 16)
+            row += [0] * (4 * stride - len(row))
+            lin_words += row
+    out.append('BLS_CONST wide_prod %s_PROD[%d] = {' % (prefix, len(prods)))
+    out += ['    {0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu},' % p for p in prods]
     out.append('};')
-    out.append('BLS_CONST wide_lin WIDE_LIN[%d] = {' % len(lins))
-    out += ['    %s,' % l for l in lins]
+    out.append('BLS_CONST uint32_t %s_LIN[%d] = {' % (prefix, len(lin_words)))
+    for i in range(0, len(lin_words), 8):
+        out.append('    ' + ', '.join('0x%08xu' % w for w in lin_words[i:i + 8]) + ',')
     out.append('};')
-    out.append('BLS_CONST wide_op WIDE_OPS[%d] = {' % len(ops))
-    for name, po, lo, ns, nl, bc, ba, np_ in ops:
-        out.append('    {%d, %d, %d, %d, %d, %d},   // WOP_%s: %d products' % (po, lo, ns, nl, bc, ba, name, np_))
+    out.append('BLS_CONST wide_op %s_OPS[%d] = {' % (prefix, len(oprows)))
+    for name, po, lo, ns, nl, stv, bs, np_ in oprows:
+        out.append('    {%d, %d, %d, %d, %d, %d},   // WOP_%s: %d products' % (po, lo, ns, nl, stv, bs, name, np_))
     out.append('};')
-    names = [o[0] for o in ops]
+    names = [o[0] for o in oprows]
     for k, name in enumerate(names):
         out.append('#define WOP_%s %d' % (name, k))
-    out.append('#define WOP_INV %d   // interpreter built-in: T <- F^-1 by the lane-local tower code' % len(names))
-    names.append('INV')
-    out.append('#define WIDE_MAX_TMP %d' % (max(o.ntmp for o in OPS) + 1))
+    if has_inv:
+        out.append('#define WOP_INV %d   // interpreter built-in: T <- F^-1 by the lane-local tower code' % len(names))
+        names.append('INV')
     out.append('// value store (indices of 16-word values)')
     for k, v in lay.base.items():
-        out.append('#define WV_%s %d' % (k, v))
-    out.append('#define WV_COUNT %d' % lay.count)
-    out.append('#define WIDE_STEPS %d' % NSTEPS)
-    out.append('#include "wide_rows.cuh"')
+        out.append('#define %s_%s %d' % (vprefix, k, v))
+    out.append('#define %s_COUNT %d' % (vprefix, lay.count))
     out.append('// programs: two words per step: op | dst << 16,  a | b << 16  (value-store indices of the arrays)')
-    for pname, st in PROGRAMS:
+    for pname, st in programs:
         words = []
         for n, d, x, y in st:
             words.append('0x%08xu' % (names.index(n) | lay.ref(d) << 16))
@@ -635,7 +879,48 @@ def emit(path, lay):
         for i in range(0, len(words), 8):
             out.append('    ' + ', '.join(words[i:i + 8]) + ',')
         out.append('};')
-    out.append('#define WIDE_PROG_MAX %d' % max(len(st) for _, st in PROGRAMS))
+    pmax = max(len(st) for _, st in programs)
+    out.append('struct %s {' % trait)
+    out.append('  enum { NPROD = %d, NLIN = %d, NOPS = %d, NV = %d, PROG_MAX = %d, CONST_BASE = %d, OP_INV = %d };' % (
+        len(prods), len(lin_words), len(oprows), lay.count, pmax, lay.base.get('CONST', -1), len(oprows) if has_inv else -1))
+    out.append('  WIDE_TB_FN const wide_prod* prods() { return %s_PROD; }' % prefix)
+    out.append('  WIDE_TB_FN const uint32_t* lins() { return %s_LIN; }' % prefix)
+    out.append('  WIDE_TB_FN const wide_op* ops() { return %s_OPS; }' % prefix)
+    out.append('};')
+    return pmax
+
+
+def emit(path):
+    lay, lay_pt = layout_f12(), layout_pt()
+    out = []
+    out.append('// GENERATED by tools/gen_wide_tables.py -- do not edit.  Operation tables and programs of the row-wide engine')
+    out.append('// (wide_engine.cuh).  Every table and program was checked against the oracle (Fp12 arithmetic, whole pairing checks, point sums) by the generator.')
+    out.append('#pragma once')
+    out.append('#include "wide_rows.cuh"')
+    out.append('// product row: scratch[out] = (ca0 V[A + a0] + ca1 V[A + a1]) * (cb0 V[B + b0] + cb1 V[B + b1]), UNREDUCED (28 columns, two words per')
+    out.append('// lane: a scratch entry is 128 bytes).  a, b: two 16-bit BYTE offsets from the step\'s operand arrays A, B;  c: the four coefficients')
+    out.append('// (int8);  out: absolute byte offset of the scratch entry')
+    out.append('struct wide_prod { uint32_t a, b, c, out; };')
+    out.append('// linear rows live in a word pool, `stride` 16-byte chunks per row of an operation: header nT | (byte offset of the output from the')
+    out.append('// destination array) << 16, two plain-value terms (byte offset from operand array A | coefficient << 16; coefficient 0 when unused),')
+    out.append('// then nT product terms (absolute byte offset of the scratch entry | coefficient << 16);  V[DST + out] = reduce(sum c_i term_i): ONE')
+    out.append('// Montgomery reduction per row, after the sum (none for a row without product terms)')
+    out.append('// operation: prod_off in rows, lin_off in 16-byte chunks; bsel: 0 = B from the step, 1 = the constants, 2 = B is A')
+    out.append('struct wide_op { uint16_t prod_off, lin_off; uint8_t nsub, nlin, stride, bsel; };')
+    out.append('#if defined(__HIPCC__)')
+    out.append('#define WIDE_TB_FN static __device__ __forceinline__')
+    out.append('#else')
+    out.append('#define WIDE_TB_FN static inline')
+    out.append('#endif')
+    out.append('// ---- table set F12: Fp12 arithmetic and the Miller loop (pairing programs)')
+    pmax = emit_set(out, OPS, lay, PROGRAMS, 'WIDE_F12', 'WV', 'wide_tb_f12', True)
+    out.append('#define WIDE_STEPS %d' % NSTEPS)
+    out.append('#define WIDE_PROG_MAX %d' % pmax)
+    out.append('// ---- table set PT: sums of sixteen points per workgroup (complete projective additions)')
+    emit_set(out, OPS_PT, lay_pt, PROGRAMS_PT, 'WIDE_PT', 'WPV', 'wide_tb_pt', False)
+    out.append('#define WIDE_PT_POINTS %d' % PT_POINTS)
+    out.append('#define WIDE_PT_SLOT_G1 %d' % G1S)
+    out.append('#define WIDE_PT_SLOT_G2 %d' % G2S)
     open(path, 'w').write('\n'.join(out) + '\n')
     open(os.path.join(os.path.dirname(path), 'wide_rows.cuh'), 'w').write(
         '// GENERATED by tools/gen_wide_tables.py -- do not edit.\n#pragma once\n'
@@ -644,7 +929,8 @@ def emit(path, lay):
 
 if __name__ == '__main__':
     assert self_check()
-    layout = check_programs()
-    emit(os.path.join(ROOT, 'agora-blsful_amd', 'csrc', 'wide_tables.cuh'), layout)
-    for o in OPS:
+    check_programs()
+    check_point_programs()
+    emit(os.path.join(ROOT, 'agora-blsful_amd', 'csrc', 'wide_tables.cuh'))
+    for o in OPS + OPS_PT:
         print(o.name, len(o.prods), 'products,', len(o.lins), 'linear rows, longest', max((len(t) for t, _ in o.lins), default=0))
