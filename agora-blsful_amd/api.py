@@ -472,7 +472,7 @@ def debug_wide_program(steps, f_raw, reps=1):
     d = wide_defs()
     words = []
     for op, dst, a, b in steps:
-        words += [d['WOP_' + op] | d['WV_' + dst] << 16, d['WV_' + a] | d['WV_' + b] << 16]
+        words += [d['WOP_' + op] | d['WV_' + dst] << 16, d['WV_' + a] | d['WV_' + b] << 16]     # ('INV', 'T', 'F', 'F'): T <- F^-1
     arr = (ctypes.c_uint32 * len(words))(*words)
     out = ctypes.create_string_buffer(576)
     _check(lib.blsgpu_debug_wide_program(ctypes.cast(arr, ctypes.c_void_p), len(steps), reps, _ptr(b''.join(f_raw)), ctypes.cast(out, ctypes.c_void_p)))

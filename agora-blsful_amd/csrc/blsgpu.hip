@@ -41,6 +41,8 @@ struct Ctx {
   hipEvent_t ev_host = nullptr;   // "the host may read what was copied so far" marker (verify_secure)
   hipStream_t side = nullptr;     // side stream: the message hash of a multi_verify tail runs beside the key sum
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t side2 = nullptr;    // second side stream: the signature's half of a cut pairing check beside the message hash
+  hipEvent_t ev_join2 = nullptr;
   uint8_t* hpin = nullptr;        // pinned host staging (sorted key bytes on their way to the host's SHA-256 stream)
   size_t hpin_cap = 0;
   uint8_t* hsmall = nullptr;      // pinned 64 KiB for the small host <-> device records of a call (offsets, flags, verdicts):
@@ -81,6 +83,10 @@ struct Lease {
     if (c->side && hipStreamQuery(c->side) != hipSuccess) {
       (void)hipGetLastError();
       (void)hipStreamSynchronize(c->side);
+    }
+    if (c->side2 && hipStreamQuery(c->side2) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipStreamSynchronize(c->side2);
     }
   }
 };
@@ -138,8 +144,9 @@ bool is_device_ptr(const void* p) {
 }
 
 // ---- bump arena in device memory, reset per call
+size_t wide_max_items();
 int arena_reserve(Ctx* c, size_t bytes) {
-  bytes += 1u << 20;               // headroom that every call may rely on (the row-wide engine's per-item records, run_pairing2)
+  bytes += (1u << 20) + wide_max_items() * (size_t)WREC_WORDS * 4;   // headroom that every call may rely on: the row-wide engine's per-item records
   if (bytes <= c->arena_cap) return 0;
   HIPCK(hipStreamSynchronize(c->stream));
   if (c->arena) HIPCK(hipFree(c->arena));
@@ -431,20 +438,48 @@ int run_pairing2(Ctx* c, size_t n, uint32_t* d_pairs, uint32_t* d_f, int32_t* d_
   return 0;
 }
 
+// the context's side stream (created on first use) starts where the main stream is now
+int side_fork(Ctx* c) {
+  if (!c->side) {
+    HIPCK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    HIPCK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIPCK(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
+    HIPCK(hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
+  }
+  HIPCK(hipEventRecord(c->ev_fork, c->stream));
+  HIPCK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+  HIPCK(hipStreamWaitEvent(c->side2, c->ev_fork, 0));
+  return 0;
+}
+
 // one core_verify per item: statuses end up in d_status (device)
 int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_t* d_sigs, int fmt, const uint8_t* d_msgs,
                      const uint64_t* d_offs, int single_msg, const dst_arg& dst, size_t n, uint32_t* d_pairs, uint32_t* d_f,
                      int32_t* d_status, int pre_status = 0) {
   if (n == 0) return 0;
   if (sg == 1 && aug == 0 && !pre_status && n <= wide_max_items() && n <= coop_max_items()) {
-    // single verifications and one-verdict tails of Bls12381G1Impl without a key prefix: the hash-to-curve on one wave per
-    // message in the row-wide field type (k_hash_to_g1_wide: ~0.45 us per dependent multiplication instead of ~1.2 us),
-    // then the identity checks and the shared to-affine inversion of k_prepare_hashed
-    uint8_t* d_hashes = (uint8_t*)arena_take(c, 144 * n);
-    if (!d_hashes) return fail(BLSGPU_E_HIP, "internal: arena too small");
-    KL(KID_HASH, k_hash_to_g1_wide, dim3((unsigned)n), dim3(BLS_BLOCK), n, d_msgs, d_offs, single_msg, dst, d_hashes);
-    KL(KID_PREPARE, k_prepare_hashed<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_pks, d_sigs, (const uint8_t*)d_hashes, d_pairs, d_status, fmt);
-    return run_pairing2(c, n, d_pairs, d_f, d_status, 1);
+    // Single verifications of Bls12381G1Impl without a key prefix, cut where the inputs allow (csrc/kernels.cuh k_pairing_pre /
+    // k_pairing_post): the side stream hashes the messages (one wave each, row-wide field type) while this stream checks keys
+    // and signatures, derives every key's line coefficients and runs the Miller loop of the (signature, -g2) pair -- two
+    // workgroups per item, none of which needs H(m); what is left after the join is the Miller loop of (H(m), key) over
+    // ready-made lines and the final exponentiation.
+    uint32_t* d_rec = (uint32_t*)arena_take(c, (size_t)WREC_WORDS * 4 * n);
+    if (!d_rec) return fail(BLSGPU_E_HIP, "internal: arena too small");
+    int rc = side_fork(c);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_hash_to_g1_wide, dim3((unsigned)n), dim3(BLS_BLOCK), 0, c->side, n, d_msgs, d_offs, single_msg, dst, (uint8_t*)nullptr, d_rec);
+    hipError_t e1 = hipGetLastError(), e2 = hipEventRecord(c->ev_join, c->side);
+    KL(KID_PREPARE, k_prepare_keys<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, 3, d_rec, d_status);
+    KL(KID_WIDE, k_pairing_pre, dim3((unsigned)n, 2), dim3(WIDE_ENGINE_BLOCK), n, d_rec, (const int32_t*)d_status, 0);
+    hipError_t e3 = hipStreamWaitEvent(c->stream, c->ev_join, 0);      // also when something failed: the side kernel reads the arena
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+      (void)hipStreamSynchronize(c->side);
+      return fail(BLSGPU_E_HIP, "side-stream launch failed");
+    }
+    KL(KID_WIDE, k_pairing_post, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), n, (const uint32_t*)d_rec, d_status);
+    HIPCK(hipGetLastError());
+    return 0;
   }
   // two lanes per item (the two SSWU maps side by side, G2 point arithmetic on the lane-split tower): always for
   // Bls12381G2Impl, whose hash-to-G2 halves its per-lane work that way; for Bls12381G1Impl only in latency mode (the
@@ -479,10 +514,19 @@ int run_f12_product_verdict(Ctx* c, uint32_t* d_f, size_t m, size_t stride, int3
   return 0;
 }
 
+// lanes (lane pairs for G2) of the first stage of a point sum.  The cap leaves a few compute units' worth of wave slots free:
+// a grid that fills the machine EXACTLY (65,536 lane pairs = 2,048 waves = two per SIMD) takes twice as long as soon as any
+// other kernel holds one slot -- the side stream's hash wave does -- because one workgroup then waits for a whole round.
 size_t accumulate_lanes(size_t n) {
+  static long cap = -1;
+  if (cap < 0) {
+    const char* e = getenv("BLSGPU_ACC_LANES");          // tuning override
+    cap = e ? atol(e) : 63488;                            // 248 of 256 compute units at 256 lane pairs each
+    if (cap < 64) cap = 64;
+  }
   size_t t = n / 4;
   if (t < 64) t = 64;
-  if (t > 65536) t = 65536;
+  if (t > (size_t)cap) t = (size_t)cap;
   return (t + 63) & ~(size_t)63;
 }
 
@@ -506,6 +550,37 @@ int run_msm2_rest(Ctx* c, const uint8_t* d_scalars, size_t n, msm2_ws& w, uint8_
 template <int G>
 int run_msm_pippenger(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_scalars, const uint32_t* d_perm, size_t n, uint8_t* d_out);
 
+// m partial sums (RAW_PROJ, device) -> partials[0].  Wide levels of the tree run on the lane-local / lane-pair fold (one
+// addition deep per launch, efficient while there are thousands of additions); the last 4,096 points go through the row-wide
+// engine, sixteen per workgroup and launch (k_point_tree_wide), between the partials and a small second buffer.
+const size_t POINT_TREE_START = 4096;
+template <int G>
+int run_point_fold(Ctx* c, uint8_t* d_partials, size_t m) {
+  const size_t psz = G == 1 ? 144 : 288;
+  size_t cur = m;
+  const bool wide = wide_max_items() >= 1;               // BLSGPU_WIDE_MAX=0 switches the row-wide engine off everywhere
+  while (cur > (wide ? POINT_TREE_START : 1)) {
+    size_t half = (cur + 1) / 2;
+    if (G == 2) KL(KID_POINT_FOLD, k_point_fold_g2s, dim3(blocks_for(2 * half)), dim3(BLS_BLOCK), cur, half, d_partials);
+    else KL(KID_POINT_FOLD, k_point_fold<G>, dim3(blocks_for(half)), dim3(BLS_BLOCK), cur, half, d_partials);
+    cur = half;
+  }
+  if (cur > 1) {
+    uint8_t* d_tmp = (uint8_t*)arena_take(c, psz * ((POINT_TREE_START + WIDE_PT_POINTS - 1) / WIDE_PT_POINTS));
+    if (!d_tmp) return fail(BLSGPU_E_HIP, "internal: arena too small");
+    const uint8_t* src = d_partials;
+    while (cur > 1) {
+      const size_t nb = (cur + WIDE_PT_POINTS - 1) / WIDE_PT_POINTS;
+      uint8_t* dst = (nb == 1 || src != d_partials) ? d_partials : d_tmp;   // one workgroup reads all its inputs before it writes
+      KL(KID_POINT_FOLD, k_point_tree_wide<G>, dim3((unsigned)nb), dim3(WIDE_ENGINE_BLOCK), cur, src, dst);
+      src = dst;
+      cur = nb;
+    }
+  }
+  HIPCK(hipGetLastError());
+  return 0;
+}
+
 // sum (or sum of scalar multiples) of n points of group G into partials[0] (RAW_PROJ, device)
 template <int G>
 int run_point_sum(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_scalars, const uint32_t* d_perm, size_t n,
@@ -524,15 +599,7 @@ int run_point_sum(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_scalar
   else
     if (G == 2 && !d_perm) KL(KID_ACCUM, k_accumulate_g2s, dim3(blocks_for(2 * T)), dim3(BLS_BLOCK), n, d_pts, fmt, d_partials, T);
     else KL(KID_ACCUM, (k_accumulate<G, 0>), dim3(nb), dim3(BLS_BLOCK), n, d_pts, fmt, d_scalars, d_perm, d_partials, T);
-  size_t cur = T;
-  while (cur > 1) {
-    size_t half = (cur + 1) / 2;
-    if (G == 2) KL(KID_POINT_FOLD, k_point_fold_g2s, dim3(blocks_for(2 * half)), dim3(BLS_BLOCK), cur, half, d_partials);
-    else KL(KID_POINT_FOLD, k_point_fold<G>, dim3(blocks_for(half)), dim3(BLS_BLOCK), cur, half, d_partials);
-    cur = half;
-  }
-  HIPCK(hipGetLastError());
-  return 0;
+  return run_point_fold<G>(c, d_partials, T);
 }
 
 // Pippenger MSM into out[0] (RAW_PROJ, device, Z = 1).  Workspace comes from the arena (caller reserved msm_ws_bytes).
@@ -658,13 +725,7 @@ int run_msm2_rest(Ctx* c, const uint8_t* d_scalars, size_t n, msm2_ws& w, uint8_
   }
   if (G == 2) KL(KID_MSM_CHUNK, k_msm2_chunk_g2q, dim3(blocks_for(4 * p.nchunks)), dim3(BLS_BLOCK), p.W, p.CH, p.Q, (const uint8_t*)w.sums, w.part);
   else KL(KID_MSM_CHUNK, k_msm2_chunk_g1p, dim3(blocks_for(2 * p.nchunks)), dim3(BLS_BLOCK), p.W, p.CH, p.Q, (const uint8_t*)w.sums, w.part);
-  size_t cur = p.nchunks;
-  while (cur > 1) {
-    size_t half = (cur + 1) / 2;
-    if (G == 2) KL(KID_POINT_FOLD, k_point_fold_g2s, dim3(blocks_for(2 * half)), dim3(BLS_BLOCK), cur, half, w.part);
-    else KL(KID_POINT_FOLD, k_point_fold<G>, dim3(blocks_for(half)), dim3(BLS_BLOCK), cur, half, w.part);
-    cur = half;
-  }
+  if (int rc = run_point_fold<G>(c, w.part, p.nchunks)) return rc;
   // Z = 1 makes the output bytes independent of the (atomic) bucket fill order; a caller that only feeds the point to the
   // pairing stages skips it
   if (normalize) KL(KID_MSM_NORM, k_normalize<G>, dim3(1), dim3(BLS_BLOCK), w.part);
@@ -712,13 +773,7 @@ int run_msm_pippenger(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_sc
   else KL(KID_MSM_BUCKET, k_msm_bucket<G>, dim3(blocks_for(p.nb)), dim3(BLS_BLOCK), p.nb, d_pts, fmt, d_perm, d_cnt, d_off, d_idx, d_sums);
   if (G == 2) KL(KID_MSM_CHUNK, k_msm_chunk_g2q, dim3(blocks_for(4 * p.nchunks)), dim3(BLS_BLOCK), p.c, p.W, p.clast, p.CH, d_sums, d_part);
   else KL(KID_MSM_CHUNK, k_msm_chunk_g1p, dim3(blocks_for(2 * p.nchunks)), dim3(BLS_BLOCK), p.c, p.W, p.clast, p.CH, d_sums, d_part);
-  size_t cur = p.nchunks;
-  while (cur > 1) {
-    size_t half = (cur + 1) / 2;
-    if (G == 2) KL(KID_POINT_FOLD, k_point_fold_g2s, dim3(blocks_for(2 * half)), dim3(BLS_BLOCK), cur, half, d_part);
-    else KL(KID_POINT_FOLD, k_point_fold<G>, dim3(blocks_for(half)), dim3(BLS_BLOCK), cur, half, d_part);
-    cur = half;
-  }
+  if (int rc = run_point_fold<G>(c, d_part, p.nchunks)) return rc;
   KL(KID_MSM_NORM, k_normalize<G>, dim3(1), dim3(BLS_BLOCK), d_part);
   HIPCK(hipGetLastError());
   HIPCK(hipMemcpyAsync(d_out, d_part, G == 1 ? 144 : 288, hipMemcpyDeviceToDevice, c->stream));
@@ -904,6 +959,8 @@ static void release_devices() {
       if (c->ev_host) (void)hipEventDestroy(c->ev_host);
       if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
       if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+      if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
+      if (c->side2) (void)hipStreamDestroy(c->side2);
       if (c->side) (void)hipStreamDestroy(c->side);
       if (c->hpin) (void)hipHostFree(c->hpin);
       if (c->hsmall) (void)hipHostFree(c->hsmall);
@@ -1151,6 +1208,59 @@ static int verify_one_tail(Ctx* c, int sig_group, int scheme, int aug_prefix, co
   return 0;
 }
 
+// The one core_verify at the end of MultiSignature::verify / verify_secure for Bls12381G1Impl when the message takes no key
+// prefix, cut in time (k_pairing_pre / k_pairing_post): BEGIN runs on the side stream, beside the whole key sum -- the hash of
+// the message, the signature's identity check, the Miller function of the (signature, -g2) pair; FINISH runs once the summed
+// key exists: its identity check and affine form, its line coefficients, the other Miller function, the final exponentiation.
+struct CutTail {
+  uint32_t* rec = nullptr;
+  int32_t* d_status = nullptr;
+};
+static int cut_tail_begin(Ctx* c, int scheme, const void* sig, int fmt, const uint8_t* msg, size_t msg_len, CutTail& t) {
+  int rc;
+  const void *d_sig, *d_msg0;
+  if ((rc = stage_in(c, sig, sig_size(1, fmt), &d_sig))) return rc;
+  if ((rc = stage_in(c, msg, msg_len, &d_msg0))) return rc;
+  uint64_t* d_offs0 = (uint64_t*)arena_take(c, 16);
+  t.rec = (uint32_t*)arena_take(c, (size_t)WREC_WORDS * 4);
+  t.d_status = (int32_t*)arena_take(c, 4);
+  if (!d_offs0 || !t.rec || !t.d_status) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  const uint64_t offs0[2] = {0, (uint64_t)msg_len};
+  if ((rc = h2d_small(c, d_offs0, offs0, 16))) return rc;
+  if ((rc = side_fork(c))) return rc;
+  hipLaunchKernelGGL(k_hash_to_g1_wide, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, 1,
+                     scheme_dst(1, scheme), (uint8_t*)nullptr, t.rec);
+  hipLaunchKernelGGL(k_prepare_keys<1>, dim3(1), dim3(BLS_BLOCK), 0, c->side2, (size_t)1, (const uint8_t*)nullptr, (const uint8_t*)d_sig, fmt, 1, t.rec,
+                     t.d_status);
+  hipLaunchKernelGGL(k_pairing_pre, dim3(1, 1), dim3(WIDE_ENGINE_BLOCK), 0, c->side2, (size_t)1, t.rec, (const int32_t*)t.d_status, 1);
+  const hipError_t e1 = hipGetLastError(), e2 = hipEventRecord(c->ev_join, c->side), e3 = hipEventRecord(c->ev_join2, c->side2);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+    (void)hipStreamSynchronize(c->side);
+    (void)hipStreamSynchronize(c->side2);
+    return fail(BLSGPU_E_HIP, "side-stream launch failed");
+  }
+  return 0;
+}
+// rc: the caller's error so far (the side stream is joined either way: its kernels read the arena)
+static int cut_tail_finish(Ctx* c, int rc, const uint8_t* d_pk_proj, CutTail& t, int32_t* status) {
+  const hipError_t e = hipStreamWaitEvent(c->stream, c->ev_join, 0), e2 = hipStreamWaitEvent(c->stream, c->ev_join2, 0);
+  if (rc || e != hipSuccess || e2 != hipSuccess) {
+    (void)hipStreamSynchronize(c->side);
+    (void)hipStreamSynchronize(c->side2);
+    return rc ? rc : fail(BLSGPU_E_HIP, "hipStreamWaitEvent failed");
+  }
+  KL(KID_PREPARE, k_prepare_keys<1>, dim3(1), dim3(BLS_BLOCK), (size_t)1, d_pk_proj, (const uint8_t*)nullptr, BLSGPU_FMT_RAW_PROJ, 2, t.rec, t.d_status);
+  KL(KID_WIDE, k_pairing_pre, dim3(1, 1), dim3(WIDE_ENGINE_BLOCK), (size_t)1, t.rec, (const int32_t*)t.d_status, 0);
+  KL(KID_WIDE, k_pairing_post, dim3(1), dim3(WIDE_ENGINE_BLOCK), (size_t)1, (const uint32_t*)t.rec, t.d_status);
+  HIPCK(hipGetLastError());
+  if ((rc = copy_out(c, status, t.d_status, 4))) return rc;
+  SYNC_FLUSH(c);
+  return 0;
+}
+static bool cut_tail_applies(int sig_group, int scheme) {
+  return sig_group == 1 && scheme != BLSGPU_SCHEME_AUG && wide_max_items() >= 1 && coop_max_items() >= 1;
+}
+
 int blsgpu_multi_verify(int sig_group, int scheme, const void* pks, size_t n, const void* sig, const uint8_t* msg,
                         size_t msg_len, int fmt, int32_t* status) try {
   int rc = check_common(sig_group, scheme, fmt);
@@ -1182,7 +1292,11 @@ int blsgpu_multi_verify(int sig_group, int scheme, const void* pks, size_t n, co
   // Unless the scheme prefixes the aggregated key to the message (MessageAugmentation, reference src/traits/sig_aug.rs:20-24),
   // H(msg) does not depend on the keys: hash it on a side stream (one wave) while the main stream sums the keys.
   uint8_t* d_hash = nullptr;
-  if (scheme != BLSGPU_SCHEME_AUG && n > 0) {
+  CutTail cut;
+  const bool use_cut = cut_tail_applies(sig_group, scheme) && n > 0;
+  if (use_cut) {
+    if ((rc = cut_tail_begin(c, scheme, sig, fmt, msg, msg_len, cut))) return rc;
+  } else if (scheme != BLSGPU_SCHEME_AUG && n > 0) {
     const void* d_msg0;
     if ((rc = stage_in(c, msg, msg_len, &d_msg0))) return rc;
     uint64_t* d_offs0 = (uint64_t*)arena_take(c, 16);
@@ -1190,16 +1304,10 @@ int blsgpu_multi_verify(int sig_group, int scheme, const void* pks, size_t n, co
     if (!d_offs0 || !d_hash) return fail(BLSGPU_E_HIP, "internal: arena too small");
     const uint64_t offs0[2] = {0, (uint64_t)msg_len};
     if ((rc = h2d_small(c, d_offs0, offs0, 16))) return rc;
-    if (!c->side) {
-      HIPCK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-      HIPCK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-      HIPCK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    }
-    HIPCK(hipEventRecord(c->ev_fork, c->stream));
-    HIPCK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    if ((rc = side_fork(c))) return rc;
     if (sig_group == 1)   // one wave, the two SSWU maps on two DPP rows in the row-wide field type (csrc/wide.cuh)
       hipLaunchKernelGGL(k_hash_to_g1_wide, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, 1,
-                         scheme_dst(sig_group, scheme), d_hash);
+                         scheme_dst(sig_group, scheme), d_hash, (uint32_t*)nullptr);
     else
       hipLaunchKernelGGL(k_hash_to_g2, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0,
                          scheme_dst(sig_group, scheme), d_hash, 1);
@@ -1209,6 +1317,7 @@ int blsgpu_multi_verify(int sig_group, int scheme, const void* pks, size_t n, co
   // MultiPublicKey::from_public_keys: the serial `g += key` of reference src/traits/pk_multi.rs:7-13 as a tree sum
   if (sig_group == 1) rc = run_point_sum<2>(c, (const uint8_t*)d_pks, fmt, nullptr, nullptr, n, d_part, T);
   else rc = run_point_sum<1>(c, (const uint8_t*)d_pks, fmt, nullptr, nullptr, n, d_part, T);
+  if (use_cut) return cut_tail_finish(c, rc, d_part, cut, status);
   if (d_hash) {
     hipError_t e = hipStreamWaitEvent(c->stream, c->ev_join, 0);    // also on the error path: the side kernel reads the arena
     if (rc) (void)hipStreamSynchronize(c->side);
@@ -1609,30 +1718,32 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
   bool full_sort = false;
   if ((rc = run_key_sort_to_host(c, d_bytes, n, width, w, c->ev_host, &full_sort))) return rc;
   // H(msg) does not depend on the keys (verify_secure never prefixes them, reference src/secure_aggregation.rs:236-246): the
-  // hash-to-curve of the final core_verify -- one wave, 1.6 ms for G1 and 4 ms for G2 of pure latency -- runs on the side
-  // stream beside everything up to the pairing: the key sort, the host's hash of the key stream and the whole key sum.
-  const void* d_msg0;
-  if ((rc = stage_in(c, msg, msg_len, &d_msg0))) return rc;
-  uint64_t* d_offs0 = (uint64_t*)arena_take(c, 16);
-  uint8_t* d_hash = (uint8_t*)arena_take(c, 288);
-  if (!d_offs0 || !d_hash) return fail(BLSGPU_E_HIP, "internal: arena too small");
-  const uint64_t offs0[2] = {0, (uint64_t)msg_len};
-  if ((rc = h2d_small(c, d_offs0, offs0, 16))) return rc;
-  if (!c->side) {
-    HIPCK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-    HIPCK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    HIPCK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  // hash-to-curve of the final core_verify -- one wave, 1 ms for G1 and 4 ms for G2 of pure latency -- runs on the side
+  // stream beside everything up to the pairing: the key sort, the host's hash of the key stream and the whole key sum; for
+  // Bls12381G1Impl the signature's half of the pairing check goes with it (cut_tail_begin).
+  uint8_t* d_hash = nullptr;
+  CutTail cut;
+  const bool use_cut = cut_tail_applies(sig_group, scheme);
+  if (use_cut) {
+    if ((rc = cut_tail_begin(c, scheme, sig, fmt, msg, msg_len, cut))) return rc;
+  } else {
+    const void* d_msg0;
+    if ((rc = stage_in(c, msg, msg_len, &d_msg0))) return rc;
+    uint64_t* d_offs0 = (uint64_t*)arena_take(c, 16);
+    d_hash = (uint8_t*)arena_take(c, 288);
+    if (!d_offs0 || !d_hash) return fail(BLSGPU_E_HIP, "internal: arena too small");
+    const uint64_t offs0[2] = {0, (uint64_t)msg_len};
+    if ((rc = h2d_small(c, d_offs0, offs0, 16))) return rc;
+    if ((rc = side_fork(c))) return rc;
+    if (sig_group == 1)
+      hipLaunchKernelGGL(k_hash_to_g1_wide, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, 1,
+                         scheme_dst(sig_group, scheme), d_hash, (uint32_t*)nullptr);
+    else
+      hipLaunchKernelGGL(k_hash_to_g2, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0,
+                         scheme_dst(sig_group, scheme), d_hash, 1);
+    HIPCK(hipGetLastError());
+    HIPCK(hipEventRecord(c->ev_join, c->side));
   }
-  HIPCK(hipEventRecord(c->ev_fork, c->stream));
-  HIPCK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-  if (sig_group == 1)
-    hipLaunchKernelGGL(k_hash_to_g1_wide, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, 1,
-                       scheme_dst(sig_group, scheme), d_hash);
-  else
-    hipLaunchKernelGGL(k_hash_to_g2, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0,
-                       scheme_dst(sig_group, scheme), d_hash, 1);
-  HIPCK(hipGetLastError());
-  HIPCK(hipEventRecord(c->ev_join, c->side));
   // ... and so does the scalar-independent part of the key sum (every key to affine, with its endomorphism images)
   const bool msm2 = msm_use_pippenger(n) && !msm_use_v1();
   msm2_ws mw;
@@ -1660,9 +1771,13 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
     if (sig_group == 1) rc = run_point_sum<2>(c, (const uint8_t*)d_pks, fmt, d_scal, nullptr, n, d_part, T);
     else rc = run_point_sum<1>(c, (const uint8_t*)d_pks, fmt, d_scal, nullptr, n, d_part, T);
   }
-  if (rc) return rc;
-  HIPCK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-  if ((rc = verify_one_tail(c, sig_group, scheme, 0, d_part, sig, fmt, msg, msg_len, status, d_hash))) return rc;
+  if (use_cut) {
+    if ((rc = cut_tail_finish(c, rc, d_part, cut, status))) return rc;
+  } else {
+    if (rc) return rc;
+    HIPCK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    if ((rc = verify_one_tail(c, sig_group, scheme, 0, d_part, sig, fmt, msg, msg_len, status, d_hash))) return rc;
+  }
   if (trace)
     fprintf(stderr, "[blsgpu] verify_secure n=%zu: compress + key sort%s + D2H %.2f ms (message hash on the side stream), key-stream SHA-256 on the host %.2f ms, rest %.2f ms\n",
             n, full_sort ? " (full-width)" : "", t1 - t0, t2 - t1, now() - t2);

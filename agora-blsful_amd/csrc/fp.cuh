@@ -536,6 +536,86 @@ BLS_FN void fp_divstep_update_de(int32_t* d, int32_t* e, const fp_divstep_mat& t
   d[FP_NL - 1] = (int32_t)cd;
   e[FP_NL - 1] = (int32_t)ce;
 }
+// The same batches for PUBLIC operands (everything on a verify path is public) when a lone lane inverts -- the row-wide engine's
+// Fp12 inversion, one item per workgroup: trailing zeros of g are divided out in one step, and up to eight low bits of g are
+// cancelled at once by a multiple of f (table of -f^-1 mod 256), as in libsecp256k1's modinv32 "var" variant; ~7 loop rounds
+// per batch instead of 28, the same transition matrix.  Data-dependent trip counts: not for kernels with one item per lane.
+BLS_CONST uint8_t FP_NEGINV256[128] = {
+    0xff, 0x55, 0x33, 0x49, 0xc7, 0x5d, 0x3b, 0x11, 0x0f, 0xe5, 0xc3, 0x59, 0xd7, 0xed, 0xcb, 0x21,
+    0x1f, 0x75, 0x53, 0x69, 0xe7, 0x7d, 0x5b, 0x31, 0x2f, 0x05, 0xe3, 0x79, 0xf7, 0x0d, 0xeb, 0x41,
+    0x3f, 0x95, 0x73, 0x89, 0x07, 0x9d, 0x7b, 0x51, 0x4f, 0x25, 0x03, 0x99, 0x17, 0x2d, 0x0b, 0x61,
+    0x5f, 0xb5, 0x93, 0xa9, 0x27, 0xbd, 0x9b, 0x71, 0x6f, 0x45, 0x23, 0xb9, 0x37, 0x4d, 0x2b, 0x81,
+    0x7f, 0xd5, 0xb3, 0xc9, 0x47, 0xdd, 0xbb, 0x91, 0x8f, 0x65, 0x43, 0xd9, 0x57, 0x6d, 0x4b, 0xa1,
+    0x9f, 0xf5, 0xd3, 0xe9, 0x67, 0xfd, 0xdb, 0xb1, 0xaf, 0x85, 0x63, 0xf9, 0x77, 0x8d, 0x6b, 0xc1,
+    0xbf, 0x15, 0xf3, 0x09, 0x87, 0x1d, 0xfb, 0xd1, 0xcf, 0xa5, 0x83, 0x19, 0x97, 0xad, 0x8b, 0xe1,
+    0xdf, 0x35, 0x13, 0x29, 0xa7, 0x3d, 0x1b, 0xf1, 0xef, 0xc5, 0xa3, 0x39, 0xb7, 0xcd, 0xab, 0x01};
+BLS_FN int32_t fp_divsteps_28_var(int32_t eta, uint32_t f0, uint32_t g0, fp_divstep_mat& t) {
+  uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
+  int i = FP_LB;
+  for (;;) {
+    const int zeros = __builtin_ctz(g | (0xffffffffu << i));      // the sentinel bit stops the count at i
+    g >>= zeros;
+    u <<= zeros;
+    v <<= zeros;
+    eta -= zeros;
+    i -= zeros;
+    if (i == 0) break;
+    if (eta < 0) {
+      uint32_t tmp;
+      eta = -eta;
+      tmp = f; f = g; g = 0u - tmp;
+      tmp = u; u = q; q = 0u - tmp;
+      tmp = v; v = r; r = 0u - tmp;
+    }
+    // eta >= 0: cancel the bottom bits of g -- at most i of them (the batch ends there), at most eta + 1 (the sign flips then)
+    const int limit = (eta + 1) > i ? i : (eta + 1);
+    const uint32_t m = (0xffffffffu >> (32 - limit)) & 255u;
+    const uint32_t w = (g * (uint32_t)FP_NEGINV256[(f >> 1) & 127u]) & m;
+    g += f * w;
+    q += u * w;
+    r += v * w;
+  }
+  t.u = (int32_t)u;
+  t.v = (int32_t)v;
+  t.q = (int32_t)q;
+  t.r = (int32_t)r;
+  return eta;
+}
+BLS_NOINLINE void fp_inv_var(fp& r, const fp& a) {   // 0 -> 0
+  fp x;
+  fp_canon(x, a);
+  int32_t f[FP_NL], g[FP_NL], d[FP_NL], e[FP_NL];
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) {
+    f[i] = (int32_t)FP_P[i];
+    g[i] = x.l[i];
+    d[i] = 0;
+    e[i] = 0;
+  }
+  e[0] = 1;
+  int32_t eta = -1;
+  for (int it = 0; it < 40; it++) {
+    fp_divstep_mat t;
+    const uint32_t f0 = (uint32_t)f[0] | ((uint32_t)f[1] << FP_LB), g0 = (uint32_t)g[0] | ((uint32_t)g[1] << FP_LB);
+    eta = fp_divsteps_28_var(eta, f0, g0, t);
+    fp_divstep_update_de(d, e, t);
+    fp_divstep_update_fg(f, g, t);
+    int32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < FP_NL; i++) nz |= g[i];
+    if (nz == 0) break;                             // g = 0: the remaining batches would change nothing
+  }
+  const int32_t neg = f[FP_NL - 1] >> 31;
+  fp y, k;
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) y.l[i] = (d[i] ^ neg) - neg;
+  FP_TRK(y.lb = FP_LB_N; y.vb = 2.0;)
+  fp_load(k, FP_R3);
+  fp_mul(r, y, k);
+}
+#if defined(BLS_FP_INV_VAR)
+BLS_FN void fp_inv(fp& r, const fp& a) { fp_inv_var(r, a); }
+#else
 BLS_NOINLINE void fp_inv(fp& r, const fp& a) {   // 0 -> 0
   fp x;
   fp_canon(x, a);                               // the integer a R mod p in [0, p), exact limbs
@@ -565,6 +645,8 @@ BLS_NOINLINE void fp_inv(fp& r, const fp& a) {   // 0 -> 0
   fp_load(k, FP_R3);
   fp_mul(r, y, k);
 }
+
+#endif
 
 // Legendre symbol test: a is a square (0 counts as square)
 BLS_FN bool fp_is_square(const fp& a) {

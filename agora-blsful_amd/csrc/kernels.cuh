@@ -271,7 +271,23 @@ __global__ void k_finalexp_wide(size_t n, const uint32_t* easy, int32_t* status)
 __global__ void k_wide_prog_test(const uint32_t* prog, int len, int reps, const uint8_t* fin, uint8_t* tout);
 bool wide_prog_is_fp12(const uint32_t* prog, size_t len);   // host: what k_wide_prog_test may be given
 __global__ void k_pairing_wide(size_t n, const uint32_t* pairs, int32_t* status, int fixed_g2);
-__global__ void k_hash_to_g1_wide(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst, uint8_t* out);
+__global__ void k_hash_to_g1_wide(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst, uint8_t* out, uint32_t* rec);
+// The same check cut where its inputs become known (Bls12381G1Impl; csrc/wide_tables.cuh programs PRE_LINES, PRE_F1, POST).
+// Per item a RECORD of engine values (16 words each) in global memory carries the operands and what the early parts hand over:
+#define WREC_P0 0        // H(m), Jacobian X Y Z                  (k_hash_to_g1_wide)
+#define WREC_P1 3        // the signature, Jacobian X Y Z          (k_prepare_keys, part 1)
+#define WREC_Q0 6        // the key, Jacobian X Y Z in Fp2: 6 values  (k_prepare_keys, part 2)
+#define WREC_F1 12       // Miller function of (signature, -g2)    (k_pairing_pre, part 1)
+#define WREC_L 24        // the key's 68 unscaled lines, 6 values each (k_pairing_pre, part 0)
+#define WREC_VALUES (24 + 6 * 68)
+#define WREC_WORDS (16 * WREC_VALUES)
+template <int SG>
+__global__ void k_prepare_keys(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int parts, uint32_t* rec, int32_t* status);
+__global__ void k_pairing_pre(size_t n, uint32_t* rec, const int32_t* status, int first_part);   // grid (n, parts): 0 = the key's lines, 1 = F1
+__global__ void k_pairing_post(size_t n, const uint32_t* rec, int32_t* status);
+// the last levels of a point sum on the engine: workgroup b <- the sum of points [16 b, 16 b + 16) (RAW_PROJ in and out)
+template <int G>
+__global__ void k_point_tree_wide(size_t m, const uint8_t* in, uint8_t* out);
 
 #if defined(BLS_TU_PREPARE1) || defined(BLS_TU_PREPARE2)
 // =====================================================================================================
@@ -522,6 +538,61 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_prepare_hashed(size_t n, const ui
 }
 template __global__ void k_prepare_hashed<1>(size_t, const uint8_t*, const uint8_t*, const uint8_t*, uint32_t*, int32_t*, int);
 template __global__ void k_prepare_hashed<2>(size_t, const uint8_t*, const uint8_t*, const uint8_t*, uint32_t*, int32_t*, int);
+
+// The operands of the cut check (k_pairing_pre / k_pairing_post) that do not depend on the message, written as engine values
+// into the item's record.  parts & 1: the signature -- identity check (first, reference src/traits/sig_core.rs:126-129);
+// parts & 2: the key -- identity check (:130-135, only if the signature passed).  Both are stored as they come, Jacobian: the
+// engine's programs evaluate lines at projective G1 points and walk the Miller loop from a projective G2 point
+// (tools/gen_wide_tables.py op_lscale, op_padd*), so NO inversion is spent on the way to the pairing.  The two parts may come
+// in separate launches (a multi-signature's key is only known after the sum): the signature part runs first and sets status,
+// the key part keeps a failure it finds there.
+template <int SG>
+__global__ void __launch_bounds__(BLS_BLOCK) k_prepare_keys(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int parts, uint32_t* rec,
+                                                          int32_t* status) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  static_assert(SG == 1, "the cut check is built for Bls12381G1Impl");
+  uint32_t* r = rec + i * WREC_WORDS;
+  auto put = [&](int v, const fp& a) {
+#pragma unroll
+    for (int k = 0; k < FP_NL; k++) r[16 * v + k] = (uint32_t)a.l[k];
+    r[16 * v + 14] = 0;
+    r[16 * v + 15] = 0;
+  };
+  int st = (parts & 1) ? BLS_OK : status[i];
+  if (parts & 1) {
+    g1_jac sig;
+    load_g1_pt(sig, sigs, i, fmt);
+    if (jac_is_inf(sig)) st = BLS_ERR_SIG_IDENTITY;
+    fp t;
+    fp_reduce(t, sig.x);
+    put(WREC_P1, t);
+    fp_reduce(t, sig.y);
+    put(WREC_P1 + 1, t);
+    fp_reduce(t, sig.z);
+    put(WREC_P1 + 2, t);
+  }
+  if (parts & 2) {
+    g2_jac pk;
+    load_g2_pt(pk, pks, i, fmt);
+    if (jac_is_inf(pk) && st == BLS_OK) st = BLS_ERR_PK_IDENTITY;
+    fp t;
+    fp_reduce(t, pk.x.c0);
+    put(WREC_Q0, t);
+    fp_reduce(t, pk.x.c1);
+    put(WREC_Q0 + 1, t);
+    fp_reduce(t, pk.y.c0);
+    put(WREC_Q0 + 2, t);
+    fp_reduce(t, pk.y.c1);
+    put(WREC_Q0 + 3, t);
+    fp_reduce(t, pk.z.c0);
+    put(WREC_Q0 + 4, t);
+    fp_reduce(t, pk.z.c1);
+    put(WREC_Q0 + 5, t);
+  }
+  status[i] = st;
+}
+template __global__ void k_prepare_keys<1>(size_t, const uint8_t*, const uint8_t*, int, int, uint32_t*, int32_t*);
 
 // status (0 = product is one) -> is_one flag (1 / 0)
 __global__ void __launch_bounds__(BLS_BLOCK) k_status_to_flag(size_t n, int32_t* status) {
@@ -1613,7 +1684,7 @@ bool wide_prog_is_fp12(const uint32_t* prog, size_t len) {
   for (size_t k = 0; k < len; k++) {
     const uint32_t w0 = prog[2 * k], w1 = prog[2 * k + 1], op = w0 & 0xffffu;
     const uint32_t refs[3] = {w0 >> 16, w1 & 0xffffu, w1 >> 16};
-    if (op >= WOP_PDBL1 && op != WOP_MUL_LINE) return false;
+    if (op >= WOP_PDBL1 && op != WOP_MUL_LINE && op != WOP_INV) return false;
     for (uint32_t r : refs)
       if (r != WV_F && r != WV_T && r != WV_U && r != WV_W && r != WV_ACC) return false;
   }
@@ -1692,16 +1763,14 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_wide(size_t n, co
   // per pair k: P = (x, y) at words w0, w0 + W1; Q = (x.c0, x.c1, y.c0, y.c1) at w0 + W2 ...
   if (row < 2) {
     const int w0 = row * 3 * W2;
-    S.V[WV_P + 2 * row][l] = ws_word(w0);
-    S.V[WV_P + 2 * row + 1][l] = ws_word(w0 + W1);
+    S.V[WV_P + 4 * row][l] = ws_word(w0);             // the G1 point as the Jacobian triple (x, y, 1): the programs take any Z
+    S.V[WV_P + 4 * row + 1][l] = ws_word(w0 + W1);
+    S.V[WV_P + 4 * row + 2][l] = l < FP_NL ? FP_ONE[l] : 0u;
+    S.V[WV_P + 4 * row + 3][l] = 0u;
     const uint32_t pt = row == 0 ? WV_PT0 : WV_PT1;
-    for (int c4 = 0; c4 < 4; c4++) {
-      const uint32_t q = ws_word(w0 + W2 + c4 * W1);
-      S.V[pt + c4][l] = q;          // T = Q
-      S.V[pt + 6 + c4][l] = q;      // Q
-    }
-    S.V[pt + 4][l] = l < FP_NL ? FP_ONE[l] : 0u;   // Z = 1
-    S.V[pt + 5][l] = 0u;
+    for (int c4 = 0; c4 < 4; c4++) S.V[pt + 6 + c4][l] = ws_word(w0 + W2 + c4 * W1);   // Q = (x, y, 1), Jacobian as the programs expect
+    S.V[pt + 10][l] = l < FP_NL ? FP_ONE[l] : 0u;
+    S.V[pt + 11][l] = 0u;
   }
   if (row == 2) {
     S.V[WV_F][l] = l < FP_NL ? FP_ONE[l] : 0u;     // f = 1
@@ -1730,6 +1799,123 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_wide(size_t n, co
   __syncthreads();
   if (threadIdx.x == 0) status[item] = S.flag ? BLS_OK : BLS_ERR_INVALID_SIGNATURE;
 }
+
+// The cut check, early parts.  blockIdx.y + first_part = 0: the key's line coefficients (program PRE_LINES: needs the key only);
+// 1: the Miller function of the (signature, -g2) pair (PRE_F1: needs the signature only).  Both leave their result in the
+// item's record; a single verification runs them side by side on two CUs while a third hashes the message.
+__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_pre(size_t n, uint32_t* rec, const int32_t* status, int first_part) {
+  __shared__ wide_lds_t<wide_tb_f12> S;
+  const size_t item = blockIdx.x;
+  const int part = first_part + (int)blockIdx.y;
+  if (item >= n) return;
+  if (status[item] != BLS_OK) return;                   // uniform over the workgroup
+  wide_consts K;
+  wide_init(K);
+  uint32_t* r = rec + item * WREC_WORDS;
+  const int l = (int)(threadIdx.x & 15u), v = (int)(threadIdx.x >> 4);
+  const uint32_t one_l = l < FP_NL ? FP_ONE[l] : 0u;
+  if (part == 0) {
+    wide_stage(S, WIDE_PROG_PRE_LINES, WIDE_PROG_PRE_LINES_LEN);
+    if (v < 6) S.V[WV_PT0 + 6 + v][l] = r[16 * (WREC_Q0 + v) + l];      // Q, Jacobian (QPREP makes it homogeneous and sets T = Q)
+    __syncthreads();
+    wide_exec(S, WIDE_PROG_PRE_LINES_LEN, K, WV_F, WV_T);
+    for (int t = threadIdx.x; t < WIDE_STEPS * 6 * 16; t += WIDE_ENGINE_BLOCK) {
+      const int st = t / 96, w = t % 96;
+      r[16 * WREC_L + 96 * st + w] = S.V[WV_L + 12 * st + (w >> 4)][w & 15];
+    }
+  } else {
+    wide_stage(S, WIDE_PROG_PRE_F1, WIDE_PROG_PRE_F1_LEN);
+    if (v < 3) S.V[WV_P + 4 + v][l] = r[16 * (WREC_P1 + v) + l];
+    if (v == 3) S.V[WV_P + 7][l] = 0u;
+    if (v >= 4) S.V[WV_F + v - 4][l] = v == 4 ? one_l : 0u;          // f = 1
+    for (int t = threadIdx.x; t < WIDE_STEPS * 6 * 16; t += WIDE_ENGINE_BLOCK) {
+      const int st = t / 96, w = (t % 96) >> 4, ll = t & 15;
+      S.V[WV_L + 12 * st + 6 + w][ll] = ll < FP_NL ? G2NEG_LINES[st][w * FP_NL + ll] : 0u;
+    }
+    __syncthreads();
+    wide_exec(S, WIDE_PROG_PRE_F1_LEN, K, WV_F, WV_T);
+    if (v < 12) r[16 * (WREC_F1 + v) + l] = S.V[WV_F + v][l];
+  }
+}
+// The cut check, late part (program POST): the Miller function of (H(m), key) from the key's lines, times the other one, the
+// final exponentiation and the comparison with one.
+__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_post(size_t n, const uint32_t* rec, int32_t* status) {
+  __shared__ wide_lds_t<wide_tb_f12> S;
+  const size_t item = blockIdx.x;
+  if (item >= n) return;
+  if (status[item] != BLS_OK) return;                   // uniform over the workgroup
+  wide_consts K;
+  wide_init(K);
+  wide_stage(S, WIDE_PROG_POST, WIDE_PROG_POST_LEN);
+  const uint32_t* r = rec + item * WREC_WORDS;
+  const int l = (int)(threadIdx.x & 15u), v = (int)(threadIdx.x >> 4);
+  if (v < 3) S.V[WV_P + v][l] = r[16 * (WREC_P0 + v) + l];
+  if (v == 3) S.V[WV_P + 3][l] = 0u;
+  if (v >= 4) S.V[WV_F + v - 4][l] = (v == 4 && l < FP_NL) ? FP_ONE[l] : 0u;   // f = 1
+  if (v < 12) S.V[WV_W + v][l] = r[16 * (WREC_F1 + v) + l];
+  for (int t = threadIdx.x; t < WIDE_STEPS * 6 * 16; t += WIDE_ENGINE_BLOCK) {
+    const int st = t / 96, w = t % 96;
+    S.V[WV_L + 12 * st + (w >> 4)][w & 15] = r[16 * WREC_L + 96 * st + w];
+  }
+  if (threadIdx.x == 0) S.flag = 1;
+  __syncthreads();
+  wide_exec(S, WIDE_PROG_POST_LEN, K, WV_F, WV_T);
+  if (threadIdx.x < 12) {
+    fp x, one;
+    w_load_local(x, S.V[WV_T + threadIdx.x]);
+    bool ok;
+    if (threadIdx.x == 0) {
+      fp_one(one);
+      ok = fp_eq(x, one);
+    } else {
+      ok = fp_is_zero(x);
+    }
+    if (!ok) S.flag = 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) status[item] = S.flag ? BLS_OK : BLS_ERR_INVALID_SIGNATURE;
+}
+
+// The tail of every point sum (MultiPublicKey::from_public_keys, the windows of a multi-scalar multiplication): a fold level of
+// the lane-local / lane-pair kernels is one addition deep and costs ~50 us however few points are left, sixteen levels for a
+// million keys.  Here one workgroup sums SIXTEEN points -- four levels of complete projective additions as table operations
+// (csrc/wide_tables.cuh, set PT; ~35 us) -- so 4,096 partial sums are one point after three launches.  in / out: RAW_PROJ
+// (Jacobian; an identity comes back as Z = 0).
+template <int G>
+__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_point_tree_wide(size_t m, const uint8_t* in, uint8_t* out) {
+  __shared__ wide_lds_t<wide_tb_pt> S;
+  constexpr int NV = G == 1 ? 3 : 6, PSZ = G == 1 ? 144 : 288;          // Fp values and bytes per point
+  const size_t base = (size_t)blockIdx.x * WIDE_PT_POINTS;
+  wide_consts K;
+  wide_init(K);
+  wide_stage(S, G == 1 ? WIDE_PROG_G1_JJ : WIDE_PROG_G2_JJ, G == 1 ? WIDE_PROG_G1_JJ_LEN : WIDE_PROG_G2_JJ_LEN);
+  if (threadIdx.x < WIDE_PT_POINTS * NV) {
+    const int i = (int)threadIdx.x / NV, v = (int)threadIdx.x % NV;
+    const int slot = G == 1 ? WIDE_PT_SLOT_G1 * (i >> 1) + 3 * (i & 1) : WIDE_PT_SLOT_G2 * (i >> 1) + 6 * (i & 1);
+    fp x;
+    bool inf = base + i >= m;
+    if (!inf) {
+      const uint32_t* w = (const uint32_t*)(in + (base + i) * PSZ);
+      inf = words_all_zero(w + (G == 1 ? 24 : 48), G == 1 ? 12 : 24);     // Z = 0
+      if (!inf) fp_from_raw(x, w + 12 * v);
+    }
+    if (inf) {                                                             // the identity as (0, 1, 0)
+      if (v == (G == 1 ? 1 : 2)) fp_one(x);
+      else fp_zero(x);
+    }
+    fp_reduce(x, x);
+    w_store_local(S.V[WPV_L0 + slot + v], x);
+  }
+  __syncthreads();
+  wide_exec(S, G == 1 ? WIDE_PROG_G1_JJ_LEN : WIDE_PROG_G2_JJ_LEN, K);
+  if (threadIdx.x < NV) {
+    fp x;
+    w_load_local(x, S.V[WPV_L4 + threadIdx.x]);
+    fp_to_raw((uint32_t*)(out + (size_t)blockIdx.x * PSZ) + 12 * threadIdx.x, x);
+  }
+}
+template __global__ void k_point_tree_wide<1>(size_t, const uint8_t*, uint8_t*);
+template __global__ void k_point_tree_wide<2>(size_t, const uint8_t*, uint8_t*);
 
 // ---- hash_to_curve to G1 for single items: ONE wave per message, the two SSWU maps on rows 0 and 1 of the wave in the
 // row-wide field type `wf` (csrc/wide.cuh), then both rows add the two points and clear the cofactor redundantly.
@@ -1831,7 +2017,8 @@ __device__ __noinline__ void jac_mul_u64_rows(jac<wf>& r, const jac<wf>& p, uint
   }
   r = acc;
 }
-__global__ void __launch_bounds__(WIDE_BLOCK) k_hash_to_g1_wide(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst, uint8_t* out) {
+__global__ void __launch_bounds__(WIDE_BLOCK) k_hash_to_g1_wide(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst, uint8_t* out,
+                                                             uint32_t* rec) {
   __shared__ uint32_t pts[4][2][3][16];     // per wave: the Jacobian points of the two maps
   const int wave = threadIdx.x >> 6, row = (threadIdx.x >> 4) & 3, l = threadIdx.x & 15;
   const size_t i = (size_t)blockIdx.x * (blockDim.x >> 6) + wave;
@@ -1864,7 +2051,17 @@ __global__ void __launch_bounds__(WIDE_BLOCK) k_hash_to_g1_wide(size_t n, const 
   jac_add(q0, q0, q1);
   jac_mul_u64_rows(q1, q0, BLS_X_ABS, row == 1);   // clear cofactor: h_eff = 1 - x = 1 + |x|
   jac_add(acc, q1, q0);
-  if (row == 0) {
+  if (row == 0 && rec) {                       // the cut check takes H(m) as engine values, Jacobian, straight from the row
+    uint32_t* r = rec + i * WREC_WORDS + 16 * WREC_P0;
+    wf t;
+    fp_reduce(t, acc.x);
+    r[l] = (uint32_t)t.v;
+    fp_reduce(t, acc.y);
+    r[16 + l] = (uint32_t)t.v;
+    fp_reduce(t, acc.z);
+    r[32 + l] = (uint32_t)t.v;
+  }
+  if (row == 0 && out) {
     fp X, Y, Z;
     wf_to_local(X, acc.x);
     wf_to_local(Y, acc.y);

@@ -59,6 +59,9 @@ int hs_device_path_only = 0;   // tools/count_fpmul.py: run exactly what the ker
 void hs_fp_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) {
   fp x, y, z; fp_from_raw(x, a); fp_from_raw(y, b); fp_mul(z, x, y); fp_to_raw(out, z);
 }
+void hs_fp_inv_var(const uint32_t* a, uint32_t* out) {   // the variable-time inversion of the lone-lane paths
+  fp x, z; fp_from_raw(x, a); fp_inv_var(z, x); fp_to_raw(out, z);
+}
 void hs_fp_ops(const uint32_t* a, const uint32_t* b, uint32_t* out) {  // add, sub, neg, inv, sqrt-flag
   fp x, y, z; fp_from_raw(x, a); fp_from_raw(y, b);
   fp_add(z, x, y); fp_to_raw(out, z);

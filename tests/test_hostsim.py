@@ -32,6 +32,10 @@ def test_fp_ops(hs):
         if c.fp_is_square(a):
             assert util.fp_from_raw(r[196:244]) ** 2 % P == a
         assert bool(int.from_bytes(r[244:248], 'little')) == (a > (P - 1) // 2)
+    # the variable-time inversion (public operands, one lane per item: the row-wide engine's Fp12 inversion)
+    for a in vals + [2 ** k for k in range(0, 381, 13)] + [P - 2 ** k for k in range(1, 380, 17)]:
+        hs.hs_fp_inv_var(util.fp_raw(a), out)
+        assert util.fp_from_raw(out.raw) == (pow(a, -1, P) if a else 0)
 
 
 def test_fp_lazy_limbs(hs):

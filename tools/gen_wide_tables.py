@@ -189,10 +189,12 @@ OPS = [op_mul(), op_sqr(), op_cyc_sqr(), op_frob(1), op_frob(2), op_conj(), op_c
 
 
 # ------------------------------------------------------------------ Miller loop on the engine
-# Point workspace of one pair (array PT, 32 values): T = X Y Z (0..5), Q = xq yq (6..9), line l0 c2 c3 (10..15), M (16..31).
+# Point workspace of one pair (array PT, 32 values): T = X Y Z (0..5), Q = Xq Yq Zq (6..11), line l0 c2 c3 (12..17), M (18..31).
 # The steps are the homogeneous-projective formulas of csrc/pairing.cuh (miller_dbl_step / miller_add_step), cut into levels
-# of independent products; the line leaves UNSCALED (c2, c3 still to be multiplied by xP, yP: LSCALE).
-PT_T, PT_Q, PT_L, PT_M = 0, 6, 10, 16
+# of independent products; the line leaves UNSCALED (c2, c3 still to be multiplied by the G1 point's coordinates: LSCALE).
+# Q is PROJECTIVE too (homogeneous; it arrives Jacobian and QPREP converts: no inversion on the key): the add step below is the
+# mixed one with theta, lambda scaled by Zq and the line by Zq^2 -- factors in Fp2, which the final exponentiation removes.
+PT_T, PT_Q, PT_L, PT_M = 0, 6, 12, 18
 
 
 def f2(slot, off):
@@ -249,56 +251,78 @@ def op_pdbl2():
     return op
 
 
+def op_qprep(stage):
+    """Q: Jacobian (X, Y, Z) -> homogeneous (X Z, Y, Z^3).  A: ZZ = Z^2 -> M0, X <- X Z;  B: Z <- Z ZZ;  C: T <- Q"""
+    op = Op('QPREP' + stage)
+    X, Z = f2(SA, PT_Q), f2(SA, PT_Q + 4)
+    if stage == 'A':
+        lin2(op, op.fp2_sqr(Z), PT_M + 0)
+        lin2(op, op.fp2_mul(X, Z), PT_Q + 0)
+    elif stage == 'B':
+        lin2(op, op.fp2_mul(Z, f2(SA, PT_M + 0)), PT_Q + 4)
+    else:
+        for k in range(6):
+            op.lin([(1, idx(SA, PT_Q + k))], idx(DST, PT_T + k))
+    return op
+
+
+# add step T <- T + Q, line through T and Q.  With theta = Y Zq - Yq Z, lambda = X Zq - Xq Z (the affine-Q quantities times Zq):
+#   cc = theta^2, dd = lambda^2, e = lambda dd, f = (Z Zq) cc, g = (X Zq) dd, h = e + f - 2 g
+#   X3 = lambda h,  Y3 = theta (g - h) - e (Y Zq),  Z3 = (Z Zq) e
+#   line (times Zq^2): l0 = theta Xq - lambda Yq,  c2 = -theta Zq,  c3 = lambda Zq
+# M: 0 theta, 2 lambda, 4 X Zq (then h), 6 Y Zq, 8 Z Zq, 10 cc (then e), 12 dd (then g - h)
 def op_padd1():
     op = Op('PADD1')
     X, Y, Z = f2(SA, PT_T), f2(SA, PT_T + 2), f2(SA, PT_T + 4)
-    xq, yq = f2(SA, PT_Q), f2(SA, PT_Q + 2)
-    yz = op.fp2_mul(yq, Z)
-    xz = op.fp2_mul(xq, Z)
-    lin2(op, sub2(([Y[0]], [Y[1]]), yz), PT_M + 0)        # theta = Y - yq Z
-    lin2(op, sub2(([X[0]], [X[1]]), xz), PT_M + 2)        # lambda = X - xq Z
+    xq, yq, zq = f2(SA, PT_Q), f2(SA, PT_Q + 2), f2(SA, PT_Q + 4)
+    yzq, xzq, zzq = op.fp2_mul(Y, zq), op.fp2_mul(X, zq), op.fp2_mul(Z, zq)
+    yqz, xqz = op.fp2_mul(yq, Z), op.fp2_mul(xq, Z)
+    lin2(op, sub2(yzq, yqz), PT_M + 0)
+    lin2(op, sub2(xzq, xqz), PT_M + 2)
+    lin2(op, xzq, PT_M + 4)
+    lin2(op, yzq, PT_M + 6)
+    lin2(op, zzq, PT_M + 8)
     return op
 
 
 def op_padd2():
     op = Op('PADD2')
     th, la = f2(SA, PT_M + 0), f2(SA, PT_M + 2)
-    xq, yq = f2(SA, PT_Q), f2(SA, PT_Q + 2)
+    xq, yq, zq = f2(SA, PT_Q), f2(SA, PT_Q + 2), f2(SA, PT_Q + 4)
     a = op.fp2_mul(th, xq)
     b = op.fp2_mul(la, yq)
     cc = op.fp2_sqr(th)
     dd = op.fp2_sqr(la)
-    lin2(op, sub2(a, b), PT_L + 0)                        # l0 = theta xq - lambda yq
-    lin2(op, ([th[0]], [th[1]]), PT_L + 2, -1)            # c2 = -theta
-    lin2(op, ([la[0]], [la[1]]), PT_L + 4)                # c3 = lambda
-    lin2(op, cc, PT_M + 4)
-    lin2(op, dd, PT_M + 6)
+    tz = op.fp2_mul(th, zq)
+    lz = op.fp2_mul(la, zq)
+    lin2(op, sub2(a, b), PT_L + 0)
+    lin2(op, tz, PT_L + 2, -1)
+    lin2(op, lz, PT_L + 4)
+    lin2(op, cc, PT_M + 10)
+    lin2(op, dd, PT_M + 12)
     return op
 
 
 def op_padd3():
     op = Op('PADD3')
-    la, cc, dd = f2(SA, PT_M + 2), f2(SA, PT_M + 4), f2(SA, PT_M + 6)
-    X, Z = f2(SA, PT_T), f2(SA, PT_T + 4)
+    la, xzq, zzq, cc, dd = f2(SA, PT_M + 2), f2(SA, PT_M + 4), f2(SA, PT_M + 8), f2(SA, PT_M + 10), f2(SA, PT_M + 12)
     e = op.fp2_mul(la, dd)
-    f = op.fp2_mul(Z, cc)
-    g = op.fp2_mul(X, dd)
+    f = op.fp2_mul(zzq, cc)
+    g = op.fp2_mul(xzq, dd)
     h = sub2(add2(e, f), (scale(g[0], 2), scale(g[1], 2)))
-    lin2(op, e, PT_M + 8)
-    lin2(op, sub2(g, h), PT_M + 10)                       # g - h
-    lin2(op, h, PT_M + 12)
+    lin2(op, e, PT_M + 10)
+    lin2(op, sub2(g, h), PT_M + 12)
+    lin2(op, h, PT_M + 4)
     return op
 
 
 def op_padd4():
     op = Op('PADD4')
-    th, la = f2(SA, PT_M + 0), f2(SA, PT_M + 2)
-    e, gh, h = f2(SA, PT_M + 8), f2(SA, PT_M + 10), f2(SA, PT_M + 12)
-    Y, Z = f2(SA, PT_T + 2), f2(SA, PT_T + 4)
+    th, la, h, yzq, zzq, e, gh = (f2(SA, PT_M + o) for o in (0, 2, 4, 6, 8, 10, 12))
     x3 = op.fp2_mul(la, h)
     t = op.fp2_mul(th, gh)
-    u = op.fp2_mul(e, Y)
-    z3 = op.fp2_mul(Z, e)
+    u = op.fp2_mul(e, yzq)
+    z3 = op.fp2_mul(zzq, e)
     lin2(op, x3, PT_T + 0)
     lin2(op, sub2(t, u), PT_T + 2)
     lin2(op, z3, PT_T + 4)
@@ -312,14 +336,33 @@ def op_copy6():
     return op
 
 
-def op_lscale():
-    """the lines of both pairs of one step (array L[step]: pair p at 6p) scaled by (xP, yP) of their pair (array P: 2p, 2p+1)"""
-    op = Op('LSCALE')
-    for pr in range(2):
-        for part, pc in ((2, 0), (4, 1)):                 # c2 * xP, c3 * yP
+def v1(off):
+    return (1, idx(SA, off))
+
+
+def op_lscale(pairs):
+    """the lines of one step (array L[step]: pair p at 6p) evaluated at the pairs' G1 points, which are JACOBIAN (X, Y, Z): the
+    line l0 + c2 x w^2 + c3 y w^3 times Z^3 (a factor in Fp, which the final exponentiation removes) is
+    l0 Z^3 + c2 (X Z) w^2 + c3 Y w^3; array P holds (X Z, Y, Z^3, -) of pair p at 4p (PPREPA / PPREPB).  No inversion anywhere."""
+    op = Op('LSCALE' + ''.join(str(p) for p in pairs))
+    for pr in pairs:
+        for part, pc in ((0, 2), (2, 0), (4, 1)):         # l0 * Z^3, c2 * XZ, c3 * Y
             for comp in range(2):
-                t = op.prod([(1, idx(SA, 6 * pr + part + comp))], [(1, idx(SB, 2 * pr + pc))])
+                t = op.prod([(1, idx(SA, 6 * pr + part + comp))], [(1, idx(SB, 4 * pr + pc))])
                 op.lin([(1, t)], idx(DST, 6 * pr + part + comp))
+    return op
+
+
+def op_pprep(stage, pairs):
+    """array P, pair p at 4p: (X, Y, Z, -) -> A: (X Z, Y, Z, Z^2) -> B: (X Z, Y, Z^3, Z^2)"""
+    op = Op('PPREP%s%s' % (stage, ''.join(str(p) for p in pairs)))
+    for pr in pairs:
+        o = 4 * pr
+        if stage == 'A':
+            op.lin([(1, op.prod([v1(o + 2)], [v1(o + 2)]))], idx(DST, o + 3))
+            op.lin([(1, op.prod([v1(o)], [v1(o + 2)]))], idx(DST, o))
+        else:
+            op.lin([(1, op.prod([v1(o + 2)], [v1(o + 3)]))], idx(DST, o + 2))
     return op
 
 
@@ -341,7 +384,8 @@ def op_mul_line():
     return op
 
 
-OPS += [op_pdbl1(), op_pdbl2(), op_padd1(), op_padd2(), op_padd3(), op_padd4(), op_copy6(), op_lscale(), op_mul_line()]
+OPS += [op_pdbl1(), op_pdbl2(), op_padd1(), op_padd2(), op_padd3(), op_padd4(), op_copy6(), op_lscale((0, 1)), op_mul_line(),
+        op_lscale((0,)), op_lscale((1,))] + [op_pprep(st, pr) for pr in ((0, 1), (0,), (1,)) for st in 'AB'] + [op_qprep(st) for st in 'ABC']
 
 
 
@@ -431,10 +475,6 @@ def op_c2h2j(stage):
     else:
         lin2(op, op.fp2_mul(f2(SA, 2), f2(SA, 12)), 2)
     return op
-
-
-def v1(off):
-    return (1, idx(SA, off))
 
 
 def op_c1add1(m):
@@ -635,9 +675,9 @@ def prog_final_hard():
 
 
 def prog_key_lines(pair):
-    """the UNSCALED line coefficients of the Miller steps of pair `pair` (its point workspace holds T = Q, Z = 1) -> L[step][pair]"""
+    """the UNSCALED line coefficients of the Miller steps of pair `pair` (its point workspace holds Q, Jacobian) -> L[step][pair]"""
     pt = 'PT%d' % pair
-    st, step = [], 0
+    st, step = [('QPREP' + x, pt, pt, pt) for x in 'ABC'], 0
     for i in range(62, -1, -1):
         st += [('PDBL1', pt, pt, pt), ('PDBL2', pt, pt, pt), ('COPY6', ('L', 12 * step + 6 * pair), pt, pt)]
         step += 1
@@ -648,17 +688,24 @@ def prog_key_lines(pair):
     return st
 
 
-def prog_miller():
-    """F <- conj(prod of the two pairs' Miller functions), the lines taken from L (scaled here by the pairs' G1 points)"""
+def prog_pprep(pairs):
+    sfx = ''.join(str(p) for p in pairs)
+    return [('PPREPA' + sfx, 'P', 'P', 'P'), ('PPREPB' + sfx, 'P', 'P', 'P')]
+
+
+def prog_miller(pairs=(0, 1)):
+    """F <- F * prod over `pairs` of the pairs' Miller functions (not yet conjugated), the lines taken from L and evaluated here at
+    the pairs' G1 points (array P, prepared by prog_pprep)"""
+    sfx = ''.join(str(p) for p in pairs)
     st, step = [], 0
     for i in range(62, -1, -1):
         if i != 62:
             st.append(('SQR', 'F', 'F', 'F'))
         for _ in range(2 if (X_ABS >> i) & 1 else 1):
             ls = ('L', 12 * step)
-            st += [('LSCALE', ls, ls, 'P'), ('MUL_LINE', 'F', 'F', ls), ('MUL_LINE', 'F', 'F', ('L', 12 * step + 6))]
+            st.append(('LSCALE' + sfx, ls, ls, 'P'))
+            st += [('MUL_LINE', 'F', 'F', ('L', 12 * step + 6 * p)) for p in pairs]
             step += 1
-    st.append(('CONJ', 'F', 'F', 'F'))
     return st
 
 
@@ -667,14 +714,20 @@ def prog_easy():
     return [('CONJ', 'U', 'F', 'F'), ('INV', 'T', 'F', 'F'), ('MUL', 'F', 'U', 'T'), ('FROB2', 'T', 'F', 'F'), ('MUL', 'F', 'T', 'F')]
 
 
+CONJ_F = [('CONJ', 'F', 'F', 'F')]                 # x < 0: the Miller function of |x| is conjugated once, after the product
 PROGRAMS = [('FINAL_HARD', prog_final_hard()),
             # core_verify of Bls12381G1Impl: pair 1's G2 argument is the constant -g2, its lines come from a table
-            ('PAIR_FIXED', prog_key_lines(0) + prog_miller() + prog_easy() + prog_final_hard()),
-            ('PAIR_GENERAL', prog_key_lines(0) + prog_key_lines(1) + prog_miller() + prog_easy() + prog_final_hard())]
+            ('PAIR_FIXED', prog_pprep((0, 1)) + prog_key_lines(0) + prog_miller() + CONJ_F + prog_easy() + prog_final_hard()),
+            ('PAIR_GENERAL', prog_pprep((0, 1)) + prog_key_lines(0) + prog_key_lines(1) + prog_miller() + CONJ_F + prog_easy() + prog_final_hard()),
+            # the same check cut where its inputs become known: the key's lines (needs the key), the Miller function of the
+            # (signature, -g2) pair (needs the signature), and the rest (needs H(m)): F <- miller(pair 0) * W, W = the other function
+            ('PRE_LINES', prog_key_lines(0)),
+            ('PRE_F1', prog_pprep((1,)) + prog_miller((1,))),
+            ('POST', prog_pprep((0,)) + prog_miller((0,)) + [('MUL', 'F', 'F', 'W')] + CONJ_F + prog_easy() + prog_final_hard())]
 
 
 def layout_f12():
-    return Layout([('F', 12), ('T', 12), ('U', 12), ('W', 12), ('ACC', 12), ('TMP', 2 * (max(o.ntmp for o in OPS) + 1)), ('CONST', 24), ('P', 4),
+    return Layout([('F', 12), ('T', 12), ('U', 12), ('W', 12), ('ACC', 12), ('TMP', 2 * (max(o.ntmp for o in OPS) + 1)), ('CONST', 24), ('P', 8),
                    ('PT0', 32), ('PT1', 32), ('L', 12 * NSTEPS)])
 
 
@@ -714,26 +767,55 @@ def check_programs():
     V[B['F']:B['F'] + 12] = flat(easy)
     sim_program(OPS, lay, prog_final_hard(), V)
     assert unflat(V[B['T']:B['T'] + 12]) == c.final_exponentiation(a), 'hard part program'
-    # whole pairing: e(P0, Q0) e(P1, Q1) with the general program
+    # whole pairing: e(P0, Q0) e(P1, Q1) with the general program, and cut into PRE_LINES / PRE_F1 / POST; the G1 points enter
+    # as Jacobian triples with random Z
     sk, h = rng.randrange(1, c.R), rng.randrange(1, c.R)
     Hm = c.E1.mul(c.G1_GEN, h)
     pk = c.E2.mul(c.G2_GEN, sk)
     sig = c.E1.mul(Hm, sk)
     negg2 = c.E2.neg(c.G2_GEN)
+
+    def jac(pt):
+        z = rng.randrange(1, P)
+        return [pt[0] * z * z % P, pt[1] * z * z * z % P, z, 0]
+
+    def set_pt(V, pr, q):
+        z = (rng.randrange(1, P), rng.randrange(P))
+        z2 = c.f2_sqr(z)
+        pt = [0] * 32
+        pt[6:12] = list(c.f2_mul(q[0], z2)) + list(c.f2_mul(q[1], c.f2_mul(z2, z))) + list(z)     # Jacobian, any Z
+        V[B['PT%d' % pr]:B['PT%d' % pr] + 32] = pt
+
     for sgn, want_one in ((sig, True), (c.E1.mul(sig, 2), False)):
         pairs = [(Hm, pk), (sgn, negg2)]
+        want = c.final_exponentiation(c.miller_loop(pairs))
         V = [0] * lay.count
         V[B['F']:B['F'] + 12] = flat(c.F12_ONE)
-        V[B['P']:B['P'] + 4] = [Hm[0], Hm[1], sgn[0], sgn[1]]
+        V[B['P']:B['P'] + 8] = jac(Hm) + jac(sgn)
         for pr, (_, q) in enumerate(pairs):
-            pt = [0] * 32
-            pt[0:6] = [q[0][0], q[0][1], q[1][0], q[1][1], 1, 0]
-            pt[6:10] = [q[0][0], q[0][1], q[1][0], q[1][1]]
-            V[B['PT%d' % pr]:B['PT%d' % pr] + 32] = pt
-        sim_program(OPS, lay, PROGRAMS[2][1], V)
-        want = c.final_exponentiation(c.miller_loop(pairs))
+            set_pt(V, pr, q)
+        sim_program(OPS, lay, dict(PROGRAMS)['PAIR_GENERAL'], V)
         assert unflat(V[B['T']:B['T'] + 12]) == want, 'pairing program'
         assert (unflat(V[B['T']:B['T'] + 12]) == c.F12_ONE) == want_one
+        # the cut: three stores that share nothing but what the device hands over (pair 0's lines, the function of pair 1)
+        V1 = [0] * lay.count
+        set_pt(V1, 0, pk)
+        sim_program(OPS, lay, dict(PROGRAMS)['PRE_LINES'], V1)
+        V2 = [0] * lay.count
+        V2[B['F']:B['F'] + 12] = flat(c.F12_ONE)
+        V2[B['P'] + 4:B['P'] + 8] = jac(sgn)
+        set_pt(V2, 1, negg2)
+        sim_program(OPS, lay, prog_key_lines(1), V2)            # stands for the table of -g2's lines
+        sim_program(OPS, lay, dict(PROGRAMS)['PRE_F1'], V2)
+        V3 = [0] * lay.count
+        V3[B['F']:B['F'] + 12] = flat(c.F12_ONE)
+        V3[B['P']:B['P'] + 4] = jac(Hm)
+        for stp in range(NSTEPS):
+            o = B['L'] + 12 * stp
+            V3[o:o + 6] = V1[o:o + 6]
+        V3[B['W']:B['W'] + 12] = V2[B['F']:B['F'] + 12]
+        sim_program(OPS, lay, dict(PROGRAMS)['POST'], V3)
+        assert unflat(V3[B['T']:B['T'] + 12]) == want, 'cut pairing programs'
     return lay
 
 
@@ -918,13 +1000,13 @@ def emit(path):
     out.append('#define WIDE_PROG_MAX %d' % pmax)
     out.append('// ---- table set PT: sums of sixteen points per workgroup (complete projective additions)')
     emit_set(out, OPS_PT, lay_pt, PROGRAMS_PT, 'WIDE_PT', 'WPV', 'wide_tb_pt', False)
-    out.append('#define WIDE_PT_POINTS %d' % PT_POINTS)
     out.append('#define WIDE_PT_SLOT_G1 %d' % G1S)
     out.append('#define WIDE_PT_SLOT_G2 %d' % G2S)
     open(path, 'w').write('\n'.join(out) + '\n')
     open(os.path.join(os.path.dirname(path), 'wide_rows.cuh'), 'w').write(
         '// GENERATED by tools/gen_wide_tables.py -- do not edit.\n#pragma once\n'
-        '#define WIDE_TABLE_ROWS %d   // DPP rows per product sub-round the engine tables are laid out for (workgroup = 16 x this many threads)\n' % ROWS)
+        '#define WIDE_TABLE_ROWS %d   // DPP rows per product sub-round the engine tables are laid out for (workgroup = 16 x this many threads)\n'
+        '#define WIDE_PT_POINTS %d    // points one workgroup sums with the point-sum programs (table set PT)\n' % (ROWS, PT_POINTS))
 
 
 if __name__ == '__main__':
