@@ -471,8 +471,10 @@ def debug_wide_program(steps, f_raw, reps=1):
     lib = init()
     d = wide_defs()
     words = []
+    def ref(r):          # 'T' or ('W', 3): an array or one value of it
+        return d['WV_' + r] if isinstance(r, str) else d['WV_' + r[0]] + r[1]
     for op, dst, a, b in steps:
-        words += [d['WOP_' + op] | d['WV_' + dst] << 16, d['WV_' + a] | d['WV_' + b] << 16]     # ('INV', 'T', 'F', 'F'): T <- F^-1
+        words += [d['WOP_' + op] | ref(dst) << 16, ref(a) | ref(b) << 16]
     arr = (ctypes.c_uint32 * len(words))(*words)
     out = ctypes.create_string_buffer(576)
     _check(lib.blsgpu_debug_wide_program(ctypes.cast(arr, ctypes.c_void_p), len(steps), reps, _ptr(b''.join(f_raw)), ctypes.cast(out, ctypes.c_void_p)))

@@ -1684,7 +1684,12 @@ bool wide_prog_is_fp12(const uint32_t* prog, size_t len) {
   for (size_t k = 0; k < len; k++) {
     const uint32_t w0 = prog[2 * k], w1 = prog[2 * k + 1], op = w0 & 0xffffu;
     const uint32_t refs[3] = {w0 >> 16, w1 & 0xffffu, w1 >> 16};
-    if (op >= WOP_PDBL1 && op != WOP_MUL_LINE && op != WOP_INV) return false;
+    if (op == WOP_FPINV) {                      // single values anywhere in the five Fp12 arrays
+      for (uint32_t r : refs)
+        if (r < WV_F || r >= WV_ACC + 12) return false;
+      continue;
+    }
+    if (op >= WOP_PDBL1 && op != WOP_MUL_LINE) return false;
     for (uint32_t r : refs)
       if (r != WV_F && r != WV_T && r != WV_U && r != WV_W && r != WV_ACC) return false;
   }
@@ -1708,7 +1713,7 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_wide_prog_test(const uint
     w_store_local(S.V[WV_T + threadIdx.x], x);
   }
   __syncthreads();
-  for (int r = 0; r < reps; r++) wide_exec(S, len, K, WV_F, WV_T);
+  for (int r = 0; r < reps; r++) wide_exec(S, len, K);
   if (threadIdx.x < 12) {
     fp x;
     w_load_local(x, S.V[WV_T + threadIdx.x]);
@@ -1727,7 +1732,7 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_finalexp_wide(size_t n, c
   for (int t = threadIdx.x; t < WIDE_EASY_WORDS; t += WIDE_ENGINE_BLOCK) S.V[WV_F + (t >> 4)][t & 15] = easy[item * WIDE_EASY_WORDS + t];
   if (threadIdx.x == 0) S.flag = 1;
   __syncthreads();
-  wide_exec(S, WIDE_PROG_FINAL_HARD_LEN, K, WV_F, WV_T);
+  wide_exec(S, WIDE_PROG_FINAL_HARD_LEN, K);
   // == 1 ?  (lane-local canonical comparison of the twelve components)
   if (threadIdx.x < 12) {
     fp x, one;
@@ -1783,7 +1788,7 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_wide(size_t n, co
     }
   if (threadIdx.x == 0) S.flag = 1;
   __syncthreads();
-  wide_exec(S, fixed_g2 ? WIDE_PROG_PAIR_FIXED_LEN : WIDE_PROG_PAIR_GENERAL_LEN, K, WV_F, WV_T);
+  wide_exec(S, fixed_g2 ? WIDE_PROG_PAIR_FIXED_LEN : WIDE_PROG_PAIR_GENERAL_LEN, K);
   if (threadIdx.x < 12) {
     fp x, one;
     w_load_local(x, S.V[WV_T + threadIdx.x]);
@@ -1818,7 +1823,7 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_pre(size_t n, uin
     wide_stage(S, WIDE_PROG_PRE_LINES, WIDE_PROG_PRE_LINES_LEN);
     if (v < 6) S.V[WV_PT0 + 6 + v][l] = r[16 * (WREC_Q0 + v) + l];      // Q, Jacobian (QPREP makes it homogeneous and sets T = Q)
     __syncthreads();
-    wide_exec(S, WIDE_PROG_PRE_LINES_LEN, K, WV_F, WV_T);
+    wide_exec(S, WIDE_PROG_PRE_LINES_LEN, K);
     for (int t = threadIdx.x; t < WIDE_STEPS * 6 * 16; t += WIDE_ENGINE_BLOCK) {
       const int st = t / 96, w = t % 96;
       r[16 * WREC_L + 96 * st + w] = S.V[WV_L + 12 * st + (w >> 4)][w & 15];
@@ -1833,7 +1838,7 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_pre(size_t n, uin
       S.V[WV_L + 12 * st + 6 + w][ll] = ll < FP_NL ? G2NEG_LINES[st][w * FP_NL + ll] : 0u;
     }
     __syncthreads();
-    wide_exec(S, WIDE_PROG_PRE_F1_LEN, K, WV_F, WV_T);
+    wide_exec(S, WIDE_PROG_PRE_F1_LEN, K);
     if (v < 12) r[16 * (WREC_F1 + v) + l] = S.V[WV_F + v][l];
   }
 }
@@ -1859,7 +1864,7 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_post(size_t n, co
   }
   if (threadIdx.x == 0) S.flag = 1;
   __syncthreads();
-  wide_exec(S, WIDE_PROG_POST_LEN, K, WV_F, WV_T);
+  wide_exec(S, WIDE_PROG_POST_LEN, K);
   if (threadIdx.x < 12) {
     fp x, one;
     w_load_local(x, S.V[WV_T + threadIdx.x]);

@@ -75,3 +75,23 @@ def test_engine_operations_match_the_oracle(api):
     assert got == c.f12_pow(a, 7)
     with pytest.raises(api.BlsGpuRuntimeError):
         api.debug_wide_program([('PDBL1', 'T', 'F', 'F')], _f12_raw(a))   # not an Fp12 operation: refused on the host
+
+
+def test_engine_fp12_inversion_program(api):
+    """the Fp12 inversion of the final exponentiation's easy part as the engine runs it: table operations (norm to Fp6, to Fp2,
+    to Fp) around the interpreter's one built-in, an inversion in Fp on a lone lane (variable-time safegcd)"""
+    from oracle.py import bls381 as c
+    rng = random.Random(9)
+    inv_prog = [('CONJ', 'U', 'F', 'F'), ('MUL', 'T', 'F', 'U'), ('F6INV1', 'T', 'T', 'T'), ('F6INV2', 'W', 'T', 'T'), ('F6INV3', 'W', 'W', 'W'),
+                ('FPINV', ('W', 3), ('W', 2), ('W', 2)), ('F6INV4', 'W', 'W', 'W'), ('F6INV5', 'T', 'T', 'W'), ('MUL', 'T', 'U', 'T')]
+    for trial in range(4):
+        a = tuple((rng.randrange(P), rng.randrange(P)) for _ in range(6))
+        if trial == 3:
+            a = ((5, 0),) + ((0, 0),) * 5                  # an element of the prime field
+        got = _f12_from(api.debug_wide_program(inv_prog, _f12_raw(a)))
+        assert got == c.f12_inv(a)
+        assert c.f12_mul(got, a) == c.F12_ONE
+    # the built-in alone, on single values: T[0] <- F[0]^-1, T[1] <- F[3]^-1
+    a = tuple((rng.randrange(1, P), rng.randrange(1, P)) for _ in range(6))
+    got = api.debug_wide_program([('FPINV', ('T', 0), ('F', 0), ('F', 0)), ('FPINV', ('T', 1), ('F', 3), ('F', 3))], _f12_raw(a))
+    assert util.fp_from_raw(got[0]) == pow(a[0][0], -1, P) and util.fp_from_raw(got[1]) == pow(a[1][1], -1, P)

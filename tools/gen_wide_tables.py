@@ -47,7 +47,7 @@ class Op:
         return t
 
     def lin(self, terms, out):
-        terms = [(k, i) for k, i in terms if k]
+        terms = [(k, i) for k, i in terms if k]        # an empty list writes zero
         assert len(terms) <= MAXLIN, (self.name, len(terms))
         self.lins.append((terms, out))
 
@@ -384,6 +384,41 @@ def op_mul_line():
     return op
 
 
+def op_f6inv(stage):
+    """the inversion of N = n0 + n1 v + n2 v^2 in Fp6 (v = w^2; N sits at the even coefficients of an Fp12 array, its odd
+    coefficients are free) cut into table operations around ONE inversion in Fp (the interpreter's built-in FPINV):
+      1: t0 = n0^2 - xi n1 n2, t1 = xi n2^2 - n0 n1, t2 = n1^2 - n0 n2        -> odd coefficients 1, 3, 5 of the array
+      2: d = n0 t0 + xi (n2 t1 + n1 t2)                                       -> dst values 0, 1
+      3: s = d0^2 + d1^2  (the norm of d)                                     -> value 2 of the same array
+      4: d^-1 = (d0, -d1) s^-1  with s^-1 at value 3                          -> values 4, 5
+      5: N^-1 = (t0, t1, t2) d^-1 -> even coefficients, zeros -> odd ones     (a = the Fp12 array, b = the array of d^-1)"""
+    op = Op('F6INV%d' % stage)
+    n = [coef(SA, 0), coef(SA, 2), coef(SA, 4)]
+    t = [coef(SA, 1), coef(SA, 3), coef(SA, 5)]
+    if stage == 1:
+        n0n0, n1n1, n2n2 = op.fp2_sqr(n[0]), op.fp2_sqr(n[1]), op.fp2_sqr(n[2])
+        n1n2, n0n1, n0n2 = op.fp2_mul(n[1], n[2]), op.fp2_mul(n[0], n[1]), op.fp2_mul(n[0], n[2])
+        lin2(op, sub2(n0n0, mul_xi(*n1n2)), 2)
+        lin2(op, sub2(mul_xi(*n2n2), n0n1), 6)
+        lin2(op, sub2(n1n1, n0n2), 10)
+    elif stage == 2:
+        a, b, cc = op.fp2_mul(n[0], t[0]), op.fp2_mul(n[2], t[1]), op.fp2_mul(n[1], t[2])
+        lin2(op, add2(a, mul_xi(*add2(b, cc))), 0)
+    elif stage == 3:
+        op.lin([(1, op.prod([v1(0)], [v1(0)])), (1, op.prod([v1(1)], [v1(1)]))], idx(DST, 2))
+    elif stage == 4:
+        op.lin([(1, op.prod([v1(0)], [v1(3)]))], idx(DST, 4))
+        op.lin([(-1, op.prod([v1(1)], [v1(3)]))], idx(DST, 5))
+    else:
+        di = ((1, idx(SB, 4)), (1, idx(SB, 5)))
+        for k in range(3):
+            lin2(op, op.fp2_mul(t[k], di), 4 * k)
+            op.lin([], idx(DST, 4 * k + 2))
+            op.lin([], idx(DST, 4 * k + 3))
+    return op
+
+
+OPS += [op_f6inv(k) for k in (1, 2, 3, 4, 5)]
 OPS += [op_pdbl1(), op_pdbl2(), op_padd1(), op_padd2(), op_padd3(), op_padd4(), op_copy6(), op_lscale((0, 1)), op_mul_line(),
         op_lscale((0,)), op_lscale((1,))] + [op_pprep(st, pr) for pr in ((0, 1), (0,), (1,)) for st in 'AB'] + [op_qprep(st) for st in 'ABC']
 
@@ -709,9 +744,16 @@ def prog_miller(pairs=(0, 1)):
     return st
 
 
+def prog_f12_inv():
+    """T <- F^-1 with U = conj(F) given: F conj(F) lies in Fp6 (even coefficients); FPINV is the interpreter's one built-in, an
+    inversion in Fp on a lone lane.  W is scratch."""
+    return [('MUL', 'T', 'F', 'U'), ('F6INV1', 'T', 'T', 'T'), ('F6INV2', 'W', 'T', 'T'), ('F6INV3', 'W', 'W', 'W'),
+            ('FPINV', ('W', 3), ('W', 2), ('W', 2)), ('F6INV4', 'W', 'W', 'W'), ('F6INV5', 'T', 'T', 'W'), ('MUL', 'T', 'U', 'T')]
+
+
 def prog_easy():
-    """F <- F^((p^6 - 1)(p^2 + 1)); INV is the interpreter's lane-local Fp12 inversion T <- F^-1"""
-    return [('CONJ', 'U', 'F', 'F'), ('INV', 'T', 'F', 'F'), ('MUL', 'F', 'U', 'T'), ('FROB2', 'T', 'F', 'F'), ('MUL', 'F', 'T', 'F')]
+    """F <- F^((p^6 - 1)(p^2 + 1))"""
+    return [('CONJ', 'U', 'F', 'F')] + prog_f12_inv() + [('MUL', 'F', 'U', 'T'), ('FROB2', 'T', 'F', 'F'), ('MUL', 'F', 'T', 'F')]
 
 
 CONJ_F = [('CONJ', 'F', 'F', 'F')]                 # x < 0: the Miller function of |x| is conjugated once, after the product
@@ -742,9 +784,8 @@ def sim_program(ops, lay, steps, V):
     if cb is not None:
         V[cb:cb + 24] = consts24()
     for name, d, x, y in steps:
-        if name == 'INV':
-            fb, tb = lay.base['F'], lay.base['T']
-            V[tb:tb + 12] = flat(c.f12_inv(unflat(V[fb:fb + 12])))
+        if name == 'FPINV':
+            V[lay.ref(d)] = c.fp_inv(V[lay.ref(x)]) if V[lay.ref(x)] else 0
             continue
         op = by[name]
         base = {DST: lay.ref(d), SA: lay.ref(x), SB: lay.ref(y), TMP: lay.base['TMP'], CONST: cb}
@@ -944,8 +985,8 @@ def emit_set(out, ops, lay, programs, prefix, vprefix, trait, has_inv):
     for k, name in enumerate(names):
         out.append('#define WOP_%s %d' % (name, k))
     if has_inv:
-        out.append('#define WOP_INV %d   // interpreter built-in: T <- F^-1 by the lane-local tower code' % len(names))
-        names.append('INV')
+        out.append('#define WOP_FPINV %d   // interpreter built-in: value dst <- (value a)^-1 in Fp on a lone lane (fp_inv_var)' % len(names))
+        names.append('FPINV')
     out.append('// value store (indices of 16-word values)')
     for k, v in lay.base.items():
         out.append('#define %s_%s %d' % (vprefix, k, v))
