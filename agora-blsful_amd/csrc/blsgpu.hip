@@ -508,7 +508,8 @@ int run_f12_fold(Ctx* c, uint32_t* d_f, size_t m, size_t stride) {
 int run_f12_product_verdict(Ctx* c, uint32_t* d_f, size_t m, size_t stride, int32_t* d_verdict) {
   int rc = run_f12_fold(c, d_f, m, stride);
   if (rc) return rc;
-  if (coop_max_items() > 0) KL(KID_FINALEXP_ONE, k_finalexp_coop, dim3(1), dim3(BLS_BLOCK), d_f, stride, d_verdict);
+  if (wide_max_items() > 0 && coop_max_items() > 0) KL(KID_FINALEXP_ONE, k_finalexp_wide_ws, dim3(1), dim3(WIDE_ENGINE_BLOCK), (const uint32_t*)d_f, stride, d_verdict);
+  else if (coop_max_items() > 0) KL(KID_FINALEXP_ONE, k_finalexp_coop, dim3(1), dim3(BLS_BLOCK), d_f, stride, d_verdict);
   else KL(KID_FINALEXP_ONE, k_finalexp_ones, dim3(1), dim3(BLS_BLOCK), d_f, stride, d_verdict);
   HIPCK(hipGetLastError());
   return 0;

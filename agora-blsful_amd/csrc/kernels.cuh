@@ -268,6 +268,7 @@ __global__ void k_wide_mul_test(size_t n, const uint8_t* a, const uint8_t* b, ui
 #define WIDE_EASY_WORDS (12 * 16)     // f^((p^6-1)(p^2+1)) of one item in the engine's value layout
 __global__ void k_pairing_coop_easy(size_t n, const uint32_t* pairs, const int32_t* status, int fixed_g2, uint32_t* easy);
 __global__ void k_finalexp_wide(size_t n, const uint32_t* easy, int32_t* status);
+__global__ void k_finalexp_wide_ws(const uint32_t* fws, size_t stride, int32_t* verdict);
 __global__ void k_wide_prog_test(const uint32_t* prog, int len, int reps, const uint8_t* fin, uint8_t* tout);
 bool wide_prog_is_fp12(const uint32_t* prog, size_t len);   // host: what k_wide_prog_test may be given
 __global__ void k_pairing_wide(size_t n, const uint32_t* pairs, int32_t* status, int fixed_g2);
@@ -1805,6 +1806,37 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_wide(size_t n, co
   if (threadIdx.x == 0) status[item] = S.flag ? BLS_OK : BLS_ERR_INVALID_SIGNATURE;
 }
 
+// the whole final exponentiation of item 0 of an Fp12 workspace (the Miller product of an aggregate verification) and the
+// comparison with one: program FINAL on one workgroup (0.65 ms against 1.3 ms for the wave-cooperative form)
+__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_finalexp_wide_ws(const uint32_t* fws, size_t stride, int32_t* verdict) {
+  __shared__ wide_lds_t<wide_tb_f12> S;
+  if (blockIdx.x != 0) return;
+  wide_consts K;
+  wide_init(K);
+  wide_stage(S, WIDE_PROG_FINAL, WIDE_PROG_FINAL_LEN);
+  const int v = (int)(threadIdx.x >> 4), l = (int)(threadIdx.x & 15u);
+  if (v < 12) {   // workspace order is the tower order c0.a0, c0.a1, c0.a2, c1.a0, c1.a1, c1.a2 -> powers 0, 2, 4, 1, 3, 5 of w
+    const int k = v >> 1, pw = k < 3 ? 2 * k : 2 * (k - 3) + 1;
+    S.V[WV_F + 2 * pw + (v & 1)][l] = l < FP_NL ? fws[(size_t)(W1 * v + l) * stride] : 0u;
+  }
+  if (threadIdx.x == 0) S.flag = 1;
+  __syncthreads();
+  wide_exec(S, WIDE_PROG_FINAL_LEN, K);
+  if (threadIdx.x < 12) {
+    fp x, one;
+    w_load_local(x, S.V[WV_T + threadIdx.x]);
+    bool ok;
+    if (threadIdx.x == 0) {
+      fp_one(one);
+      ok = fp_eq(x, one);
+    } else {
+      ok = fp_is_zero(x);
+    }
+    if (!ok) S.flag = 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *verdict = S.flag ? BLS_OK : BLS_ERR_INVALID_SIGNATURE;
+}
 // The cut check, early parts.  blockIdx.y + first_part = 0: the key's line coefficients (program PRE_LINES: needs the key only);
 // 1: the Miller function of the (signature, -g2) pair (PRE_F1: needs the signature only).  Both leave their result in the
 // item's record; a single verification runs them side by side on two CUs while a third hashes the message.

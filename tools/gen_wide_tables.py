@@ -758,6 +758,7 @@ def prog_easy():
 
 CONJ_F = [('CONJ', 'F', 'F', 'F')]                 # x < 0: the Miller function of |x| is conjugated once, after the product
 PROGRAMS = [('FINAL_HARD', prog_final_hard()),
+            ('FINAL', prog_easy() + prog_final_hard()),              # the whole final exponentiation of a Miller product (aggregate verify)
             # core_verify of Bls12381G1Impl: pair 1's G2 argument is the constant -g2, its lines come from a table
             ('PAIR_FIXED', prog_pprep((0, 1)) + prog_key_lines(0) + prog_miller() + CONJ_F + prog_easy() + prog_final_hard()),
             ('PAIR_GENERAL', prog_pprep((0, 1)) + prog_key_lines(0) + prog_key_lines(1) + prog_miller() + CONJ_F + prog_easy() + prog_final_hard()),
