@@ -328,3 +328,29 @@ def test_in_library_multi_device(tmp_path):
         assert s['av_dev_%d' % sg] == [1, [0, 0]]
         for mode in ([0] if sg == 1 else [0, 1]):
             assert s['vs_%d_%d' % (sg, mode)] == [0, 0, 1, 1]
+
+
+@pytest.mark.parametrize('group', [1, 2])
+def test_point_sum_tail_on_the_engine(api, group):
+    """the last levels of every point sum run on the row-wide engine (k_point_tree_wide: sixteen points per workgroup, complete
+    projective additions, csrc/wide_tables.cuh set PT): sums that cancel to the identity, identities among and instead of the
+    inputs, inputs that repeat (the doubling case of the addition law), sizes around the sixteen-point groups"""
+    from oracle.py import bls381 as c
+    rng = random.Random(40 + group)
+    E, gen, raw, comp = (c.E1, c.G1_GEN, util.g1_raw, c.g1_compress) if group == 1 else (c.E2, c.G2_GEN, util.g2_raw, c.g2_compress)
+    base = [E.mul(gen, rng.randrange(1, c.R)) for _ in range(6)]
+
+    def check(pts):
+        want = None
+        for q in pts:
+            want = E.add(want, q)
+        got = api.serialize(group, [api.point_sum(group, [raw(q, rng) for q in pts])])[0]
+        assert got == comp(want), len(pts)
+
+    check([base[0], E.neg(base[0])])                                   # cancels in the first addition
+    check([None] * 40)                                                  # nothing but identities
+    check([base[k % 3] for k in range(48)] + [E.neg(base[k % 3]) for k in range(48)])   # cancels only at the top of the tree
+    check([base[0]] * 256)                                              # every addition is a doubling
+    for n in (15, 16, 17, 31, 33, 255, 257, 1023, 1025):
+        pts = [base[rng.randrange(6)] if rng.random() < 0.8 else None for _ in range(n)]
+        check(pts)
