@@ -470,10 +470,38 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
     if (rc) return rc;
     hipLaunchKernelGGL(k_hash_to_g1_wide, dim3((unsigned)n), dim3(BLS_BLOCK), 0, c->side, n, d_msgs, d_offs, single_msg, dst, (uint8_t*)nullptr, d_rec);
     hipError_t e1 = hipGetLastError(), e2 = hipEventRecord(c->ev_join, c->side);
-    KL(KID_PREPARE, k_prepare_keys<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, 3, d_rec, d_status);
-    KL(KID_WIDE, k_pairing_pre, dim3((unsigned)n, 2), dim3(WIDE_ENGINE_BLOCK), n, d_rec, (const int32_t*)d_status, 0);
+    KL(KID_PREPARE, k_prepare_keys<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_pks, d_sigs, (const uint8_t*)nullptr, fmt, 3, d_rec, d_status);
+    KL(KID_WIDE, k_pairing_pre, dim3((unsigned)n, 2), dim3(WIDE_ENGINE_BLOCK), n, d_rec, (const int32_t*)d_status, 0, 1);
     hipError_t e3 = hipStreamWaitEvent(c->stream, c->ev_join, 0);      // also when something failed: the side kernel reads the arena
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+      (void)hipStreamSynchronize(c->side);
+      return fail(BLSGPU_E_HIP, "side-stream launch failed");
+    }
+    KL(KID_WIDE, k_pairing_post, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), n, (const uint32_t*)d_rec, d_status);
+    HIPCK(hipGetLastError());
+    return 0;
+  }
+  if (sg == 2 && aug == 0 && !pre_status && (!single_msg || n == 1) && n <= wide_max_items() && n <= coop_max_items()) {
+    // The same cut for Bls12381G2Impl, pairs (key, H(m)) (-g1, signature): this stream checks keys and signatures and runs
+    // the signature's lines and Miller function; the side stream hashes to G2 (two lanes per message: the row-wide hash is
+    // built for G1 only) and derives the lines of H(m); after the join the Miller function of (key, H(m)) and the rest.
+    uint32_t* d_rec = (uint32_t*)arena_take(c, (size_t)WREC_WORDS * 4 * n);
+    uint8_t* d_hashes = (uint8_t*)arena_take(c, 288 * n);
+    if (!d_rec || !d_hashes) return fail(BLSGPU_E_HIP, "internal: arena too small");
+    int rc = side_fork(c);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_hash_to_g2, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), 0, c->side, n, d_msgs, d_offs, dst, d_hashes, 1);
+    hipLaunchKernelGGL(k_prepare_keys<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), 0, c->side, n, (const uint8_t*)nullptr, (const uint8_t*)nullptr,
+                       (const uint8_t*)d_hashes, 0, 4, d_rec, d_status);
+    hipError_t e1 = hipGetLastError();
+    KL(KID_PREPARE, k_prepare_keys<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_pks, d_sigs, (const uint8_t*)nullptr, fmt, 3, d_rec, d_status);
+    // the lines of H(m) skip items that failed the identity checks: the side stream waits for the statuses written just above
+    hipError_t e3 = hipEventRecord(c->ev_fork, c->stream), e4 = hipStreamWaitEvent(c->side, c->ev_fork, 0);
+    hipLaunchKernelGGL(k_pairing_pre, dim3((unsigned)n, 1), dim3(WIDE_ENGINE_BLOCK), 0, c->side, n, d_rec, (const int32_t*)d_status, 0, 0);
+    hipError_t e5 = hipGetLastError(), e6 = hipEventRecord(c->ev_join, c->side);
+    KL(KID_WIDE, k_pairing_pre, dim3((unsigned)n, 1), dim3(WIDE_ENGINE_BLOCK), n, d_rec, (const int32_t*)d_status, 2, 2);
+    hipError_t e7 = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    if (e1 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess || e6 != hipSuccess || e7 != hipSuccess) {
       (void)hipStreamSynchronize(c->side);
       return fail(BLSGPU_E_HIP, "side-stream launch failed");
     }
@@ -1216,24 +1244,48 @@ static int verify_one_tail(Ctx* c, int sig_group, int scheme, int aug_prefix, co
 struct CutTail {
   uint32_t* rec = nullptr;
   int32_t* d_status = nullptr;
+  int sg = 1;
 };
-static int cut_tail_begin(Ctx* c, int scheme, const void* sig, int fmt, const uint8_t* msg, size_t msg_len, CutTail& t) {
+static int cut_tail_begin(Ctx* c, int sig_group, int scheme, const void* sig, int fmt, const uint8_t* msg, size_t msg_len, CutTail& t) {
   int rc;
   const void *d_sig, *d_msg0;
-  if ((rc = stage_in(c, sig, sig_size(1, fmt), &d_sig))) return rc;
+  t.sg = sig_group;
+  if ((rc = stage_in(c, sig, sig_size(sig_group, fmt), &d_sig))) return rc;
   if ((rc = stage_in(c, msg, msg_len, &d_msg0))) return rc;
   uint64_t* d_offs0 = (uint64_t*)arena_take(c, 16);
   t.rec = (uint32_t*)arena_take(c, (size_t)WREC_WORDS * 4);
   t.d_status = (int32_t*)arena_take(c, 4);
-  if (!d_offs0 || !t.rec || !t.d_status) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  uint8_t* d_hash = (uint8_t*)arena_take(c, 288);
+  if (!d_offs0 || !t.rec || !t.d_status || !d_hash) return fail(BLSGPU_E_HIP, "internal: arena too small");
   const uint64_t offs0[2] = {0, (uint64_t)msg_len};
   if ((rc = h2d_small(c, d_offs0, offs0, 16))) return rc;
   if ((rc = side_fork(c))) return rc;
-  hipLaunchKernelGGL(k_hash_to_g1_wide, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, 1,
-                     scheme_dst(1, scheme), (uint8_t*)nullptr, t.rec);
-  hipLaunchKernelGGL(k_prepare_keys<1>, dim3(1), dim3(BLS_BLOCK), 0, c->side2, (size_t)1, (const uint8_t*)nullptr, (const uint8_t*)d_sig, fmt, 1, t.rec,
-                     t.d_status);
-  hipLaunchKernelGGL(k_pairing_pre, dim3(1, 1), dim3(WIDE_ENGINE_BLOCK), 0, c->side2, (size_t)1, t.rec, (const int32_t*)t.d_status, 1);
+  if (sig_group == 1) {
+    hipLaunchKernelGGL(k_hash_to_g1_wide, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, 1,
+                       scheme_dst(1, scheme), (uint8_t*)nullptr, t.rec);
+    hipLaunchKernelGGL(k_prepare_keys<1>, dim3(1), dim3(BLS_BLOCK), 0, c->side2, (size_t)1, (const uint8_t*)nullptr, (const uint8_t*)d_sig,
+                       (const uint8_t*)nullptr, fmt, 1, t.rec, t.d_status);
+    hipLaunchKernelGGL(k_pairing_pre, dim3(1, 1), dim3(WIDE_ENGINE_BLOCK), 0, c->side2, (size_t)1, t.rec, (const int32_t*)t.d_status, 1, 1);
+  } else {
+    // Bls12381G2Impl: both G2 points are known now (H(m) after its hash, the signature at once): the side stream hashes and
+    // derives the lines of H(m); the second one runs the signature's lines and the Miller function of (-g1, signature).  The
+    // summed key is a G1 point and only scales lines: it enters in POST.
+    hipLaunchKernelGGL(k_prepare_keys<2>, dim3(1), dim3(BLS_BLOCK), 0, c->side2, (size_t)1, (const uint8_t*)nullptr, (const uint8_t*)d_sig,
+                       (const uint8_t*)nullptr, fmt, 1, t.rec, t.d_status);
+    hipLaunchKernelGGL(k_pairing_pre, dim3(1, 1), dim3(WIDE_ENGINE_BLOCK), 0, c->side2, (size_t)1, t.rec, (const int32_t*)t.d_status, 2, 2);
+    const hipError_t ea = hipEventRecord(c->ev_join2, c->side2);
+    hipLaunchKernelGGL(k_hash_to_g2, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0,
+                       scheme_dst(2, scheme), d_hash, 1);
+    hipLaunchKernelGGL(k_prepare_keys<2>, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)nullptr, (const uint8_t*)nullptr,
+                       (const uint8_t*)d_hash, 0, 4, t.rec, t.d_status);
+    const hipError_t eb = hipStreamWaitEvent(c->side, c->ev_join2, 0);      // the lines of H(m) read the status the signature part set
+    hipLaunchKernelGGL(k_pairing_pre, dim3(1, 1), dim3(WIDE_ENGINE_BLOCK), 0, c->side, (size_t)1, t.rec, (const int32_t*)t.d_status, 0, 0);
+    if (ea != hipSuccess || eb != hipSuccess) {
+      (void)hipStreamSynchronize(c->side);
+      (void)hipStreamSynchronize(c->side2);
+      return fail(BLSGPU_E_HIP, "side-stream launch failed");
+    }
+  }
   const hipError_t e1 = hipGetLastError(), e2 = hipEventRecord(c->ev_join, c->side), e3 = hipEventRecord(c->ev_join2, c->side2);
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
     (void)hipStreamSynchronize(c->side);
@@ -1242,7 +1294,7 @@ static int cut_tail_begin(Ctx* c, int scheme, const void* sig, int fmt, const ui
   }
   return 0;
 }
-// rc: the caller's error so far (the side stream is joined either way: its kernels read the arena)
+// rc: the caller's error so far (the side streams are joined either way: their kernels read the arena)
 static int cut_tail_finish(Ctx* c, int rc, const uint8_t* d_pk_proj, CutTail& t, int32_t* status) {
   const hipError_t e = hipStreamWaitEvent(c->stream, c->ev_join, 0), e2 = hipStreamWaitEvent(c->stream, c->ev_join2, 0);
   if (rc || e != hipSuccess || e2 != hipSuccess) {
@@ -1250,8 +1302,14 @@ static int cut_tail_finish(Ctx* c, int rc, const uint8_t* d_pk_proj, CutTail& t,
     (void)hipStreamSynchronize(c->side2);
     return rc ? rc : fail(BLSGPU_E_HIP, "hipStreamWaitEvent failed");
   }
-  KL(KID_PREPARE, k_prepare_keys<1>, dim3(1), dim3(BLS_BLOCK), (size_t)1, d_pk_proj, (const uint8_t*)nullptr, BLSGPU_FMT_RAW_PROJ, 2, t.rec, t.d_status);
-  KL(KID_WIDE, k_pairing_pre, dim3(1, 1), dim3(WIDE_ENGINE_BLOCK), (size_t)1, t.rec, (const int32_t*)t.d_status, 0);
+  if (t.sg == 1) {
+    KL(KID_PREPARE, k_prepare_keys<1>, dim3(1), dim3(BLS_BLOCK), (size_t)1, d_pk_proj, (const uint8_t*)nullptr, (const uint8_t*)nullptr, BLSGPU_FMT_RAW_PROJ, 2,
+       t.rec, t.d_status);
+    KL(KID_WIDE, k_pairing_pre, dim3(1, 1), dim3(WIDE_ENGINE_BLOCK), (size_t)1, t.rec, (const int32_t*)t.d_status, 0, 0);
+  } else {
+    KL(KID_PREPARE, k_prepare_keys<2>, dim3(1), dim3(BLS_BLOCK), (size_t)1, d_pk_proj, (const uint8_t*)nullptr, (const uint8_t*)nullptr, BLSGPU_FMT_RAW_PROJ, 2,
+       t.rec, t.d_status);
+  }
   KL(KID_WIDE, k_pairing_post, dim3(1), dim3(WIDE_ENGINE_BLOCK), (size_t)1, (const uint32_t*)t.rec, t.d_status);
   HIPCK(hipGetLastError());
   if ((rc = copy_out(c, status, t.d_status, 4))) return rc;
@@ -1259,7 +1317,8 @@ static int cut_tail_finish(Ctx* c, int rc, const uint8_t* d_pk_proj, CutTail& t,
   return 0;
 }
 static bool cut_tail_applies(int sig_group, int scheme) {
-  return sig_group == 1 && scheme != BLSGPU_SCHEME_AUG && wide_max_items() >= 1 && coop_max_items() >= 1;
+  (void)sig_group;
+  return scheme != BLSGPU_SCHEME_AUG && wide_max_items() >= 1 && coop_max_items() >= 1;
 }
 
 int blsgpu_multi_verify(int sig_group, int scheme, const void* pks, size_t n, const void* sig, const uint8_t* msg,
@@ -1296,7 +1355,7 @@ int blsgpu_multi_verify(int sig_group, int scheme, const void* pks, size_t n, co
   CutTail cut;
   const bool use_cut = cut_tail_applies(sig_group, scheme) && n > 0;
   if (use_cut) {
-    if ((rc = cut_tail_begin(c, scheme, sig, fmt, msg, msg_len, cut))) return rc;
+    if ((rc = cut_tail_begin(c, sig_group, scheme, sig, fmt, msg, msg_len, cut))) return rc;
   } else if (scheme != BLSGPU_SCHEME_AUG && n > 0) {
     const void* d_msg0;
     if ((rc = stage_in(c, msg, msg_len, &d_msg0))) return rc;
@@ -1726,7 +1785,7 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
   CutTail cut;
   const bool use_cut = cut_tail_applies(sig_group, scheme);
   if (use_cut) {
-    if ((rc = cut_tail_begin(c, scheme, sig, fmt, msg, msg_len, cut))) return rc;
+    if ((rc = cut_tail_begin(c, sig_group, scheme, sig, fmt, msg, msg_len, cut))) return rc;
   } else {
     const void* d_msg0;
     if ((rc = stage_in(c, msg, msg_len, &d_msg0))) return rc;

@@ -273,18 +273,20 @@ __global__ void k_wide_prog_test(const uint32_t* prog, int len, int reps, const 
 bool wide_prog_is_fp12(const uint32_t* prog, size_t len);   // host: what k_wide_prog_test may be given
 __global__ void k_pairing_wide(size_t n, const uint32_t* pairs, int32_t* status, int fixed_g2);
 __global__ void k_hash_to_g1_wide(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst, uint8_t* out, uint32_t* rec);
-// The same check cut where its inputs become known (Bls12381G1Impl; csrc/wide_tables.cuh programs PRE_LINES, PRE_F1, POST).
+// The same check cut where its inputs become known (csrc/wide_tables.cuh programs PRE_LINES, PRE_F1 / PRE_F1G, POST).  The pairs
+// are (P0, Q0) (P1, Q1) = (H(m), key) (signature, -g2) for Bls12381G1Impl and (key, H(m)) (-g1, signature) for Bls12381G2Impl.
 // Per item a RECORD of engine values (16 words each) in global memory carries the operands and what the early parts hand over:
-#define WREC_P0 0        // H(m), Jacobian X Y Z                  (k_hash_to_g1_wide)
-#define WREC_P1 3        // the signature, Jacobian X Y Z          (k_prepare_keys, part 1)
-#define WREC_Q0 6        // the key, Jacobian X Y Z in Fp2: 6 values  (k_prepare_keys, part 2)
+#define WREC_P0 0        // pair 0's G1 point, Jacobian X Y Z      (G1Impl: k_hash_to_g1_wide;  G2Impl: the key, k_prepare_keys part 2)
+#define WREC_P1 3        // G1Impl: the signature, Jacobian X Y Z  (k_prepare_keys, part 1)
+#define WREC_Q0 6        // pair 0's G2 point, Jacobian in Fp2: 6 values (G1Impl: the key, part 2;  G2Impl: H(m), part 4)
 #define WREC_F1 12       // Miller function of (signature, -g2)    (k_pairing_pre, part 1)
-#define WREC_L 24        // the key's 68 unscaled lines, 6 values each (k_pairing_pre, part 0)
-#define WREC_VALUES (24 + 6 * 68)
+#define WREC_L 24        // pair 0's 68 unscaled lines, 6 values each (k_pairing_pre, part 0)
+#define WREC_Q1 (24 + 6 * 68)   // Bls12381G2Impl only: pair 1's G2 point (the signature), Jacobian: 6 values
+#define WREC_VALUES (WREC_Q1 + 6)
 #define WREC_WORDS (16 * WREC_VALUES)
 template <int SG>
-__global__ void k_prepare_keys(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int parts, uint32_t* rec, int32_t* status);
-__global__ void k_pairing_pre(size_t n, uint32_t* rec, const int32_t* status, int first_part);   // grid (n, parts): 0 = the key's lines, 1 = F1
+__global__ void k_prepare_keys(size_t n, const uint8_t* pks, const uint8_t* sigs, const uint8_t* hashes, int fmt, int parts, uint32_t* rec, int32_t* status);
+__global__ void k_pairing_pre(size_t n, uint32_t* rec, const int32_t* status, int first_part, int second_part);   // grid (n, 1 or 2): part 0 = pair 0's lines, 1 = F1 (G1Impl), 2 = F1 (G2Impl)
 __global__ void k_pairing_post(size_t n, const uint32_t* rec, int32_t* status);
 // the last levels of a point sum on the engine: workgroup b <- the sum of points [16 b, 16 b + 16) (RAW_PROJ in and out)
 template <int G>
@@ -542,58 +544,76 @@ template __global__ void k_prepare_hashed<2>(size_t, const uint8_t*, const uint8
 
 // The operands of the cut check (k_pairing_pre / k_pairing_post) that do not depend on the message, written as engine values
 // into the item's record.  parts & 1: the signature -- identity check (first, reference src/traits/sig_core.rs:126-129);
-// parts & 2: the key -- identity check (:130-135, only if the signature passed).  Both are stored as they come, Jacobian: the
+// parts & 2: the key -- identity check (:130-135, only if the signature passed); parts & 4 (Bls12381G2Impl): H(m) from
+// k_hash_to_g2's output.  All are stored as they come, Jacobian: the
 // engine's programs evaluate lines at projective G1 points and walk the Miller loop from a projective G2 point
 // (tools/gen_wide_tables.py op_lscale, op_padd*), so NO inversion is spent on the way to the pairing.  The two parts may come
 // in separate launches (a multi-signature's key is only known after the sum): the signature part runs first and sets status,
 // the key part keeps a failure it finds there.
 template <int SG>
-__global__ void __launch_bounds__(BLS_BLOCK) k_prepare_keys(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int parts, uint32_t* rec,
-                                                          int32_t* status) {
+__global__ void __launch_bounds__(BLS_BLOCK) k_prepare_keys(size_t n, const uint8_t* pks, const uint8_t* sigs, const uint8_t* hashes, int fmt, int parts,
+                                                          uint32_t* rec, int32_t* status) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  static_assert(SG == 1, "the cut check is built for Bls12381G1Impl");
   uint32_t* r = rec + i * WREC_WORDS;
   auto put = [&](int v, const fp& a) {
+    fp t;
+    fp_reduce(t, a);
 #pragma unroll
-    for (int k = 0; k < FP_NL; k++) r[16 * v + k] = (uint32_t)a.l[k];
+    for (int k = 0; k < FP_NL; k++) r[16 * v + k] = (uint32_t)t.l[k];
     r[16 * v + 14] = 0;
     r[16 * v + 15] = 0;
   };
-  int st = (parts & 1) ? BLS_OK : status[i];
-  if (parts & 1) {
-    g1_jac sig;
-    load_g1_pt(sig, sigs, i, fmt);
-    if (jac_is_inf(sig)) st = BLS_ERR_SIG_IDENTITY;
-    fp t;
-    fp_reduce(t, sig.x);
-    put(WREC_P1, t);
-    fp_reduce(t, sig.y);
-    put(WREC_P1 + 1, t);
-    fp_reduce(t, sig.z);
-    put(WREC_P1 + 2, t);
+  auto put_g1 = [&](int v, const g1_jac& p) {
+    put(v, p.x);
+    put(v + 1, p.y);
+    put(v + 2, p.z);
+  };
+  auto put_g2 = [&](int v, const g2_jac& p) {
+    put(v, p.x.c0);
+    put(v + 1, p.x.c1);
+    put(v + 2, p.y.c0);
+    put(v + 3, p.y.c1);
+    put(v + 4, p.z.c0);
+    put(v + 5, p.z.c1);
+  };
+  int st = (parts & 1) ? BLS_OK : ((parts & 2) ? status[i] : BLS_OK);
+  if (SG == 1) {
+    if (parts & 1) {
+      g1_jac sig;
+      load_g1_pt(sig, sigs, i, fmt);
+      if (jac_is_inf(sig)) st = BLS_ERR_SIG_IDENTITY;
+      put_g1(WREC_P1, sig);
+    }
+    if (parts & 2) {
+      g2_jac pk;
+      load_g2_pt(pk, pks, i, fmt);
+      if (jac_is_inf(pk) && st == BLS_OK) st = BLS_ERR_PK_IDENTITY;
+      put_g2(WREC_Q0, pk);
+    }
+  } else {
+    if (parts & 1) {
+      g2_jac sig;
+      load_g2_pt(sig, sigs, i, fmt);
+      if (jac_is_inf(sig)) st = BLS_ERR_SIG_IDENTITY;
+      put_g2(WREC_Q1, sig);
+    }
+    if (parts & 2) {
+      g1_jac pk;
+      load_g1_pt(pk, pks, i, fmt);
+      if (jac_is_inf(pk) && st == BLS_OK) st = BLS_ERR_PK_IDENTITY;
+      put_g1(WREC_P0, pk);
+    }
+    if (parts & 4) {                     // H(m) in G2, as k_hash_to_g2 left it (RAW_PROJ); touches no status
+      g2_jac h;
+      load_g2_pt(h, hashes, i, 0);
+      put_g2(WREC_Q0, h);
+    }
   }
-  if (parts & 2) {
-    g2_jac pk;
-    load_g2_pt(pk, pks, i, fmt);
-    if (jac_is_inf(pk) && st == BLS_OK) st = BLS_ERR_PK_IDENTITY;
-    fp t;
-    fp_reduce(t, pk.x.c0);
-    put(WREC_Q0, t);
-    fp_reduce(t, pk.x.c1);
-    put(WREC_Q0 + 1, t);
-    fp_reduce(t, pk.y.c0);
-    put(WREC_Q0 + 2, t);
-    fp_reduce(t, pk.y.c1);
-    put(WREC_Q0 + 3, t);
-    fp_reduce(t, pk.z.c0);
-    put(WREC_Q0 + 4, t);
-    fp_reduce(t, pk.z.c1);
-    put(WREC_Q0 + 5, t);
-  }
-  status[i] = st;
+  if (parts & 3) status[i] = st;
 }
-template __global__ void k_prepare_keys<1>(size_t, const uint8_t*, const uint8_t*, int, int, uint32_t*, int32_t*);
+template __global__ void k_prepare_keys<1>(size_t, const uint8_t*, const uint8_t*, const uint8_t*, int, int, uint32_t*, int32_t*);
+template __global__ void k_prepare_keys<2>(size_t, const uint8_t*, const uint8_t*, const uint8_t*, int, int, uint32_t*, int32_t*);
 
 // status (0 = product is one) -> is_one flag (1 / 0)
 __global__ void __launch_bounds__(BLS_BLOCK) k_status_to_flag(size_t n, int32_t* status) {
@@ -1840,10 +1860,10 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_finalexp_wide_ws(const ui
 // The cut check, early parts.  blockIdx.y + first_part = 0: the key's line coefficients (program PRE_LINES: needs the key only);
 // 1: the Miller function of the (signature, -g2) pair (PRE_F1: needs the signature only).  Both leave their result in the
 // item's record; a single verification runs them side by side on two CUs while a third hashes the message.
-__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_pre(size_t n, uint32_t* rec, const int32_t* status, int first_part) {
+__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_pre(size_t n, uint32_t* rec, const int32_t* status, int first_part, int second_part) {
   __shared__ wide_lds_t<wide_tb_f12> S;
   const size_t item = blockIdx.x;
-  const int part = first_part + (int)blockIdx.y;
+  const int part = blockIdx.y == 0 ? first_part : second_part;
   if (item >= n) return;
   if (status[item] != BLS_OK) return;                   // uniform over the workgroup
   wide_consts K;
@@ -1861,16 +1881,25 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_pre(size_t n, uin
       r[16 * WREC_L + 96 * st + w] = S.V[WV_L + 12 * st + (w >> 4)][w & 15];
     }
   } else {
-    wide_stage(S, WIDE_PROG_PRE_F1, WIDE_PROG_PRE_F1_LEN);
-    if (v < 3) S.V[WV_P + 4 + v][l] = r[16 * (WREC_P1 + v) + l];
-    if (v == 3) S.V[WV_P + 7][l] = 0u;
-    if (v >= 4) S.V[WV_F + v - 4][l] = v == 4 ? one_l : 0u;          // f = 1
-    for (int t = threadIdx.x; t < WIDE_STEPS * 6 * 16; t += WIDE_ENGINE_BLOCK) {
-      const int st = t / 96, w = (t % 96) >> 4, ll = t & 15;
-      S.V[WV_L + 12 * st + 6 + w][ll] = ll < FP_NL ? G2NEG_LINES[st][w * FP_NL + ll] : 0u;
+    const int general = part == 2;                       // Bls12381G2Impl: pair 1 = (-g1, signature), lines from the signature
+    if (general) wide_stage(S, WIDE_PROG_PRE_F1G, WIDE_PROG_PRE_F1G_LEN);
+    else wide_stage(S, WIDE_PROG_PRE_F1, WIDE_PROG_PRE_F1_LEN);
+    if (general) {
+      if (v < 6) S.V[WV_PT1 + 6 + v][l] = r[16 * (WREC_Q1 + v) + l];
+      if (v == 6) S.V[WV_P + 4][l] = l < FP_NL ? G1_GEN_X[l] : 0u;                               // P1 = -g1 = (x, -y, 1)
+      if (v == 7) S.V[WV_P + 5][l] = l < FP_NL ? (uint32_t)(-(int32_t)G1_GEN_Y[l]) : 0u;
+      if (v == 8) S.V[WV_P + 6][l] = one_l;
+    } else {
+      if (v < 3) S.V[WV_P + 4 + v][l] = r[16 * (WREC_P1 + v) + l];
+      for (int t = threadIdx.x; t < WIDE_STEPS * 6 * 16; t += WIDE_ENGINE_BLOCK) {
+        const int st = t / 96, w = (t % 96) >> 4, ll = t & 15;
+        S.V[WV_L + 12 * st + 6 + w][ll] = ll < FP_NL ? G2NEG_LINES[st][w * FP_NL + ll] : 0u;
+      }
     }
+    if (v == 9) S.V[WV_P + 7][l] = 0u;
+    if (threadIdx.x < 12 * 16) S.V[WV_F + v][l] = v == 0 ? one_l : 0u;          // f = 1
     __syncthreads();
-    wide_exec(S, WIDE_PROG_PRE_F1_LEN, K);
+    wide_exec(S, general ? WIDE_PROG_PRE_F1G_LEN : WIDE_PROG_PRE_F1_LEN, K);
     if (v < 12) r[16 * (WREC_F1 + v) + l] = S.V[WV_F + v][l];
   }
 }

@@ -766,6 +766,8 @@ PROGRAMS = [('FINAL_HARD', prog_final_hard()),
             # (signature, -g2) pair (needs the signature), and the rest (needs H(m)): F <- miller(pair 0) * W, W = the other function
             ('PRE_LINES', prog_key_lines(0)),
             ('PRE_F1', prog_pprep((1,)) + prog_miller((1,))),
+            # Bls12381G2Impl: pair 1 is (-g1, signature): its lines come from the signature, then the same Miller function
+            ('PRE_F1G', prog_key_lines(1) + prog_pprep((1,)) + prog_miller((1,))),
             ('POST', prog_pprep((0,)) + prog_miller((0,)) + [('MUL', 'F', 'F', 'W')] + CONJ_F + prog_easy() + prog_final_hard())]
 
 
@@ -847,8 +849,11 @@ def check_programs():
         V2[B['F']:B['F'] + 12] = flat(c.F12_ONE)
         V2[B['P'] + 4:B['P'] + 8] = jac(sgn)
         set_pt(V2, 1, negg2)
+        V2g = list(V2)
         sim_program(OPS, lay, prog_key_lines(1), V2)            # stands for the table of -g2's lines
         sim_program(OPS, lay, dict(PROGRAMS)['PRE_F1'], V2)
+        sim_program(OPS, lay, dict(PROGRAMS)['PRE_F1G'], V2g)
+        assert V2g[B['F']:B['F'] + 12] == V2[B['F']:B['F'] + 12], 'PRE_F1G'
         V3 = [0] * lay.count
         V3[B['F']:B['F'] + 12] = flat(c.F12_ONE)
         V3[B['P']:B['P'] + 4] = jac(Hm)
