@@ -299,6 +299,12 @@ size_t coop_max_items() {
 
 // batches up to this size finish on the row-wide engine (one 256-thread workgroup per item; csrc/wide_engine.cuh):
 // BLSGPU_WIDE_MAX overrides (0 = never).  One workgroup occupies the four SIMDs of a CU, so 256 items run side by side.
+// measurement aid (tools/dbg/hash_phases.py): BLSGPU_HASH_STOP=k makes k_hash_to_g1_wide return after its k-th phase when it is
+// launched through blsgpu_hash_to_g1 (the output is then meaningless); 0 / unset: the whole hash
+int hash_phase_stop() {
+  const char* e = getenv("BLSGPU_HASH_STOP");
+  return e ? atoi(e) & 0xff : 0;
+}
 size_t wide_max_items() {
   static long v = -1;
   if (v < 0) {
@@ -2061,7 +2067,9 @@ static int hash_to_group(int group, const uint8_t* msgs, const uint64_t* msg_off
   dst_arg d = make_dst(dst, dst_len);
   // two lanes per message as in run_verify_items: always for G2, for G1 only in latency mode (small batches)
   const int two = (group == 2 || n <= coop_max_items()) ? 1 : 0;
-  if (group == 1) KL(KID_HASH, k_hash_to_g1, dim3(blocks_for(two ? 2 * n : n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out, two);
+  if (group == 1 && n <= wide_max_items())   // a few messages: one wave each in the row-wide field type (0.98 ms against 1.6 ms of latency)
+    KL(KID_HASH, k_hash_to_g1_wide, dim3((unsigned)n), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, hash_phase_stop() << 8, d, d_out, (uint32_t*)nullptr);
+  else if (group == 1) KL(KID_HASH, k_hash_to_g1, dim3(blocks_for(two ? 2 * n : n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out, two);
   else KL(KID_HASH, k_hash_to_g2, dim3(blocks_for(two ? 2 * n : n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out, two);
   HIPCK(hipGetLastError());
   if (d_out != out && (rc = copy_out(c, out, d_out, osz * n))) return rc;

@@ -2083,25 +2083,177 @@ __device__ __noinline__ void jac_mul_u64_rows(jac<wf>& r, const jac<wf>& p, uint
   }
   r = acc;
 }
+// ---- expand_message_xmd (RFC 9380 5.3.1, SHA-256) by a whole WAVE for one message.  The streaming one-lane version of
+// h2c.cuh appends byte by byte into a word array with a run-time index, i.e. a scratch read-modify-write per byte: 0.36 ms
+// of pure latency for the ~300 bytes of a 32-byte message -- a third of the single-message hash.  Here lane L fetches byte L of
+// the current 64-byte block straight from where it lives (zero pad, message, length / DST suffix, padding), the block meets in
+// LDS, and every lane runs the compression on registers (fully unrolled, the sixteen message words passed by value): ~5 us per
+// block, ~11 blocks.  All 64 lanes of the wave must call it; every lane returns the same words.
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+__device__ __noinline__ u32x8 sha256_compress_v(u32x8 hv, u32x16 wv) {
+  uint32_t w[16], h[8];
+#pragma unroll
+  for (int i = 0; i < 16; i++) w[i] = wv[i];
+#pragma unroll
+  for (int i = 0; i < 8; i++) h[i] = hv[i];
+  uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+  for (int i = 0; i < 64; i++) {
+    uint32_t wi;
+    if (i < 16) {
+      wi = w[i];
+    } else {
+      const uint32_t w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
+      const uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+      const uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+      wi = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
+      w[i & 15] = wi;
+    }
+    const uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+    const uint32_t ch = (e & f) ^ (~e & g);
+    const uint32_t t1 = hh + S1 + ch + SHA256_K[i] + wi;
+    const uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+    const uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+    const uint32_t t2 = S0 + mj;
+    hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+  }
+  u32x8 r;
+  r[0] = h[0] + a; r[1] = h[1] + b; r[2] = h[2] + c; r[3] = h[3] + d;
+  r[4] = h[4] + e; r[5] = h[5] + f; r[6] = h[6] + g; r[7] = h[7] + hh;
+  return r;
+}
+__device__ __forceinline__ u32x8 sha256_iv() {
+  u32x8 h;
+  h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a;
+  h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
+  return h;
+}
+// the block that the lanes wrote byte by byte (stream order) -> sixteen big-endian words on every lane
+__device__ __forceinline__ u32x16 sha256_block_from_lds(uint8_t* blk) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  u32x16 w;
+  const uint32_t* q = (const uint32_t*)blk;
+#pragma unroll
+  for (int j = 0; j < 16; j++) w[j] = __builtin_bswap32(q[j]);
+  __builtin_amdgcn_wave_barrier();
+  return w;
+}
+// out: NOUT / 4 big-endian words (word 0 = the first four bytes of the uniform bytes).  blk: 64 bytes of LDS owned by this wave.
+template <int NOUT>
+__device__ __forceinline__ void expand_message_xmd_wave(uint32_t* out, const uint8_t* m, uint32_t m_len, const dst_arg& dst, uint8_t* blk) {
+  const uint32_t L = threadIdx.x & 63u;
+  const uint32_t dl = dst.len;
+  // b0 = H(Z_pad || msg || I2OSP(NOUT, 2) || 0 || DST || len(DST)): the stream after the 64 zero bytes, whose compression from
+  // the initial state is data-independent but is simply run (one block of eleven)
+  const uint32_t total = 64 + m_len + 3 + dl + 1;
+  const uint32_t nblk = (total + 9 + 63) >> 6;
+  u32x8 h = sha256_iv();
+  for (uint32_t kb = 0; kb < nblk; kb++) {
+    uint32_t pos = kb * 64 + L, byte = 0;
+    if (pos >= 64 && pos < total) {
+      uint32_t q = pos - 64;
+      if (q < m_len) {
+        byte = m[q];
+      } else {
+        q -= m_len;
+        if (q == 0) byte = (uint32_t)(NOUT >> 8);
+        else if (q == 1) byte = (uint32_t)(NOUT & 255);
+        else if (q == 2) byte = 0;
+        else if (q - 3 < dl) byte = dst.b[q - 3];
+        else byte = dl;
+      }
+    } else if (pos == total) {
+      byte = 0x80;
+    } else if (kb == nblk - 1 && L >= 60) {
+      byte = ((total << 3) >> (8 * (63 - L))) & 255u;          // the bit length, big-endian (below 2^32)
+    }
+    blk[L] = (uint8_t)byte;
+    h = sha256_compress_v(h, sha256_block_from_lds(blk));
+  }
+  const u32x8 b0 = h;
+  u32x8 prev;
+#pragma unroll
+  for (int j = 0; j < 8; j++) prev[j] = 0;
+  const uint32_t total_i = 32 + 1 + dl + 1, nblk_i = (total_i + 9 + 63) >> 6;
+  for (int bi = 1; bi <= NOUT / 32; bi++) {
+    u32x8 x;
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = b0[j] ^ prev[j];
+    h = sha256_iv();
+    for (uint32_t kb = 0; kb < nblk_i; kb++) {
+      const uint32_t pos = kb * 64 + L;
+      uint32_t byte = 0;
+      if (pos < 32) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) word = (pos >> 2) == (uint32_t)j ? x[j] : word;
+        byte = (word >> (8 * (3 - (pos & 3)))) & 255u;
+      } else if (pos == 32) {
+        byte = (uint32_t)bi;
+      } else if (pos < 33 + dl) {
+        byte = dst.b[pos - 33];
+      } else if (pos == 33 + dl) {
+        byte = dl;
+      } else if (pos == total_i) {
+        byte = 0x80;
+      } else if (kb == nblk_i - 1 && L >= 60) {
+        byte = ((total_i << 3) >> (8 * (63 - L))) & 255u;
+      }
+      blk[L] = (uint8_t)byte;
+      h = sha256_compress_v(h, sha256_block_from_lds(blk));
+    }
+    prev = h;
+#pragma unroll
+    for (int j = 0; j < 8; j++) out[8 * (bi - 1) + j] = h[j];
+  }
+}
+// 64 uniform bytes given as sixteen big-endian words -> Fp (Montgomery), as fp_from_be64
+__device__ __forceinline__ void fp_from_be_words(fp& r, const uint32_t* bw) {
+  fp lo, hi, t, k;
+  uint32_t w[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) w[i] = i < 4 ? bw[3 - i] : 0u;
+  fp_set_words(hi, w);
+#pragma unroll
+  for (int i = 0; i < 12; i++) w[i] = bw[15 - i];
+  fp_set_words(lo, w);
+  fp_load(k, FP_R2);
+  fp_mul(t, k, lo);
+  fp_load(k, FP_R2_384);
+  fp_mul(hi, k, hi);
+  fp_add(t, t, hi);
+  fp_reduce(r, t);
+}
+
 __global__ void __launch_bounds__(WIDE_BLOCK) k_hash_to_g1_wide(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst, uint8_t* out,
                                                              uint32_t* rec) {
   __shared__ uint32_t pts[4][2][3][16];     // per wave: the Jacobian points of the two maps
+  __shared__ __attribute__((aligned(16))) uint8_t shablk[4][64];
   const int wave = threadIdx.x >> 6, row = (threadIdx.x >> 4) & 3, l = threadIdx.x & 15;
   const size_t i = (size_t)blockIdx.x * (blockDim.x >> 6) + wave;
   wf_setup();
   __syncthreads();
   if (i >= n) return;
-  if (row >= 2) return;                       // rows 2 and 3 of the wave stay idle: the hash has two independent maps
-  const size_t mi = single_msg ? 0 : i;
-  uint8_t ub[128];
-  expand_message_xmd<128>(ub, nullptr, 0, msgs + offs[mi], (uint32_t)(offs[mi + 1] - offs[mi]), dst.b, dst.len);
+  const int stop = single_msg >> 8;            // measurement aid (blsgpu.hip hash_phase_stop): leave after phase `stop`
+  const size_t mi = (single_msg & 1) ? 0 : i;
+  uint32_t ubw[32];
+  expand_message_xmd_wave<128>(ubw, msgs + offs[mi], (uint32_t)(offs[mi + 1] - offs[mi]), dst, shablk[wave]);   // the whole wave
+  if (row >= 2) return;                       // rows 2 and 3 of the wave stay idle from here: the hash has two independent maps
+  uint32_t uw[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) uw[j] = row == 1 ? ubw[16 + j] : ubw[j];    // u0 on row 0, u1 on row 1
   fp ul;
-  fp_from_be64(ul, ub + 64 * row);            // u0 on row 0, u1 on row 1 (every lane of the row computes the same value)
+  fp_from_be_words(ul, uw);                   // every lane of the row computes the same value
   wf u, xn, xd, y;
   wf_from_local(u, ul);
+  if (stop == 1) return;
   sswu_g1(xn, xd, y, u);
+  if (stop == 2) return;
   jac<wf> mine, q0, q1, acc;
   iso_map_g1_wide(mine, xn, xd, y);
+  if (stop == 3) return;
   // both rows take both points and continue with identical operands
   pts[wave][row][0][l] = (uint32_t)mine.x.v;
   pts[wave][row][1][l] = (uint32_t)mine.y.v;
@@ -2115,7 +2267,9 @@ __global__ void __launch_bounds__(WIDE_BLOCK) k_hash_to_g1_wide(size_t n, const 
   q1.y.v = (wfp)pts[wave][1][1][l];
   q1.z.v = (wfp)pts[wave][1][2][l];
   jac_add(q0, q0, q1);
+  if (stop == 4) return;
   jac_mul_u64_rows(q1, q0, BLS_X_ABS, row == 1);   // clear cofactor: h_eff = 1 - x = 1 + |x|
+  if (stop == 5) return;
   jac_add(acc, q1, q0);
   if (row == 0 && rec) {                       // the cut check takes H(m) as engine values, Jacobian, straight from the row
     uint32_t* r = rec + i * WREC_WORDS + 16 * WREC_P0;
