@@ -7,10 +7,14 @@
 #include "tower_split.cuh"
 
 // ------------------------------------------------------------------ SHA-256 (streaming, one lane = one hash)
+// The block buffer is addressed with a run-time index, so it lives in scratch: bytes are therefore gathered in a register and
+// stored a WORD at a time (one store per four bytes, never a read-modify-write), and the compression copies the sixteen words
+// into registers once and runs fully unrolled on them.
 struct sha256_ctx {
   uint32_t h[8];
   uint32_t w[16];
-  uint32_t fill;    // bytes in w
+  uint32_t cur;     // the bytes of the word being filled
+  uint32_t fill;    // bytes in the block
   uint32_t total;   // total bytes (messages < 512 MiB)
 };
 
@@ -25,8 +29,12 @@ BLS_CONST uint32_t SHA256_K[64] = {
 
 BLS_FN uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
 
-BLS_NOINLINE void sha256_compress(uint32_t* h, uint32_t* w) {
+BLS_NOINLINE void sha256_compress(uint32_t* h, const uint32_t* wsrc) {
+  uint32_t w[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) w[i] = wsrc[i];
   uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
   for (int i = 0; i < 64; i++) {
     uint32_t wi;
     if (i < 16) {
@@ -52,19 +60,20 @@ BLS_NOINLINE void sha256_compress(uint32_t* h, uint32_t* w) {
 BLS_FN void sha256_init(sha256_ctx& c) {
   c.h[0] = 0x6a09e667; c.h[1] = 0xbb67ae85; c.h[2] = 0x3c6ef372; c.h[3] = 0xa54ff53a;
   c.h[4] = 0x510e527f; c.h[5] = 0x9b05688c; c.h[6] = 0x1f83d9ab; c.h[7] = 0x5be0cd19;
-  for (int i = 0; i < 16; i++) c.w[i] = 0;
+  c.cur = 0;
   c.fill = 0;
   c.total = 0;
 }
 BLS_FN void sha256_byte(sha256_ctx& c, uint8_t b) {
-  uint32_t idx = c.fill >> 2, sh = 24 - 8 * (c.fill & 3);
-  c.w[idx] |= (uint32_t)b << sh;
+  c.cur = (c.cur << 8) | b;
   c.fill++;
   c.total++;
-  if (c.fill == 64) {
-    sha256_compress(c.h, c.w);
-    for (int i = 0; i < 16; i++) c.w[i] = 0;
-    c.fill = 0;
+  if ((c.fill & 3u) == 0) {
+    c.w[(c.fill >> 2) - 1] = c.cur;
+    if (c.fill == 64) {
+      sha256_compress(c.h, c.w);
+      c.fill = 0;
+    }
   }
 }
 BLS_FN void sha256_update(sha256_ctx& c, const uint8_t* p, uint32_t n) {
