@@ -657,6 +657,7 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_f12_export(const uint32_t* fws, s
 #endif  // BLS_TU_FINALEXP
 
 #if defined(BLS_TU_POINTS)
+#include "msm2.cuh"     // jac_madd
 // =====================================================================================================
 // hash_to_point batches
 // two_lanes: two adjacent lanes per message run the two SSWU maps side by side (and, for G2, the cofactor clearing on the
@@ -690,6 +691,8 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_accumulate(size_t n, const uint8_
   if (t >= T) return;
   if (G == 1) {
     g1_jac acc, p;
+    fp one;
+    fp_one(one);
     jac_set_inf(acc);
     for (size_t i = t; i < n; i += T) {
       size_t src = perm ? perm[i] : i;
@@ -699,7 +702,8 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_accumulate(size_t n, const uint8_
         scalar_load_mod_r(k, scalars, i);
         jac_mul_scalar(p, p, k);
       }
-      jac_add(acc, acc, p);
+      if (!WITH_SCALARS && fp_eq(p.z, one)) jac_madd(acc, acc, p.x, p.y);     // Z = 1 (deserialised, RAW_AFF): the mixed addition
+      else jac_add(acc, acc, p);
     }
     store_g1_pt(partials, t, acc);
   } else {
@@ -718,15 +722,20 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_accumulate(size_t n, const uint8_
     store_g2_pt(partials, t, acc);
   }
 }
-// The same for G2 without scalars on two lanes per accumulator (MultiPublicKey::from_public_keys over G2 keys)
+// The same for G2 without scalars on two lanes per accumulator (MultiPublicKey::from_public_keys over G2 keys).  A key that
+// comes from deserialisation has Z = 1 (so does every RAW_AFF input): it takes the mixed addition, 7M + 4S instead of 11M + 5S.
 __global__ void __launch_bounds__(BLS_BLOCK, 2) k_accumulate_g2s(size_t n, const uint8_t* pts, int fmt, uint8_t* partials, size_t T) {
   const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
   if (t >= T) return;
   jac<hfp2> acc, p;
+  hfp2 one, d;
+  fe_one(one);
   jac_set_inf(acc);
   for (size_t i = t; i < n; i += T) {
     ld_g2s_fmt(p, pts, i, fmt);
-    jac_add(acc, acc, p);
+    fe_sub(d, p.z, one);
+    if (fe_is_zero(d)) jac_madd(acc, acc, p.x, p.y);
+    else jac_add(acc, acc, p);
   }
   st_g2s(partials, t, acc);
 }

@@ -192,13 +192,22 @@ def roofline_of(prof, alg_bytes_per_launch_of_dominant):
 
 
 # ------------------------------------------------------------------------------------------------- configs 3, 4, 5
-def run_config3(h, steps, warmup, n_total=None):
-    """MultiSignature::verify (reference src/multi_signature.rs:127-135): n G2 keys, one message, sharded key sum."""
+def run_config3(h, steps, warmup, n_total=None, as_deserialised=False):
+    """MultiSignature::verify (reference src/multi_signature.rs:127-135): n G2 keys, one message, sharded key sum.
+    as_deserialised: the keys as a verifier that received them on the wire holds them (Z = 1: serialised and decompressed once,
+    outside the timed region) instead of the device signer's Jacobian points with arbitrary Z."""
     api, sh = h.api, h.sh
     n = n_total or CONFIG_SIZES[3]
     lo, hi = h.bd.shard_range(n, h.rank, h.world)
     nl = hi - lo
     d_pks, d_sigs, _, _ = h.sign(1, api.POP, nl, lo, FIXED_MSG * nl, 32)
+    if as_deserialised:
+        wire = h.ops.serialize(2, d_pks, nl)
+        st = h.torch.empty(nl, dtype=h.torch.int32, device=h.dev)
+        h.torch.cuda.synchronize()
+        api._check(h.lib.blsgpu_deserialize(2, h.P(wire), nl, api.FMT_COMPRESSED, h.P(d_pks), h.P(st)))
+        assert int(st.abs().sum().item()) == 0
+        del wire, st
     agg = h.global_sum(1, h.ops.point_sum(1, d_sigs, nl))
     del d_sigs
     bad = agg.clone()
@@ -219,7 +228,8 @@ def run_config3(h, steps, warmup, n_total=None):
     assert all(r == api.OK for r in res)
     out = {'metric': 'MultiSignature::verify public keys/s (one verification of an n-key multi-signature)', 'value': n * steps / dt,
            'unit': 'public keys/s', 'ms_per_step': dt / steps * 1e3, 'scaling': 'strong',
-           'config': {'workload': 'configs[2]: MultiSignature<Bls12381G1Impl>::verify, %d G2 public keys (RAW_PROJ, resident in HBM), one 32-byte message, PoP scheme' % n,
+           'config': {'workload': 'configs[2]: MultiSignature<Bls12381G1Impl>::verify, %d G2 public keys (RAW_PROJ%s, resident in HBM), one 32-byte message, PoP scheme'
+                      % (n, ' as deserialised: Z = 1' if as_deserialised else ', Jacobian with arbitrary Z'),
                       'keys_total': n, 'keys_per_gpu': nl, 'sharding': 'contiguous key ranges, all-gather of one 288-byte partial sum per rank'},
            'collective_ms_per_step': sh.collective_s / steps * 1e3,
            'kernel_ms': {k: round(v[0] / v[1], 3) for k, v in prof.items()}}
@@ -401,6 +411,7 @@ def main():
     ap.add_argument('--config', type=int, default=2, choices=[2, 3, 4, 5])
     ap.add_argument('--variant', default='g1m', choices=sorted(VARIANTS))
     ap.add_argument('--size', type=int, default=None, help='total size of config 3 / 4 / 5 (default: BASELINE.json\'s)')
+    ap.add_argument('--keys-as-deserialised', action='store_true', help='config 3: feed keys with Z = 1 (what a verifier holds after decoding the wire bytes)')
     ap.add_argument('--no-extras', action='store_true', help='config 2 only: do not time configs 3-5 after the headline measurement')
     args = ap.parse_args()
     h = Harness(args)
@@ -426,8 +437,12 @@ def main():
             if out is not None:
                 out['other_configs'] = extras
     else:
-        fn = {3: run_config3, 4: run_config4}.get(args.config)
-        out = fn(h, args.steps, args.warmup, args.size) if fn else run_config5(h, args.steps, args.warmup, args.variant, args.size)
+        if args.config == 3:
+            out = run_config3(h, args.steps, args.warmup, args.size, args.keys_as_deserialised)
+        elif args.config == 4:
+            out = run_config4(h, args.steps, args.warmup, args.size)
+        else:
+            out = run_config5(h, args.steps, args.warmup, args.variant, args.size)
         out.update(common)
     if h.rank == 0:
         print(json.dumps(out), flush=True)

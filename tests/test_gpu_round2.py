@@ -354,3 +354,29 @@ def test_point_sum_tail_on_the_engine(api, group):
     for n in (15, 16, 17, 31, 33, 255, 257, 1023, 1025):
         pts = [base[rng.randrange(6)] if rng.random() < 0.8 else None for _ in range(n)]
         check(pts)
+
+
+@pytest.mark.parametrize('group', [1, 2])
+def test_point_sum_of_deserialised_keys(api, group):
+    """keys with Z = 1 (what decoding the wire bytes yields) and RAW_AFF inputs take the mixed addition in the first stage of a
+    point sum: same group element as the oracle's serial sum, incl. a repeated key (the doubling branch of the mixed adder), a
+    key and its negative, identities, and Z = 1 mixed with arbitrary Z in one call"""
+    from oracle.py import bls381 as c
+    rng = random.Random(60 + group)
+    E, gen, raw, comp = (c.E1, c.G1_GEN, util.g1_raw, c.g1_compress) if group == 1 else (c.E2, c.G2_GEN, util.g2_raw, c.g2_compress)
+    aff_raw, aff_sz = (util.g1_aff_raw, 96) if group == 1 else (util.g2_aff_raw, 192)
+    base = [E.mul(gen, rng.randrange(1, c.R)) for _ in range(5)]
+    for n in (1, 2, 7, 64, 65, 700):
+        pts = [base[rng.randrange(5)] for _ in range(n)]
+        if n >= 7:
+            pts[3] = E.neg(pts[2])
+            pts[5] = None
+        want = None
+        for q in pts:
+            want = E.add(want, q)
+        got = api.serialize(group, [api.point_sum(group, [raw(q) for q in pts])])[0]                       # RAW_PROJ, Z = 1
+        assert got == comp(want), n
+        mixed = [raw(q) if k % 2 else raw(q, rng) for k, q in enumerate(pts)]                               # Z = 1 next to random Z
+        assert api.serialize(group, [api.point_sum(group, mixed)])[0] == comp(want), n
+        affs = [aff_raw(q) if q is not None else bytes(aff_sz) for q in pts]                                # RAW_AFF (identity = zeros)
+        assert api.serialize(group, [api.point_sum(group, affs, fmt=api.FMT_RAW_AFFINE)])[0] == comp(want), n
