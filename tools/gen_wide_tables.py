@@ -340,16 +340,19 @@ def v1(off):
     return (1, idx(SA, off))
 
 
-def op_lscale(pairs):
+def op_lscale(pairs, nsteps=1):
     """the lines of one step (array L[step]: pair p at 6p) evaluated at the pairs' G1 points, which are JACOBIAN (X, Y, Z): the
     line l0 + c2 x w^2 + c3 y w^3 times Z^3 (a factor in Fp, which the final exponentiation removes) is
-    l0 Z^3 + c2 (X Z) w^2 + c3 Y w^3; array P holds (X Z, Y, Z^3, -) of pair p at 4p (PPREPA / PPREPB).  No inversion anywhere."""
-    op = Op('LSCALE' + ''.join(str(p) for p in pairs))
-    for pr in pairs:
-        for part, pc in ((0, 2), (2, 0), (4, 1)):         # l0 * Z^3, c2 * XZ, c3 * Y
-            for comp in range(2):
-                t = op.prod([(1, idx(SA, 6 * pr + part + comp))], [(1, idx(SB, 4 * pr + pc))])
-                op.lin([(1, t)], idx(DST, 6 * pr + part + comp))
+    l0 Z^3 + c2 (X Z) w^2 + c3 Y w^3; array P holds (X Z, Y, Z^3, -) of pair p at 4p (PPREPA / PPREPB).  No inversion anywhere.
+    nsteps > 1: the same for that many consecutive steps in one operation (the lines of a Miller loop are all known before it
+    starts: evaluating them eight steps at a time fills the sixteen rows and saves sixty program steps)."""
+    op = Op('LSCALE' + ''.join(str(p) for p in pairs) + ('X%d' % nsteps if nsteps > 1 else ''))
+    for st in range(nsteps):
+        for pr in pairs:
+            for part, pc in ((0, 2), (2, 0), (4, 1)):         # l0 * Z^3, c2 * XZ, c3 * Y
+                for comp in range(2):
+                    t = op.prod([(1, idx(SA, 12 * st + 6 * pr + part + comp))], [(1, idx(SB, 4 * pr + pc))])
+                    op.lin([(1, t)], idx(DST, 12 * st + 6 * pr + part + comp))
     return op
 
 
@@ -420,7 +423,7 @@ def op_f6inv(stage):
 
 OPS += [op_f6inv(k) for k in (1, 2, 3, 4, 5)]
 OPS += [op_pdbl1(), op_pdbl2(), op_padd1(), op_padd2(), op_padd3(), op_padd4(), op_copy6(), op_lscale((0, 1)), op_mul_line(),
-        op_lscale((0,)), op_lscale((1,))] + [op_pprep(st, pr) for pr in ((0, 1), (0,), (1,)) for st in 'AB'] + [op_qprep(st) for st in 'ABC']
+        op_lscale((0,)), op_lscale((1,)), op_lscale((0,), 8), op_lscale((0,), 4), op_lscale((1,), 8), op_lscale((1,), 4)] + [op_pprep(st, pr) for pr in ((0, 1), (0,), (1,)) for st in 'AB'] + [op_qprep(st) for st in 'ABC']
 
 
 
@@ -730,15 +733,23 @@ def prog_pprep(pairs):
 
 def prog_miller(pairs=(0, 1)):
     """F <- F * prod over `pairs` of the pairs' Miller functions (not yet conjugated), the lines taken from L and evaluated here at
-    the pairs' G1 points (array P, prepared by prog_pprep)"""
+    the pairs' G1 points (array P, prepared by prog_pprep): for a single pair all 68 lines up front, eight steps per operation"""
     sfx = ''.join(str(p) for p in pairs)
     st, step = [], 0
+    packed = len(pairs) == 1
+    if packed:
+        for s0 in range(0, NSTEPS, 8):
+            k = min(8, NSTEPS - s0)
+            assert k in (8, 4)
+            ls = ('L', 12 * s0)
+            st.append(('LSCALE%sX%d' % (sfx, k), ls, ls, 'P'))
     for i in range(62, -1, -1):
         if i != 62:
             st.append(('SQR', 'F', 'F', 'F'))
         for _ in range(2 if (X_ABS >> i) & 1 else 1):
             ls = ('L', 12 * step)
-            st.append(('LSCALE' + sfx, ls, ls, 'P'))
+            if not packed:
+                st.append(('LSCALE' + sfx, ls, ls, 'P'))
             st += [('MUL_LINE', 'F', 'F', ('L', 12 * step + 6 * p)) for p in pairs]
             step += 1
     return st
