@@ -35,7 +35,7 @@ EXPORTS = [
     'blsgpu_aggregate_partial', 'blsgpu_fp12_product_is_one', 'blsgpu_core_verify', 'blsgpu_deserialize', 'blsgpu_pop_verify_batch', 'blsgpu_aggregate_secure',
     'blsgpu_signcrypt_valid_batch', 'blsgpu_sig_proof_verify_batch', 'blsgpu_pairing2_check_batch',
     'blsgpu_init_devices', 'blsgpu_device_count', 'blsgpu_sort_keys', 'blsgpu_sorted_keys_digest',
-    'blsgpu_coefficients_for_range', 'blsgpu_first_duplicate_message', 'blsgpu_first_occurrence', 'blsgpu_core_verify_hashed', 'blsgpu_debug_wide_mul', 'blsgpu_debug_wide_program', 'blsgpu_signatures_from_tagged', 'blsgpu_signatures_to_tagged',
+    'blsgpu_coefficients_for_range', 'blsgpu_first_duplicate_message', 'blsgpu_first_occurrence', 'blsgpu_core_verify_hashed', 'blsgpu_debug_wide_mul', 'blsgpu_debug_wide_program', 'blsgpu_verify_batch_grouped', 'blsgpu_signatures_from_tagged', 'blsgpu_signatures_to_tagged',
 ]
 
 
@@ -141,6 +141,7 @@ def load_library(path=None):
         lib.blsgpu_core_verify_hashed.argtypes = [ci, vp, vp, vp, sz, i32p]
         lib.blsgpu_debug_wide_mul.argtypes = [u8p, u8p, sz, ci, u8p]
         lib.blsgpu_debug_wide_program.argtypes = [vp, sz, ci, u8p, u8p]
+        lib.blsgpu_verify_batch_grouped.argtypes = [ci, ci, vp, vp, u8p, vp, sz, ci, ctypes.c_uint64, i32p]
         lib.blsgpu_signatures_from_tagged.argtypes = [ci, u8p, sz, u8p, vp, i32p]
         lib.blsgpu_signatures_to_tagged.argtypes = [ci, u8p, vp, sz, ci, u8p]
         _lib = lib
@@ -188,6 +189,20 @@ def verify_batch(sig_group, scheme, pks, sigs, msgs, fmt=FMT_RAW_PROJ):
     _check(lib.blsgpu_verify_batch(sig_group, scheme, _ptr(pkb), _ptr(sgb), _ptr(blob), ctypes.cast(offs, ctypes.c_void_p), n, fmt,
                                    ctypes.cast(st, ctypes.c_void_p)))
     return list(st)
+
+
+def verify_batch_grouped(sig_group, scheme, pks, sigs, msgs, seed=0x626c73677075, fmt=FMT_RAW_PROJ):
+    """the OPT-IN grouped form of verify_batch (groups of eight items share one final exponentiation through a random linear
+    combination; failing groups are re-verified item by item): same status list up to a 2^-64 chance per group that holds an
+    invalid item (include/blsgpu.h)."""
+    lib = init()
+    n = len(msgs)
+    offs, blob = _offsets(msgs)
+    st = (ctypes.c_int32 * max(n, 1))()
+    pkb, sgb = b''.join(pks), b''.join(sigs)
+    _check(lib.blsgpu_verify_batch_grouped(sig_group, scheme, _ptr(pkb), _ptr(sgb), _ptr(blob), ctypes.cast(offs, ctypes.c_void_p), n, fmt, seed,
+                                           ctypes.cast(st, ctypes.c_void_p)))
+    return list(st)[:n]
 
 
 DST = {  # reference src/impls/g1.rs:110-119, src/impls/g2.rs:108-117

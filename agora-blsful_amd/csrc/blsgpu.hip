@@ -1204,6 +1204,98 @@ int blsgpu_verify_batch(int sig_group, int scheme, const void* pks, const void* 
 }
 API_CATCH
 
+/* Opt-in grouped verification of independent items (Bls12381G1Impl): groups of GROUPED_ITEMS items share one final
+ * exponentiation through a random linear combination (csrc/kernels.cuh k_prepare_grouped); every group that fails -- and only
+ * those -- is re-verified item by item with the kernels of blsgpu_verify_batch, so the status vector equals that call's except
+ * that an invalid item whose group passes the combined check (probability below 2^-64 per group, over the seed) is reported
+ * valid.  seed: the generator of the per-item scalars; the same seed gives the same run. */
+int blsgpu_verify_batch_grouped(int sig_group, int scheme, const void* pks, const void* sigs, const uint8_t* msgs, const uint64_t* msg_offsets, size_t n,
+                                int fmt, uint64_t seed, int32_t* status) try {
+  int rc = check_common(sig_group, scheme, fmt);
+  if (rc) return rc;
+  if (sig_group != 1) return fail(BLSGPU_E_ARG, "grouped verification is built for sig_group 1 (Bls12381G1Impl)");
+  if (n == 0) return 0;
+  if (!pks || !sigs || !msg_offsets || !status) return fail(BLSGPU_E_ARG, "null argument");
+  if (n >= 0xffffffffull) return fail(BLSGPU_E_ARG, "more than 2^32 - 2 items");
+  CTX_ACQUIRE(c);
+  std::vector<uint64_t> offs_h(n + 1);
+  if (is_device_ptr(msg_offsets)) HIPCK(hipMemcpy(offs_h.data(), msg_offsets, 8 * (n + 1), hipMemcpyDeviceToHost));
+  else memcpy(offs_h.data(), msg_offsets, 8 * (n + 1));
+  const uint64_t total = offs_h[n];
+  const size_t psz = pk_size(1, fmt), ssz = sig_size(1, fmt), pkb = psz * n, sgb = ssz * n;
+  const size_t ng = (n + GROUPED_ITEMS - 1) / GROUPED_ITEMS, m = (GROUPED_ITEMS + 1) * ng;
+  const size_t need = 2 * (pad256(pkb) + pad256(sgb) + pad256(total) + pad256(8 * (n + 1))) + 3 * pad256(4 * n) + pad256(144 * n) +
+                      pad256((size_t)WS_PAIR1_WORDS * 4 * m) + pad256((size_t)WS_F_WORDS * 4 * m) + pad256(4 * m) + pad256((size_t)WS_F_WORDS * 4 * ng) +
+                      pad256(4 * ng) + 2 * pad256((size_t)WS_PAIRS_WORDS * 4 * n) + 16384;
+  if ((rc = arena_reserve(c, need))) return rc;
+  c->arena_off = 0;
+  const void *d_pks, *d_sigs, *d_msgs, *d_offs;
+  if ((rc = stage_in(c, pks, pkb, &d_pks))) return rc;
+  if ((rc = stage_in(c, sigs, sgb, &d_sigs))) return rc;
+  if ((rc = stage_in(c, msgs, total, &d_msgs))) return rc;
+  if ((rc = stage_in(c, msg_offsets, 8 * (n + 1), &d_offs))) return rc;
+  int32_t* d_status = (int32_t*)arena_take(c, 4 * n);
+  uint8_t* d_scaled = (uint8_t*)arena_take(c, 144 * n);
+  uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)WS_PAIR1_WORDS * 4 * m);
+  uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * m);
+  int32_t* d_skip = (int32_t*)arena_take(c, 4 * m);
+  uint32_t* d_fg = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * ng);
+  int32_t* d_gst = (int32_t*)arena_take(c, 4 * ng);
+  if (!d_status || !d_scaled || !d_pairs || !d_f || !d_skip || !d_fg || !d_gst) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  const int aug = scheme == BLSGPU_SCHEME_AUG;
+  const dst_arg dst = scheme_dst(1, scheme);
+  HIPCK(hipMemsetAsync(d_skip, 0xff, 4 * m, c->stream));
+  HIPCK(hipMemsetAsync(d_gst, 0, 4 * ng, c->stream));
+  KL(KID_PREPARE, k_prepare_grouped<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sigs, fmt, aug, (const uint8_t*)d_msgs,
+     (const uint64_t*)d_offs, dst, (uint64_t)seed, ng, d_pairs, d_skip, d_scaled, d_status);
+  KL(KID_ACCUM, k_group_sigsum, dim3(blocks_for(ng)), dim3(BLS_BLOCK), ng, n, (const uint8_t*)d_scaled, d_pairs, d_skip);
+  MILLER1_LAUNCH(m, m, d_pairs, d_skip, d_f);
+  KL(KID_F12_FOLD, k_f12_mul3, dim3(blocks_for(ng)), dim3(BLS_BLOCK), ng, (const uint32_t*)d_f, m, d_fg);
+  KL(KID_FINALEXP, k_finalexps, dim3(blocks_for(2 * ng)), dim3(BLS_BLOCK), ng, (const uint32_t*)d_fg, d_gst);
+  HIPCK(hipGetLastError());
+  std::vector<int32_t> gst(ng);
+  HIPCK(hipMemcpyAsync(gst.data(), d_gst, 4 * ng, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(hipStreamSynchronize(c->stream));
+  // the groups that failed: their items once more, one by one (identity failures keep the status they already have: the
+  // per-item kernels find the same)
+  std::vector<uint32_t> idx;
+  for (size_t g = 0; g < ng; g++)
+    if (gst[g] != BLS_OK)
+      for (size_t i = g * GROUPED_ITEMS; i < n && i < (g + 1) * GROUPED_ITEMS; i++) idx.push_back((uint32_t)i);
+  if (!idx.empty()) {
+    const size_t cnt = idx.size();
+    std::vector<uint64_t> offs2(cnt + 1);
+    offs2[0] = 0;
+    for (size_t j = 0; j < cnt; j++) offs2[j + 1] = offs2[j] + (offs_h[idx[j] + 1] - offs_h[idx[j]]);
+    uint32_t* d_idx = (uint32_t*)arena_take(c, 4 * cnt);
+    uint64_t* d_offs2 = (uint64_t*)arena_take(c, 8 * (cnt + 1));
+    uint8_t* d_pks2 = (uint8_t*)arena_take(c, psz * cnt);
+    uint8_t* d_sigs2 = (uint8_t*)arena_take(c, ssz * cnt);
+    uint8_t* d_msgs2 = (uint8_t*)arena_take(c, offs2[cnt] ? offs2[cnt] : 1);
+    int32_t* d_st2 = (int32_t*)arena_take(c, 4 * cnt);
+    uint32_t* d_pairs2 = (uint32_t*)arena_take(c, (size_t)WS_PAIRS_WORDS * 4 * cnt);
+    uint32_t* d_f2 = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * cnt);
+    if (!d_idx || !d_offs2 || !d_pks2 || !d_sigs2 || !d_msgs2 || !d_st2 || !d_pairs2 || !d_f2) return fail(BLSGPU_E_HIP, "internal: arena too small");
+    HIPCK(hipMemcpyAsync(d_idx, idx.data(), 4 * cnt, hipMemcpyHostToDevice, c->stream));
+    HIPCK(hipMemcpyAsync(d_offs2, offs2.data(), 8 * (cnt + 1), hipMemcpyHostToDevice, c->stream));
+    KL(KID_COMPRESS, k_gather_rows, dim3(blocks_for(cnt * (psz / 4))), dim3(BLS_BLOCK), cnt, (const uint32_t*)d_idx, (const uint32_t*)d_pks, psz / 4, (uint32_t*)d_pks2);
+    KL(KID_COMPRESS, k_gather_rows, dim3(blocks_for(cnt * (ssz / 4))), dim3(BLS_BLOCK), cnt, (const uint32_t*)d_idx, (const uint32_t*)d_sigs, ssz / 4, (uint32_t*)d_sigs2);
+    KL(KID_COMPRESS, k_gather_ragged, dim3(blocks_for(cnt)), dim3(BLS_BLOCK), cnt, (const uint32_t*)d_idx, (const uint64_t*)d_offs, (const uint64_t*)d_offs2,
+       (const uint8_t*)d_msgs, d_msgs2);
+    HIPCK(hipGetLastError());
+    if ((rc = run_verify_items(c, 1, aug, d_pks2, d_sigs2, fmt, d_msgs2, d_offs2, 0, dst, cnt, d_pairs2, d_f2, d_st2))) {
+      (void)hipStreamSynchronize(c->stream);      // idx / offs2 are read by the copies above
+      return rc;
+    }
+    KL(KID_COMPRESS, k_scatter_i32, dim3(blocks_for(cnt)), dim3(BLS_BLOCK), cnt, (const uint32_t*)d_idx, (const int32_t*)d_st2, d_status);
+    HIPCK(hipGetLastError());
+  }
+  if ((rc = copy_out(c, status, d_status, 4 * n))) return rc;
+  SYNC_FLUSH(c);
+  return 0;
+}
+API_CATCH
+
 // aug_prefix: MultiSignature::verify under MessageAugmentation prefixes the (aggregated) key bytes
 // (reference src/traits/sig_aug.rs:20-24); verify_secure_message_augmentation does NOT, it only switches the DST
 // (reference src/secure_aggregation.rs:236-246).

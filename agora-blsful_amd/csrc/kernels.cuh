@@ -208,6 +208,13 @@ template <int SG>
 __global__ void k_prepare_proof(size_t n, const uint8_t* commitments, const uint8_t* proofs, const uint8_t* pks, const uint8_t* ys,
                                 int fmt, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint32_t* pairs, int32_t* status);
 __global__ void k_f12_fold(size_t m, size_t half, uint32_t* fws, size_t stride);
+// grouped (random-linear-combination) verification, blsgpu_verify_batch_grouped: see the kernels for the layout
+#define GROUPED_ITEMS 8            // items per group; a group is GROUPED_ITEMS + 1 pairs = three Miller loops of three pairs
+template <int SG>
+__global__ void k_prepare_grouped(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int aug, const uint8_t* msgs, const uint64_t* offs,
+                                  dst_arg dst, uint64_t seed, size_t ng, uint32_t* pairs, int32_t* skip, uint8_t* scaled_sigs, int32_t* status);
+__global__ void k_group_sigsum(size_t ng, size_t n, const uint8_t* scaled_sigs, uint32_t* pairs, int32_t* skip);
+__global__ void k_f12_mul3(size_t ng, const uint32_t* fin, size_t stride_in, uint32_t* fout);
 __global__ void k_f12_import(size_t n, const uint8_t* src, uint32_t* fws, size_t stride);
 __global__ void k_f12_export(const uint32_t* fws, size_t stride, uint8_t* dst);
 __global__ void k_hash_to_g1(size_t n, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint8_t* out, int two_lanes);
@@ -332,6 +339,60 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare(size_t n, const uint8_
   ws_st_pair(pairs, n, i, 0, P[0], Q[0]);
   ws_st_pair(pairs, n, i, 1, P[1], Q[1]);
 }
+// Grouped verification (opt-in, blsgpu_verify_batch_grouped): GROUPED_ITEMS items share ONE final exponentiation.  With per-item
+// scalars r_i (64 bits from a seeded generator) a group is accepted iff
+//     prod_i e(r_i H(m_i), pk_i) * e(sum_i r_i sig_i, -g2) == 1,
+// which holds for valid signatures and, for a group that contains an invalid one, with probability below 2^-64; a group that
+// fails is re-verified item by item, so a valid item is never rejected and the statuses are those of blsgpu_verify_batch.
+// This kernel: the per-item checks and hash of k_prepare, then A_i = r_i H(m_i) (affine, with the key: one pair of the
+// group's Miller loops) and B_i = r_i sig_i (Jacobian, for k_group_sigsum).  Pair slots: item i sits at (i / 8) + (i % 8) ng
+// of a workspace of 9 ng one-pair items, so that k_miller1s (items g, g + q, g + 2q per loop, q = 3 ng) leaves the three
+// partial products of group c at c, c + ng, c + 2 ng.  skip[] arrives all ones.
+__device__ __forceinline__ uint64_t grouped_scalar(uint64_t seed, uint64_t i) {   // splitmix64 of (seed, i), never zero
+  uint64_t z = seed + 0x9e3779b97f4a7c15ull * (i + 1);
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  z ^= z >> 31;
+  return z | 1ull;
+}
+template <int SG>
+__global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare_grouped(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int aug, const uint8_t* msgs,
+                                                             const uint64_t* offs, dst_arg dst, uint64_t seed, size_t ng, uint32_t* pairs, int32_t* skip,
+                                                             uint8_t* scaled_sigs, int32_t* status) {
+  static_assert(SG == 1, "grouped verification is built for Bls12381G1Impl");
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t slot = i / GROUPED_ITEMS + (i % GROUPED_ITEMS) * ng, stride = (GROUPED_ITEMS + 1) * ng;
+  const uint8_t* m = msgs + offs[i];
+  const uint32_t mlen = (uint32_t)(offs[i + 1] - offs[i]);
+  g1_aff P[2];
+  g2_aff Q[2];
+  g2_jac pk;
+  g1_jac sig, a, b;
+  load_g2_pt(pk, pks, i, fmt);
+  load_g1_pt(sig, sigs, i, fmt);
+  const int st = prepare_g1impl(P, Q, pk, sig, aug, m, mlen, dst.b, dst.len);
+  status[i] = st;
+  if (st != BLS_OK) {              // excluded from its group (the slot stays skipped); its status is final
+    jac_set_inf(b);
+    store_g1_pt(scaled_sigs, i, b);
+    return;
+  }
+  const uint64_t r = grouped_scalar(seed, i);
+  jac_from_aff(a, P[0]);
+  jac_mul_u64(a, a, r);
+  jac_from_aff(b, P[1]);
+  jac_mul_u64(b, b, r);
+  g1_aff A;
+  jac_to_aff(A, a);
+  ws_st_pair(pairs, stride, slot, 0, A, Q[0]);
+  skip[slot] = A.inf ? 1 : 0;
+  store_g1_pt(scaled_sigs, i, b);
+}
+#if defined(BLS_TU_PREPARE1)
+template __global__ void k_prepare_grouped<1>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, dst_arg, uint64_t, size_t,
+                                              uint32_t*, int32_t*, uint8_t*, int32_t*);
+#endif
 #if defined(BLS_TU_PREPARE1)
 template __global__ void k_prepare<1>(size_t, const uint8_t*, const uint8_t*, int, int, const uint8_t*, const uint64_t*, int, dst_arg, uint32_t*, int32_t*, int, int);
 #else
@@ -636,6 +697,19 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_f12_fold(size_t m, size_t half, u
   ws_st_fp12(fws, stride, i, a);
 }
 
+// grouped verification: the three partial Miller products of group c (at c, c + ng, c + 2 ng of the input workspace) -> out[c]
+__global__ void __launch_bounds__(BLS_BLOCK) k_f12_mul3(size_t ng, const uint32_t* fin, size_t stride_in, uint32_t* fout) {
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ng) return;
+  fp12 a, b;
+  ws_ld_fp12(a, fin, stride_in, c);
+  ws_ld_fp12(b, fin, stride_in, c + ng);
+  fp12_mul(a, a, b);
+  ws_ld_fp12(b, fin, stride_in, c + 2 * ng);
+  fp12_mul(a, a, b);
+  ws_st_fp12(fout, ng, c, a);
+}
+
 // Fp12 partial products cross the C ABI as 576-byte records (c0.a0, c0.a1, c0.a2, c1.a0, c1.a1, c1.a2; each Fp2 =
 // c0 then c1; Montgomery limbs): array-of-records <-> word-major workspace
 __global__ void __launch_bounds__(BLS_BLOCK) k_f12_import(size_t n, const uint8_t* src, uint32_t* fws, size_t stride) {
@@ -769,6 +843,31 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_point_fold(size_t m, size_t half,
     jac_add(a, a, b);
     store_g2_pt(partials, i, a);
   }
+}
+
+// grouped verification: the group's pair (sum_i r_i sig_i, -g2) at slot c + 8 ng; an identity sum (every item excluded) is skipped
+__global__ void __launch_bounds__(BLS_BLOCK) k_group_sigsum(size_t ng, size_t n, const uint8_t* scaled_sigs, uint32_t* pairs, int32_t* skip) {
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ng) return;
+  g1_jac acc, p;
+  jac_set_inf(acc);
+  for (int k = 0; k < GROUPED_ITEMS; k++) {
+    const size_t i = c * GROUPED_ITEMS + k;
+    if (i >= n) break;
+    load_g1_pt(p, scaled_sigs, i, 0);
+    jac_add(acc, acc, p);
+  }
+  const size_t slot = c + (size_t)GROUPED_ITEMS * ng, stride = (GROUPED_ITEMS + 1) * ng;
+  if (jac_is_inf(acc)) {
+    skip[slot] = 1;
+    return;
+  }
+  g1_aff S;
+  g2_aff Q;
+  jac_to_aff(S, acc);
+  g2_neg_gen(Q);
+  ws_st_pair(pairs, stride, slot, 0, S, Q);
+  skip[slot] = 0;
 }
 
 // =====================================================================================================

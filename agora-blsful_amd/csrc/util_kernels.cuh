@@ -37,6 +37,10 @@ __global__ void k_dup_find(size_t n, const uint32_t* slot_of, const uint32_t* mi
 __global__ void k_dup_fin(const uint32_t* best, const uint32_t* slot_of, const uint32_t* minidx, uint64_t* out2);
 __global__ void k_untag(size_t n, size_t width, const uint8_t* in, uint8_t* out_bytes, uint8_t* out_tags, int32_t* status);
 __global__ void k_tag(size_t n, size_t width, const uint8_t* tags, const uint8_t* in_bytes, uint8_t* out);
+// the items idx[0..cnt) of an array of rows (row_words 32-bit words each) / of a ragged byte array, packed; and statuses back
+__global__ void k_gather_rows(size_t cnt, const uint32_t* idx, const uint32_t* src, size_t row_words, uint32_t* dst);
+__global__ void k_gather_ragged(size_t cnt, const uint32_t* idx, const uint64_t* offs_src, const uint64_t* offs_dst, const uint8_t* src, uint8_t* dst);
+__global__ void k_scatter_i32(size_t cnt, const uint32_t* idx, const int32_t* src, int32_t* dst);
 
 #if defined(BLS_TU_UTIL)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -366,5 +370,23 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_tag(size_t n, size_t width, const
   uint8_t* r = out + i * (width + 1);
   r[0] = tags[i];
   for (size_t k = 0; k < width; k++) r[1 + k] = in_bytes[i * width + k];
+}
+// ---- gather / scatter of item subsets (the per-item fallback of grouped verification)
+__global__ void __launch_bounds__(BLS_BLOCK) k_gather_rows(size_t cnt, const uint32_t* idx, const uint32_t* src, size_t row_words, uint32_t* dst) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= cnt * row_words) return;
+  const size_t j = t / row_words, w = t % row_words;
+  dst[t] = src[(size_t)idx[j] * row_words + w];
+}
+__global__ void __launch_bounds__(BLS_BLOCK) k_gather_ragged(size_t cnt, const uint32_t* idx, const uint64_t* offs_src, const uint64_t* offs_dst, const uint8_t* src,
+                                                          uint8_t* dst) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cnt) return;
+  const uint64_t a = offs_src[idx[j]], len = offs_src[idx[j] + 1] - a, b = offs_dst[j];
+  for (uint64_t k = 0; k < len; k++) dst[b + k] = src[a + k];
+}
+__global__ void __launch_bounds__(BLS_BLOCK) k_scatter_i32(size_t cnt, const uint32_t* idx, const int32_t* src, int32_t* dst) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < cnt) dst[idx[j]] = src[j];
 }
 #endif  // BLS_TU_UTIL

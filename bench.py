@@ -337,6 +337,39 @@ def run_config5(h, steps, warmup, variant='g1m', n_total=None):
     return out
 
 
+def run_config2_grouped(h, steps, warmup, n, tampered_every):
+    """config 2 through the OPT-IN grouped entry (blsgpu_verify_batch_grouped: eight items share one final exponentiation through
+    a seeded random linear combination; failing groups are re-verified item by item).  NOT the headline: the status vector equals
+    blsgpu_verify_batch's only up to a 2^-64 chance per group that holds an invalid item.  tampered_every: 0 = all valid,
+    k = every k-th item tampered (100 = the headline's 1 %); the per-item fallback of the failing groups is inside the time."""
+    torch, api, lib, dev, P = h.torch, h.api, h.lib, h.dev, h.P
+    _, msgs = gen_inputs(n, h.rank * n)
+    d_pks, d_sigs, d_msgs, d_offs = h.sign(1, api.POP, n, h.rank * n, b''.join(msgs), 32)
+    d_status = torch.full((n,), -7, dtype=torch.int32, device=dev)
+    expect = torch.zeros(n, dtype=torch.int32, device=dev)
+    if tampered_every:
+        bad = torch.arange(37 % tampered_every, n, tampered_every, device=dev)
+        d_msgs[bad * 32] ^= 1
+        expect[bad] = api.INVALID_SIGNATURE
+    torch.cuda.synchronize()
+    seeds = iter(range(1, 1 << 30))
+
+    def step():
+        api._check(lib.blsgpu_verify_batch_grouped(1, api.POP, P(d_pks), P(d_sigs), P(d_msgs), P(d_offs), n, api.FMT_RAW_PROJ, next(seeds), P(d_status)))
+
+    def check():
+        assert torch.equal(d_status, expect), 'grouped verification: verdict vector differs from the expected one'
+
+    dt, prof = h.timed(step, steps, warmup, after_warmup=check)
+    check()
+    return {'metric': 'BLS12-381 sig verifications/sec (batch, opt-in grouped mode)', 'value': h.world * n * steps / dt, 'unit': 'verifications/s',
+            'ms_per_step': dt / steps * 1e3, 'scaling': 'weak',
+            'config': {'workload': 'configs[1] through blsgpu_verify_batch_grouped: %d items per GPU, groups of 8 share one final exponentiation, %s, '
+                                   'per-item fallback of failing groups included' % (n, 'every %d-th item tampered' % tampered_every if tampered_every else 'all valid'),
+                       'items_per_gpu': n},
+            'kernel_ms': {k: round(v[0] / v[1], 3) for k, v in prof.items()}}
+
+
 # ------------------------------------------------------------------------------------------------- config 2 (headline)
 def run_config2(h, args):
     torch, api, lib = h.torch, h.api, h.lib
@@ -412,12 +445,16 @@ def main():
     ap.add_argument('--variant', default='g1m', choices=sorted(VARIANTS))
     ap.add_argument('--size', type=int, default=None, help='total size of config 3 / 4 / 5 (default: BASELINE.json\'s)')
     ap.add_argument('--keys-as-deserialised', action='store_true', help='config 3: feed keys with Z = 1 (what a verifier holds after decoding the wire bytes)')
+    ap.add_argument('--grouped', type=int, default=None, metavar='K', help='config 2 through the opt-in grouped entry with every K-th item tampered (0: all valid); not the headline')
     ap.add_argument('--no-extras', action='store_true', help='config 2 only: do not time configs 3-5 after the headline measurement')
     args = ap.parse_args()
     h = Harness(args)
     common = {'n_gpus': h.world, 'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': True, 'vs_baseline': None, 'dtype': 'u32',
               'data': 'synthetic'}
-    if args.config == 2:
+    if args.config == 2 and args.grouped is not None:
+        out = run_config2_grouped(h, args.steps, args.warmup, args.n, args.grouped)
+        out.update(common)
+    elif args.config == 2:
         out = run_config2(h, args)
         if not args.no_extras:
             extras = {}
@@ -426,7 +463,9 @@ def main():
                              ('config4_aggregate_verify_262144', lambda: run_config4(h, k, 1)),
                              ('config5_verify_secure_65536_g1impl_modern', lambda: run_config5(h, k, 1, 'g1m')),
                              ('config5_verify_secure_65536_g2impl_modern', lambda: run_config5(h, k, 1, 'g2m')),
-                             ('config5_verify_secure_65536_g2impl_legacy', lambda: run_config5(h, k, 1, 'g2l'))):
+                             ('config5_verify_secure_65536_g2impl_legacy', lambda: run_config5(h, k, 1, 'g2l')),
+                             ('config2_grouped_optin_1pct_tampered', lambda: run_config2_grouped(h, k, 1, args.n, 100)),
+                             ('config2_grouped_optin_all_valid', lambda: run_config2_grouped(h, k, 1, args.n, 0))):
                 try:
                     r = fn()
                     r.update({'n_gpus': h.world, 'steps': k, 'warmup': 1})

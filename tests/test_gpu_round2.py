@@ -380,3 +380,40 @@ def test_point_sum_of_deserialised_keys(api, group):
         assert api.serialize(group, [api.point_sum(group, mixed)])[0] == comp(want), n
         affs = [aff_raw(q) if q is not None else bytes(aff_sz) for q in pts]                                # RAW_AFF (identity = zeros)
         assert api.serialize(group, [api.point_sum(group, affs, fmt=api.FMT_RAW_AFFINE)])[0] == comp(want), n
+
+
+def test_grouped_verification_matches_per_item(api):
+    """blsgpu_verify_batch_grouped (opt-in: groups of eight items share one final exponentiation through a seeded random linear
+    combination, failing groups are re-verified item by item) returns the status vector of blsgpu_verify_batch: tampered
+    messages, swapped signatures, identity signatures and keys, sizes around the group boundaries, all three schemes, several
+    seeds, and a batch with no and with only invalid items."""
+    rng = random.Random(808)
+    for scheme in (api.BASIC, api.AUG, api.POP):
+        for n in (1, 7, 8, 9, 16, 41, 200):
+            sks = [rng.randrange(1, 2 ** 250) for _ in range(n)]
+            msgs = [bytes([rng.randrange(256) for _ in range(rng.randrange(0, 70))]) for _ in range(n)]
+            pks, sigs = api.sign_batch(1, scheme, sks, msgs)
+            pks, sigs, msgs = list(pks), list(sigs), list(msgs)
+            for i in range(n):
+                roll = rng.random()
+                if roll < 0.10:
+                    msgs[i] = msgs[i] + b'!'                                  # tampered message
+                elif roll < 0.15 and n > 1:
+                    sigs[i] = sigs[(i + 1) % n]                               # someone else's signature
+                elif roll < 0.18:
+                    sigs[i] = util.g1_raw(None)                               # identity signature
+                elif roll < 0.21:
+                    pks[i] = util.g2_raw(None)                                # identity key
+            want = api.verify_batch(1, scheme, pks, sigs, msgs)
+            for seed in (1, 0xdeadbeef):
+                assert api.verify_batch_grouped(1, scheme, pks, sigs, msgs, seed) == want, (scheme, n, seed)
+    # all valid (no fallback at all) and all invalid (every group falls back)
+    n = 64
+    sks = [1000 + i for i in range(n)]
+    msgs = [b'm%d' % i for i in range(n)]
+    pks, sigs = api.sign_batch(1, api.POP, sks, msgs)
+    assert api.verify_batch_grouped(1, api.POP, pks, sigs, msgs) == [0] * n
+    assert api.verify_batch_grouped(1, api.POP, pks, sigs, [m + b'x' for m in msgs]) == [1] * n
+    assert api.verify_batch_grouped(1, api.POP, [], [], []) == []
+    with pytest.raises(api.BlsGpuRuntimeError):
+        api.verify_batch_grouped(2, api.POP, pks, sigs, msgs)                 # built for Bls12381G1Impl only
