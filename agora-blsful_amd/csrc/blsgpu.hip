@@ -309,7 +309,7 @@ size_t wide_max_items() {
   static long v = -1;
   if (v < 0) {
     const char* e = getenv("BLSGPU_WIDE_MAX");
-    v = e ? atol(e) : 256;
+    v = e ? atol(e) : 512;    // measured (tools/dbg/small.py): 1.9 ms up to 256 items (one workgroup per CU), 3.4 ms at 512, 5.3 ms at 768; the wave-cooperative path: 4.6-4.8 ms flat
     if (v < 0) v = 0;
     if (v > 4096) v = 4096;
   }
