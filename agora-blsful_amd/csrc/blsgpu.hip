@@ -496,7 +496,8 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
     if (!d_rec || !d_hashes) return fail(BLSGPU_E_HIP, "internal: arena too small");
     int rc = side_fork(c);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_hash_to_g2, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), 0, c->side, n, d_msgs, d_offs, dst, d_hashes, 1);
+    hipLaunchKernelGGL(k_hash_to_g2, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), 0, c->side, n, d_msgs, d_offs, dst, d_hashes, 3);
+    hipLaunchKernelGGL(k_g2_clear_wide, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), 0, c->side, n, d_hashes);
     hipLaunchKernelGGL(k_prepare_keys<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), 0, c->side, n, (const uint8_t*)nullptr, (const uint8_t*)nullptr,
                        (const uint8_t*)d_hashes, 0, 4, d_rec, d_status);
     hipError_t e1 = hipGetLastError();
@@ -1373,7 +1374,8 @@ static int cut_tail_begin(Ctx* c, int sig_group, int scheme, const void* sig, in
     hipLaunchKernelGGL(k_pairing_pre, dim3(1, 1), dim3(WIDE_ENGINE_BLOCK), 0, c->side2, (size_t)1, t.rec, (const int32_t*)t.d_status, 2, 2);
     const hipError_t ea = hipEventRecord(c->ev_join2, c->side2);
     hipLaunchKernelGGL(k_hash_to_g2, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0,
-                       scheme_dst(2, scheme), d_hash, 1);
+                       scheme_dst(2, scheme), d_hash, 3);
+    hipLaunchKernelGGL(k_g2_clear_wide, dim3(1), dim3(WIDE_ENGINE_BLOCK), 0, c->side, (size_t)1, d_hash);
     hipLaunchKernelGGL(k_prepare_keys<2>, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)nullptr, (const uint8_t*)nullptr,
                        (const uint8_t*)d_hash, 0, 4, t.rec, t.d_status);
     const hipError_t eb = hipStreamWaitEvent(c->side, c->ev_join2, 0);      // the lines of H(m) read the status the signature part set
@@ -2162,7 +2164,11 @@ static int hash_to_group(int group, const uint8_t* msgs, const uint64_t* msg_off
   if (group == 1 && n <= wide_max_items())   // a few messages: one wave each in the row-wide field type (0.98 ms against 1.6 ms of latency)
     KL(KID_HASH, k_hash_to_g1_wide, dim3((unsigned)n), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, hash_phase_stop() << 8, d, d_out, (uint32_t*)nullptr);
   else if (group == 1) KL(KID_HASH, k_hash_to_g1, dim3(blocks_for(two ? 2 * n : n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out, two);
-  else KL(KID_HASH, k_hash_to_g2, dim3(blocks_for(two ? 2 * n : n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out, two);
+  else if (n <= wide_max_items() && hash_phase_stop() != 8) {   // a few messages: the cofactor clearing on the row-wide engine (BLSGPU_HASH_STOP=8: not)
+    KL(KID_HASH, k_hash_to_g2, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out, 3);
+    if (hash_phase_stop() != 9) KL(KID_HASH, k_g2_clear_wide, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), n, d_out);   // 9: measurement aid, no clearing
+  } else
+    KL(KID_HASH, k_hash_to_g2, dim3(blocks_for(two ? 2 * n : n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out, two);
   HIPCK(hipGetLastError());
   if (d_out != out && (rc = copy_out(c, out, d_out, osz * n))) return rc;
   SYNC_FLUSH(c);

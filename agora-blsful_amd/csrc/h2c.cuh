@@ -460,8 +460,9 @@ BLS_NOINLINE void iso_map_g2(g2_jac& r, const fp2& x, const fp2& y) {
   fp2_mul(t, t, YN);
   fp2_mul(r.y, t, y);
 }
+// no_clear: stop before the cofactor clearing (the caller clears it elsewhere: k_g2_clear_wide)
 BLS_NOINLINE void hash_to_g2(g2_jac& r, const uint8_t* pre, uint32_t pre_len, const uint8_t* m, uint32_t m_len,
-                       const uint8_t* dst, uint32_t dst_len, int lane2 = -1) {
+                       const uint8_t* dst, uint32_t dst_len, int lane2 = -1, bool no_clear = false) {
   uint8_t ub[256];
   expand_message_xmd<256>(ub, pre, pre_len, m, m_len, dst, dst_len);
   fp2 u0, u1, x, y;
@@ -489,7 +490,8 @@ BLS_NOINLINE void hash_to_g2(g2_jac& r, const uint8_t* pre, uint32_t pre_len, co
     s1.y.v = lane2 ? q1.y.c1 : q1.y.c0;
     s1.z.v = lane2 ? q1.z.c1 : q1.z.c0;
     jac_add(sum, s0, s1);
-    g2_clear_cofactor(h, sum);
+    if (no_clear) h = sum;
+    else g2_clear_cofactor(h, sum);
     fp px, py, pz;
     fp_lane_swap(px, h.x.v);
     fp_lane_swap(py, h.y.v);
@@ -513,5 +515,6 @@ BLS_NOINLINE void hash_to_g2(g2_jac& r, const uint8_t* pre, uint32_t pre_len, co
   sswu_g2(x, y, u1);
   iso_map_g2(q1, x, y);
   jac_add(q0, q0, q1);
-  g2_clear_cofactor(r, q0);
+  if (no_clear) r = q0;
+  else g2_clear_cofactor(r, q0);
 }

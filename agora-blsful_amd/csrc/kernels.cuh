@@ -298,6 +298,8 @@ __global__ void k_pairing_post(size_t n, const uint32_t* rec, int32_t* status);
 // the last levels of a point sum on the engine: workgroup b <- the sum of points [16 b, 16 b + 16) (RAW_PROJ in and out)
 template <int G>
 __global__ void k_point_tree_wide(size_t m, const uint8_t* in, uint8_t* out);
+// the cofactor clearing of hash-to-G2 on the engine: pts[i] <- h_eff pts[i] (RAW_PROJ, in place), one workgroup per point
+__global__ void k_g2_clear_wide(size_t n, uint8_t* pts);
 
 #if defined(BLS_TU_PREPARE1) || defined(BLS_TU_PREPARE2)
 // =====================================================================================================
@@ -745,13 +747,16 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_hash_to_g1(size_t n, const uint8_
   hash_to_g1(h, nullptr, 0, msgs + offs[i], (uint32_t)(offs[i + 1] - offs[i]), dst.b, dst.len, lane2);
   if (lane2 <= 0) store_g1_pt(out, i, h);
 }
+// two_lanes bit 1 (value 2): stop before the cofactor clearing (k_g2_clear_wide does it on the row-wide engine)
 __global__ void __launch_bounds__(BLS_BLOCK) k_hash_to_g2(size_t n, const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint8_t* out, int two_lanes) {
+  const bool no_clear = (two_lanes & 2) != 0;
+  two_lanes &= 1;
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t i = two_lanes ? gid >> 1 : gid;
   const int lane2 = two_lanes ? (int)(gid & 1) : -1;
   if (i >= n) return;
   g2_jac h;
-  hash_to_g2(h, nullptr, 0, msgs + offs[i], (uint32_t)(offs[i + 1] - offs[i]), dst.b, dst.len, lane2);
+  hash_to_g2(h, nullptr, 0, msgs + offs[i], (uint32_t)(offs[i + 1] - offs[i]), dst.b, dst.len, lane2, no_clear);
   if (lane2 <= 0) store_g2_pt(out, i, h);
 }
 
@@ -2090,6 +2095,44 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_point_tree_wide(size_t m,
 }
 template __global__ void k_point_tree_wide<1>(size_t, const uint8_t*, uint8_t*);
 template __global__ void k_point_tree_wide<2>(size_t, const uint8_t*, uint8_t*);
+
+// hash-to-G2 of a few messages spends more than half its time in the cofactor clearing when a lane pair walks it (two scalar
+// multiplications by |x|: 126 doublings and 20 additions of ~20 us each).  Here it is program G2_CLEAR of table set PT: 142
+// complete projective additions as two table steps each, psi as one (conjugates are linear, its two constants sit in the
+// value store), ~0.45 ms.  In place on RAW_PROJ points.
+__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_g2_clear_wide(size_t n, uint8_t* pts) {
+  __shared__ wide_lds_t<wide_tb_pt> S;
+  const size_t i = blockIdx.x;
+  if (i >= n) return;
+  wide_consts K;
+  wide_init(K);
+  wide_stage(S, WIDE_PROG_G2_CLEAR, WIDE_PROG_G2_CLEAR_LEN);
+  uint32_t* w = (uint32_t*)(pts + i * 288);
+  if (threadIdx.x < 6) {
+    const int v = (int)threadIdx.x;
+    fp x;
+    if (words_all_zero(w + 48, 24)) {            // Z = 0: the identity as (0, 1, 0)
+      if (v == 2) fp_one(x);
+      else fp_zero(x);
+    } else {
+      fp_from_raw(x, w + 12 * v);
+    }
+    fp_reduce(x, x);
+    w_store_local(S.V[WPV_R0 + v], x);
+  }
+  if (threadIdx.x >= 64 && threadIdx.x < 64 + 4 * 16) {   // psi's constants cx, cy (real, imaginary limbs)
+    const int t = (int)threadIdx.x - 64, v = t >> 4, l = t & 15;
+    const uint32_t* src = v < 2 ? PSI_CX : PSI_CY;
+    S.V[WPV_CONST + v][l] = l < FP_NL ? src[(v & 1) * FP_NL + l] : 0u;
+  }
+  __syncthreads();
+  wide_exec(S, WIDE_PROG_G2_CLEAR_LEN, K);
+  if (threadIdx.x < 6) {
+    fp x;
+    w_load_local(x, S.V[WPV_R3 + threadIdx.x]);
+    fp_to_raw(w + 12 * threadIdx.x, x);
+  }
+}
 
 // ---- hash_to_curve to G1 for single items: ONE wave per message, the two SSWU maps on rows 0 and 1 of the wave in the
 // row-wide field type `wf` (csrc/wide.cuh), then both rows add the two points and clear the cofactor redundantly.

@@ -23,6 +23,8 @@ P = c.P
 DST, SA, SB, TMP, CONST = 0, 1, 2, 3, 4
 MAXLIN = 18
 ROWS = int(os.environ.get('WIDE_ROWS', '16'))     # DPP rows of the workgroup = products per sub-round (16: four waves, one per SIMD)
+X_ABS = 0xd201000000010000       # |x| of the curve (x < 0)
+NSTEPS = 68                      # Miller steps: 63 doublings interleaved with 5 additions
 
 
 def idx(slot, off):
@@ -569,8 +571,59 @@ def op_c1h2j(stage):
     return op
 
 
+# ---- general-register forms for straight-line point programs (the cofactor clearing of hash-to-G2): a REGISTER is a pair slot whose
+# first operand holds the point; an addition takes its operands from two registers (array A and array B of the step) and
+# leaves the m values in the scratch register, the second level turns them into a point anywhere
+def op_c2gadd1():
+    op = Op('C2GADD1')
+    X1, Y1, Z1 = (f2(SA, 2 * j) for j in range(3))
+    X2, Y2, Z2 = (f2(SB, 2 * j) for j in range(3))
+    t0, t1, t2 = op.fp2_mul(X1, X2), op.fp2_mul(Y1, Y2), op.fp2_mul(Z1, Z2)
+    t3 = sub2(sub2(fp2_mul_sum(op, X1, Y1, X2, Y2), t0), t1)
+    t4 = sub2(sub2(fp2_mul_sum(op, Y1, Z1, Y2, Z2), t1), t2)
+    t5 = sub2(sub2(fp2_mul_sum(op, X1, Z1, X2, Z2), t0), t2)
+    bt2 = b3_g2(t2)
+    lin2(op, t0, 0, 3)
+    lin2(op, sub2(t1, bt2), 2)
+    lin2(op, add2(t1, bt2), 4)
+    lin2(op, t3, 6)
+    lin2(op, t4, 8)
+    lin2(op, b3_g2(t5), 10)
+    return op
+
+
+def op_c2gadd2():
+    op = Op('C2GADD2')
+    m0, m1, m2, m3, m4, m5 = (f2(SA, 2 * j) for j in range(6))
+    lin2(op, sub2(op.fp2_mul(m3, m1), op.fp2_mul(m4, m5)), 0)
+    lin2(op, add2(op.fp2_mul(m1, m2), op.fp2_mul(m5, m0)), 2)
+    lin2(op, add2(op.fp2_mul(m2, m4), op.fp2_mul(m0, m3)), 4)
+    return op
+
+
+def op_c2neg():
+    op = Op('C2NEG')
+    for k in range(6):
+        op.lin([(-1 if k in (2, 3) else 1, idx(SA, k))], idx(DST, k))
+    return op
+
+
+def op_c2psi():
+    """psi on homogeneous coordinates: (X : Y : Z) -> (cx conj X : cy conj Y : conj Z); constants cx, cy at CONST 0..3"""
+    op = Op('C2PSI')
+    cx, cy = f2(CONST, 0), f2(CONST, 2)
+    X = ((1, idx(SA, 0)), (-1, idx(SA, 1)))
+    Y = ((1, idx(SA, 2)), (-1, idx(SA, 3)))
+    lin2(op, op.fp2_mul(X, cx), 0)
+    lin2(op, op.fp2_mul(Y, cy), 2)
+    op.lin([(1, idx(SA, 4))], idx(DST, 4))
+    op.lin([(-1, idx(SA, 5))], idx(DST, 5))
+    return op
+
+
 OPS_PT = ([op_c2add1(m) for m in (4, 2, 1)] + [op_c2add2(m) for m in (4, 2, 1)] + [op_c2j2h('A', 8), op_c2j2h('B', 8), op_c2h2j('A'), op_c2h2j('B')] +
-          [op_c1add1(m) for m in (8, 4, 2, 1)] + [op_c1add2(m) for m in (8, 4, 2, 1)] + [op_c1j2h('A', 8), op_c1j2h('B', 8), op_c1h2j('A'), op_c1h2j('B')])
+          [op_c1add1(m) for m in (8, 4, 2, 1)] + [op_c1add2(m) for m in (8, 4, 2, 1)] + [op_c1j2h('A', 8), op_c1j2h('B', 8), op_c1h2j('A'), op_c1h2j('B')] +
+          [op_c2gadd1(), op_c2gadd2(), op_c2neg(), op_c2psi(), op_c2j2h('A', 1), op_c2j2h('B', 1)])
 PT_POINTS = 16                     # points per workgroup: a tree of four levels
 
 
@@ -596,7 +649,36 @@ def prog_point_tree(g, jac_in, jac_out):
     return st
 
 
+def prog_g2_clear_cofactor():
+    """h_eff P on G2 (RFC 9380 G.3, Budroni-Pintore, as oracle g2_clear_cofactor) over registers R0..R4 (R0 = P, Jacobian in,
+    Jacobian out in R3): x = -|x|, so [x]Q = -[|x|]Q by double-and-add from the top bit, every point operation a complete addition"""
+    def add(d, a, b):
+        return [('C2GADD1', 'MS', a, b), ('C2GADD2', d, 'MS', 'MS')]
+
+    def mul_x(d, base, acc):                    # d <- [x] base, acc: a work register (neither d's operand base nor ... d may be acc)
+        st = []
+        for i in range(62, -1, -1):             # bit 63 is set: the accumulator starts as base; the first doubling reads base itself
+            st += add(acc, base, base) if i == 62 else add(acc, acc, acc)
+            if (X_ABS >> i) & 1:
+                st += add(acc, acc, base)
+        return st + [('C2NEG', d, acc, acc)]
+
+    st = [('C2J2HAX1', 'R0', 'R0', 'R0'), ('C2J2HBX1', 'R0', 'R0', 'R0')]
+    st += mul_x('R1', 'R0', 'R4')                                         # t1 = [x] P
+    st += [('C2PSI', 'R2', 'R0', 'R0')]                                   # t2 = psi(P)
+    st += add('R4', 'R0', 'R0') + [('C2PSI', 'R3', 'R4', 'R4'), ('C2PSI', 'R3', 'R3', 'R3')]     # t3 = psi^2(2P)
+    st += [('C2NEG', 'R4', 'R2', 'R2')] + add('R3', 'R3', 'R4')           # t3 -= t2
+    st += add('R2', 'R1', 'R2')                                           # t2 = t1 + t2
+    st += mul_x('R2', 'R2', 'R4')                                         # t2 = [x] t2   (acc = R4, base R2 is read until the last step)
+    st += add('R3', 'R3', 'R2')                                           # t3 += t2
+    st += [('C2NEG', 'R4', 'R1', 'R1')] + add('R3', 'R3', 'R4')           # t3 -= t1
+    st += [('C2NEG', 'R4', 'R0', 'R0')] + add('R3', 'R3', 'R4')           # t3 -= P
+    st += [('C2H2JA', 'R3', 'R3', 'R3'), ('C2H2JB', 'R3', 'R3', 'R3')]
+    return st
+
+
 PROGRAMS_PT = [('G%d_%s%s' % (g, 'J' if ji else 'H', 'J' if jo else 'H'), prog_point_tree(g, ji, jo)) for g in (1, 2) for ji in (1, 0) for jo in (1, 0)]
+PROGRAMS_PT += [('G2_CLEAR', prog_g2_clear_cofactor())]
 
 
 # ------------------------------------------------------------------ simulation of the engine on integers
@@ -665,8 +747,6 @@ def self_check():
 
 
 # ------------------------------------------------------------------ programs: sequences of (op, dst, a, b) over the value store
-X_ABS = 0xd201000000010000
-NSTEPS = 68                      # Miller steps: 63 doublings interleaved with 5 additions
 
 
 class Layout:
@@ -788,7 +868,14 @@ def layout_f12():
 
 
 def layout_pt():
-    return Layout([('L0', 8 * G2S), ('L1', 4 * G2S), ('L2', 2 * G2S), ('L3', G2S), ('L4', G2S), ('TMP', 2 * (max(o.ntmp for o in OPS_PT) + 1))])
+    return Layout([('L0', 8 * G2S), ('L1', 4 * G2S), ('L2', 2 * G2S), ('L3', G2S), ('L4', G2S), ('TMP', 2 * (max(o.ntmp for o in OPS_PT) + 1)),
+                   ('R0', G2S), ('R1', G2S), ('R2', G2S), ('R3', G2S), ('R4', G2S), ('MS', 12), ('CONST', 4)])
+
+
+def psi_consts():
+    cx = c.f2_inv(c.f2_pow(c.XI, (P - 1) // 3))
+    cy = c.f2_inv(c.f2_pow(c.XI, (P - 1) // 2))
+    return [cx[0], cx[1], cy[0], cy[1]]
 
 
 def sim_program(ops, lay, steps, V):
@@ -796,7 +883,8 @@ def sim_program(ops, lay, steps, V):
     by = {o.name: o for o in ops}
     cb = lay.base.get('CONST')
     if cb is not None:
-        V[cb:cb + 24] = consts24()
+        k = consts24() if 'F' in lay.base else psi_consts()        # the constants of the table set: Frobenius (F12) / psi (PT)
+        V[cb:cb + len(k)] = k
     for name, d, x, y in steps:
         if name == 'FPINV':
             V[lay.ref(d)] = c.fp_inv(V[lay.ref(x)]) if V[lay.ref(x)] else 0
@@ -939,6 +1027,34 @@ def check_point_programs():
                         zi = inv(Z)
                         got = (fmul(X, zi), fmul(Y, zi))
                     assert got == want, (name, case)
+    # the cofactor clearing of hash-to-G2: points of E2(Fp2) OUTSIDE the subgroup (sums of two mapped points), the identity, a
+    # point already in G2; Jacobian in and out
+    B = lay.base
+    for case in range(4):
+        if case < 2:
+            q = c.E2.add(c.map_to_curve_g2((rng.randrange(P), rng.randrange(P))), c.map_to_curve_g2((rng.randrange(P), rng.randrange(P))))
+        elif case == 2:
+            q = c.E2.mul(c.G2_GEN, rng.randrange(1, c.R))
+        else:
+            q = None
+        want = c.g2_clear_cofactor(q) if q is not None else None
+        V = [0] * lay.count
+        if q is None:
+            V[B['R0']:B['R0'] + 6] = [0, 0, 1, 0, 0, 0]
+        else:
+            z = (rng.randrange(1, P), rng.randrange(P))
+            z2 = c.f2_sqr(z)
+            V[B['R0']:B['R0'] + 6] = list(c.f2_mul(q[0], z2)) + list(c.f2_mul(q[1], c.f2_mul(z2, z))) + list(z)
+        sim_program(OPS_PT, lay, dict(PROGRAMS_PT)['G2_CLEAR'], V)
+        o = B['R3']
+        X, Y, Z = (V[o], V[o + 1]), (V[o + 2], V[o + 3]), (V[o + 4], V[o + 5])
+        if Z == (0, 0):
+            got = None
+        else:
+            zi = c.f2_inv(Z)
+            zi2 = c.f2_sqr(zi)
+            got = (c.f2_mul(X, zi2), c.f2_mul(Y, c.f2_mul(zi2, zi)))
+        assert got == want, ('G2_CLEAR', case)
     return lay
 
 
@@ -1021,8 +1137,8 @@ def emit_set(out, ops, lay, programs, prefix, vprefix, trait, has_inv):
         out.append('};')
     pmax = max(len(st) for _, st in programs)
     out.append('struct %s {' % trait)
-    out.append('  enum { NPROD = %d, NLIN = %d, NOPS = %d, NV = %d, PROG_MAX = %d, CONST_BASE = %d, OP_INV = %d };' % (
-        len(prods), len(lin_words), len(oprows), lay.count, pmax, lay.base.get('CONST', -1), len(oprows) if has_inv else -1))
+    out.append('  enum { NPROD = %d, NLIN = %d, NOPS = %d, NV = %d, PROG_MAX = %d, CONST_BASE = %d, OP_INV = %d, FROB_CONSTS = %d };' % (
+        len(prods), len(lin_words), len(oprows), lay.count, pmax, lay.base.get('CONST', -1), len(oprows) if has_inv else -1, 1 if has_inv else 0))
     out.append('  WIDE_TB_FN const wide_prod* prods() { return %s_PROD; }' % prefix)
     out.append('  WIDE_TB_FN const uint32_t* lins() { return %s_LIN; }' % prefix)
     out.append('  WIDE_TB_FN const wide_op* ops() { return %s_OPS; }' % prefix)
