@@ -456,7 +456,9 @@ def main():
         out.update(common)
     elif args.config == 2:
         out = run_config2(h, args)
-        if not args.no_extras:
+        # the other configs ride along only in the one-GPU run: at N > 1 they are collectives over RCCL, and a rank that fails
+        # inside one would leave the others waiting -- the scaling run measures the headline only (use --config 3|4|5 --gpus N)
+        if not args.no_extras and h.world == 1:
             extras = {}
             k = max(1, min(args.steps, 3))
             for name, fn in (('config3_multi_verify_1048576', lambda: run_config3(h, k, 1)),
