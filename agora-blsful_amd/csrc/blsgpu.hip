@@ -301,6 +301,7 @@ size_t coop_max_items() {
 // BLSGPU_WIDE_MAX overrides (0 = never).  One workgroup occupies the four SIMDs of a CU, so 256 items run side by side.
 // measurement aid (tools/dbg/hash_phases.py): BLSGPU_HASH_STOP=k makes k_hash_to_g1_wide return after its k-th phase when it is
 // launched through blsgpu_hash_to_g1 (the output is then meaningless); 0 / unset: the whole hash
+int hash_phase_stop();
 int hash_phase_stop() {
   const char* e = getenv("BLSGPU_HASH_STOP");
   return e ? atoi(e) & 0xff : 0;
@@ -459,6 +460,16 @@ int side_fork(Ctx* c) {
   return 0;
 }
 
+// hash-to-G1 of a few messages on `stream`: one workgroup per message with the cofactor clearing on the engine while every
+// message gets its own CU (up to 256), one wave per message beyond that.  flags: bit 0 = every item hashes message 0.
+void launch_hash_g1_small(hipStream_t stream, size_t n, const uint8_t* d_msgs, const uint64_t* d_offs, int flags, const dst_arg& dst, uint8_t* d_out,
+                          uint32_t* d_rec) {
+  if (n <= 256 && hash_phase_stop() == 0)
+    hipLaunchKernelGGL(k_hash_to_g1_engine, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), 0, stream, n, d_msgs, d_offs, flags, dst, d_out, d_rec);
+  else
+    hipLaunchKernelGGL(k_hash_to_g1_wide, dim3((unsigned)n), dim3(BLS_BLOCK), 0, stream, n, d_msgs, d_offs, flags | hash_phase_stop() << 8, dst, d_out, d_rec);
+}
+
 // one core_verify per item: statuses end up in d_status (device)
 int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_t* d_sigs, int fmt, const uint8_t* d_msgs,
                      const uint64_t* d_offs, int single_msg, const dst_arg& dst, size_t n, uint32_t* d_pairs, uint32_t* d_f,
@@ -474,7 +485,7 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
     if (!d_rec) return fail(BLSGPU_E_HIP, "internal: arena too small");
     int rc = side_fork(c);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_hash_to_g1_wide, dim3((unsigned)n), dim3(BLS_BLOCK), 0, c->side, n, d_msgs, d_offs, single_msg, dst, (uint8_t*)nullptr, d_rec);
+    launch_hash_g1_small(c->side, n, d_msgs, d_offs, single_msg, dst, (uint8_t*)nullptr, d_rec);
     hipError_t e1 = hipGetLastError(), e2 = hipEventRecord(c->ev_join, c->side);
     KL(KID_PREPARE, k_prepare_keys<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_pks, d_sigs, (const uint8_t*)nullptr, fmt, 3, d_rec, d_status);
     KL(KID_WIDE, k_pairing_pre, dim3((unsigned)n, 2), dim3(WIDE_ENGINE_BLOCK), n, d_rec, (const int32_t*)d_status, 0, 1);
@@ -1360,8 +1371,7 @@ static int cut_tail_begin(Ctx* c, int sig_group, int scheme, const void* sig, in
   if ((rc = h2d_small(c, d_offs0, offs0, 16))) return rc;
   if ((rc = side_fork(c))) return rc;
   if (sig_group == 1) {
-    hipLaunchKernelGGL(k_hash_to_g1_wide, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, 1,
-                       scheme_dst(1, scheme), (uint8_t*)nullptr, t.rec);
+    launch_hash_g1_small(c->side, 1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, 1, scheme_dst(1, scheme), (uint8_t*)nullptr, t.rec);
     hipLaunchKernelGGL(k_prepare_keys<1>, dim3(1), dim3(BLS_BLOCK), 0, c->side2, (size_t)1, (const uint8_t*)nullptr, (const uint8_t*)d_sig,
                        (const uint8_t*)nullptr, fmt, 1, t.rec, t.d_status);
     hipLaunchKernelGGL(k_pairing_pre, dim3(1, 1), dim3(WIDE_ENGINE_BLOCK), 0, c->side2, (size_t)1, t.rec, (const int32_t*)t.d_status, 1, 1);
@@ -1466,8 +1476,7 @@ int blsgpu_multi_verify(int sig_group, int scheme, const void* pks, size_t n, co
     if ((rc = h2d_small(c, d_offs0, offs0, 16))) return rc;
     if ((rc = side_fork(c))) return rc;
     if (sig_group == 1)   // one wave, the two SSWU maps on two DPP rows in the row-wide field type (csrc/wide.cuh)
-      hipLaunchKernelGGL(k_hash_to_g1_wide, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, 1,
-                         scheme_dst(sig_group, scheme), d_hash, (uint32_t*)nullptr);
+      launch_hash_g1_small(c->side, 1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, 1, scheme_dst(sig_group, scheme), d_hash, (uint32_t*)nullptr);
     else
       hipLaunchKernelGGL(k_hash_to_g2, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0,
                          scheme_dst(sig_group, scheme), d_hash, 1);
@@ -1896,8 +1905,7 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
     if ((rc = h2d_small(c, d_offs0, offs0, 16))) return rc;
     if ((rc = side_fork(c))) return rc;
     if (sig_group == 1)
-      hipLaunchKernelGGL(k_hash_to_g1_wide, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, 1,
-                         scheme_dst(sig_group, scheme), d_hash, (uint32_t*)nullptr);
+      launch_hash_g1_small(c->side, 1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, 1, scheme_dst(sig_group, scheme), d_hash, (uint32_t*)nullptr);
     else
       hipLaunchKernelGGL(k_hash_to_g2, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0,
                          scheme_dst(sig_group, scheme), d_hash, 1);
@@ -2162,7 +2170,11 @@ static int hash_to_group(int group, const uint8_t* msgs, const uint64_t* msg_off
   // two lanes per message as in run_verify_items: always for G2, for G1 only in latency mode (small batches)
   const int two = (group == 2 || n <= coop_max_items()) ? 1 : 0;
   if (group == 1 && n <= wide_max_items())   // a few messages: one wave each in the row-wide field type (0.98 ms against 1.6 ms of latency)
-    KL(KID_HASH, k_hash_to_g1_wide, dim3((unsigned)n), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, hash_phase_stop() << 8, d, d_out, (uint32_t*)nullptr);
+  {
+    prof_pre(c, KID_HASH);
+    launch_hash_g1_small(c->stream, n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, 0, d, d_out, (uint32_t*)nullptr);
+    prof_post(c);
+  }
   else if (group == 1) KL(KID_HASH, k_hash_to_g1, dim3(blocks_for(two ? 2 * n : n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out, two);
   else if (n <= wide_max_items() && hash_phase_stop() != 8) {   // a few messages: the cofactor clearing on the row-wide engine (BLSGPU_HASH_STOP=8: not)
     KL(KID_HASH, k_hash_to_g2, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out, 3);

@@ -269,4 +269,27 @@ def check_point_programs():
             zi2 = c.f2_sqr(zi)
             got = (c.f2_mul(X, zi2), c.f2_mul(Y, c.f2_mul(zi2, zi)))
         assert got == want, ('G2_CLEAR', case)
+    # the cofactor clearing of hash-to-G1: (1 - x) P for points of E1(Fp) outside the subgroup, in it, and the identity
+    for case in range(4):
+        if case < 2:
+            q = c.E1.add(c.map_to_curve_g1(rng.randrange(P)), c.map_to_curve_g1(rng.randrange(P)))
+        elif case == 2:
+            q = c.E1.mul(c.G1_GEN, rng.randrange(1, c.R))
+        else:
+            q = None
+        want = c.E1.mul(q, c.H_EFF_G1) if q is not None else None
+        V = [0] * lay.count
+        if q is None:
+            V[B['R0']:B['R0'] + 3] = [0, 1, 0]
+        else:
+            z = rng.randrange(1, P)
+            V[B['R0']:B['R0'] + 3] = [q[0] * z * z % P, q[1] * z * z * z % P, z]
+        sim_program(OPS_PT, lay, dict(PROGRAMS_PT)['G1_CLEAR'], V)
+        X, Y, Z = V[B['R1']:B['R1'] + 3]
+        if Z == 0:
+            got = None
+        else:
+            zi = c.fp_inv(Z)
+            got = (X * zi * zi % P, Y * zi * zi * zi % P)
+        assert got == want, ('G1_CLEAR', case)
     return lay

@@ -622,9 +622,34 @@ def op_c2psi():
     return op
 
 
+def op_c1gadd1():
+    op = Op('C1GADD1')
+    X1, Y1, Z1 = (v1(j) for j in range(3))
+    X2, Y2, Z2 = ((1, idx(SB, j)) for j in range(3))
+    t0, t1, t2 = op.prod([X1], [X2]), op.prod([Y1], [Y2]), op.prod([Z1], [Z2])
+    T3, T4, T5 = op.prod([X1, Y1], [X2, Y2]), op.prod([Y1, Z1], [Y2, Z2]), op.prod([X1, Z1], [X2, Z2])
+    op.lin([(3, t0)], idx(DST, 0))
+    op.lin([(1, t1), (-12, t2)], idx(DST, 1))
+    op.lin([(1, t1), (12, t2)], idx(DST, 2))
+    op.lin([(1, T3), (-1, t0), (-1, t1)], idx(DST, 3))
+    op.lin([(1, T4), (-1, t1), (-1, t2)], idx(DST, 4))
+    op.lin([(12, T5), (-12, t0), (-12, t2)], idx(DST, 5))
+    return op
+
+
+def op_c1gadd2():
+    op = Op('C1GADD2')
+    m0, m1, m2, m3, m4, m5 = (v1(j) for j in range(6))
+    op.lin([(1, op.prod([m3], [m1])), (-1, op.prod([m4], [m5]))], idx(DST, 0))
+    op.lin([(1, op.prod([m1], [m2])), (1, op.prod([m5], [m0]))], idx(DST, 1))
+    op.lin([(1, op.prod([m2], [m4])), (1, op.prod([m0], [m3]))], idx(DST, 2))
+    return op
+
+
 OPS_PT = ([op_c2add1(m) for m in (4, 2, 1)] + [op_c2add2(m) for m in (4, 2, 1)] + [op_c2j2h('A', 8), op_c2j2h('B', 8), op_c2h2j('A'), op_c2h2j('B')] +
           [op_c1add1(m) for m in (8, 4, 2, 1)] + [op_c1add2(m) for m in (8, 4, 2, 1)] + [op_c1j2h('A', 8), op_c1j2h('B', 8), op_c1h2j('A'), op_c1h2j('B')] +
-          [op_c2gadd1(), op_c2gadd2(), op_c2neg(), op_c2psi(), op_c2j2h('A', 1), op_c2j2h('B', 1)])
+          [op_c2gadd1(), op_c2gadd2(), op_c2neg(), op_c2psi(), op_c2j2h('A', 1), op_c2j2h('B', 1),
+           op_c1gadd1(), op_c1gadd2(), op_c1j2h('A', 1), op_c1j2h('B', 1)])
 PT_POINTS = 16                     # points per workgroup: a tree of four levels
 
 
@@ -679,7 +704,22 @@ def prog_g2_clear_cofactor():
 
 
 PROGRAMS_PT = [('G%d_%s%s' % (g, 'J' if ji else 'H', 'J' if jo else 'H'), prog_point_tree(g, ji, jo)) for g in (1, 2) for ji in (1, 0) for jo in (1, 0)]
-PROGRAMS_PT += [('G2_CLEAR', prog_g2_clear_cofactor())]
+def prog_g1_clear_cofactor():
+    """h_eff P = (1 - x) P = P + |x| P on G1 (RFC 9380 8.8.1): double-and-add from the top bit, complete additions; registers as
+    for G2 (R0 = P Jacobian in, R1 = the result, Jacobian out)"""
+    def add(d, a, b):
+        return [('C1GADD1', 'MS', a, b), ('C1GADD2', d, 'MS', 'MS')]
+
+    st = [('C1J2HAX1', 'R0', 'R0', 'R0'), ('C1J2HBX1', 'R0', 'R0', 'R0')]
+    for i in range(62, -1, -1):
+        st += add('R1', 'R0', 'R0') if i == 62 else add('R1', 'R1', 'R1')
+        if (X_ABS >> i) & 1:
+            st += add('R1', 'R1', 'R0')
+    st += add('R1', 'R1', 'R0')
+    return st + [('C1H2JA', 'R1', 'R1', 'R1'), ('C1H2JB', 'R1', 'R1', 'R1')]
+
+
+PROGRAMS_PT += [('G2_CLEAR', prog_g2_clear_cofactor()), ('G1_CLEAR', prog_g1_clear_cofactor())]
 
 
 # ------------------------------------------------------------------ programs: sequences of (op, dst, a, b) over the value store
