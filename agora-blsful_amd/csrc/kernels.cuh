@@ -2449,13 +2449,14 @@ __global__ void __launch_bounds__(WIDE_BLOCK) k_hash_to_g1_wide(size_t n, const 
     }
   }
 }
-// One workgroup per message: wave 0 runs the hash as above up to q = map(u0) + map(u1); the cofactor clearing (1 + |x|) q -- 64
-// doublings and 6 additions, 0.29 ms on the two rows -- is then program G1_CLEAR of table set PT on all four waves: 70 complete
-// additions as two table steps each, 0.17 ms.
+// One workgroup per message: wave 0 runs expand_message_xmd and the two SSWU maps (the square-root chains: dependent
+// multiplications, the row-wide field type's business); everything behind them is program G1_HASH_TAIL of table set PT on all
+// four waves -- the 11-isogeny of both points as eight table steps (every polynomial ONE linear row over monomial x constant
+// products: 15 us where the Horner chains took 87), their sum, and the cofactor clearing (1 + |x|) q as 70 complete additions
+// (0.17 ms where the two rows took 0.29).  (A point on a pole of the isogeny would need the identity here; no message hashes there.)
 __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_hash_to_g1_engine(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst,
                                                                        uint8_t* out, uint32_t* rec) {
   __shared__ wide_lds_t<wide_tb_pt> S;
-  __shared__ uint32_t pts[2][3][16];
   __shared__ __attribute__((aligned(16))) uint8_t shablk[64];
   const int wave = threadIdx.x >> 6, row = (threadIdx.x >> 4) & 3, l = threadIdx.x & 15;
   const size_t i = blockIdx.x;
@@ -2463,7 +2464,7 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_hash_to_g1_engine(size_t 
   wide_consts K;
   wide_init(K);
   wf_setup();
-  wide_stage(S, WIDE_PROG_G1_CLEAR, WIDE_PROG_G1_CLEAR_LEN);
+  wide_stage(S, WIDE_PROG_G1_HASH_TAIL, WIDE_PROG_G1_HASH_TAIL_LEN);
   __syncthreads();
   if (wave == 0) {
     const size_t mi = (single_msg & 1) ? 0 : i;
@@ -2475,37 +2476,26 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_hash_to_g1_engine(size_t 
       for (int j = 0; j < 16; j++) uw[j] = row == 1 ? ubw[16 + j] : ubw[j];    // u0 on row 0, u1 on row 1
       fp ul;
       fp_from_be_words(ul, uw);
-      wf u, xn, xd, y;
+      wf u, xn, xd, y, t;
       wf_from_local(u, ul);
       sswu_g1(xn, xd, y, u);
-      jac<wf> mine, q0, q1;
-      iso_map_g1_wide(mine, xn, xd, y);
-      pts[row][0][l] = (uint32_t)mine.x.v;
-      pts[row][1][l] = (uint32_t)mine.y.v;
-      pts[row][2][l] = (uint32_t)mine.z.v;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      q0.x.v = (wfp)pts[0][0][l];
-      q0.y.v = (wfp)pts[0][1][l];
-      q0.z.v = (wfp)pts[0][2][l];
-      q1.x.v = (wfp)pts[1][0][l];
-      q1.y.v = (wfp)pts[1][1][l];
-      q1.z.v = (wfp)pts[1][2][l];
-      jac_add(q0, q0, q1);                       // both rows: identical operands
-      if (row == 0) {
-        wf t;
-        const bool inf = fp_is_zero(q0.z);       // the identity enters the engine as (0, 1, 0)
-        fp_reduce(t, q0.x);
-        S.V[WPV_R0][l] = inf ? 0u : (uint32_t)t.v;
-        fp_reduce(t, q0.y);
-        S.V[WPV_R0 + 1][l] = inf ? (l < FP_NL ? FP_ONE[l] : 0u) : (uint32_t)t.v;
-        fp_reduce(t, q0.z);
-        S.V[WPV_R0 + 2][l] = inf ? 0u : (uint32_t)t.v;
-      }
+      uint32_t (*iso)[16] = &S.V[WPV_ISO + WIDE_PT_ISO_STRIDE * row];      // x' = xn / xd and y of map `row`
+      fp_reduce(t, xn);
+      iso[0][l] = (uint32_t)t.v;
+      fp_reduce(t, xd);
+      iso[1][l] = (uint32_t)t.v;
+      fp_reduce(t, y);
+      iso[2][l] = (uint32_t)t.v;
+    }
+  } else {                                                  // meanwhile: the isogeny's 55 coefficients into the constants (xnum, xden, ynum, yden)
+    for (int t = (int)threadIdx.x - 64; t < 55 * 16; t += WIDE_ENGINE_BLOCK - 64) {
+      const int v = t >> 4, ll = t & 15;
+      const uint32_t* src = v < 12 ? ISO1_XNUM[v] : (v < 23 ? ISO1_XDEN[v - 12] : (v < 39 ? ISO1_YNUM[v - 23] : ISO1_YDEN[v - 39]));
+      S.V[WPV_CONST + WIDE_PT_ISO_K + v][ll] = ll < FP_NL ? src[ll] : 0u;
     }
   }
   __syncthreads();
-  wide_exec(S, WIDE_PROG_G1_CLEAR_LEN, K);
+  wide_exec(S, WIDE_PROG_G1_HASH_TAIL_LEN, K);
   const int v = (int)(threadIdx.x >> 4);
   if (rec && v < 3) rec[i * WREC_WORDS + 16 * (WREC_P0 + v) + l] = S.V[WPV_R1 + v][l];
   if (out && threadIdx.x < 3) {

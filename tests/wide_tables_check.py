@@ -19,6 +19,7 @@ OPS, OPS_PT, PROGRAMS, PROGRAMS_PT = g.OPS, g.OPS_PT, g.PROGRAMS, g.PROGRAMS_PT
 NSTEPS, PT_POINTS, G1S, G2S = g.NSTEPS, g.PT_POINTS, g.G1S, g.G2S
 layout_f12, layout_pt, prog_final_hard, prog_key_lines = g.layout_f12, g.layout_pt, g.prog_final_hard, g.prog_key_lines
 g1_point_off, g2_point_off = g.g1_point_off, g.g2_point_off
+TABLES = g       # (functions below use g and gen as local names)
 
 
 def consts24():
@@ -87,9 +88,15 @@ def self_check():
 
 
 def psi_consts():
+    """the constants of table set PT: psi's cx, cy, then the coefficients of the 11-isogeny (xnum, xden, ynum, yden; low to high)"""
+    from oracle.py import iso_consts
     cx = c.f2_inv(c.f2_pow(c.XI, (P - 1) // 3))
     cy = c.f2_inv(c.f2_pow(c.XI, (P - 1) // 2))
-    return [cx[0], cx[1], cy[0], cy[1]]
+    k = [cx[0], cx[1], cy[0], cy[1]]
+    for tab in iso_consts.G1_ISO:
+        k += list(tab)
+    assert len(k) == TABLES.ISO_K + 12 + 11 + 16 + 16
+    return k
 
 
 def sim_program(ops, lay, steps, V):
@@ -292,4 +299,20 @@ def check_point_programs():
             zi = c.fp_inv(Z)
             got = (X * zi * zi % P, Y * zi * zi * zi % P)
         assert got == want, ('G1_CLEAR', case)
+    # everything behind the two SSWU maps of hash-to-G1 (isogeny of both points, sum, clearing) against the oracle's own chain;
+    # x' enters as a fraction xn / xd with a random denominator
+    from oracle.py import iso_consts
+    for case in range(3):
+        us = [rng.randrange(P), rng.randrange(P)]
+        qs = [c._sswu(c.E1_ISO, iso_consts.G1_Z, u, c.fp_is_square, c.fp_sqrt, c._sgn0_fp, 1) for u in us]
+        want = c.E1.mul(c.E1.add(c.map_to_curve_g1(us[0]), c.map_to_curve_g1(us[1])), c.H_EFF_G1)
+        V = [0] * lay.count
+        for m, q in enumerate(qs):
+            d = rng.randrange(1, P)
+            o = B['ISO'] + TABLES.ISO_STRIDE * m
+            V[o + TABLES.ISO_XN], V[o + TABLES.ISO_XD], V[o + TABLES.ISO_Y] = q[0] * d % P, d, q[1]
+        sim_program(OPS_PT, lay, dict(PROGRAMS_PT)['G1_HASH_TAIL'], V)
+        X, Y, Z = V[B['R1']:B['R1'] + 3]
+        zi = c.fp_inv(Z)
+        assert (X * zi * zi % P, Y * zi * zi * zi % P) == want, ('G1_HASH_TAIL', case)
     return lay

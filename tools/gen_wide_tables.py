@@ -646,10 +646,92 @@ def op_c1gadd2():
     return op
 
 
+# ---- the 11-isogeny of hash-to-G1 for the two mapped points at once (array ISO: map m at ISO_STRIDE m).  The SSWU map leaves
+# x' = xn / xd and y; the rational map x = xnum(x') / xden(x'), y = y ynum(x') / yden(x') is evaluated on homogenised polynomials
+# (sum_i k_i xn^i xd^(deg - i)): powers of xn and xd in four levels, the 33 mixed monomials in one step, then every polynomial is ONE
+# linear row over (monomial x constant) products -- a single reduction per polynomial, where a Horner chain is ~100 dependent
+# multiplications -- and two steps assemble the homogeneous point (XN YD : y YN zx : zx YD), zx = XD xd.  Constants: array
+# CONST of table set PT, ISO_K + (0, 12, 23, 39) for xnum (12), xden (11), ynum (16), yden (16), coefficient of x^i at i.
+ISO_STRIDE, ISO_XN, ISO_XD, ISO_Y, ISO_POW_N, ISO_POW_D, ISO_MONO, ISO_POLY, ISO_ZX, ISO_B, ISO_PT = 80, 0, 1, 2, 3, 17, 31, 64, 68, 70, 73
+ISO_K = 4
+ISO_KOFF = {'xnum': ISO_K, 'xden': ISO_K + 12, 'ynum': ISO_K + 23, 'yden': ISO_K + 39}
+ISO_DEG = {'xnum': 11, 'xden': 10, 'ynum': 15, 'yden': 15}
+
+
+def iso_pow(m, var, k):
+    """value index of var^k (k >= 1) of map m"""
+    base = ISO_STRIDE * m
+    if k == 1:
+        return base + (ISO_XN if var == 'n' else ISO_XD)
+    return base + (ISO_POW_N if var == 'n' else ISO_POW_D) + k - 2
+
+
+def iso_mono(m, deg, i):
+    """value index of xn^i xd^(deg - i) of map m (the pure powers live in the power tables)"""
+    if i == 0:
+        return iso_pow(m, 'd', deg)
+    if i == deg:
+        return iso_pow(m, 'n', deg)
+    off = {11: 0, 10: 10, 15: 19}[deg]
+    return ISO_STRIDE * m + ISO_MONO + off + i - 1
+
+
+def op_iso_pow(level):
+    op = Op('C1ISOP%d' % level)
+    lo, hi, mul = {1: (2, 2, 1), 2: (3, 4, 2), 3: (5, 8, 4), 4: (9, 15, 8)}[level]
+    for m in range(2):
+        for var in 'nd':
+            for k in range(lo, hi + 1):
+                t = op.prod([(1, idx(SA, iso_pow(m, var, mul)))], [(1, idx(SA, iso_pow(m, var, k - mul)))])
+                op.lin([(1, t)], idx(DST, iso_pow(m, var, k)))
+    return op
+
+
+def op_iso_mono():
+    op = Op('C1ISOM')
+    for m in range(2):
+        for deg in (11, 10, 15):
+            for i in range(1, deg):
+                t = op.prod([(1, idx(SA, iso_pow(m, 'n', i)))], [(1, idx(SA, iso_pow(m, 'd', deg - i)))])
+                op.lin([(1, t)], idx(DST, iso_mono(m, deg, i)))
+    return op
+
+
+def op_iso_poly():
+    op = Op('C1ISOK')
+    for m in range(2):
+        for j, name in enumerate(('xnum', 'xden', 'ynum', 'yden')):
+            deg, monic = ISO_DEG[name], name in ('xden', 'yden')
+            terms = []
+            for i in range(deg + 1):
+                if monic and i == deg:
+                    terms.append((1, idx(SA, iso_mono(m, deg, i))))          # leading coefficient 1: the monomial itself
+                else:
+                    terms.append((1, op.prod([(1, idx(SA, iso_mono(m, deg, i)))], [(1, idx(CONST, ISO_KOFF[name] + i))])))
+            op.lin(terms, idx(DST, ISO_STRIDE * m + ISO_POLY + j))
+    return op
+
+
+def op_iso_asm(stage):
+    op = Op('C1ISOA%d' % stage)
+    for m in range(2):
+        b = ISO_STRIDE * m
+        XN, XD, YN, YD = (b + ISO_POLY + j for j in range(4))
+        if stage == 1:
+            op.lin([(1, op.prod([(1, idx(SA, XD))], [(1, idx(SA, b + ISO_XD))]))], idx(DST, b + ISO_ZX))
+            op.lin([(1, op.prod([(1, idx(SA, XN))], [(1, idx(SA, YD))]))], idx(DST, b + ISO_PT))
+            op.lin([(1, op.prod([(1, idx(SA, b + ISO_Y))], [(1, idx(SA, YN))]))], idx(DST, b + ISO_B))
+        else:
+            op.lin([(1, op.prod([(1, idx(SA, b + ISO_B))], [(1, idx(SA, b + ISO_ZX))]))], idx(DST, b + ISO_PT + 1))
+            op.lin([(1, op.prod([(1, idx(SA, b + ISO_ZX))], [(1, idx(SA, YD))]))], idx(DST, b + ISO_PT + 2))
+    return op
+
+
 OPS_PT = ([op_c2add1(m) for m in (4, 2, 1)] + [op_c2add2(m) for m in (4, 2, 1)] + [op_c2j2h('A', 8), op_c2j2h('B', 8), op_c2h2j('A'), op_c2h2j('B')] +
           [op_c1add1(m) for m in (8, 4, 2, 1)] + [op_c1add2(m) for m in (8, 4, 2, 1)] + [op_c1j2h('A', 8), op_c1j2h('B', 8), op_c1h2j('A'), op_c1h2j('B')] +
           [op_c2gadd1(), op_c2gadd2(), op_c2neg(), op_c2psi(), op_c2j2h('A', 1), op_c2j2h('B', 1),
-           op_c1gadd1(), op_c1gadd2(), op_c1j2h('A', 1), op_c1j2h('B', 1)])
+           op_c1gadd1(), op_c1gadd2(), op_c1j2h('A', 1), op_c1j2h('B', 1)] +
+          [op_iso_pow(k) for k in (1, 2, 3, 4)] + [op_iso_mono(), op_iso_poly(), op_iso_asm(1), op_iso_asm(2)])
 PT_POINTS = 16                     # points per workgroup: a tree of four levels
 
 
@@ -719,7 +801,16 @@ def prog_g1_clear_cofactor():
     return st + [('C1H2JA', 'R1', 'R1', 'R1'), ('C1H2JB', 'R1', 'R1', 'R1')]
 
 
-PROGRAMS_PT += [('G2_CLEAR', prog_g2_clear_cofactor()), ('G1_CLEAR', prog_g1_clear_cofactor())]
+def prog_g1_hash_tail():
+    """everything of hash-to-G1 behind the two SSWU maps: the isogeny of both points, their sum, the cofactor clearing; result
+    (Jacobian) in R1"""
+    st = [('C1ISOP%d' % k, 'ISO', 'ISO', 'ISO') for k in (1, 2, 3, 4)]
+    st += [('C1ISOM', 'ISO', 'ISO', 'ISO'), ('C1ISOK', 'ISO', 'ISO', 'ISO'), ('C1ISOA1', 'ISO', 'ISO', 'ISO'), ('C1ISOA2', 'ISO', 'ISO', 'ISO')]
+    st += [('C1GADD1', 'MS', ('ISO', ISO_PT), ('ISO', ISO_STRIDE + ISO_PT)), ('C1GADD2', 'R0', 'MS', 'MS')]
+    return st + prog_g1_clear_cofactor()[2:]        # R0 is homogeneous already: skip the Jacobian -> homogeneous steps
+
+
+PROGRAMS_PT += [('G2_CLEAR', prog_g2_clear_cofactor()), ('G1_CLEAR', prog_g1_clear_cofactor()), ('G1_HASH_TAIL', prog_g1_hash_tail())]
 
 
 # ------------------------------------------------------------------ programs: sequences of (op, dst, a, b) over the value store
@@ -845,7 +936,7 @@ def layout_f12():
 
 def layout_pt():
     return Layout([('L0', 8 * G2S), ('L1', 4 * G2S), ('L2', 2 * G2S), ('L3', G2S), ('L4', G2S), ('TMP', 2 * (max(o.ntmp for o in OPS_PT) + 1)),
-                   ('R0', G2S), ('R1', G2S), ('R2', G2S), ('R3', G2S), ('R4', G2S), ('MS', 12), ('CONST', 4)])
+                   ('R0', G2S), ('R1', G2S), ('R2', G2S), ('R3', G2S), ('R4', G2S), ('MS', 12), ('CONST', 64), ('ISO', 2 * ISO_STRIDE)])
 
 
 # ------------------------------------------------------------------ emission
@@ -964,6 +1055,8 @@ def emit(path):
     out.append('#define WIDE_PROG_MAX %d' % pmax)
     out.append('// ---- table set PT: sums of sixteen points per workgroup (complete projective additions)')
     emit_set(out, OPS_PT, lay_pt, PROGRAMS_PT, 'WIDE_PT', 'WPV', 'wide_tb_pt', False)
+    out.append('#define WIDE_PT_ISO_STRIDE %d   // values per mapped point in array ISO (x\' = xn / xd at 0, 1; y at 2)' % ISO_STRIDE)
+    out.append('#define WIDE_PT_ISO_K %d        // first isogeny coefficient in array CONST' % ISO_K)
     out.append('#define WIDE_PT_SLOT_G1 %d' % G1S)
     out.append('#define WIDE_PT_SLOT_G2 %d' % G2S)
     open(path, 'w').write('\n'.join(out) + '\n')
