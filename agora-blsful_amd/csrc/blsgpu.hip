@@ -198,6 +198,31 @@ int stage_in(Ctx* c, const void* p, size_t bytes, const void** out) {
   *out = d;
   return 0;
 }
+// Several SMALL host buffers of one call (a single verification's key, signature, message, offsets) as ONE host-to-device copy
+// through the context's pinned ring instead of one pageable copy each (~8 us apiece on the latency path).  Returns false when it
+// does not apply (a device pointer among them, too large, ring full): the caller then stages one by one.
+bool stage_in_packed(Ctx* c, const void* const* ptrs, const size_t* sizes, const void** outs, int k) {
+  size_t total = 0;
+  for (int j = 0; j < k; j++) {
+    if (sizes[j] && is_device_ptr(ptrs[j])) return false;
+    total += pad256(sizes[j]);
+  }
+  if (total == 0 || total > 16384) return false;
+  uint8_t* h = (uint8_t*)hsmall_take(c, total);
+  uint8_t* d = h ? (uint8_t*)arena_take(c, total) : nullptr;
+  if (!h || !d) return false;
+  size_t off = 0;
+  for (int j = 0; j < k; j++) {
+    if (sizes[j]) memcpy(h + off, ptrs[j], sizes[j]);
+    outs[j] = d + off;
+    off += pad256(sizes[j]);
+  }
+  if (hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return true;
+}
 int copy_out(Ctx* c, void* dst, const void* dsrc, size_t bytes) {
   if (bytes == 0) return 0;
   HIPCK(hipMemcpyAsync(dst, dsrc, bytes, is_device_ptr(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
@@ -1177,10 +1202,22 @@ int blsgpu_verify_batch(int sig_group, int scheme, const void* pks, const void* 
   if (rc) return rc;
   c->arena_off = 0;
   const void *d_pks, *d_sigs, *d_msgs, *d_offs;
-  if ((rc = stage_in(c, pks, pkb, &d_pks))) return rc;
-  if ((rc = stage_in(c, sigs, sgb, &d_sigs))) return rc;
-  if ((rc = stage_in(c, msgs, total, &d_msgs))) return rc;
-  if ((rc = stage_in(c, msg_offsets, 8 * (n + 1), &d_offs))) return rc;
+  {
+    const void* ptrs[4] = {pks, sigs, msgs, msg_offsets};
+    const size_t sizes[4] = {pkb, sgb, (size_t)total, 8 * (n + 1)};
+    const void* outs[4];
+    if (stage_in_packed(c, ptrs, sizes, outs, 4)) {
+      d_pks = outs[0];
+      d_sigs = outs[1];
+      d_msgs = outs[2];
+      d_offs = outs[3];
+    } else {
+      if ((rc = stage_in(c, pks, pkb, &d_pks))) return rc;
+      if ((rc = stage_in(c, sigs, sgb, &d_sigs))) return rc;
+      if ((rc = stage_in(c, msgs, total, &d_msgs))) return rc;
+      if ((rc = stage_in(c, msg_offsets, 8 * (n + 1), &d_offs))) return rc;
+    }
+  }
   int32_t* d_status = (int32_t*)arena_take(c, 4 * n);
   uint32_t* d_pairs = (uint32_t*)arena_take(c, (size_t)WS_PAIRS_WORDS * 4 * n);
   uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * n);
