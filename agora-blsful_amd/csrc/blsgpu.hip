@@ -486,10 +486,10 @@ int side_fork(Ctx* c) {
 }
 
 // hash-to-G1 of a few messages on `stream`: one workgroup per message with the cofactor clearing on the engine while every
-// message gets its own CU (up to 256), one wave per message beyond that.  flags: bit 0 = every item hashes message 0.
+// message gets its own CU (up to 128 messages), one wave per message beyond that.  flags: bit 0 = every item hashes message 0.
 void launch_hash_g1_small(hipStream_t stream, size_t n, const uint8_t* d_msgs, const uint64_t* d_offs, int flags, const dst_arg& dst, uint8_t* d_out,
                           uint32_t* d_rec) {
-  if (n <= 256 && hash_phase_stop() == 0)
+  if (n <= 128 && hash_phase_stop() == 0)     // measured (tools/dbg/small.py): at 256 items the pre-workgroups compete for the CUs and the one-wave hash wins
     hipLaunchKernelGGL(k_hash_to_g1_engine, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), 0, stream, n, d_msgs, d_offs, flags, dst, d_out, d_rec);
   else
     hipLaunchKernelGGL(k_hash_to_g1_wide, dim3((unsigned)n), dim3(BLS_BLOCK), 0, stream, n, d_msgs, d_offs, flags | hash_phase_stop() << 8, dst, d_out, d_rec);
@@ -551,6 +551,15 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
     KL(KID_WIDE, k_pairing_post, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), n, (const uint32_t*)d_rec, d_status);
     HIPCK(hipGetLastError());
     return 0;
+  }
+  if (sg == 1 && aug == 0 && !pre_status && n > wide_max_items() && n <= 1024 && n <= coop_max_items() && wide_max_items() > 0) {
+    // 513 to 1,024 items (measured: 4.1 / 4.6 ms at 768 / 1,024 against 4.8 / 5.1; at 2,048 the two-lane hash wins): the wave-cooperative pairing, but with the one-wave row-wide hash (0.74 ms while every
+    // message has a SIMD to itself, against 1.6 ms for the two-lane hash inside k_prepare) and the shared to-affine inversion after it
+    uint8_t* d_hashes = (uint8_t*)arena_take(c, 144 * n);
+    if (!d_hashes) return fail(BLSGPU_E_HIP, "internal: arena too small");
+    KL(KID_HASH, k_hash_to_g1_wide, dim3((unsigned)n), dim3(BLS_BLOCK), n, d_msgs, d_offs, single_msg & 1, dst, d_hashes, (uint32_t*)nullptr);
+    KL(KID_PREPARE, k_prepare_hashed<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_pks, d_sigs, (const uint8_t*)d_hashes, d_pairs, d_status, fmt);
+    return run_pairing2(c, n, d_pairs, d_f, d_status, 1);
   }
   // two lanes per item (the two SSWU maps side by side, G2 point arithmetic on the lane-split tower): always for
   // Bls12381G2Impl, whose hash-to-G2 halves its per-lane work that way; for Bls12381G1Impl only in latency mode (the

@@ -281,7 +281,7 @@ bool wide_prog_is_fp12(const uint32_t* prog, size_t len);   // host: what k_wide
 __global__ void k_pairing_wide(size_t n, const uint32_t* pairs, int32_t* status, int fixed_g2);
 __global__ void k_hash_to_g1_wide(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst, uint8_t* out, uint32_t* rec);
 // the same with one WORKGROUP per message: wave 0 hashes up to the sum of the two mapped points, then all four waves clear the
-// cofactor on the engine (program G1_CLEAR); for up to 256 messages (one workgroup per CU)
+// cofactor on the engine (program G1_HASH_TAIL); for up to 128 messages
 __global__ void k_hash_to_g1_engine(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst, uint8_t* out, uint32_t* rec);
 // The same check cut where its inputs become known (csrc/wide_tables.cuh programs PRE_LINES, PRE_F1 / PRE_F1G, POST).  The pairs
 // are (P0, Q0) (P1, Q1) = (H(m), key) (signature, -g2) for Bls12381G1Impl and (key, H(m)) (-g1, signature) for Bls12381G2Impl.
