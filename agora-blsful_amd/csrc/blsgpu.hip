@@ -595,14 +595,17 @@ int run_f12_product_verdict(Ctx* c, uint32_t* d_f, size_t m, size_t stride, int3
   return 0;
 }
 
-// lanes (lane pairs for G2) of the first stage of a point sum.  The cap leaves a few compute units' worth of wave slots free:
-// a grid that fills the machine EXACTLY (65,536 lane pairs = 2,048 waves = two per SIMD) takes twice as long as soon as any
-// other kernel holds one slot -- the side stream's hash wave does -- because one workgroup then waits for a whole round.
+// lanes (lane pairs for G2) of the first stage of a point sum.  The cap leaves a few compute units' worth of wave slots free in
+// every XCD: a grid that fills the machine EXACTLY (65,536 lane pairs = 2,048 waves = two per SIMD) takes twice as long as soon
+// as other kernels hold a few slots, because some workgroups then wait for a whole round -- and the side streams do hold
+// slots: the engine workgroups of the message hash and of the signature's Miller function take a whole CU each (their waves
+// use 355 registers), and workgroups go round-robin to the 8 XCDs, so two of them in one XCD cost it 16 slots.  Measured
+// (tools/dbg/acc.py, 2^20 keys): 1.15 / 1.17 ms at 58,368 / 57,344 lane pairs, 1.28 at 59,392, 1.48 at 61,440.
 size_t accumulate_lanes(size_t n) {
   static long cap = -1;
   if (cap < 0) {
     const char* e = getenv("BLSGPU_ACC_LANES");          // tuning override
-    cap = e ? atol(e) : 63488;                            // 248 of 256 compute units at 256 lane pairs each
+    cap = e ? atol(e) : 57344;                            // 224 of 256 compute units at 256 lane pairs each
     if (cap < 64) cap = 64;
   }
   size_t t = n / 4;
