@@ -229,6 +229,23 @@ int copy_out(Ctx* c, void* dst, const void* dsrc, size_t bytes) {
   return 0;
 }
 
+// a call's verdicts: copy, then wait for the stream.  A few verdicts for host memory travel through the pinned record buffer (a
+// device-to-host copy into pageable memory makes the runtime stage and wait internally, ~10 us more on a 1.5 ms call).
+void prof_flush(Ctx* c);
+int copy_out_and_sync(Ctx* c, void* dst, const void* dsrc, size_t bytes) {
+  void* h = nullptr;
+  if (bytes && bytes <= 4096 && !is_device_ptr(dst) && (h = hsmall_take(c, bytes))) {
+    HIPCK(hipMemcpyAsync(h, dsrc, bytes, hipMemcpyDeviceToHost, c->stream));
+  } else {
+    int rc = copy_out(c, dst, dsrc, bytes);
+    if (rc) return rc;
+  }
+  HIPCK(hipStreamSynchronize(c->stream));
+  prof_flush(c);
+  if (h) memcpy(dst, h, bytes);
+  return 0;
+}
+
 size_t g1_size(int fmt) { return fmt == BLSGPU_FMT_RAW_PROJ ? 144 : fmt == BLSGPU_FMT_RAW_AFFINE ? 96 : 48; }
 size_t g2_size(int fmt) { return fmt == BLSGPU_FMT_RAW_PROJ ? 288 : fmt == BLSGPU_FMT_RAW_AFFINE ? 192 : 96; }
 size_t pk_size(int sg, int fmt) { return sg == 1 ? g2_size(fmt) : g1_size(fmt); }
@@ -471,7 +488,9 @@ int run_pairing2(Ctx* c, size_t n, uint32_t* d_pairs, uint32_t* d_f, int32_t* d_
 }
 
 // the context's side stream (created on first use) starts where the main stream is now
-int side_fork(Ctx* c) {
+// which: bit 0 = mark the fork point on the main stream, bit 1 = make the side streams wait for it (a caller may enqueue the
+// main stream's next kernel between the two: the host's enqueue time of the side work then is off that kernel's path)
+int side_fork(Ctx* c, int which = 3) {
   if (!c->side) {
     HIPCK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     HIPCK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -479,9 +498,11 @@ int side_fork(Ctx* c) {
     HIPCK(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
     HIPCK(hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
   }
-  HIPCK(hipEventRecord(c->ev_fork, c->stream));
-  HIPCK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-  HIPCK(hipStreamWaitEvent(c->side2, c->ev_fork, 0));
+  if (which & 1) HIPCK(hipEventRecord(c->ev_fork, c->stream));
+  if (which & 2) {
+    HIPCK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    HIPCK(hipStreamWaitEvent(c->side2, c->ev_fork, 0));
+  }
   return 0;
 }
 
@@ -495,6 +516,17 @@ void launch_hash_g1_small(hipStream_t stream, size_t n, const uint8_t* d_msgs, c
     hipLaunchKernelGGL(k_hash_to_g1_wide, dim3((unsigned)n), dim3(BLS_BLOCK), 0, stream, n, d_msgs, d_offs, flags | hash_phase_stop() << 8, dst, d_out, d_rec);
 }
 
+// hash-to-G2 of a few messages on `stream` (RAW_PROJ out): one workgroup per message on the engine up to 128 messages, beyond
+// that two lanes per message for the maps and one workgroup per point for the cofactor clearing.  flags as above.
+void launch_hash_g2_small(hipStream_t stream, size_t n, const uint8_t* d_msgs, const uint64_t* d_offs, int flags, const dst_arg& dst, uint8_t* d_out) {
+  if (n <= 128 && hash_phase_stop() == 0) {
+    hipLaunchKernelGGL(k_hash_to_g2_engine, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), 0, stream, n, d_msgs, d_offs, flags, dst, d_out);
+  } else {
+    hipLaunchKernelGGL(k_hash_to_g2, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), 0, stream, n, d_msgs, d_offs, dst, d_out, 3);
+    hipLaunchKernelGGL(k_g2_clear_wide, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), 0, stream, n, d_out);
+  }
+}
+
 // one core_verify per item: statuses end up in d_status (device)
 int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_t* d_sigs, int fmt, const uint8_t* d_msgs,
                      const uint64_t* d_offs, int single_msg, const dst_arg& dst, size_t n, uint32_t* d_pairs, uint32_t* d_f,
@@ -502,19 +534,28 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
   if (n == 0) return 0;
   if (sg == 1 && aug == 0 && !pre_status && n <= wide_max_items() && n <= coop_max_items()) {
     // Single verifications of Bls12381G1Impl without a key prefix, cut where the inputs allow (csrc/kernels.cuh k_pairing_pre /
-    // k_pairing_post): the side stream hashes the messages (one wave each, row-wide field type) while this stream checks keys
-    // and signatures, derives every key's line coefficients and runs the Miller loop of the (signature, -g2) pair -- two
+    // k_pairing_post): this stream hashes the messages (row-wide field type) while the side stream checks keys and
+    // signatures, derives every key's line coefficients and runs the Miller loop of the (signature, -g2) pair -- two
     // workgroups per item, none of which needs H(m); what is left after the join is the Miller loop of (H(m), key) over
     // ready-made lines and the final exponentiation.
     uint32_t* d_rec = (uint32_t*)arena_take(c, (size_t)WREC_WORDS * 4 * n);
     if (!d_rec) return fail(BLSGPU_E_HIP, "internal: arena too small");
-    int rc = side_fork(c);
+    // the LONG chain -- staging copy, hash, then the rest of the check -- stays on this stream and is enqueued first, so that
+    // neither an event hand-over (~20 us each) nor the host's enqueue time of the side work sits on the critical path; the
+    // side stream does what finishes early anyway
+    int rc = side_fork(c, 1);
     if (rc) return rc;
-    launch_hash_g1_small(c->side, n, d_msgs, d_offs, single_msg, dst, (uint8_t*)nullptr, d_rec);
+    prof_pre(c, KID_HASH);
+    launch_hash_g1_small(c->stream, n, d_msgs, d_offs, single_msg, dst, (uint8_t*)nullptr, d_rec);
+    prof_post(c);
+    if ((rc = side_fork(c, 2))) {
+      (void)hipStreamSynchronize(c->stream);
+      return rc;
+    }
+    hipLaunchKernelGGL(k_prepare_keys<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), 0, c->side, n, d_pks, d_sigs, (const uint8_t*)nullptr, fmt, 3, d_rec, d_status);
+    hipLaunchKernelGGL(k_pairing_pre, dim3((unsigned)n, 2), dim3(WIDE_ENGINE_BLOCK), 0, c->side, n, d_rec, (const int32_t*)d_status, 0, 1);
     hipError_t e1 = hipGetLastError(), e2 = hipEventRecord(c->ev_join, c->side);
-    KL(KID_PREPARE, k_prepare_keys<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_pks, d_sigs, (const uint8_t*)nullptr, fmt, 3, d_rec, d_status);
-    KL(KID_WIDE, k_pairing_pre, dim3((unsigned)n, 2), dim3(WIDE_ENGINE_BLOCK), n, d_rec, (const int32_t*)d_status, 0, 1);
-    hipError_t e3 = hipStreamWaitEvent(c->stream, c->ev_join, 0);      // also when something failed: the side kernel reads the arena
+    hipError_t e3 = hipStreamWaitEvent(c->stream, c->ev_join, 0);      // also when something failed: the side kernels read the arena
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
       (void)hipStreamSynchronize(c->side);
       return fail(BLSGPU_E_HIP, "side-stream launch failed");
@@ -524,27 +565,33 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
     return 0;
   }
   if (sg == 2 && aug == 0 && !pre_status && (!single_msg || n == 1) && n <= wide_max_items() && n <= coop_max_items()) {
-    // The same cut for Bls12381G2Impl, pairs (key, H(m)) (-g1, signature): this stream checks keys and signatures and runs
-    // the signature's lines and Miller function; the side stream hashes to G2 (two lanes per message: the row-wide hash is
-    // built for G1 only) and derives the lines of H(m); after the join the Miller function of (key, H(m)) and the rest.
+    // The same cut for Bls12381G2Impl, pairs (key, H(m)) (-g1, signature): this stream carries the long chain -- the hash to G2
+    // (row-wide maps, cofactor clearing on the engine), H(m)'s record and lines -- and is enqueued first; the side stream
+    // checks keys and signatures and runs the signature's lines and Miller function; after the join the Miller function of
+    // (key, H(m)) and the rest.
     uint32_t* d_rec = (uint32_t*)arena_take(c, (size_t)WREC_WORDS * 4 * n);
     uint8_t* d_hashes = (uint8_t*)arena_take(c, 288 * n);
     if (!d_rec || !d_hashes) return fail(BLSGPU_E_HIP, "internal: arena too small");
-    int rc = side_fork(c);
+    int rc = side_fork(c, 1);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_hash_to_g2, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), 0, c->side, n, d_msgs, d_offs, dst, d_hashes, 3);
-    hipLaunchKernelGGL(k_g2_clear_wide, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), 0, c->side, n, d_hashes);
-    hipLaunchKernelGGL(k_prepare_keys<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), 0, c->side, n, (const uint8_t*)nullptr, (const uint8_t*)nullptr,
-                       (const uint8_t*)d_hashes, 0, 4, d_rec, d_status);
-    hipError_t e1 = hipGetLastError();
-    KL(KID_PREPARE, k_prepare_keys<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_pks, d_sigs, (const uint8_t*)nullptr, fmt, 3, d_rec, d_status);
-    // the lines of H(m) skip items that failed the identity checks: the side stream waits for the statuses written just above
-    hipError_t e3 = hipEventRecord(c->ev_fork, c->stream), e4 = hipStreamWaitEvent(c->side, c->ev_fork, 0);
-    hipLaunchKernelGGL(k_pairing_pre, dim3((unsigned)n, 1), dim3(WIDE_ENGINE_BLOCK), 0, c->side, n, d_rec, (const int32_t*)d_status, 0, 0);
-    hipError_t e5 = hipGetLastError(), e6 = hipEventRecord(c->ev_join, c->side);
-    KL(KID_WIDE, k_pairing_pre, dim3((unsigned)n, 1), dim3(WIDE_ENGINE_BLOCK), n, d_rec, (const int32_t*)d_status, 2, 2);
-    hipError_t e7 = hipStreamWaitEvent(c->stream, c->ev_join, 0);
-    if (e1 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess || e6 != hipSuccess || e7 != hipSuccess) {
+    prof_pre(c, KID_HASH);
+    launch_hash_g2_small(c->stream, n, d_msgs, d_offs, 0, dst, d_hashes);
+    prof_post(c);
+    KL(KID_PREPARE, k_prepare_keys<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (const uint8_t*)d_hashes, 0, 4,
+       d_rec, d_status);
+    if ((rc = side_fork(c, 2))) {
+      (void)hipStreamSynchronize(c->stream);
+      return rc;
+    }
+    hipLaunchKernelGGL(k_prepare_keys<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), 0, c->side, n, d_pks, d_sigs, (const uint8_t*)nullptr, fmt, 3, d_rec, d_status);
+    // the lines of H(m) skip items that failed the identity checks: this stream waits for the statuses written just above
+    hipError_t e1 = hipGetLastError(), e2 = hipEventRecord(c->ev_join2, c->side);
+    hipLaunchKernelGGL(k_pairing_pre, dim3((unsigned)n, 1), dim3(WIDE_ENGINE_BLOCK), 0, c->side, n, d_rec, (const int32_t*)d_status, 2, 2);
+    hipError_t e3 = hipGetLastError(), e4 = hipEventRecord(c->ev_join, c->side);
+    hipError_t e5 = hipStreamWaitEvent(c->stream, c->ev_join2, 0);
+    KL(KID_WIDE, k_pairing_pre, dim3((unsigned)n, 1), dim3(WIDE_ENGINE_BLOCK), n, d_rec, (const int32_t*)d_status, 0, 0);
+    hipError_t e6 = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess || e6 != hipSuccess) {
       (void)hipStreamSynchronize(c->side);
       return fail(BLSGPU_E_HIP, "side-stream launch failed");
     }
@@ -1268,8 +1315,7 @@ int blsgpu_verify_batch(int sig_group, int scheme, const void* pks, const void* 
   rc = run_verify_items(c, sig_group, scheme == BLSGPU_SCHEME_AUG, (const uint8_t*)d_pks, (const uint8_t*)d_sigs, kfmt,
                         (const uint8_t*)d_msgs, (const uint64_t*)d_offs, 0, scheme_dst(sig_group, scheme), n, d_pairs, d_f, d_status, pre);
   if (rc) return rc;
-  if ((rc = copy_out(c, status, d_status, 4 * n))) return rc;
-  SYNC_FLUSH(c);
+  if ((rc = copy_out_and_sync(c, status, d_status, 4 * n))) return rc;
   return 0;
 }
 API_CATCH
@@ -1360,8 +1406,7 @@ int blsgpu_verify_batch_grouped(int sig_group, int scheme, const void* pks, cons
     KL(KID_COMPRESS, k_scatter_i32, dim3(blocks_for(cnt)), dim3(BLS_BLOCK), cnt, (const uint32_t*)d_idx, (const int32_t*)d_st2, d_status);
     HIPCK(hipGetLastError());
   }
-  if ((rc = copy_out(c, status, d_status, 4 * n))) return rc;
-  SYNC_FLUSH(c);
+  if ((rc = copy_out_and_sync(c, status, d_status, 4 * n))) return rc;
   return 0;
 }
 API_CATCH
@@ -1400,8 +1445,7 @@ static int verify_one_tail(Ctx* c, int sig_group, int scheme, int aug_prefix, co
                           scheme_dst(sig_group, scheme), 1, d_pairs, d_f, d_status);
   }
   if (rc) return rc;
-  if ((rc = copy_out(c, status, d_status, 4))) return rc;
-  SYNC_FLUSH(c);
+  if ((rc = copy_out_and_sync(c, status, d_status, 4))) return rc;
   return 0;
 }
 
@@ -1441,9 +1485,7 @@ static int cut_tail_begin(Ctx* c, int sig_group, int scheme, const void* sig, in
                        (const uint8_t*)nullptr, fmt, 1, t.rec, t.d_status);
     hipLaunchKernelGGL(k_pairing_pre, dim3(1, 1), dim3(WIDE_ENGINE_BLOCK), 0, c->side2, (size_t)1, t.rec, (const int32_t*)t.d_status, 2, 2);
     const hipError_t ea = hipEventRecord(c->ev_join2, c->side2);
-    hipLaunchKernelGGL(k_hash_to_g2, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0,
-                       scheme_dst(2, scheme), d_hash, 3);
-    hipLaunchKernelGGL(k_g2_clear_wide, dim3(1), dim3(WIDE_ENGINE_BLOCK), 0, c->side, (size_t)1, d_hash);
+    launch_hash_g2_small(c->side, 1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, 1, scheme_dst(2, scheme), d_hash);
     hipLaunchKernelGGL(k_prepare_keys<2>, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)nullptr, (const uint8_t*)nullptr,
                        (const uint8_t*)d_hash, 0, 4, t.rec, t.d_status);
     const hipError_t eb = hipStreamWaitEvent(c->side, c->ev_join2, 0);      // the lines of H(m) read the status the signature part set
@@ -1480,8 +1522,7 @@ static int cut_tail_finish(Ctx* c, int rc, const uint8_t* d_pk_proj, CutTail& t,
   }
   KL(KID_WIDE, k_pairing_post, dim3(1), dim3(WIDE_ENGINE_BLOCK), (size_t)1, (const uint32_t*)t.rec, t.d_status);
   HIPCK(hipGetLastError());
-  if ((rc = copy_out(c, status, t.d_status, 4))) return rc;
-  SYNC_FLUSH(c);
+  if ((rc = copy_out_and_sync(c, status, t.d_status, 4))) return rc;
   return 0;
 }
 static bool cut_tail_applies(int sig_group, int scheme) {
@@ -1536,8 +1577,7 @@ int blsgpu_multi_verify(int sig_group, int scheme, const void* pks, size_t n, co
     if (sig_group == 1)   // one wave, the two SSWU maps on two DPP rows in the row-wide field type (csrc/wide.cuh)
       launch_hash_g1_small(c->side, 1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, 1, scheme_dst(sig_group, scheme), d_hash, (uint32_t*)nullptr);
     else
-      hipLaunchKernelGGL(k_hash_to_g2, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0,
-                         scheme_dst(sig_group, scheme), d_hash, 1);
+      launch_hash_g2_small(c->side, 1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, 1, scheme_dst(sig_group, scheme), d_hash);
     HIPCK(hipGetLastError());
     HIPCK(hipEventRecord(c->ev_join, c->side));
   }
@@ -1965,8 +2005,7 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
     if (sig_group == 1)
       launch_hash_g1_small(c->side, 1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, 1, scheme_dst(sig_group, scheme), d_hash, (uint32_t*)nullptr);
     else
-      hipLaunchKernelGGL(k_hash_to_g2, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0,
-                         scheme_dst(sig_group, scheme), d_hash, 1);
+      launch_hash_g2_small(c->side, 1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, 1, scheme_dst(sig_group, scheme), d_hash);
     HIPCK(hipGetLastError());
     HIPCK(hipEventRecord(c->ev_join, c->side));
   }
@@ -2234,7 +2273,11 @@ static int hash_to_group(int group, const uint8_t* msgs, const uint64_t* msg_off
     prof_post(c);
   }
   else if (group == 1) KL(KID_HASH, k_hash_to_g1, dim3(blocks_for(two ? 2 * n : n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out, two);
-  else if (n <= wide_max_items() && hash_phase_stop() != 8) {   // a few messages: the cofactor clearing on the row-wide engine (BLSGPU_HASH_STOP=8: not)
+  else if (n <= wide_max_items() && hash_phase_stop() == 0) {   // a few messages: row-wide maps and the engine (one workgroup per message up to 128)
+    prof_pre(c, KID_HASH);
+    launch_hash_g2_small(c->stream, n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, 0, d, d_out);
+    prof_post(c);
+  } else if (n <= wide_max_items() && hash_phase_stop() != 8) {   // measurement aids (BLSGPU_HASH_STOP=8: clearing in the lane-pair kernel; 9: none)
     KL(KID_HASH, k_hash_to_g2, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out, 3);
     if (hash_phase_stop() != 9) KL(KID_HASH, k_g2_clear_wide, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), n, d_out);   // 9: measurement aid, no clearing
   } else
@@ -2373,8 +2416,7 @@ int blsgpu_pop_verify_batch(int sig_group, const void* pks, const void* proofs, 
   rc = run_verify_items(c, sig_group, 2, (const uint8_t*)d_pks, (const uint8_t*)d_sigs, fmt, (const uint8_t*)d_offs, d_offs, 1,
                         make_dst((const uint8_t*)pd, strlen(pd)), n, d_pairs, d_f, d_status);
   if (rc) return rc;
-  if ((rc = copy_out(c, status, d_status, 4 * n))) return rc;
-  SYNC_FLUSH(c);
+  if ((rc = copy_out_and_sync(c, status, d_status, 4 * n))) return rc;
   return 0;
 }
 API_CATCH
@@ -2689,8 +2731,7 @@ static int core_verify_entry(int sig_group, const dst_arg& dst, int aug, const v
   rc = run_verify_items(c, sig_group, aug, (const uint8_t*)d_pks, (const uint8_t*)d_sigs, fmt, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, 0,
                         dst, n, d_pairs, d_f, d_status);
   if (rc) return rc;
-  if ((rc = copy_out(c, status, d_status, 4 * n))) return rc;
-  SYNC_FLUSH(c);
+  if ((rc = copy_out_and_sync(c, status, d_status, 4 * n))) return rc;
   return 0;
 }
 int blsgpu_core_verify(int sig_group, const uint8_t* dst, size_t dst_len, const void* pks, const void* sigs, const uint8_t* msgs,
@@ -2727,8 +2768,7 @@ int blsgpu_core_verify_hashed(int sig_group, const void* pks, const void* sigs, 
   if (sig_group == 1) KL(KID_PREPARE, k_prepare_hashed<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sigs, (const uint8_t*)d_h, d_pairs, d_status, 0);
   else KL(KID_PREPARE, k_prepare_hashed<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sigs, (const uint8_t*)d_h, d_pairs, d_status, 0);
   if ((rc = run_pairing2(c, n, d_pairs, d_f, d_status, sig_group == 1 ? 1 : 0))) return rc;
-  if ((rc = copy_out(c, status, d_status, 4 * n))) return rc;
-  SYNC_FLUSH(c);
+  if ((rc = copy_out_and_sync(c, status, d_status, 4 * n))) return rc;
   return 0;
 }
 API_CATCH
@@ -2785,8 +2825,7 @@ int blsgpu_sig_proof_verify_batch(int sig_group, int scheme, const void* commitm
     KL(KID_PREPARE, k_prepare_proof<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_u, (const uint8_t*)d_v, (const uint8_t*)d_pks,
        (const uint8_t*)d_ys, fmt, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_status);
   if ((rc = run_pairing2(c, n, d_pairs, d_f, d_status, sig_group == 1 ? 1 : 0))) return rc;
-  if ((rc = copy_out(c, status, d_status, 4 * n))) return rc;
-  SYNC_FLUSH(c);
+  if ((rc = copy_out_and_sync(c, status, d_status, 4 * n))) return rc;
   return 0;
 }
 API_CATCH

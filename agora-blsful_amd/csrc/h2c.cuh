@@ -338,8 +338,11 @@ BLS_NOINLINE void hash_to_g1(g1_jac& r, const uint8_t* pre, uint32_t pre_len, co
 // Projective form: x1 = xn / xd with xn = B (tv2 + 1), xd = -A tv2 (Z A when tv2 = 0), g(x1) = num / xd^3, so
 // y1 = sqrt(num xd) / xd^2; the one Fp inversion for 1 / xd rides in the square root's own inversion (fp2_sqrt_inv).
 // When g(x1) is not a square, x2 = (Z u^2) x1 and g(x2) = (Z u^2)^3 g(x1).
-BLS_NOINLINE void sswu_g2(fp2& x, fp2& y, const fp2& u) {
-  fp2 A, B, Z, tv1, tv2, xn, xd, xd2, xd3, num, w, t, Y;
+// F2 = fp2 (one lane) or wf2 (one DPP row, csrc/wide_fp2.cuh: the latency path of Bls12381G2Impl)
+template <class F2>
+BLS_NOINLINE void sswu_g2(F2& x, F2& y, const F2& u) {
+  typedef decltype(F2::c0) F;
+  F2 A, B, Z, tv1, tv2, xn, xd, xd2, xd3, num, w, t, Y;
   fp2_load(A, SSWU2_A);
   fp2_load(B, SSWU2_B);
   fp2_load(Z, SSWU2_Z);
@@ -363,7 +366,7 @@ BLS_NOINLINE void sswu_g2(fp2& x, fp2& y, const fp2& u) {
   fp2_mul(t, B, xd3);
   fp2_add(num, num, t);              // xn^3 + A xn xd^2 + B xd^3
   fp2_mul(w, num, xd);
-  fp nxd, nt, inxd;
+  F nxd, nt, inxd;
   fp_sqr(nxd, xd.c0);
   fp_sqr(nt, xd.c1);
   fp_add(nxd, nxd, nt);
@@ -371,7 +374,7 @@ BLS_NOINLINE void sswu_g2(fp2& x, fp2& y, const fp2& u) {
   // Branch-free choice between x1 and x2 (lanes of a wave would otherwise run the square root twice):
   // sn = norm(w)^((p+1)/4) is a root of norm(w) when g(x1) is a square and satisfies sn^2 = -norm(w) otherwise; in that
   // case norm(w tv1^3) = norm(w) (norm(Z) norm(u)^2)^3 has the root sn * cZ * norm(u)^3 with the constant cZ^2 = -norm(Z)^3.
-  fp n, sn, c2, nu, nu3, cz, root;
+  F n, sn, c2, nu, nu3, cz, root;
   fp_sqr(n, w.c0);
   fp_sqr(nt, w.c1);
   fp_add(n, n, nt);
@@ -391,7 +394,7 @@ BLS_NOINLINE void sswu_g2(fp2& x, fp2& y, const fp2& u) {
   fp_mul(root, root, nu3);
   fp_cmov(root, sn, sq1);
   {
-    fp2 t3, w2, xn2;
+    F2 t3, w2, xn2;
     fp2_sqr(t3, tv1);
     fp2_mul(t3, t3, tv1);
     fp2_mul(w2, w, t3);
@@ -404,7 +407,7 @@ BLS_NOINLINE void sswu_g2(fp2& x, fp2& y, const fp2& u) {
   if (fp_is_zero(w.c1)) {            // real w (probability 2^-381): the generic routine handles it
     fp2_sqrt_inv(Y, w, &nxd, &inxd);
   } else {                           // complex method with the root of the norm already in hand (tower.cuh fp2_sqrt_inv)
-    fp h, tt, s, d, prod, pi;
+    F h, tt, s, d, prod, pi;
     fp_load(h, FP_HALF);
     fp_add(tt, w.c0, root);
     fp_mul(tt, tt, h);
@@ -421,12 +424,12 @@ BLS_NOINLINE void sswu_g2(fp2& x, fp2& y, const fp2& u) {
     fp_mul(d, w.c1, d);
     Y.c0 = s;
     Y.c1 = d;
-    fp2 alt;
+    F2 alt;
     alt.c0 = d;
     alt.c1 = s;
     fp2_cmov(Y, alt, !direct);
   }
-  fp2 xdi;
+  F2 xdi;
   fp2_conj(xdi, xd);
   fp2_mul_fp(xdi, xdi, inxd);        // 1 / xd
   fp2_mul(x, xn, xdi);
@@ -434,8 +437,9 @@ BLS_NOINLINE void sswu_g2(fp2& x, fp2& y, const fp2& u) {
   fp2_mul(y, Y, t);
   if (fp2_sgn0(u) != fp2_sgn0(y)) fp2_neg(y, y);
 }
-BLS_FN void iso2_poly(fp2& r, const uint32_t (*k)[2 * FP_NL], int deg, const fp2& x) {
-  fp2 acc, c;
+template <class F2>
+BLS_FN void iso2_poly(F2& r, const uint32_t (*k)[2 * FP_NL], int deg, const F2& x) {
+  F2 acc, c;
   fp2_load(acc, k[deg]);
   for (int i = deg - 1; i >= 0; i--) {
     fp2_mul(acc, acc, x);
@@ -459,6 +463,20 @@ BLS_NOINLINE void iso_map_g2(g2_jac& r, const fp2& x, const fp2& y) {
   fp2_mul(t, t, yd2);
   fp2_mul(t, t, YN);
   fp2_mul(r.y, t, y);
+}
+// the same map to HOMOGENEOUS coordinates (X : Y : Z) = (XN YD : y YN XD : XD YD), three products instead of nine (the complete
+// additions of the engine's point programs take them as they are)
+template <class F2>
+BLS_FN void iso_map_g2_hom(F2& X, F2& Y, F2& Z, const F2& x, const F2& y) {
+  F2 XN, XD, YN, YD, t;
+  iso2_poly(XN, ISO2_XNUM, 3, x);
+  iso2_poly(XD, ISO2_XDEN, 2, x);
+  iso2_poly(YN, ISO2_YNUM, 3, x);
+  iso2_poly(YD, ISO2_YDEN, 3, x);
+  fp2_mul(X, XN, YD);
+  fp2_mul(t, YN, XD);
+  fp2_mul(Y, t, y);
+  fp2_mul(Z, XD, YD);
 }
 // no_clear: stop before the cofactor clearing (the caller clears it elsewhere: k_g2_clear_wide)
 BLS_NOINLINE void hash_to_g2(g2_jac& r, const uint8_t* pre, uint32_t pre_len, const uint8_t* m, uint32_t m_len,

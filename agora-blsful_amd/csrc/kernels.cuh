@@ -303,6 +303,10 @@ template <int G>
 __global__ void k_point_tree_wide(size_t m, const uint8_t* in, uint8_t* out);
 // the cofactor clearing of hash-to-G2 on the engine: pts[i] <- h_eff pts[i] (RAW_PROJ, in place), one workgroup per point
 __global__ void k_g2_clear_wide(size_t n, uint8_t* pts);
+// hash-to-G2 with one WORKGROUP per message: wave 0 expands the message and runs the two SSWU maps and isogenies on two DPP rows
+// (row-wide Fp2, csrc/wide_fp2.cuh), then all four waves add the two points and clear the cofactor on the engine (program
+// G2_HASH_TAIL).  out: RAW_PROJ (Jacobian).  single_msg bit 0: every item hashes message 0.  For up to 128 messages.
+__global__ void k_hash_to_g2_engine(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst, uint8_t* out);
 
 #if defined(BLS_TU_PREPARE1) || defined(BLS_TU_PREPARE2)
 // =====================================================================================================
@@ -1789,6 +1793,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_pairing_coop_easy(size_t n, co
 #if defined(BLS_TU_WIDE)
 // =====================================================================================================
 #include "wide.cuh"
+#include "wide_fp2.cuh"
 // self-test of the row-wide multiplier: item i = a_i * b_i (caller format: 48-byte Montgomery words), `reps` chained
 // multiplications by b (reps = 1: the plain product), four items per wave
 __global__ void __launch_bounds__(WIDE_BLOCK) k_wide_mul_test(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, int reps) {
@@ -1826,7 +1831,7 @@ bool wide_prog_is_fp12(const uint32_t* prog, size_t len) {
         if (r < WV_F || r >= WV_ACC + 12) return false;
       continue;
     }
-    if (op >= WOP_PDBL1 && op != WOP_MUL_LINE) return false;
+    if (op >= WOP_PDBL1 && op != WOP_MUL_LINE && op != WOP_CYC_SQRC) return false;
     for (uint32_t r : refs)
       if (r != WV_F && r != WV_T && r != WV_U && r != WV_W && r != WV_ACC) return false;
   }
@@ -2502,6 +2507,65 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_hash_to_g1_engine(size_t 
     fp x;
     w_load_local(x, S.V[WPV_R1 + threadIdx.x]);
     fp_to_raw((uint32_t*)(out + i * 144) + 12 * threadIdx.x, x);
+  }
+}
+__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_hash_to_g2_engine(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst,
+                                                                       uint8_t* out) {
+  __shared__ wide_lds_t<wide_tb_pt> S;
+  __shared__ __attribute__((aligned(16))) uint8_t shablk[64];
+  const int wave = threadIdx.x >> 6, row = (threadIdx.x >> 4) & 3, l = threadIdx.x & 15;
+  const size_t i = blockIdx.x;
+  if (i >= n) return;
+  wide_consts K;
+  wide_init(K);
+  wf_setup();
+  wide_stage(S, WIDE_PROG_G2_HASH_TAIL, WIDE_PROG_G2_HASH_TAIL_LEN);
+  __syncthreads();
+  if (wave == 0) {
+    const size_t mi = (single_msg & 1) ? 0 : i;
+    uint32_t ubw[64];
+    expand_message_xmd_wave<256>(ubw, msgs + offs[mi], (uint32_t)(offs[mi + 1] - offs[mi]), dst, shablk);   // the whole wave
+    if (row < 2) {                                          // u0 = (words 0..15, 16..31) on row 0, u1 = (32..47, 48..63) on row 1
+      uint32_t uw[16];
+      fp ul;
+      wf2 u, x, y, X, Y, Z, one;
+#pragma unroll
+      for (int j = 0; j < 16; j++) uw[j] = row == 1 ? ubw[32 + j] : ubw[j];
+      fp_from_be_words(ul, uw);
+      wf_from_local(u.c0, ul);
+#pragma unroll
+      for (int j = 0; j < 16; j++) uw[j] = row == 1 ? ubw[48 + j] : ubw[16 + j];
+      fp_from_be_words(ul, uw);
+      wf_from_local(u.c1, ul);
+      sswu_g2(x, y, u);
+      iso_map_g2_hom(X, Y, Z, x, y);
+      const bool inf = fp2_is_zero(Z);                      // an exceptional point of the isogeny: the identity (0 : 1 : 0)
+      fp2_one(one);
+      fp2_cmov(Y, one, inf);
+      fp_zero(one.c0);
+      fp2_cmov(X, one, inf);
+      fp2_reduce(X, X);
+      fp2_reduce(Y, Y);
+      fp2_reduce(Z, Z);
+      uint32_t (*pt)[16] = &S.V[row == 1 ? WPV_R1 : WPV_R0];
+      pt[0][l] = (uint32_t)X.c0.v;
+      pt[1][l] = (uint32_t)X.c1.v;
+      pt[2][l] = (uint32_t)Y.c0.v;
+      pt[3][l] = (uint32_t)Y.c1.v;
+      pt[4][l] = (uint32_t)Z.c0.v;
+      pt[5][l] = (uint32_t)Z.c1.v;
+    }
+  } else if (threadIdx.x < 64 + 4 * 16) {                   // meanwhile: psi's constants cx, cy (real, imaginary limbs)
+    const int t = (int)threadIdx.x - 64, v = t >> 4;
+    const uint32_t* src = v < 2 ? PSI_CX : PSI_CY;
+    S.V[WPV_CONST + v][l] = l < FP_NL ? src[(v & 1) * FP_NL + l] : 0u;
+  }
+  __syncthreads();
+  wide_exec(S, WIDE_PROG_G2_HASH_TAIL_LEN, K);
+  if (threadIdx.x < 6) {
+    fp x;
+    w_load_local(x, S.V[WPV_R3 + threadIdx.x]);
+    fp_to_raw((uint32_t*)(out + i * 288) + 12 * threadIdx.x, x);
   }
 }
 #endif  // BLS_TU_WIDE

@@ -69,6 +69,8 @@ def test_engine_operations_match_the_oracle(api):
         for _ in range(5):
             want = c.f12_sqr(want)
         assert got == want
+        # the conjugating variant reads F and writes T directly (first / last step of a power by x)
+        assert _f12_from(api.debug_wide_program([('CYC_SQR', 'ACC', 'F', 'F'), ('CYC_SQRC', 'T', 'ACC', 'ACC')], rg)) == c.f12_conj(c.f12_sqr(c.f12_sqr(g)))
     # the same program run repeatedly on its own output (reps): T <- T * F after T <- F
     a = tuple((rng.randrange(P), rng.randrange(P)) for _ in range(6))
     got = _f12_from(api.debug_wide_program([('MUL', 'W', 'W', 'F'), ('COPY', 'T', 'W', 'W')], _f12_raw(a), 6))

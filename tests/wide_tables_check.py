@@ -79,6 +79,7 @@ def self_check():
         g = c.f12_mul(c.f12_frob(t, 2), t)
         assert unflat(run(by['CYC_SQR'], flat(g))) == c.f12_sqr(g)
         assert unflat(run(by['CYC_SQR'], flat(g), alias=True)) == c.f12_sqr(g)
+        assert unflat(run(by['CYC_SQRC'], flat(g))) == c.f12_conj(c.f12_sqr(g))
         # sparse line multiplication
         line = [rng.randrange(P) for _ in range(6)]
         sparse = ((line[0], line[1]), (0, 0), (line[2], line[3]), (line[4], line[5]), (0, 0), (0, 0))
@@ -276,6 +277,24 @@ def check_point_programs():
             zi2 = c.f2_sqr(zi)
             got = (c.f2_mul(X, zi2), c.f2_mul(Y, c.f2_mul(zi2, zi)))
         assert got == want, ('G2_CLEAR', case)
+    # the tail of hash-to-G2: two mapped points (homogeneous, any scaling; the second one may be the identity) -> h_eff (q0 + q1)
+    for case in range(3):
+        q0 = c.map_to_curve_g2((rng.randrange(P), rng.randrange(P)))
+        q1 = c.map_to_curve_g2((rng.randrange(P), rng.randrange(P))) if case < 2 else None
+        want = c.g2_clear_cofactor(c.E2.add(q0, q1))
+        V = [0] * lay.count
+        for reg, q in (('R0', q0), ('R1', q1)):
+            if q is None:
+                V[B[reg]:B[reg] + 6] = [0, 0, 1, 0, 0, 0]
+            else:
+                z = (rng.randrange(1, P), rng.randrange(P))
+                V[B[reg]:B[reg] + 6] = list(c.f2_mul(q[0], z)) + list(c.f2_mul(q[1], z)) + list(z)
+        sim_program(OPS_PT, lay, dict(PROGRAMS_PT)['G2_HASH_TAIL'], V)
+        o = B['R3']
+        X, Y, Z = (V[o], V[o + 1]), (V[o + 2], V[o + 3]), (V[o + 4], V[o + 5])
+        zi = c.f2_inv(Z)
+        zi2 = c.f2_sqr(zi)
+        assert (c.f2_mul(X, zi2), c.f2_mul(Y, c.f2_mul(zi2, zi))) == want, ('G2_HASH_TAIL', case)
     # the cofactor clearing of hash-to-G1: (1 - x) P for points of E1(Fp) outside the subgroup, in it, and the identity
     for case in range(4):
         if case < 2:

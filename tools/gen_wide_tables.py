@@ -128,10 +128,11 @@ def op_sqr():
     return op
 
 
-def op_cyc_sqr():
+def op_cyc_sqr(conj=False):
     """Granger-Scott squaring in the cyclotomic subgroup; the Fp4 pairs are (c0, c3), (c1, c4), (c2, c5):
-    (a + b s)^2 = (a^2 + xi b^2) + 2ab s;  new = 3 t - 2 z (even coefficients) / 3 t + 2 z (odd)"""
-    op = Op('CYC_SQR')
+    (a + b s)^2 = (a^2 + xi b^2) + 2ab s;  new = 3 t - 2 z (even coefficients) / 3 t + 2 z (odd).
+    conj: the conjugate of the square (odd coefficients negated) -- the last step of a power by the negative x"""
+    op = Op('CYC_SQRC' if conj else 'CYC_SQR')
     halves = {}
     for m in range(3):
         a, b = coef(SA, m), coef(SA, m + 3)
@@ -151,7 +152,7 @@ def op_cyc_sqr():
         sgn = 2 if (k & 1) else -2
         for comp in range(2):
             z = idx(SA, 2 * k + comp)
-            op.lin(merge(scale(t[comp], 3) + [(sgn, z)]), idx(DST, 2 * k + comp))
+            op.lin(scale(merge(scale(t[comp], 3) + [(sgn, z)]), -1 if conj and (k & 1) else 1), idx(DST, 2 * k + comp))
     return op
 
 
@@ -427,6 +428,7 @@ def op_f6inv(stage):
 OPS += [op_f6inv(k) for k in (1, 2, 3, 4, 5)]
 OPS += [op_pdbl1(), op_pdbl2(), op_padd1(), op_padd2(), op_padd3(), op_padd4(), op_copy6(), op_lscale((0, 1)), op_mul_line(),
         op_lscale((0,)), op_lscale((1,)), op_lscale((0,), 8), op_lscale((0,), 4), op_lscale((1,), 8), op_lscale((1,), 4)] + [op_pprep(st, pr) for pr in ((0, 1), (0,), (1,)) for st in 'AB'] + [op_qprep(st) for st in 'ABC']
+OPS += [op_cyc_sqr(True)]
 
 
 
@@ -810,7 +812,14 @@ def prog_g1_hash_tail():
     return st + prog_g1_clear_cofactor()[2:]        # R0 is homogeneous already: skip the Jacobian -> homogeneous steps
 
 
-PROGRAMS_PT += [('G2_CLEAR', prog_g2_clear_cofactor()), ('G1_CLEAR', prog_g1_clear_cofactor()), ('G1_HASH_TAIL', prog_g1_hash_tail())]
+def prog_g2_hash_tail():
+    """hash-to-G2 behind the two SSWU maps and their isogenies: R0, R1 = the two points of E2 (homogeneous); their sum, then the
+    cofactor clearing; result (Jacobian) in R3"""
+    return [('C2GADD1', 'MS', 'R0', 'R1'), ('C2GADD2', 'R0', 'MS', 'MS')] + prog_g2_clear_cofactor()[2:]
+
+
+PROGRAMS_PT += [('G2_CLEAR', prog_g2_clear_cofactor()), ('G1_CLEAR', prog_g1_clear_cofactor()), ('G1_HASH_TAIL', prog_g1_hash_tail()),
+                ('G2_HASH_TAIL', prog_g2_hash_tail())]
 
 
 # ------------------------------------------------------------------ programs: sequences of (op, dst, a, b) over the value store
@@ -834,13 +843,13 @@ class Layout:
 
 
 def prog_pow_x(dst, a):
-    """dst = a^x (x < 0) in the cyclotomic subgroup"""
-    st = [('COPY', 'ACC', a, a)]
+    """dst = a^x (x < 0) in the cyclotomic subgroup: the first squaring reads a, the last one conjugates (|x| is even) and writes dst"""
+    assert X_ABS % 2 == 0 and a != 'ACC'
+    st = []
     for i in range(62, -1, -1):
-        st.append(('CYC_SQR', 'ACC', 'ACC', 'ACC'))
+        st.append(('CYC_SQRC' if i == 0 else 'CYC_SQR', dst if i == 0 else 'ACC', a if i == 62 else 'ACC', 'ACC'))
         if (X_ABS >> i) & 1:
             st.append(('MUL', 'ACC', 'ACC', a))
-    st.append(('CONJ', dst, 'ACC', 'ACC'))
     return st
 
 
