@@ -417,3 +417,24 @@ def test_grouped_verification_matches_per_item(api):
     assert api.verify_batch_grouped(1, api.POP, [], [], []) == []
     with pytest.raises(api.BlsGpuRuntimeError):
         api.verify_batch_grouped(2, api.POP, pks, sigs, msgs)                 # built for Bls12381G1Impl only
+
+
+# ------------------------------------------------------------------ hash-to-curve paths of different batch sizes
+@pytest.mark.parametrize('group', [1, 2])
+def test_hash_to_point_paths_agree_and_match_the_c_restatement(api, group):
+    """HashToPoint::hash_to_point (reference src/impls/g1.rs:17-19, g2.rs:15-17): up to 128 messages take one workgroup each
+    (row-wide SSWU maps, the rest on the engine), more take the one-wave / lane-pair kernels: both against oracle/c on ragged
+    message lengths (empty, one SHA block, across block edges), and against each other on the shared prefix of the batch."""
+    rng = random.Random(77 + group)
+    bo = util.load_c_oracle()
+    lens = [0, 1, 31, 32, 54, 55, 56, 63, 64, 65, 119, 120, 127, 128, 129, 200, 257]
+    msgs = [rng.randbytes(lens[i % len(lens)]) for i in range(140)]
+    dst = b'BLS_SIG_BLS12381G%d_XMD:SHA-256_SSWU_RO_POP_' % group
+    small = api.serialize(group, api.hash_to_point(group, msgs[:128], dst))
+    large = api.serialize(group, api.hash_to_point(group, msgs, dst))
+    assert large[:128] == small
+    width = 48 if group == 1 else 96
+    for i in list(range(0, 140, 7)) + [127, 128, 139]:
+        out = ctypes.create_string_buffer(width)
+        bo.bo_hash_to_point(group, msgs[i], len(msgs[i]), dst, len(dst), out)
+        assert large[i] == out.raw, i
