@@ -604,6 +604,31 @@ def op_c2gadd2():
     return op
 
 
+def scale2(v, k):
+    return (scale(v[0], k), scale(v[1], k))
+
+
+def op_c2dbl1():
+    """doubling on E'(Fp2) (Renes-Costello-Batina 2016, algorithm 9 for a = 0), complete like the addition; first half:
+    A = Y^2, B = Y Z, C = 3b' Z^2, D = X Y  ->  MS = (A, B, C, D, E = A - 3C, F = A + C): ten products, one sub-round"""
+    op = Op('C2DBL1')
+    X, Y, Z = (f2(SA, 2 * j) for j in range(3))
+    A, B, C, D = op.fp2_sqr(Y), op.fp2_mul(Y, Z), b3_g2(op.fp2_sqr(Z)), op.fp2_mul(X, Y)
+    for j, v in enumerate((A, B, C, D, sub2(A, scale2(C, 3)), add2(A, C))):
+        lin2(op, v, 2 * j)
+    return op
+
+
+def op_c2dbl2():
+    """second half: X3 = 2 E D, Y3 = E F + 8 A C, Z3 = 8 A B (twelve products, one sub-round)"""
+    op = Op('C2DBL2')
+    A, B, C, D, E, F = (f2(SA, 2 * j) for j in range(6))
+    lin2(op, op.fp2_mul(E, D), 0, 2)
+    lin2(op, add2(op.fp2_mul(E, F), scale2(op.fp2_mul(A, C), 8)), 2)
+    lin2(op, op.fp2_mul(A, B), 4, 8)
+    return op
+
+
 def op_c2neg():
     op = Op('C2NEG')
     for k in range(6):
@@ -733,7 +758,7 @@ OPS_PT = ([op_c2add1(m) for m in (4, 2, 1)] + [op_c2add2(m) for m in (4, 2, 1)] 
           [op_c1add1(m) for m in (8, 4, 2, 1)] + [op_c1add2(m) for m in (8, 4, 2, 1)] + [op_c1j2h('A', 8), op_c1j2h('B', 8), op_c1h2j('A'), op_c1h2j('B')] +
           [op_c2gadd1(), op_c2gadd2(), op_c2neg(), op_c2psi(), op_c2j2h('A', 1), op_c2j2h('B', 1),
            op_c1gadd1(), op_c1gadd2(), op_c1j2h('A', 1), op_c1j2h('B', 1)] +
-          [op_iso_pow(k) for k in (1, 2, 3, 4)] + [op_iso_mono(), op_iso_poly(), op_iso_asm(1), op_iso_asm(2)])
+          [op_iso_pow(k) for k in (1, 2, 3, 4)] + [op_iso_mono(), op_iso_poly(), op_iso_asm(1), op_iso_asm(2)] + [op_c2dbl1(), op_c2dbl2()])
 PT_POINTS = 16                     # points per workgroup: a tree of four levels
 
 
@@ -763,6 +788,8 @@ def prog_g2_clear_cofactor():
     """h_eff P on G2 (RFC 9380 G.3, Budroni-Pintore, as oracle g2_clear_cofactor) over registers R0..R4 (R0 = P, Jacobian in,
     Jacobian out in R3): x = -|x|, so [x]Q = -[|x|]Q by double-and-add from the top bit, every point operation a complete addition"""
     def add(d, a, b):
+        if a == b:                              # a doubling: 10 + 12 products in two sub-rounds instead of 21 + 18 in four
+            return [('C2DBL1', 'MS', a, a), ('C2DBL2', d, 'MS', 'MS')]
         return [('C2GADD1', 'MS', a, b), ('C2GADD2', d, 'MS', 'MS')]
 
     def mul_x(d, base, acc):                    # d <- [x] base, acc: a work register (neither d's operand base nor ... d may be acc)
