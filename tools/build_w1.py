@@ -9,6 +9,8 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'agora-blsful_amd', 'csrc')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+sys.path.insert(0, ROOT)
+from __graft_entry__ import TU_FLAGS  # noqa: E402  (the per-unit flags of the default build)
 
 
 def main():
@@ -21,7 +23,7 @@ def main():
             objs.append(o)
             tpb = '512' if f == 'tu_wide.hip' else '64'
             procs.append(subprocess.Popen([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-DBLS_SPLIT_WAVES=1',
-                                           '--gpu-max-threads-per-block=' + tpb, '-c', os.path.join(CSRC, f), '-o', o]))
+                                           '--gpu-max-threads-per-block=' + tpb] + TU_FLAGS.get(f, []) + ['-c', os.path.join(CSRC, f), '-o', o]))
         for f, p in zip(srcs, procs):
             if p.wait() != 0:
                 sys.exit('hipcc failed on ' + f)
