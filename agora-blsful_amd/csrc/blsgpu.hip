@@ -516,11 +516,16 @@ void launch_hash_g1_small(hipStream_t stream, size_t n, const uint8_t* d_msgs, c
     hipLaunchKernelGGL(k_hash_to_g1_wide, dim3((unsigned)n), dim3(BLS_BLOCK), 0, stream, n, d_msgs, d_offs, flags | hash_phase_stop() << 8, dst, d_out, d_rec);
 }
 
-// hash-to-G2 of a few messages on `stream` (RAW_PROJ out): one workgroup per message on the engine up to 128 messages, beyond
-// that two lanes per message for the maps and one workgroup per point for the cofactor clearing.  flags as above.
-void launch_hash_g2_small(hipStream_t stream, size_t n, const uint8_t* d_msgs, const uint64_t* d_offs, int flags, const dst_arg& dst, uint8_t* d_out) {
+// hash-to-G2 of a few messages on `stream` (RAW_PROJ out): one workgroup per message on the engine up to 128 messages; beyond
+// that one WAVE per message for the maps and one workgroup per message for the engine program (d_pts: 768 bytes of scratch per
+// message), or -- without scratch -- two lanes per message for the maps and one workgroup per point for the clearing.
+void launch_hash_g2_small(hipStream_t stream, size_t n, const uint8_t* d_msgs, const uint64_t* d_offs, int flags, const dst_arg& dst, uint8_t* d_out,
+                          uint32_t* d_pts = nullptr) {
   if (n <= 128 && hash_phase_stop() == 0) {
     hipLaunchKernelGGL(k_hash_to_g2_engine, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), 0, stream, n, d_msgs, d_offs, flags, dst, d_out);
+  } else if (d_pts && hash_phase_stop() == 0) {
+    hipLaunchKernelGGL(k_hash_to_g2_maps, dim3((unsigned)n), dim3(BLS_BLOCK), 0, stream, n, d_msgs, d_offs, flags, dst, d_pts);
+    hipLaunchKernelGGL(k_g2_hash_tail_wide, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), 0, stream, n, (const uint32_t*)d_pts, d_out);
   } else {
     hipLaunchKernelGGL(k_hash_to_g2, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), 0, stream, n, d_msgs, d_offs, dst, d_out, 3);
     hipLaunchKernelGGL(k_g2_clear_wide, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), 0, stream, n, d_out);
@@ -571,11 +576,12 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
     // (key, H(m)) and the rest.
     uint32_t* d_rec = (uint32_t*)arena_take(c, (size_t)WREC_WORDS * 4 * n);
     uint8_t* d_hashes = (uint8_t*)arena_take(c, 288 * n);
+    uint32_t* d_maps = n > 128 ? (uint32_t*)arena_take(c, 768 * n) : nullptr;      // nullptr (arena full): the lane-pair maps
     if (!d_rec || !d_hashes) return fail(BLSGPU_E_HIP, "internal: arena too small");
     int rc = side_fork(c, 1);
     if (rc) return rc;
     prof_pre(c, KID_HASH);
-    launch_hash_g2_small(c->stream, n, d_msgs, d_offs, 0, dst, d_hashes);
+    launch_hash_g2_small(c->stream, n, d_msgs, d_offs, 0, dst, d_hashes, d_maps);
     prof_post(c);
     KL(KID_PREPARE, k_prepare_keys<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (const uint8_t*)d_hashes, 0, 4,
        d_rec, d_status);
@@ -2275,7 +2281,7 @@ static int hash_to_group(int group, const uint8_t* msgs, const uint64_t* msg_off
   else if (group == 1) KL(KID_HASH, k_hash_to_g1, dim3(blocks_for(two ? 2 * n : n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out, two);
   else if (n <= wide_max_items() && hash_phase_stop() == 0) {   // a few messages: row-wide maps and the engine (one workgroup per message up to 128)
     prof_pre(c, KID_HASH);
-    launch_hash_g2_small(c->stream, n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, 0, d, d_out);
+    launch_hash_g2_small(c->stream, n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, 0, d, d_out, n > 128 ? (uint32_t*)arena_take(c, 768 * n) : nullptr);
     prof_post(c);
   } else if (n <= wide_max_items() && hash_phase_stop() != 8) {   // measurement aids (BLSGPU_HASH_STOP=8: clearing in the lane-pair kernel; 9: none)
     KL(KID_HASH, k_hash_to_g2, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, d, d_out, 3);

@@ -307,6 +307,10 @@ __global__ void k_g2_clear_wide(size_t n, uint8_t* pts);
 // (row-wide Fp2, csrc/wide_fp2.cuh), then all four waves add the two points and clear the cofactor on the engine (program
 // G2_HASH_TAIL).  out: RAW_PROJ (Jacobian).  single_msg bit 0: every item hashes message 0.  For up to 128 messages.
 __global__ void k_hash_to_g2_engine(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst, uint8_t* out);
+// the same for more messages as two launches: the maps with one WAVE per message (pts: 12 engine values = 768 bytes per message),
+// then the engine program with one workgroup per message
+__global__ void k_hash_to_g2_maps(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst, uint32_t* pts);
+__global__ void k_g2_hash_tail_wide(size_t n, const uint32_t* pts, uint8_t* out);
 
 #if defined(BLS_TU_PREPARE1) || defined(BLS_TU_PREPARE2)
 // =====================================================================================================
@@ -2509,6 +2513,37 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_hash_to_g1_engine(size_t 
     fp_to_raw((uint32_t*)(out + i * 144) + 12 * threadIdx.x, x);
   }
 }
+// one SSWU map and its 3-isogeny on this DPP row (row 0: u0, row 1: u1 of the 64 expanded words): the point of E2, homogeneous,
+// as six engine values at pt (LDS or global)
+__device__ __forceinline__ void hash_g2_map_row(const uint32_t* ubw, int row, int l, uint32_t (*pt)[16]) {
+  uint32_t uw[16];
+  fp ul;
+  wf2 u, x, y, X, Y, Z, one;
+#pragma unroll
+  for (int j = 0; j < 16; j++) uw[j] = row == 1 ? ubw[32 + j] : ubw[j];
+  fp_from_be_words(ul, uw);
+  wf_from_local(u.c0, ul);
+#pragma unroll
+  for (int j = 0; j < 16; j++) uw[j] = row == 1 ? ubw[48 + j] : ubw[16 + j];
+  fp_from_be_words(ul, uw);
+  wf_from_local(u.c1, ul);
+  sswu_g2(x, y, u);
+  iso_map_g2_hom(X, Y, Z, x, y);
+  const bool inf = fp2_is_zero(Z);                      // an exceptional point of the isogeny: the identity (0 : 1 : 0)
+  fp2_one(one);
+  fp2_cmov(Y, one, inf);
+  fp_zero(one.c0);
+  fp2_cmov(X, one, inf);
+  fp2_reduce(X, X);
+  fp2_reduce(Y, Y);
+  fp2_reduce(Z, Z);
+  pt[0][l] = (uint32_t)X.c0.v;
+  pt[1][l] = (uint32_t)X.c1.v;
+  pt[2][l] = (uint32_t)Y.c0.v;
+  pt[3][l] = (uint32_t)Y.c1.v;
+  pt[4][l] = (uint32_t)Z.c0.v;
+  pt[5][l] = (uint32_t)Z.c1.v;
+}
 __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_hash_to_g2_engine(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst,
                                                                        uint8_t* out) {
   __shared__ wide_lds_t<wide_tb_pt> S;
@@ -2525,40 +2560,46 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_hash_to_g2_engine(size_t 
     const size_t mi = (single_msg & 1) ? 0 : i;
     uint32_t ubw[64];
     expand_message_xmd_wave<256>(ubw, msgs + offs[mi], (uint32_t)(offs[mi + 1] - offs[mi]), dst, shablk);   // the whole wave
-    if (row < 2) {                                          // u0 = (words 0..15, 16..31) on row 0, u1 = (32..47, 48..63) on row 1
-      uint32_t uw[16];
-      fp ul;
-      wf2 u, x, y, X, Y, Z, one;
-#pragma unroll
-      for (int j = 0; j < 16; j++) uw[j] = row == 1 ? ubw[32 + j] : ubw[j];
-      fp_from_be_words(ul, uw);
-      wf_from_local(u.c0, ul);
-#pragma unroll
-      for (int j = 0; j < 16; j++) uw[j] = row == 1 ? ubw[48 + j] : ubw[16 + j];
-      fp_from_be_words(ul, uw);
-      wf_from_local(u.c1, ul);
-      sswu_g2(x, y, u);
-      iso_map_g2_hom(X, Y, Z, x, y);
-      const bool inf = fp2_is_zero(Z);                      // an exceptional point of the isogeny: the identity (0 : 1 : 0)
-      fp2_one(one);
-      fp2_cmov(Y, one, inf);
-      fp_zero(one.c0);
-      fp2_cmov(X, one, inf);
-      fp2_reduce(X, X);
-      fp2_reduce(Y, Y);
-      fp2_reduce(Z, Z);
-      uint32_t (*pt)[16] = &S.V[row == 1 ? WPV_R1 : WPV_R0];
-      pt[0][l] = (uint32_t)X.c0.v;
-      pt[1][l] = (uint32_t)X.c1.v;
-      pt[2][l] = (uint32_t)Y.c0.v;
-      pt[3][l] = (uint32_t)Y.c1.v;
-      pt[4][l] = (uint32_t)Z.c0.v;
-      pt[5][l] = (uint32_t)Z.c1.v;
-    }
+    if (row < 2) hash_g2_map_row(ubw, row, l, &S.V[row == 1 ? WPV_R1 : WPV_R0]);
   } else if (threadIdx.x < 64 + 4 * 16) {                   // meanwhile: psi's constants cx, cy (real, imaginary limbs)
     const int t = (int)threadIdx.x - 64, v = t >> 4;
     const uint32_t* src = v < 2 ? PSI_CX : PSI_CY;
     S.V[WPV_CONST + v][l] = l < FP_NL ? src[(v & 1) * FP_NL + l] : 0u;
+  }
+  __syncthreads();
+  wide_exec(S, WIDE_PROG_G2_HASH_TAIL_LEN, K);
+  if (threadIdx.x < 6) {
+    fp x;
+    w_load_local(x, S.V[WPV_R3 + threadIdx.x]);
+    fp_to_raw((uint32_t*)(out + i * 288) + 12 * threadIdx.x, x);
+  }
+}
+// The same in two launches for more messages than there are CUs: one WAVE per message for the maps (pts: twelve engine values
+// per message, the two points), then one workgroup per message for the engine program.
+__global__ void __launch_bounds__(WIDE_BLOCK) k_hash_to_g2_maps(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst, uint32_t* pts) {
+  __shared__ __attribute__((aligned(16))) uint8_t shablk[4][64];
+  const int wave = threadIdx.x >> 6, row = (threadIdx.x >> 4) & 3, l = threadIdx.x & 15;
+  const size_t i = (size_t)blockIdx.x * (blockDim.x >> 6) + wave;
+  wf_setup();
+  __syncthreads();
+  if (i >= n) return;
+  const size_t mi = (single_msg & 1) ? 0 : i;
+  uint32_t ubw[64];
+  expand_message_xmd_wave<256>(ubw, msgs + offs[mi], (uint32_t)(offs[mi + 1] - offs[mi]), dst, shablk[wave]);
+  if (row < 2) hash_g2_map_row(ubw, row, l, (uint32_t (*)[16])(pts + (i * 12 + 6 * row) * 16));
+}
+__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_g2_hash_tail_wide(size_t n, const uint32_t* pts, uint8_t* out) {
+  __shared__ wide_lds_t<wide_tb_pt> S;
+  const size_t i = blockIdx.x;
+  if (i >= n) return;
+  wide_consts K;
+  wide_init(K);
+  wide_stage(S, WIDE_PROG_G2_HASH_TAIL, WIDE_PROG_G2_HASH_TAIL_LEN);
+  const int v = (int)(threadIdx.x >> 4), l = (int)(threadIdx.x & 15u);
+  if (v < 12) S.V[(v < 6 ? WPV_R0 : WPV_R1 - 6) + v][l] = pts[(i * 12 + v) * 16 + l];
+  else if (v < 16) {
+    const uint32_t* src = v < 14 ? PSI_CX : PSI_CY;
+    S.V[WPV_CONST + v - 12][l] = l < FP_NL ? src[(v & 1) * FP_NL + l] : 0u;
   }
   __syncthreads();
   wide_exec(S, WIDE_PROG_G2_HASH_TAIL_LEN, K);
