@@ -434,6 +434,9 @@ def run_config2(h, args):
     return out
 
 
+RESULT_FD = 1          # where the result line goes (__main__ moves stdout proper out of the libraries' reach)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -486,10 +489,15 @@ def main():
             out = run_config5(h, args.steps, args.warmup, args.variant, args.size)
         out.update(common)
     if h.rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(RESULT_FD, (json.dumps(out) + '\n').encode())
     if h.dist is not None:
         h.dist.destroy_process_group()
 
 
 if __name__ == '__main__':
+    # stdout carries ONE line, the result: whatever libraries write there (RCCL prints a five-line version banner on stdout when
+    # its communicator comes up) goes to stderr instead
+    sys.stdout.flush()
+    RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
     main()
