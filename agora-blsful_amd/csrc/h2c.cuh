@@ -296,8 +296,10 @@ __device__ __noinline__ void jac_mul_u64_pair(g1_jac& r, const g1_jac& p, uint64
   r = acc;
 }
 #endif
+// no_clear: stop before the cofactor clearing -- the point of E1(Fp) whose multiple by h_eff is the hash (aggregate verification
+// applies h_eff to the product of the pairings instead: csrc/wide_tables.cuh program AGG_COFACTOR)
 BLS_NOINLINE void hash_to_g1(g1_jac& r, const uint8_t* pre, uint32_t pre_len, const uint8_t* m, uint32_t m_len,
-                       const uint8_t* dst, uint32_t dst_len, int lane2 = -1) {
+                       const uint8_t* dst, uint32_t dst_len, int lane2 = -1, bool no_clear = false) {
   uint8_t ub[128];
   expand_message_xmd<128>(ub, pre, pre_len, m, m_len, dst, dst_len);
   fp u0, u1, xn, xd, y;
@@ -325,6 +327,10 @@ BLS_NOINLINE void hash_to_g1(g1_jac& r, const uint8_t* pre, uint32_t pre_len, co
     iso_map_g1(q1, xn, xd, y);
   }
   jac_add(q0, q0, q1);
+  if (no_clear) {
+    r = q0;
+    return;
+  }
   // clear cofactor: h_eff = 1 - x = 1 + |x|
 #if defined(__HIPCC__)
   if (lane2 >= 0) jac_mul_u64_pair(q1, q0, BLS_X_ABS, lane2 != 0);

@@ -1,7 +1,7 @@
 """Randomised differential campaign on the GPU box: the C ABI against oracle/c (test infrastructure, the checker) on inputs no
 fixed test holds -- random batch sizes on both sides of every path boundary (1 / 128 / 512 / 1,024 / 6,144 items), random
 message lengths, random tampering (swapped signatures, flipped message bytes, identity points), all three schemes, both
-groups; hash-to-curve of random messages; MultiSignature::verify and verify_secure of random key sets.  Not collected by pytest
+groups; hash-to-curve of random messages; MultiSignature::verify, verify_secure and AggregateSignature::verify of random key sets.  Not collected by pytest
 (minutes, not seconds): python tests/stress_parity.py --seconds 480 [--seed S].  Prints one line per round and a summary; exits
 non-zero at the first mismatch with the seed and the round that reproduce it."""
 import argparse
@@ -104,6 +104,38 @@ def round_multi(api, bo, rng, log):
     return int(got) == int(want)
 
 
+def round_aggregate(api, bo, rng, log):
+    """AggregateSignature::verify: n (key, message) pairs under one summed signature; valid, a changed message, an identity key,
+    a repeated message (an error for Basic, fine for the others), an identity signature"""
+    sg, scheme, n = rng.choice((1, 2)), rng.choice((0, 1, 2)), rng.choice((1, 2, 3, 4, 50, 191, 192, 193, 1000, 5000))
+    sks = [rng.randrange(1, c.R) for _ in range(n)]
+    msgs = [i.to_bytes(4, 'big') + rng.randbytes(rng.choice((0, 28, 60))) for i in range(n)]
+    pks, sigs = api.sign_batch(sg, scheme, sks, msgs)
+    pks, msgs = list(pks), list(msgs)
+    agg = api.point_sum(sg, list(sigs))
+    mode = rng.randrange(5)
+    if mode == 1:
+        msgs[rng.randrange(n)] += b'?'
+    elif mode == 2:
+        i = rng.randrange(n)
+        pks[i] = pks[i][:2 * len(pks[i]) // 3] + bytes(len(pks[i]) // 3)
+    elif mode == 3 and n > 1:
+        i, j = rng.sample(range(n), 2)
+        msgs[i] = msgs[j]
+    elif mode == 4:
+        agg = agg[:2 * len(agg) // 3] + bytes(len(agg) // 3)
+    got = api.aggregate_verify(sg, scheme, pks, msgs, agg)
+    offs, blob = [0], b''
+    for m in msgs:
+        blob += m
+        offs.append(len(blob))
+    o = (ctypes.c_uint64 * (n + 1))(*offs)
+    aux = (ctypes.c_uint64 * 2)()
+    st = bo.bo_aggregate_verify(sg, scheme, V(ctypes.c_char_p(b''.join(pks))), V(ctypes.c_char_p(blob)), V(o), n, V(ctypes.c_char_p(agg)), 16, V(aux))
+    log('aggregate_verify sg=%d scheme=%d n=%d mode=%d -> %s' % (sg, scheme, n, mode, st))
+    return got == (st, (aux[0], aux[1]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--seconds', type=float, default=480.0)
@@ -117,7 +149,7 @@ def main():
     t0, rounds, counts = time.time(), 0, {}
     print('seed', args.seed, flush=True)
     while time.time() - t0 < args.seconds:
-        kind = rng.choices((round_verify_batch, round_hash, round_multi), (5, 2, 2))[0]
+        kind = rng.choices((round_verify_batch, round_hash, round_multi, round_aggregate), (5, 2, 2, 3))[0]
         state = rng.getstate()
         line = []
         ok = kind(api, bo, rng, line.append)
