@@ -468,32 +468,44 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare_agg(size_t n, const ui
     const bool inf = jac_is_inf(pk);
     if (lane2 <= 0) bad[i] = inf ? 1 : 0;
     if (inf) return;
-    jac_to_aff(Q, pk);
     uint8_t pre[96];
-    uint32_t pre_len = 0;
-    if (aug) {
-      g2_compress(pre, Q, false);
-      pre_len = 96;
-    }
     g1_jac h;
-    hash_to_g1(h, pre, pre_len, m, mlen, dst.b, dst.len, lane2, (two_lanes & 2) != 0);
-    jac_to_aff(P, h);
+    if (aug) {                               // the key's bytes prefix the message: its affine form comes first
+      jac_to_aff(Q, pk);
+      g2_compress(pre, Q, false);
+      hash_to_g1(h, pre, 96, m, mlen, dst.b, dst.len, lane2, (two_lanes & 2) != 0);
+      jac_to_aff(P, h);
+    } else {
+      hash_to_g1(h, pre, 0, m, mlen, dst.b, dst.len, lane2, (two_lanes & 2) != 0);
+      if (jac_is_inf(h)) {                   // cannot happen for a hash output in practice; keep the generic path correct
+        jac_to_aff(Q, pk);
+        jac_to_aff(P, h);
+      } else {
+        g1g2_to_aff(P, Q, h, pk);            // one inversion for both affine forms
+      }
+    }
   } else {
     g1_jac pk;
     load_g1_pt(pk, pks, i, fmt);
     const bool inf = jac_is_inf(pk);
     if (lane2 <= 0) bad[i] = inf ? 1 : 0;
     if (inf) return;
-    jac_to_aff(P, pk);
     uint8_t pre[48];
-    uint32_t pre_len = 0;
-    if (aug) {
-      g1_compress(pre, P, false);
-      pre_len = 48;
-    }
     g2_jac h;
-    hash_to_g2(h, pre, pre_len, m, mlen, dst.b, dst.len, lane2);
-    jac_to_aff(Q, h);
+    if (aug) {
+      jac_to_aff(P, pk);
+      g1_compress(pre, P, false);
+      hash_to_g2(h, pre, 48, m, mlen, dst.b, dst.len, lane2);
+      jac_to_aff(Q, h);
+    } else {
+      hash_to_g2(h, pre, 0, m, mlen, dst.b, dst.len, lane2);
+      if (jac_is_inf(h)) {
+        jac_to_aff(P, pk);
+        jac_to_aff(Q, h);
+      } else {
+        g1g2_to_aff(P, Q, pk, h);
+      }
+    }
   }
   if (lane2 <= 0) ws_st_pair(pairs, stride, i, 0, P, Q);
 }
