@@ -619,11 +619,14 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
   // Fp-only remainder would run redundantly and a full batch is faster with one lane per item -- both measured)
   const int two_lanes = (sg == 2 || n <= coop_max_items()) ? 1 : 0;
   unsigned nb = blocks_for(two_lanes ? 2 * n : n);
+  // Bls12381G1Impl: the message points stay UNCLEARED (a third of the hash) and the second pair is (sig, -[c] g2), c = h_eff^-1
+  // mod r, whose line table is as constant as -g2's: e(h P', pk) e(sig, -g2) = 1  <=>  e(P', pk) e(sig, -[c] g2) = 1
+  // (csrc/g2neg_lines.cuh; fixed_g2 = 2 selects that table)
   if (sg == 1)
-    KL(KID_PREPARE, k_prepare<1>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status, pre_status, two_lanes);
+    KL(KID_PREPARE, k_prepare<1>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status, pre_status, two_lanes | 2);
   else
     KL(KID_PREPARE, k_prepare<2>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status, pre_status, two_lanes);
-  return run_pairing2(c, n, d_pairs, d_f, d_status, sg == 1 ? 1 : 0);
+  return run_pairing2(c, n, d_pairs, d_f, d_status, sg == 1 ? 2 : 0);
 }
 
 // product of m Fp12 values in a workspace (stride given) folded into item 0
@@ -1620,37 +1623,21 @@ static int aggregate_enqueue(Ctx* c, int sig_group, int scheme, const uint8_t* d
   HIPCK(hipMemsetAsync(d_bad, 0, 4 * m, c->stream));
   const dst_arg dst = scheme_dst(sig_group, scheme);
   const int aug = scheme == BLSGPU_SCHEME_AUG;
-  // Bls12381G1Impl with the engine available: the messages are hashed to E1(Fp) without the cofactor clearing (a third of the
-  // hash), the cofactor is applied once to the product of the pairs' Miller functions (k_agg_cofactor_wide), and the
-  // (signature, -g2) pair, which must stay out of that power, takes the engine's Miller function on the side stream
-  const bool gt_cofactor = sig_group == 1 && n > 0 && wide_max_items() > 0 && coop_max_items() > 0;
-  uint32_t* d_wrec = nullptr;
-  int32_t* d_wst = nullptr;
-  if (gt_cofactor && has_sig) {
-    d_wrec = (uint32_t*)arena_take(c, (size_t)WREC_WORDS * 4);
-    d_wst = (int32_t*)arena_take(c, 4);
-    if (!d_wrec || !d_wst) return fail(BLSGPU_E_HIP, "internal: arena too small");
-    if ((rc = side_fork(c))) return rc;
-    hipLaunchKernelGGL(k_prepare_keys<1>, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)nullptr, d_sig, (const uint8_t*)nullptr, fmt, 1, d_wrec, d_wst);
-    hipLaunchKernelGGL(k_pairing_pre, dim3(1, 1), dim3(WIDE_ENGINE_BLOCK), 0, c->side, (size_t)1, d_wrec, (const int32_t*)d_wst, 1, 1);
-    const hipError_t e1 = hipGetLastError(), e2 = hipEventRecord(c->ev_join, c->side);
-    if (e1 != hipSuccess || e2 != hipSuccess) {
-      (void)hipStreamSynchronize(c->side);
-      return fail(BLSGPU_E_HIP, "side-stream launch failed");
-    }
-  }
-  rc = 0;
+  // Bls12381G1Impl: the messages are hashed to E1(Fp) WITHOUT the cofactor clearing (a third of the hash) and the signature's
+  // pair is (sig, -[c] g2) instead of (sig, -g2): the same verdict (csrc/g2neg_lines.cuh), also shard by shard -- only the
+  // product of all records is ever exponentiated
+  const int agg_flags = sig_group == 1 ? 2 : 1;
   if (mm > 0) {
     // the workspace stride is always n + 1 (k_prepare_agg's layout); without a signature lane n stays idle
     if (sig_group == 1)
-      KL(KID_PREPARE_AGG, k_prepare_agg<1>, dim3(blocks_for(mm)), dim3(BLS_BLOCK), n, d_pks, d_sig, fmt, aug, d_msgs, d_offs, dst, d_pairs, d_bad, gt_cofactor ? 2 : 0, has_sig);
+      KL(KID_PREPARE_AGG, k_prepare_agg<1>, dim3(blocks_for(mm)), dim3(BLS_BLOCK), n, d_pks, d_sig, fmt, aug, d_msgs, d_offs, dst, d_pairs, d_bad, agg_flags, has_sig);
     else
-      KL(KID_PREPARE_AGG, k_prepare_agg<2>, dim3(blocks_for(2 * mm)), dim3(BLS_BLOCK), n, d_pks, d_sig, fmt, aug, d_msgs, d_offs, dst, d_pairs, d_bad, 1, has_sig);
+      KL(KID_PREPARE_AGG, k_prepare_agg<2>, dim3(blocks_for(2 * mm)), dim3(BLS_BLOCK), n, d_pks, d_sig, fmt, aug, d_msgs, d_offs, dst, d_pairs, d_bad, agg_flags, has_sig);
     if (n) KL(KID_FIRST_BAD, k_first_bad, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const int32_t*)d_bad, d_min);
   }
   KL(KID_FIRST_BAD, k_first_bad_fin, dim3(1), dim3(BLS_BLOCK), n, (const int32_t*)d_bad, has_sig, (const unsigned long long*)d_min, d_first);
-  if (hipGetLastError() != hipSuccess) rc = fail(BLSGPU_E_HIP, "kernel launch failed");
-  if (!rc && mm == 0) {            // an empty shard: the neutral record
+  HIPCK(hipGetLastError());
+  if (mm == 0) {                   // an empty shard: the neutral record
     if (d_rec) {
       uint8_t one[576];
       memset(one, 0, sizeof one);
@@ -1660,25 +1647,7 @@ static int aggregate_enqueue(Ctx* c, int sig_group, int scheme, const uint8_t* d
     if (d_verdict) HIPCK(hipMemsetAsync(d_verdict, 0, 4, c->stream));   // the empty product is one
     return 0;
   }
-  if (!rc) {
-    const size_t cnt = gt_cofactor ? n : mm;      // with the cofactor in the target group the signature's lane stays out of the product
-    MILLER1_LAUNCH(cnt, m, d_pairs, d_bad, d_f);
-    if (gt_cofactor) rc = run_f12_fold(c, d_f, MILLER1_OUTPUTS(cnt), m);
-  }
-  if (d_wrec) {                    // also on the error path: the side kernels read the arena
-    const hipError_t e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
-    if (rc || e != hipSuccess) {
-      (void)hipStreamSynchronize(c->side);
-      return rc ? rc : fail(BLSGPU_E_HIP, "hipStreamWaitEvent failed");
-    }
-  }
-  if (rc) return rc;
-  if (gt_cofactor) {
-    KL(KID_FINALEXP_ONE, k_agg_cofactor_wide, dim3(1), dim3(WIDE_ENGINE_BLOCK), d_f, m, (const uint32_t*)d_wrec, (const int32_t*)d_wst, d_verdict);
-    if (!d_verdict) KL(KID_F12_IO, k_f12_export, dim3(1), dim3(BLS_BLOCK), d_f, m, d_rec);
-    HIPCK(hipGetLastError());
-    return 0;
-  }
+  MILLER1_LAUNCH(mm, m, d_pairs, d_bad, d_f);
   if (d_verdict) {
     if ((rc = run_f12_product_verdict(c, d_f, MILLER1_OUTPUTS(mm), m, d_verdict))) return rc;
   } else {

@@ -341,6 +341,7 @@ __device__ __noinline__ void coop_miller2(coop_shared& S, const g1_aff* P, const
   const bool second = me == 1;
   const bool owner = me < 2;
   const bool table = second && fixed_g2;          // this owner scales rows of the -g2 line table instead of stepping a point
+  const uint32_t (*LINES)[6 * FP_NL] = fixed_g2 == 2 ? G2NEGC_LINES : G2NEG_LINES;   // 2: the table of -[c] g2 (uncleared message points)
   g1_aff Pm;
   aff<hfp2> Qm;
   fp_sel(Pm.x, second, P[1].x, P[0].x);
@@ -374,10 +375,10 @@ __device__ __noinline__ void coop_miller2(coop_shared& S, const g1_aff* P, const
     hfp2 a, b, c, e, f, h, g, s;
     if (owner) {
       if (table) {
-        fp2_load(l0, &G2NEG_LINES[row][0]);
-        fp2_load(t, &G2NEG_LINES[row][2 * FP_NL]);
+        fp2_load(l0, &LINES[row][0]);
+        fp2_load(t, &LINES[row][2 * FP_NL]);
         coop_job_put(S, me, 0, t, xp2);
-        fp2_load(t, &G2NEG_LINES[row][4 * FP_NL]);
+        fp2_load(t, &LINES[row][4 * FP_NL]);
         coop_job_put(S, me, 1, t, yp2);
       } else {
         fp2_add(h, T.y, T.z);
@@ -473,10 +474,10 @@ __device__ __noinline__ void coop_miller2(coop_shared& S, const g1_aff* P, const
     if ((BLS_X_ABS >> i) & 1) {
       if (owner) {
         if (table) {
-          fp2_load(l0, &G2NEG_LINES[row][0]);
-          fp2_load(t, &G2NEG_LINES[row][2 * FP_NL]);
+          fp2_load(l0, &LINES[row][0]);
+          fp2_load(t, &LINES[row][2 * FP_NL]);
           fp2_mul_fp(l2, t, Pm.x);
-          fp2_load(t, &G2NEG_LINES[row][4 * FP_NL]);
+          fp2_load(t, &LINES[row][4 * FP_NL]);
           fp2_mul_fp(l3, t, Pm.y);
         } else {
           miller_add_step(T, l0, l2, l3, Qm.x, Qm.y, Pm.x, Pm.y);

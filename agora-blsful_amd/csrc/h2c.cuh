@@ -296,8 +296,8 @@ __device__ __noinline__ void jac_mul_u64_pair(g1_jac& r, const g1_jac& p, uint64
   r = acc;
 }
 #endif
-// no_clear: stop before the cofactor clearing -- the point of E1(Fp) whose multiple by h_eff is the hash (aggregate verification
-// applies h_eff to the product of the pairings instead: csrc/wide_tables.cuh program AGG_COFACTOR)
+// no_clear: stop before the cofactor clearing -- the point of E1(Fp) whose multiple by h_eff is the hash (verification pairs it
+// with -[c] g2 instead of -g2 and needs no clearing: csrc/g2neg_lines.cuh)
 BLS_NOINLINE void hash_to_g1(g1_jac& r, const uint8_t* pre, uint32_t pre_len, const uint8_t* m, uint32_t m_len,
                        const uint8_t* dst, uint32_t dst_len, int lane2 = -1, bool no_clear = false) {
   uint8_t ub[128];

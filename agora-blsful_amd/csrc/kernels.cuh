@@ -276,11 +276,6 @@ __global__ void k_wide_mul_test(size_t n, const uint8_t* a, const uint8_t* b, ui
 __global__ void k_pairing_coop_easy(size_t n, const uint32_t* pairs, const int32_t* status, int fixed_g2, uint32_t* easy);
 __global__ void k_finalexp_wide(size_t n, const uint32_t* easy, int32_t* status);
 __global__ void k_finalexp_wide_ws(const uint32_t* fws, size_t stride, int32_t* verdict);
-// The end of an aggregate verification of Bls12381G1Impl whose messages were hashed WITHOUT the cofactor clearing (k_prepare_agg,
-// two_lanes bit 1): F = the folded product of the pairs' Miller functions at fws (item 0), W = the Miller function of the
-// (signature, -g2) pair in the record `rec` (k_pairing_pre part 1; nullptr or a failed status: one).  F <- F^(1 + |x|) conj(W)
-// (program AGG_COFACTOR), then either the final exponentiation's verdict or -- verdict == nullptr -- F back at fws.
-__global__ void k_agg_cofactor_wide(uint32_t* fws, size_t stride, const uint32_t* rec, const int32_t* rec_status, int32_t* verdict);
 __global__ void k_wide_prog_test(const uint32_t* prog, int len, int reps, const uint8_t* fin, uint8_t* tout);
 bool wide_prog_is_fp12(const uint32_t* prog, size_t len);   // host: what k_wide_prog_test may be given
 __global__ void k_pairing_wide(size_t n, const uint32_t* pairs, int32_t* status, int fixed_g2);
@@ -325,11 +320,13 @@ template <int SG>
 __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int aug,
                                                      const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst,
                                                      uint32_t* pairs, int32_t* status, int pre_status, int two_lanes) {
-  // two_lanes (small batches, single-verify tails): two adjacent lanes per item run the two SSWU maps of the hash side by
+  // two_lanes bit 0 (small batches, single-verify tails): two adjacent lanes per item run the two SSWU maps of the hash side by
   // side (h2c.cuh) and everything else redundantly with identical operands; lane 0 of the pair stores.
+  // bit 1 (SG == 1): the message point stays uncleared and pair 1 becomes (sig, -[c] g2) (verify.cuh prepare_g1impl): the
+  // pairing that follows must take the line table of THAT point (fixed_g2 = 2)
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t i = two_lanes ? gid >> 1 : gid;
-  const int lane2 = two_lanes ? (int)(gid & 1) : -1;
+  const size_t i = (two_lanes & 1) ? gid >> 1 : gid;
+  const int lane2 = (two_lanes & 1) ? (int)(gid & 1) : -1;
   if (i >= n) return;
   if (pre_status && status[i] != BLS_OK) return;   // the item already failed to decode
   size_t mi = single_msg ? 0 : i;
@@ -343,7 +340,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare(size_t n, const uint8_
     g1_jac sig;
     load_g2_pt(pk, pks, i, fmt);
     load_g1_pt(sig, sigs, i, fmt);
-    st = prepare_g1impl(P, Q, pk, sig, aug, m, mlen, dst.b, dst.len, lane2);
+    st = prepare_g1impl(P, Q, pk, sig, aug, m, mlen, dst.b, dst.len, lane2, (two_lanes & 2) != 0);
   } else {
     g1_jac pk;
     g2_jac sig;
@@ -431,7 +428,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare_agg(size_t n, const ui
                                                          const uint8_t* msgs, const uint64_t* offs, dst_arg dst, uint32_t* pairs,
                                                          int32_t* bad, int two_lanes, int has_sig) {
   // two_lanes bit 0: as k_prepare (two adjacent lanes per item, the hash's two SSWU maps side by side; lane 0 stores);
-  // bit 1 (SG == 1): the hashes stay in E1(Fp), their cofactor is applied to the product of the pairings (k_agg_cofactor_wide)
+  // bit 1 (SG == 1): the hashes stay in E1(Fp), uncleared, and the signature's pair is (sig, -[c] g2) (verify.cuh g2_negc_gen)
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t i = (two_lanes & 1) ? gid >> 1 : gid;
   const int lane2 = (two_lanes & 1) ? (int)(gid & 1) : -1;
@@ -447,7 +444,8 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare_agg(size_t n, const ui
       if (lane2 <= 0) bad[i] = inf ? 1 : 0;
       if (inf) return;
       jac_to_aff(P, s);
-      g2_neg_gen(Q);
+      if (two_lanes & 2) g2_negc_gen(Q);          // the pairs' message points are uncleared: (sig, -[c] g2) balances them
+      else g2_neg_gen(Q);
     } else {
       g2_jac s;
       load_g2_pt(s, sig, 0, fmt);
@@ -1119,7 +1117,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_miller2s(size_t 
   }
   __shared__ uint32_t fsh[F12_SH_WORDS * BLS_BLOCK];   // the accumulator, packed (tower_split.cuh)
   f12_sh acc = {lds_column(fsh)};
-  if (fixed_g2) miller_loop_fixed_g2(acc, P[0], Q[0], P[1]);
+  if (fixed_g2) miller_loop_fixed_g2(acc, P[0], Q[0], P[1], fixed_g2 == 2 ? G2NEGC_LINES : G2NEG_LINES);   // 2: pair 1 is (sig, -[c] g2)
   else miller_loop<2>(acc, P, Q);
   fp12_t<hfp2> f;
   sh_ld_f12(f, acc.sh);
@@ -1945,11 +1943,13 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_wide(size_t n, co
     S.V[WV_F][l] = l < FP_NL ? FP_ONE[l] : 0u;     // f = 1
     for (int v = 1; v < 12; v++) S.V[WV_F + v][l] = 0u;
   }
-  if (fixed_g2)                                      // pair 1's unscaled lines: the precomputed table of -g2
+  if (fixed_g2) {                                    // pair 1's unscaled lines: the precomputed table of -g2 (2: of -[c] g2)
+    const uint32_t (*lines)[6 * FP_NL] = fixed_g2 == 2 ? G2NEGC_LINES : G2NEG_LINES;
     for (int t = threadIdx.x; t < WIDE_STEPS * 6 * 16; t += WIDE_ENGINE_BLOCK) {
       const int st = t / 96, v = (t % 96) >> 4, ll = t & 15;
-      S.V[WV_L + 12 * st + 6 + v][ll] = ll < FP_NL ? G2NEG_LINES[st][v * FP_NL + ll] : 0u;
+      S.V[WV_L + 12 * st + 6 + v][ll] = ll < FP_NL ? lines[st][v * FP_NL + ll] : 0u;
     }
+  }
   if (threadIdx.x == 0) S.flag = 1;
   __syncthreads();
   wide_exec(S, fixed_g2 ? WIDE_PROG_PAIR_FIXED_LEN : WIDE_PROG_PAIR_GENERAL_LEN, K);
@@ -1971,43 +1971,6 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_wide(size_t n, co
 
 // the whole final exponentiation of item 0 of an Fp12 workspace (the Miller product of an aggregate verification) and the
 // comparison with one: program FINAL on one workgroup (0.65 ms against 1.3 ms for the wave-cooperative form)
-__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_agg_cofactor_wide(uint32_t* fws, size_t stride, const uint32_t* rec, const int32_t* rec_status,
-                                                                        int32_t* verdict) {
-  __shared__ wide_lds_t<wide_tb_f12> S;
-  if (blockIdx.x != 0) return;
-  wide_consts K;
-  wide_init(K);
-  const int len = verdict ? WIDE_PROG_AGG_FINAL_LEN : WIDE_PROG_AGG_COFACTOR_LEN;
-  wide_stage(S, verdict ? WIDE_PROG_AGG_FINAL : WIDE_PROG_AGG_COFACTOR, len);
-  const int v = (int)(threadIdx.x >> 4), l = (int)(threadIdx.x & 15u);
-  const bool have_w = rec != nullptr && *rec_status == BLS_OK;          // uniform
-  const int k = v >> 1, pw = k < 3 ? 2 * k : 2 * (k - 3) + 1;            // workspace (tower) order -> powers of w, as k_finalexp_wide_ws
-  if (v < 12) {
-    S.V[WV_F + 2 * pw + (v & 1)][l] = l < FP_NL ? fws[(size_t)(W1 * v + l) * stride] : 0u;
-    S.V[WV_W + v][l] = have_w ? rec[16 * (WREC_F1 + v) + l] : ((v == 0 && l < FP_NL) ? FP_ONE[l] : 0u);
-  }
-  if (threadIdx.x == 0) S.flag = 1;
-  __syncthreads();
-  wide_exec(S, len, K);
-  if (!verdict) {
-    if (v < 12 && l < FP_NL) fws[(size_t)(W1 * v + l) * stride] = S.V[WV_F + 2 * pw + (v & 1)][l];
-    return;
-  }
-  if (threadIdx.x < 12) {
-    fp x, one;
-    w_load_local(x, S.V[WV_T + threadIdx.x]);
-    bool ok;
-    if (threadIdx.x == 0) {
-      fp_one(one);
-      ok = fp_eq(x, one);
-    } else {
-      ok = fp_is_zero(x);
-    }
-    if (!ok) S.flag = 0;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) *verdict = S.flag ? BLS_OK : BLS_ERR_INVALID_SIGNATURE;
-}
 __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_finalexp_wide_ws(const uint32_t* fws, size_t stride, int32_t* verdict) {
   __shared__ wide_lds_t<wide_tb_f12> S;
   if (blockIdx.x != 0) return;

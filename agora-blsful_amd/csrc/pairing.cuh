@@ -183,9 +183,9 @@ BLS_FN void miller_loop(ACC& f, const g1_aff* P, const aff<F2>* Q) {
 
 // The same product for exactly two pairs whose SECOND G2 argument is the constant -g2 (core_verify of Bls12381G1Impl:
 // e(H(m), pk) e(sig, -g2), reference src/traits/sig_core.rs:136-138): that pair's point arithmetic is replaced by the
-// precomputed table G2NEG_LINES (tools/gen_g2_lines.py); only the two Fp2-by-Fp scalings by (xP, yP) remain.
+// precomputed table (G2NEG_LINES, or G2NEGC_LINES for -[c] g2: tools/gen_g2_lines.py); only the two Fp2-by-Fp scalings by (xP, yP) remain.
 template <class ACC, class F2>
-BLS_FN void miller_loop_fixed_g2(ACC& f, const g1_aff& P0, const aff<F2>& Q0, const g1_aff& P1) {
+BLS_FN void miller_loop_fixed_g2(ACC& f, const g1_aff& P0, const aff<F2>& Q0, const g1_aff& P1, const uint32_t (*lines)[6 * FP_NL] = G2NEG_LINES) {
   g2_hom_t<F2> T;
   T.x = Q0.x;
   T.y = Q0.y;
@@ -199,10 +199,10 @@ BLS_FN void miller_loop_fixed_g2(ACC& f, const g1_aff& P0, const aff<F2>& Q0, co
       if (step == 1 && !((BLS_X_ABS >> i) & 1)) break;
       if (step == 0) miller_dbl_step(T, l0, l2, l3, P0.x, P0.y);
       else miller_add_step(T, l0, l2, l3, Q0.x, Q0.y, P0.x, P0.y);
-      fp2_load(m0, &G2NEG_LINES[row][0]);
-      fp2_load(t, &G2NEG_LINES[row][2 * FP_NL]);
+      fp2_load(m0, &lines[row][0]);
+      fp2_load(t, &lines[row][2 * FP_NL]);
       fp2_mul_fp(m2, t, P1.x);
-      fp2_load(t, &G2NEG_LINES[row][4 * FP_NL]);
+      fp2_load(t, &lines[row][4 * FP_NL]);
       fp2_mul_fp(m3, t, P1.y);
       acc_mul_2lines(f, l0, l2, l3, m0, m2, m3);
       row++;

@@ -84,6 +84,13 @@ BLS_FN void g1_neg_gen(g1_aff& r) {
   fp_neg(r.y, y);
   r.inf = false;
 }
+// -[c] g2, c = h_eff^-1 mod r: the second pair's G2 member when the message point of a Bls12381G1Impl verification is not
+// cofactor-cleared (csrc/g2neg_lines.cuh, tools/gen_g2_lines.py: e(h P', pk) e(sig, -g2) = 1  <=>  e(P', pk) e(sig, -[c] g2) = 1)
+BLS_FN void g2_negc_gen(g2_aff& r) {
+  fp2_load(r.x, G2_NEGC_X);
+  fp2_load(r.y, G2_NEGC_Y);
+  r.inf = false;
+}
 BLS_FN void g2_neg_gen(g2_aff& r) {
   fp2_load(r.x, G2_GEN_X);
   fp2 y;
@@ -97,8 +104,10 @@ BLS_FN void g2_neg_gen(g2_aff& r) {
 // with augmentation the key must be affine (compressed) before hashing, so that path keeps two.
 // mode: 0 = message as given, 1 = MessageAugmentation (key bytes || message, reference src/traits/sig_aug.rs:20-24),
 //       2 = proof of possession (the message IS the key bytes, reference src/traits/sig_pop.rs:67-70)
+// no_clear: P[0] is the message point BEFORE its cofactor clearing and Q[1] = -[c] g2 instead of -g2 (same verdict, a third
+// of the hash saved; see g2_negc_gen)
 BLS_FN int prepare_g1impl(g1_aff* P, g2_aff* Q, const g2_jac& pk, const g1_jac& sig, int mode, const uint8_t* msg,
-                          uint32_t msg_len, const uint8_t* dst, uint32_t dst_len, int lane2 = -1) {
+                          uint32_t msg_len, const uint8_t* dst, uint32_t dst_len, int lane2 = -1, bool no_clear = false) {
   if (jac_is_inf(sig)) return BLS_ERR_SIG_IDENTITY;
   if (jac_is_inf(pk)) return BLS_ERR_PK_IDENTITY;
   g1_jac h;
@@ -106,11 +115,11 @@ BLS_FN int prepare_g1impl(g1_aff* P, g2_aff* Q, const g2_jac& pk, const g1_jac& 
     g1g2_to_aff(P[1], Q[0], sig, pk);
     uint8_t pre[96];
     g2_compress(pre, Q[0], false);
-    if (mode == 1) hash_to_g1(h, pre, 96, msg, msg_len, dst, dst_len, lane2);
-    else hash_to_g1(h, nullptr, 0, pre, 96, dst, dst_len, lane2);
+    if (mode == 1) hash_to_g1(h, pre, 96, msg, msg_len, dst, dst_len, lane2, no_clear);
+    else hash_to_g1(h, nullptr, 0, pre, 96, dst, dst_len, lane2, no_clear);
     jac_to_aff(P[0], h);
   } else {
-    hash_to_g1(h, nullptr, 0, msg, msg_len, dst, dst_len, lane2);
+    hash_to_g1(h, nullptr, 0, msg, msg_len, dst, dst_len, lane2, no_clear);
     if (jac_is_inf(h)) {            // cannot happen for a hash output in practice; keep the generic path correct
       g1g2_to_aff(P[1], Q[0], sig, pk);
       jac_to_aff(P[0], h);
@@ -123,7 +132,8 @@ BLS_FN int prepare_g1impl(g1_aff* P, g2_aff* Q, const g2_jac& pk, const g1_jac& 
       g2_apply_ninv(Q[0], pk, n);
     }
   }
-  g2_neg_gen(Q[1]);
+  if (no_clear) g2_negc_gen(Q[1]);
+  else g2_neg_gen(Q[1]);
   return BLS_OK;
 }
 

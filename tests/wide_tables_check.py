@@ -184,28 +184,6 @@ def check_programs():
         V3[B['W']:B['W'] + 12] = V2[B['F']:B['F'] + 12]
         sim_program(OPS, lay, dict(PROGRAMS)['POST'], V3)
         assert unflat(V3[B['T']:B['T'] + 12]) == want, 'cut pairing programs'
-    # aggregate verification with the cofactor of hash-to-G1 applied in the target group: messages mapped to E1(Fp) and NOT
-    # cleared, three (point, key) pairs, the aggregate signature over the cleared points; valid, invalid, and without a signature
-    pts = [c.E1.add(c.map_to_curve_g1(rng.randrange(P)), c.map_to_curve_g1(rng.randrange(P))) for _ in range(3)]
-    sks = [rng.randrange(1, c.R) for _ in range(3)]
-    keys = [c.E2.mul(c.G2_GEN, k) for k in sks]
-    agg = None
-    for pt, k in zip(pts, sks):
-        agg = c.E1.add(agg, c.E1.mul(c.E1.mul(pt, c.H_EFF_G1), k))
-    f_pairs = c.miller_loop(list(zip(pts, keys)))                                   # conjugated, as the batch kernels leave it
-    for sgn, want_one in ((agg, True), (c.E1.mul(agg, 3), False), (None, False)):
-        w_raw = c.f12_conj(c.miller_loop([(sgn, negg2)])) if sgn is not None else c.F12_ONE      # PRE_F1's convention: not conjugated
-        cleared = [(c.E1.mul(pt, c.H_EFF_G1), q) for pt, q in zip(pts, keys)] + ([(sgn, negg2)] if sgn is not None else [])
-        want = c.final_exponentiation(c.miller_loop(cleared))
-        V = [0] * lay.count
-        V[B['F']:B['F'] + 12] = flat(f_pairs)
-        V[B['W']:B['W'] + 12] = flat(w_raw)
-        Vc = list(V)
-        sim_program(OPS, lay, dict(PROGRAMS)['AGG_FINAL'], V)
-        assert unflat(V[B['T']:B['T'] + 12]) == want, 'AGG_FINAL'
-        assert (want == c.F12_ONE) == want_one
-        sim_program(OPS, lay, dict(PROGRAMS)['AGG_COFACTOR'], Vc)                   # the exported record: same value after the exponentiation
-        assert c.final_exponentiation(unflat(Vc[B['F']:B['F'] + 12])) == want, 'AGG_COFACTOR'
     return lay
 
 

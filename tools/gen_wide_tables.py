@@ -950,20 +950,6 @@ def prog_easy():
     return [('CONJ', 'U', 'F', 'F')] + prog_f12_inv() + [('MUL', 'F', 'U', 'T'), ('FROB2', 'T', 'F', 'F'), ('MUL', 'F', 'T', 'F')]
 
 
-def prog_agg_cofactor():
-    """F <- F^(1 + |x|) * conj(W).  AggregateSignature::verify of Bls12381G1Impl hashes every message to E1(Fp) WITHOUT clearing the
-    cofactor: for P' in E1(Fp) and Q in G2 the reduced pairing satisfies e(Q, P')^h = e(Q, h P') (it is well defined on
-    E1(Fp) / r E1(Fp)), so the cofactor h_eff = 1 - x = 1 + |x| of hash-to-G1 is applied ONCE, to the product F of the
-    pairs' Miller functions (conjugated already) -- 63 squarings and 7 multiplications per call instead of 64 doublings and 6
-    additions per message.  W: the Miller function of the (signature, -g2) pair as PRE_F1 leaves it (not conjugated), or one."""
-    st = [('CONJ', 'W', 'W', 'W')]
-    for i in range(62, -1, -1):
-        st.append(('SQR', 'ACC', 'F' if i == 62 else 'ACC', 'ACC'))
-        if (X_ABS >> i) & 1:
-            st.append(('MUL', 'ACC', 'ACC', 'F'))
-    return st + [('MUL', 'F', 'F', 'ACC'), ('MUL', 'F', 'F', 'W')]
-
-
 CONJ_F = [('CONJ', 'F', 'F', 'F')]                 # x < 0: the Miller function of |x| is conjugated once, after the product
 PROGRAMS = [('FINAL_HARD', prog_final_hard()),
             ('FINAL', prog_easy() + prog_final_hard()),              # the whole final exponentiation of a Miller product (aggregate verify)
@@ -976,10 +962,7 @@ PROGRAMS = [('FINAL_HARD', prog_final_hard()),
             ('PRE_F1', prog_pprep((1,)) + prog_miller((1,))),
             # Bls12381G2Impl: pair 1 is (-g1, signature): its lines come from the signature, then the same Miller function
             ('PRE_F1G', prog_key_lines(1) + prog_pprep((1,)) + prog_miller((1,))),
-            ('POST', prog_pprep((0,)) + prog_miller((0,)) + [('MUL', 'F', 'F', 'W')] + CONJ_F + prog_easy() + prog_final_hard()),
-            # the end of an aggregate verification whose messages were hashed without the cofactor clearing
-            ('AGG_COFACTOR', prog_agg_cofactor()),
-            ('AGG_FINAL', prog_agg_cofactor() + prog_easy() + prog_final_hard())]
+            ('POST', prog_pprep((0,)) + prog_miller((0,)) + [('MUL', 'F', 'F', 'W')] + CONJ_F + prog_easy() + prog_final_hard())]
 
 
 def layout_f12():
