@@ -286,10 +286,10 @@ __global__ void k_hash_to_g1_engine(size_t n, const uint8_t* msgs, const uint64_
 // The same check cut where its inputs become known (csrc/wide_tables.cuh programs PRE_LINES, PRE_F1 / PRE_F1G, POST).  The pairs
 // are (P0, Q0) (P1, Q1) = (H(m), key) (signature, -g2) for Bls12381G1Impl and (key, H(m)) (-g1, signature) for Bls12381G2Impl.
 // Per item a RECORD of engine values (16 words each) in global memory carries the operands and what the early parts hand over:
-#define WREC_P0 0        // pair 0's G1 point, Jacobian X Y Z      (G1Impl: k_hash_to_g1_wide;  G2Impl: the key, k_prepare_keys part 2)
+#define WREC_P0 0        // pair 0's G1 point, Jacobian X Y Z      (G1Impl: the message point BEFORE its cofactor clearing, k_hash_to_g1_*;  G2Impl: the key, k_prepare_keys part 2)
 #define WREC_P1 3        // G1Impl: the signature, Jacobian X Y Z  (k_prepare_keys, part 1)
 #define WREC_Q0 6        // pair 0's G2 point, Jacobian in Fp2: 6 values (G1Impl: the key, part 2;  G2Impl: H(m), part 4)
-#define WREC_F1 12       // Miller function of (signature, -g2)    (k_pairing_pre, part 1)
+#define WREC_F1 12       // G1Impl: Miller function of (signature, -[c] g2), the pair that balances the uncleared P0 (k_pairing_pre, part 1)
 #define WREC_L 24        // pair 0's 68 unscaled lines, 6 values each (k_pairing_pre, part 0)
 #define WREC_Q1 (24 + 6 * 68)   // Bls12381G2Impl only: pair 1's G2 point (the signature), Jacobian: 6 values
 #define WREC_VALUES (WREC_Q1 + 6)
@@ -2036,7 +2036,7 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_pre(size_t n, uin
       if (v < 3) S.V[WV_P + 4 + v][l] = r[16 * (WREC_P1 + v) + l];
       for (int t = threadIdx.x; t < WIDE_STEPS * 6 * 16; t += WIDE_ENGINE_BLOCK) {
         const int st = t / 96, w = (t % 96) >> 4, ll = t & 15;
-        S.V[WV_L + 12 * st + 6 + w][ll] = ll < FP_NL ? G2NEG_LINES[st][w * FP_NL + ll] : 0u;
+        S.V[WV_L + 12 * st + 6 + w][ll] = ll < FP_NL ? G2NEGC_LINES[st][w * FP_NL + ll] : 0u;   // the lines of -[c] g2: P0 is uncleared
       }
     }
     if (v == 9) S.V[WV_P + 7][l] = 0u;
@@ -2449,9 +2449,13 @@ __global__ void __launch_bounds__(WIDE_BLOCK) k_hash_to_g1_wide(size_t n, const 
   q1.z.v = (wfp)pts[wave][1][2][l];
   jac_add(q0, q0, q1);
   if (stop == 4) return;
-  jac_mul_u64_rows(q1, q0, BLS_X_ABS, row == 1);   // clear cofactor: h_eff = 1 - x = 1 + |x|
-  if (stop == 5) return;
-  jac_add(acc, q1, q0);
+  if (rec != nullptr && out == nullptr) {          // the record of a cut check takes the point uncleared (see k_hash_to_g1_engine)
+    acc = q0;
+  } else {
+    jac_mul_u64_rows(q1, q0, BLS_X_ABS, row == 1);   // clear cofactor: h_eff = 1 - x = 1 + |x|
+    if (stop == 5) return;
+    jac_add(acc, q1, q0);
+  }
   if (row == 0 && rec) {                       // the cut check takes H(m) as engine values, Jacobian, straight from the row
     uint32_t* r = rec + i * WREC_WORDS + 16 * WREC_P0;
     wf t;
@@ -2491,7 +2495,10 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_hash_to_g1_engine(size_t 
   wide_consts K;
   wide_init(K);
   wf_setup();
-  wide_stage(S, WIDE_PROG_G1_HASH_TAIL, WIDE_PROG_G1_HASH_TAIL_LEN);
+  // the record of a cut check takes the message point UNCLEARED (its second pair is (sig, -[c] g2): csrc/g2neg_lines.cuh)
+  const bool no_clear = rec != nullptr && out == nullptr;
+  const int prog_len = no_clear ? WIDE_PROG_G1_HASH_MAP_LEN : WIDE_PROG_G1_HASH_TAIL_LEN, res = no_clear ? WPV_R0 : WPV_R1;
+  wide_stage(S, no_clear ? WIDE_PROG_G1_HASH_MAP : WIDE_PROG_G1_HASH_TAIL, prog_len);
   __syncthreads();
   if (wave == 0) {
     const size_t mi = (single_msg & 1) ? 0 : i;
@@ -2522,12 +2529,12 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_hash_to_g1_engine(size_t 
     }
   }
   __syncthreads();
-  wide_exec(S, WIDE_PROG_G1_HASH_TAIL_LEN, K);
+  wide_exec(S, prog_len, K);
   const int v = (int)(threadIdx.x >> 4);
-  if (rec && v < 3) rec[i * WREC_WORDS + 16 * (WREC_P0 + v) + l] = S.V[WPV_R1 + v][l];
+  if (rec && v < 3) rec[i * WREC_WORDS + 16 * (WREC_P0 + v) + l] = S.V[res + v][l];
   if (out && threadIdx.x < 3) {
     fp x;
-    w_load_local(x, S.V[WPV_R1 + threadIdx.x]);
+    w_load_local(x, S.V[res + threadIdx.x]);
     fp_to_raw((uint32_t*)(out + i * 144) + 12 * threadIdx.x, x);
   }
 }

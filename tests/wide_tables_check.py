@@ -330,8 +330,13 @@ def check_point_programs():
             d = rng.randrange(1, P)
             o = B['ISO'] + TABLES.ISO_STRIDE * m
             V[o + TABLES.ISO_XN], V[o + TABLES.ISO_XD], V[o + TABLES.ISO_Y] = q[0] * d % P, d, q[1]
+        Vm = list(V)
         sim_program(OPS_PT, lay, dict(PROGRAMS_PT)['G1_HASH_TAIL'], V)
         X, Y, Z = V[B['R1']:B['R1'] + 3]
         zi = c.fp_inv(Z)
         assert (X * zi * zi % P, Y * zi * zi * zi % P) == want, ('G1_HASH_TAIL', case)
+        sim_program(OPS_PT, lay, dict(PROGRAMS_PT)['G1_HASH_MAP'], Vm)          # the same point before the clearing, in R0
+        X, Y, Z = Vm[B['R0']:B['R0'] + 3]
+        zi = c.fp_inv(Z)
+        assert c.E1.mul((X * zi * zi % P, Y * zi * zi * zi % P), c.H_EFF_G1) == want, ('G1_HASH_MAP', case)
     return lay

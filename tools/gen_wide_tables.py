@@ -845,8 +845,14 @@ def prog_g2_hash_tail():
     return [('C2GADD1', 'MS', 'R0', 'R1'), ('C2GADD2', 'R0', 'MS', 'MS')] + prog_g2_clear_cofactor()[2:]
 
 
+def prog_g1_hash_map():
+    """the same WITHOUT the cofactor clearing: the isogeny of both points and their sum, Jacobian in R0 -- what a Bls12381G1Impl
+    verification pairs with the key when its second pair is (sig, -[c] g2) (csrc/g2neg_lines.cuh)"""
+    return prog_g1_hash_tail()[:10] + [('C1H2JA', 'R0', 'R0', 'R0'), ('C1H2JB', 'R0', 'R0', 'R0')]
+
+
 PROGRAMS_PT += [('G2_CLEAR', prog_g2_clear_cofactor()), ('G1_CLEAR', prog_g1_clear_cofactor()), ('G1_HASH_TAIL', prog_g1_hash_tail()),
-                ('G2_HASH_TAIL', prog_g2_hash_tail())]
+                ('G2_HASH_TAIL', prog_g2_hash_tail()), ('G1_HASH_MAP', prog_g1_hash_map())]
 
 
 # ------------------------------------------------------------------ programs: sequences of (op, dst, a, b) over the value store
