@@ -215,8 +215,8 @@ int blsgpu_signatures_to_tagged(int sig_group, const uint8_t* schemes, const voi
 /* Sharded aggregate verify (one process per GPU): the shard-local part of core_aggregate_verify
  * (src/traits/sig_core.rs:149-178).  out_f12 (576 B) = an Fp12 value whose final exponentiation is the product of the pairings
  * of the shard's (H(m_i), pk_i) pairs [times (sig, -g) when sig != NULL] -- a product of Miller values (for Bls12381G1Impl
- * taken at the uncleared hashes and raised to the cofactor of hash-to-G1 once); only products of such records and their
- * final exponentiation are meaningful; *first_bad = local index of the first identity
+ * taken at the message points before their cofactor clearing, the signature's at -[c] g2, c = h_eff^-1 mod r: the same
+ * verdict); only products of such records and their final exponentiation are meaningful; *first_bad = local index of the first identity
  * key, n when the signature is the identity, -1 otherwise (identity pairs contribute 1 to the record, so it can always be
  * folded).  out_f12 and first_bad may be device pointers: then nothing crosses to the host and the caller hands them to
  * RCCL as they are.  Ranks exchange the records (all-gather) and finish with blsgpu_fp12_product_is_one.

@@ -226,11 +226,14 @@ int hs_decompress(int group, const uint8_t* in, int legacy, uint8_t* out) {
 }
 // the lane-split tower (tower_split.cuh host emulation) on the same pairs: what k_miller2s / k_finalexps compute
 static void to_split(aff<hfp2>& r, const g2_aff& q) { r.x.c[0] = q.x.c0; r.x.c[1] = q.x.c1; r.y.c[0] = q.y.c0; r.y.c[1] = q.y.c1; r.inf = q.inf; }
+// 1 (what the kernels do for Bls12381G1Impl): the message point stays uncleared, pair 1 is (sig, -[c] g2) with its own line table
+// (csrc/g2neg_lines.cuh); 0: the textbook form with the cleared hash and -g2
+int hs_no_clear = 1;
 static int verdict_split(int sig_group, const g1_aff* P, const g2_aff* Q) {
   aff<hfp2> QQ[2];
   to_split(QQ[0], Q[0]); to_split(QQ[1], Q[1]);
   fp12_t<hfp2> f;
-  if (sig_group == 1) miller_loop_fixed_g2(f, P[0], QQ[0], P[1]);
+  if (sig_group == 1) miller_loop_fixed_g2(f, P[0], QQ[0], P[1], hs_no_clear ? G2NEGC_LINES : G2NEG_LINES);
   else miller_loop<2>(f, P, QQ);
 #ifdef BLS_COUNT_FPMUL
   hs_phase_marks[1] = g_fpmul_halves;
@@ -247,7 +250,7 @@ int hs_verify(int sig_group, const uint32_t* pk, const uint32_t* sig, int aug, c
   int st;
   if (sig_group == 1) {
     g2_jac k; g1_jac s; load_g2_jac(k, pk); load_g1_jac(s, sig);
-    st = prepare_g1impl(P, Q, k, s, aug, msg, len, dst, dlen);
+    st = prepare_g1impl(P, Q, k, s, aug, msg, len, dst, dlen, -1, hs_no_clear != 0);
   } else {
     g1_jac k; g2_jac s; load_g1_jac(k, pk); load_g2_jac(s, sig);
     st = prepare_g2impl(P, Q, k, s, aug, msg, len, dst, dlen);
@@ -258,7 +261,7 @@ int hs_verify(int sig_group, const uint32_t* pk, const uint32_t* sig, int aug, c
 #endif
   if (hs_device_path_only) return verdict_split(sig_group, P, Q);
   fp12 f;
-  if (sig_group == 1) miller_loop_fixed_g2(f, P[0], Q[0], P[1]);   // as k_miller2 does for Bls12381G1Impl
+  if (sig_group == 1) miller_loop_fixed_g2(f, P[0], Q[0], P[1], hs_no_clear ? G2NEGC_LINES : G2NEG_LINES);   // as k_miller2 does for Bls12381G1Impl
   else miller_loop<2>(f, P, Q);
   const int v = pairing_verdict(f);
   const int vs = verdict_split(sig_group, P, Q);

@@ -204,7 +204,11 @@ def test_verify_items(hs):
         pk, sig = C.pk_from_bytes(bytes.fromhex(pk_h)), C.sig_from_bytes(bytes.fromhex(sig_h))
         assert hs.hs_verify(2, util.g1_raw(pk, rng), util.g2_raw(sig, rng), 0, msg, len(msg), dst, len(dst)) == 0
         assert hs.hs_verify(2, util.g1_raw(pk, rng), util.g2_raw(sig, rng), 0, b'hellp', 5, dst, len(dst)) == 1
-    for C, sg in ((ref.G1Impl, 1), (ref.G2Impl, 2)):
+    # Bls12381G1Impl twice: as the kernels verify (message point uncleared, second pair (sig, -[c] g2), its own line table) and
+    # in the textbook form (cleared hash, -g2): the same verdicts
+    no_clear = ctypes.c_int.in_dll(hs, 'hs_no_clear')
+    for C, sg, nc in ((ref.G1Impl, 1, 1), (ref.G1Impl, 1, 0), (ref.G2Impl, 2, 1)):
+        no_clear.value = nc
         pkraw, sigraw = (util.g2_raw, util.g1_raw) if sg == 1 else (util.g1_raw, util.g2_raw)
         for sch in (ref.BASIC, ref.AUG, ref.POP):
             sk = ref.keygen_from_hash(bytes([sch + 7 * sg]) * 32)
@@ -218,6 +222,7 @@ def test_verify_items(hs):
             assert hs.hs_verify(sg, pkraw(pk, rng), sigraw(None), aug, m, len(m), d, len(d)) == 2
             assert hs.hs_verify(sg, pkraw(None), sigraw(sig, rng), aug, m, len(m), d, len(d)) == 3
             assert hs.hs_verify(sg, pkraw(None), sigraw(None), aug, m, len(m), d, len(d)) == 2
+    no_clear.value = 1
 
 
 def test_decompress(hs):
