@@ -610,9 +610,10 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
     // message has a SIMD to itself, against 1.6 ms for the two-lane hash inside k_prepare) and the shared to-affine inversion after it
     uint8_t* d_hashes = (uint8_t*)arena_take(c, 144 * n);
     if (!d_hashes) return fail(BLSGPU_E_HIP, "internal: arena too small");
-    KL(KID_HASH, k_hash_to_g1_wide, dim3((unsigned)n), dim3(BLS_BLOCK), n, d_msgs, d_offs, single_msg & 1, dst, d_hashes, (uint32_t*)nullptr);
+    // the hashes stay uncleared (bit 1) and the fixed pair is (sig, -[c] g2) (table 2), as everywhere for this implementation
+    KL(KID_HASH, k_hash_to_g1_wide, dim3((unsigned)n), dim3(BLS_BLOCK), n, d_msgs, d_offs, (single_msg & 1) | 2, dst, d_hashes, (uint32_t*)nullptr);
     KL(KID_PREPARE, k_prepare_hashed<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_pks, d_sigs, (const uint8_t*)d_hashes, d_pairs, d_status, fmt);
-    return run_pairing2(c, n, d_pairs, d_f, d_status, 1);
+    return run_pairing2(c, n, d_pairs, d_f, d_status, 2);
   }
   // two lanes per item (the two SSWU maps side by side, G2 point arithmetic on the lane-split tower): always for
   // Bls12381G2Impl, whose hash-to-G2 halves its per-lane work that way; for Bls12381G1Impl only in latency mode (the

@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare_grouped(size_t n, cons
   g1_jac sig, a, b;
   load_g2_pt(pk, pks, i, fmt);
   load_g1_pt(sig, sigs, i, fmt);
-  const int st = prepare_g1impl(P, Q, pk, sig, aug, m, mlen, dst.b, dst.len);
+  const int st = prepare_g1impl(P, Q, pk, sig, aug, m, mlen, dst.b, dst.len, -1, true);   // uncleared message point: the group's last pair balances it
   status[i] = st;
   if (st != BLS_OK) {              // excluded from its group (the slot stays skipped); its status is final
     jac_set_inf(b);
@@ -877,7 +877,8 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_point_fold(size_t m, size_t half,
   }
 }
 
-// grouped verification: the group's pair (sum_i r_i sig_i, -g2) at slot c + 8 ng; an identity sum (every item excluded) is skipped
+// grouped verification: the group's pair (sum_i r_i sig_i, -[c] g2) at slot c + 8 ng (the items' message points are uncleared:
+// verify.cuh g2_negc_gen); an identity sum (every item excluded) is skipped
 __global__ void __launch_bounds__(BLS_BLOCK) k_group_sigsum(size_t ng, size_t n, const uint8_t* scaled_sigs, uint32_t* pairs, int32_t* skip) {
   const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ng) return;
@@ -897,7 +898,7 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_group_sigsum(size_t ng, size_t n,
   g1_aff S;
   g2_aff Q;
   jac_to_aff(S, acc);
-  g2_neg_gen(Q);
+  g2_negc_gen(Q);
   ws_st_pair(pairs, stride, slot, 0, S, Q);
   skip[slot] = 0;
 }
@@ -2449,7 +2450,7 @@ __global__ void __launch_bounds__(WIDE_BLOCK) k_hash_to_g1_wide(size_t n, const 
   q1.z.v = (wfp)pts[wave][1][2][l];
   jac_add(q0, q0, q1);
   if (stop == 4) return;
-  if (rec != nullptr && out == nullptr) {          // the record of a cut check takes the point uncleared (see k_hash_to_g1_engine)
+  if ((rec != nullptr && out == nullptr) || (single_msg & 2)) {   // the record of a cut check takes the point uncleared (see k_hash_to_g1_engine); bit 1 of single_msg asks for it in `out` as well
     acc = q0;
   } else {
     jac_mul_u64_rows(q1, q0, BLS_X_ABS, row == 1);   // clear cofactor: h_eff = 1 - x = 1 + |x|
