@@ -438,3 +438,18 @@ def test_hash_to_point_paths_agree_and_match_the_c_restatement(api, group):
         out = ctypes.create_string_buffer(width)
         bo.bo_hash_to_point(group, msgs[i], len(msgs[i]), dst, len(dst), out)
         assert large[i] == out.raw, i
+
+
+# ------------------------------------------------------------------ a short leg of the randomised campaign inside the suite
+def test_randomised_campaign_short(api):
+    """tests/stress_parity.py (random sizes across every path boundary, tamperings, schemes, both implementations; verify_batch,
+    hash-to-curve, MultiSignature::verify, verify_secure, AggregateSignature::verify against oracle/c) for a fixed seed and a
+    bounded number of rounds; the long runs are recorded in profiles/r02_stress_parity.txt."""
+    import stress_parity as sp
+    bo = util.load_c_oracle()
+    rng = random.Random(20261004)
+    kinds = (sp.round_verify_batch, sp.round_hash, sp.round_multi, sp.round_aggregate)
+    for k in range(40):
+        kind = kinds[k % 4] if k < 8 else rng.choices(kinds, (5, 2, 2, 3))[0]
+        line = []
+        assert kind(api, bo, rng, line.append), (k, line)
