@@ -519,17 +519,22 @@ void launch_hash_g1_small(hipStream_t stream, size_t n, const uint8_t* d_msgs, c
 // hash-to-G2 of a few messages on `stream` (RAW_PROJ out): one workgroup per message on the engine up to 128 messages; beyond
 // that one WAVE per message for the maps and one workgroup per message for the engine program (d_pts: 768 bytes of scratch per
 // message), or -- without scratch -- two lanes per message for the maps and one workgroup per point for the clearing.
-void launch_hash_g2_small(hipStream_t stream, size_t n, const uint8_t* d_msgs, const uint64_t* d_offs, int flags, const dst_arg& dst, uint8_t* d_out,
-                          uint32_t* d_pts = nullptr) {
+bool launch_hash_g2_small(hipStream_t stream, size_t n, const uint8_t* d_msgs, const uint64_t* d_offs, int flags, const dst_arg& dst, uint8_t* d_out,
+                          uint32_t* d_pts = nullptr, uint32_t* d_rec = nullptr) {
+  // d_rec: the records of a cut check (WREC_Q0 of item i <- H(m_i)); true when they were written -- the lane-pair form only
+  // fills d_out and the caller converts (k_prepare_keys part 4)
   if (n <= 128 && hash_phase_stop() == 0) {
-    hipLaunchKernelGGL(k_hash_to_g2_engine, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), 0, stream, n, d_msgs, d_offs, flags, dst, d_out);
-  } else if (d_pts && hash_phase_stop() == 0) {
-    hipLaunchKernelGGL(k_hash_to_g2_maps, dim3((unsigned)n), dim3(BLS_BLOCK), 0, stream, n, d_msgs, d_offs, flags, dst, d_pts);
-    hipLaunchKernelGGL(k_g2_hash_tail_wide, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), 0, stream, n, (const uint32_t*)d_pts, d_out);
-  } else {
-    hipLaunchKernelGGL(k_hash_to_g2, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), 0, stream, n, d_msgs, d_offs, dst, d_out, 3);
-    hipLaunchKernelGGL(k_g2_clear_wide, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), 0, stream, n, d_out);
+    hipLaunchKernelGGL(k_hash_to_g2_engine, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), 0, stream, n, d_msgs, d_offs, flags, dst, d_out, d_rec);
+    return d_rec != nullptr;
   }
+  if (d_pts && hash_phase_stop() == 0) {
+    hipLaunchKernelGGL(k_hash_to_g2_maps, dim3((unsigned)n), dim3(BLS_BLOCK), 0, stream, n, d_msgs, d_offs, flags, dst, d_pts);
+    hipLaunchKernelGGL(k_g2_hash_tail_wide, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), 0, stream, n, (const uint32_t*)d_pts, d_out, d_rec);
+    return d_rec != nullptr;
+  }
+  hipLaunchKernelGGL(k_hash_to_g2, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), 0, stream, n, d_msgs, d_offs, dst, d_out, 3);
+  hipLaunchKernelGGL(k_g2_clear_wide, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), 0, stream, n, d_out);
+  return false;
 }
 
 // one core_verify per item: statuses end up in d_status (device)
@@ -581,10 +586,11 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
     int rc = side_fork(c, 1);
     if (rc) return rc;
     prof_pre(c, KID_HASH);
-    launch_hash_g2_small(c->stream, n, d_msgs, d_offs, 0, dst, d_hashes, d_maps);
+    const bool rec_done = launch_hash_g2_small(c->stream, n, d_msgs, d_offs, 0, dst, d_hashes, d_maps, d_rec);
     prof_post(c);
-    KL(KID_PREPARE, k_prepare_keys<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (const uint8_t*)d_hashes, 0, 4,
-       d_rec, d_status);
+    if (!rec_done)
+      KL(KID_PREPARE, k_prepare_keys<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (const uint8_t*)d_hashes, 0, 4,
+         d_rec, d_status);
     if ((rc = side_fork(c, 2))) {
       (void)hipStreamSynchronize(c->stream);
       return rc;
@@ -1495,9 +1501,9 @@ static int cut_tail_begin(Ctx* c, int sig_group, int scheme, const void* sig, in
                        (const uint8_t*)nullptr, fmt, 1, t.rec, t.d_status);
     hipLaunchKernelGGL(k_pairing_pre, dim3(1, 1), dim3(WIDE_ENGINE_BLOCK), 0, c->side2, (size_t)1, t.rec, (const int32_t*)t.d_status, 2, 2);
     const hipError_t ea = hipEventRecord(c->ev_join2, c->side2);
-    launch_hash_g2_small(c->side, 1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, 1, scheme_dst(2, scheme), d_hash);
-    hipLaunchKernelGGL(k_prepare_keys<2>, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)nullptr, (const uint8_t*)nullptr,
-                       (const uint8_t*)d_hash, 0, 4, t.rec, t.d_status);
+    if (!launch_hash_g2_small(c->side, 1, (const uint8_t*)d_msg0, (const uint64_t*)d_offs0, 1, scheme_dst(2, scheme), d_hash, nullptr, t.rec))
+      hipLaunchKernelGGL(k_prepare_keys<2>, dim3(1), dim3(BLS_BLOCK), 0, c->side, (size_t)1, (const uint8_t*)nullptr, (const uint8_t*)nullptr,
+                         (const uint8_t*)d_hash, 0, 4, t.rec, t.d_status);
     const hipError_t eb = hipStreamWaitEvent(c->side, c->ev_join2, 0);      // the lines of H(m) read the status the signature part set
     hipLaunchKernelGGL(k_pairing_pre, dim3(1, 1), dim3(WIDE_ENGINE_BLOCK), 0, c->side, (size_t)1, t.rec, (const int32_t*)t.d_status, 0, 0);
     if (ea != hipSuccess || eb != hipSuccess) {

@@ -306,11 +306,11 @@ __global__ void k_g2_clear_wide(size_t n, uint8_t* pts);
 // hash-to-G2 with one WORKGROUP per message: wave 0 expands the message and runs the two SSWU maps and isogenies on two DPP rows
 // (row-wide Fp2, csrc/wide_fp2.cuh), then all four waves add the two points and clear the cofactor on the engine (program
 // G2_HASH_TAIL).  out: RAW_PROJ (Jacobian).  single_msg bit 0: every item hashes message 0.  For up to 128 messages.
-__global__ void k_hash_to_g2_engine(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst, uint8_t* out);
+__global__ void k_hash_to_g2_engine(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst, uint8_t* out, uint32_t* rec);   // out / rec: either may be null; rec: the cut check's record (WREC_Q0)
 // the same for more messages as two launches: the maps with one WAVE per message (pts: 12 engine values = 768 bytes per message),
 // then the engine program with one workgroup per message
 __global__ void k_hash_to_g2_maps(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst, uint32_t* pts);
-__global__ void k_g2_hash_tail_wide(size_t n, const uint32_t* pts, uint8_t* out);
+__global__ void k_g2_hash_tail_wide(size_t n, const uint32_t* pts, uint8_t* out, uint32_t* rec);
 
 #if defined(BLS_TU_PREPARE1) || defined(BLS_TU_PREPARE2)
 // =====================================================================================================
@@ -2571,7 +2571,7 @@ __device__ __forceinline__ void hash_g2_map_row(const uint32_t* ubw, int row, in
   pt[5][l] = (uint32_t)Z.c1.v;
 }
 __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_hash_to_g2_engine(size_t n, const uint8_t* msgs, const uint64_t* offs, int single_msg, dst_arg dst,
-                                                                       uint8_t* out) {
+                                                                       uint8_t* out, uint32_t* rec) {
   __shared__ wide_lds_t<wide_tb_pt> S;
   __shared__ __attribute__((aligned(16))) uint8_t shablk[64];
   const int wave = threadIdx.x >> 6, row = (threadIdx.x >> 4) & 3, l = threadIdx.x & 15;
@@ -2594,7 +2594,9 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_hash_to_g2_engine(size_t 
   }
   __syncthreads();
   wide_exec(S, WIDE_PROG_G2_HASH_TAIL_LEN, K);
-  if (threadIdx.x < 6) {
+  if (rec && (threadIdx.x >> 4) < 6)     // the cut check's record takes H(m) as it stands here: six engine values, Jacobian (what k_prepare_keys part 4 would write)
+    rec[i * WREC_WORDS + 16 * (WREC_Q0 + (threadIdx.x >> 4)) + (threadIdx.x & 15u)] = S.V[WPV_R3 + (threadIdx.x >> 4)][threadIdx.x & 15u];
+  if (out && threadIdx.x < 6) {
     fp x;
     w_load_local(x, S.V[WPV_R3 + threadIdx.x]);
     fp_to_raw((uint32_t*)(out + i * 288) + 12 * threadIdx.x, x);
@@ -2614,7 +2616,7 @@ __global__ void __launch_bounds__(WIDE_BLOCK) k_hash_to_g2_maps(size_t n, const 
   expand_message_xmd_wave<256>(ubw, msgs + offs[mi], (uint32_t)(offs[mi + 1] - offs[mi]), dst, shablk[wave]);
   if (row < 2) hash_g2_map_row(ubw, row, l, (uint32_t (*)[16])(pts + (i * 12 + 6 * row) * 16));
 }
-__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_g2_hash_tail_wide(size_t n, const uint32_t* pts, uint8_t* out) {
+__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_g2_hash_tail_wide(size_t n, const uint32_t* pts, uint8_t* out, uint32_t* rec) {
   __shared__ wide_lds_t<wide_tb_pt> S;
   const size_t i = blockIdx.x;
   if (i >= n) return;
@@ -2629,7 +2631,9 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_g2_hash_tail_wide(size_t 
   }
   __syncthreads();
   wide_exec(S, WIDE_PROG_G2_HASH_TAIL_LEN, K);
-  if (threadIdx.x < 6) {
+  if (rec && (threadIdx.x >> 4) < 6)     // the cut check's record takes H(m) as it stands here: six engine values, Jacobian (what k_prepare_keys part 4 would write)
+    rec[i * WREC_WORDS + 16 * (WREC_Q0 + (threadIdx.x >> 4)) + (threadIdx.x & 15u)] = S.V[WPV_R3 + (threadIdx.x >> 4)][threadIdx.x & 15u];
+  if (out && threadIdx.x < 6) {
     fp x;
     w_load_local(x, S.V[WPV_R3 + threadIdx.x]);
     fp_to_raw((uint32_t*)(out + i * 288) + 12 * threadIdx.x, x);
