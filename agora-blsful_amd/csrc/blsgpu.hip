@@ -458,7 +458,7 @@ struct NestedScope {     // the calling thread's own follow-up calls (fold, fina
 // ---- shared device pipelines (stream-ordered; caller holds the context mutex) ------------------------
 
 // the two-pair pairing check of every item whose status is still BLS_OK: status <- OK / INVALID_SIGNATURE.
-// fixed_g2: the second pair's G2 member is -g2 (precomputed lines)
+// fixed_g2: the second pair's G2 member is a constant with precomputed lines: 1 = -g2, 2 = -[c] g2 (csrc/g2neg_lines.cuh)
 int run_pairing2(Ctx* c, size_t n, uint32_t* d_pairs, uint32_t* d_f, int32_t* d_status, int fixed_g2) {
   if (n <= wide_max_items() && n <= coop_max_items()) {
     // single verifications and the one-verdict tails on the row-wide engine (csrc/wide_engine.cuh): one 256-thread workgroup

@@ -330,7 +330,8 @@ __device__ __noinline__ void coop_mul_line_with_jobs(coop_shared& S, coop_f12& f
   coop_reduce<2>(S, f);
 }
 
-// Miller loop of two pairs into S.f.  fixed_g2: pair 1's G2 member is -g2 (line table), else both pairs are general.
+// Miller loop of two pairs into S.f.  fixed_g2: pair 1's G2 member is a constant with a line table -- 1: -g2, 2: -[c] g2 (the
+// pair that balances an uncleared message point, csrc/g2neg_lines.cuh) --, 0: both pairs are general.
 // Lane pair k (k = 0, 1) owns pair k's point T.  The doubling step -- nine dependent Fp2 products when one lane pair runs
 // it alone, the serial part of the loop -- is cut into two rounds of independent products spread over lane pairs
 // (coop_jobs: XY, Y^2, Z^2, X^2, (Y+Z)^2, then XY(B-F), (B+F)^2, E^2, BH and the two line scalings), with the owner doing
