@@ -18,7 +18,10 @@
  *   - Point formats (fmt):
  *       BLSGPU_FMT_RAW_PROJ    Jacobian (X, Y, Z), Montgomery form, little-endian limbs: the in-memory layout of
  *                              blst_p1 (144 B) / blst_p2 (288 B) that G1Projective / G2Projective wrap; Z = 0 is
- *                              the identity.  A `&[PublicKey<C>]` slice can be passed as it is.
+ *                              the identity.  A `&[PublicKey<C>]` slice can be passed as it is.  RAW points are what the
+ *                              reference's types hold -- members of the prime-order subgroups (from_bytes checks it);
+ *                              verification relies on that (its verdict for a point outside its subgroup, which no
+ *                              reference value can be, is unspecified).
  *       BLSGPU_FMT_RAW_AFFINE  (x, y) Montgomery, 96 B / 192 B; all-zero = identity.
  *       BLSGPU_FMT_COMPRESSED  ZCash compressed encoding 48 B / 96 B (modern), checked on decode.
  *       BLSGPU_FMT_LEGACY      Dash legacy header variant of the same (src/impls/legacy.rs:9-67).
