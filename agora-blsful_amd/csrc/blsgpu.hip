@@ -27,10 +27,10 @@ thread_local bool t_nested = false;  // inside a sharded call: the per-device su
 
 enum {
   KID_PREPARE, KID_MILLER2, KID_FINALEXP, KID_PREPARE_AGG, KID_PAIRS_AFF, KID_MILLER1, KID_F12_FOLD, KID_FINALEXP_ONE,
-  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_F12_IO, KID_MSM_SORT, KID_MSM_BUCKET, KID_MSM_CHUNK, KID_DECOMPRESS, KID_PAIRING_COOP, KID_KEY_SORT, KID_COEFF, KID_DUP, KID_FIRST_BAD, KID_MSM_PREP, KID_MSM_NORM, KID_MSM_MERGE, KID_WIDE, KID_COUNT
+  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_F12_IO, KID_MSM_SORT, KID_MSM_BUCKET, KID_MSM_CHUNK, KID_DECOMPRESS, KID_PAIRING_COOP, KID_KEY_SORT, KID_COEFF, KID_DUP, KID_FIRST_BAD, KID_MSM_PREP, KID_MSM_NORM, KID_MSM_MERGE, KID_WIDE, KID_LINES, KID_COUNT
 };
 const char* KID_NAMES[KID_COUNT] = {"k_prepare", "k_miller2", "k_finalexp", "k_prepare_agg", "k_pairs_to_affine", "k_miller1", "k_f12_fold",
-                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign", "k_f12_io", "k_msm_sort", "k_msm_bucket", "k_msm_chunk", "k_decompress", "k_pairing_coop", "k_key_sort", "k_sha256_coeff", "k_duplicate_rule", "k_first_identity", "k_msm_prep", "k_normalize", "k_msm_merge", "k_wide"};
+                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign", "k_f12_io", "k_msm_sort", "k_msm_bucket", "k_msm_chunk", "k_decompress", "k_pairing_coop", "k_key_sort", "k_sha256_coeff", "k_duplicate_rule", "k_first_identity", "k_msm_prep", "k_normalize", "k_msm_merge", "k_wide", "k_lines2"};
 
 struct Ctx {
   int dev = -1;
@@ -47,6 +47,8 @@ struct Ctx {
   size_t hpin_cap = 0;
   uint8_t* hsmall = nullptr;      // pinned 64 KiB for the small host <-> device records of a call (offsets, flags, verdicts):
   size_t hsmall_off = 0;          // they outlive every early return, unlike stack variables
+  uint32_t* lines_ws = nullptr;   // merged line values on their way from k_lines2s to k_millerf2s (kernels.cuh): 19 KB per lane
+  size_t lines_cap = 0;           // bytes; grown on demand, kept between calls
   // optional per-kernel timing with HIP events on `stream` (blsgpu_profile_*)
   bool prof_on = false;
   struct Pending { int kid; hipEvent_t e0, e1; };
@@ -457,6 +459,38 @@ struct NestedScope {     // the calling thread's own follow-up calls (fold, fina
 
 // ---- shared device pipelines (stream-ordered; caller holds the context mutex) ------------------------
 
+// items per pass of the two-kernel Miller loop (0: the one-kernel loop); one full machine round of lane pairs by default
+size_t miller_chunk_items() {
+  static long v = -1;
+  if (v < 0) {
+    const char* e = getenv("BLSGPU_MILLER_CHUNK");
+    v = e ? atol(e) : 65536;
+    const char* o = getenv("BLSGPU_MILLER_V1");
+    if (o && atoi(o)) v = 0;
+    if (v < 0) v = 0;
+  }
+  return (size_t)v;
+}
+size_t lanes_for(size_t items) { return (2 * items + BLS_BLOCK - 1) / BLS_BLOCK * BLS_BLOCK; }
+// the context's line workspace; 0 on success, non-zero (and no error recorded) when the device has no room for it
+int lines_reserve(Ctx* c, size_t bytes) {
+  if (bytes <= c->lines_cap) return 0;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return 1;
+  }
+  if (c->lines_ws) (void)hipFree(c->lines_ws);
+  c->lines_ws = nullptr;
+  c->lines_cap = 0;
+  if (hipMalloc((void**)&c->lines_ws, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    c->lines_ws = nullptr;
+    return 1;
+  }
+  c->lines_cap = bytes;
+  return 0;
+}
+
 // the two-pair pairing check of every item whose status is still BLS_OK: status <- OK / INVALID_SIGNATURE.
 // fixed_g2: the second pair's G2 member is a constant with precomputed lines: 1 = -g2, 2 = -[c] g2 (csrc/g2neg_lines.cuh)
 int run_pairing2(Ctx* c, size_t n, uint32_t* d_pairs, uint32_t* d_f, int32_t* d_status, int fixed_g2) {
@@ -480,7 +514,20 @@ int run_pairing2(Ctx* c, size_t n, uint32_t* d_pairs, uint32_t* d_f, int32_t* d_
   } else if (n <= coop_max_items()) {  // small batches: one wave per item
     KL(KID_PAIRING_COOP, k_pairing_coop, dim3((unsigned)n), dim3(BLS_BLOCK), n, d_pairs, d_status, fixed_g2);
   } else {                      // two lanes per item (tower_split.cuh)
-    KL(KID_MILLER2, k_miller2s, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_pairs, d_status, d_f, fixed_g2);
+    // The Miller loop in two kernels (kernels.cuh k_lines2s / k_millerf2s), a chunk of at most miller_chunk_items() items at a
+    // time: the chunk's merged line values pass through the context's line workspace.  BLSGPU_MILLER_V1=1, or no memory for
+    // that workspace: the one-kernel loop of rounds 1 and 2.
+    const size_t chunk = !fixed_g2 ? 0 : n < miller_chunk_items() ? n : miller_chunk_items();   // two general pairs: the one-kernel loop
+    if (chunk && lines_reserve(c, (size_t)MILLER_ENTRIES * LINE5_WORDS * 4 * lanes_for(chunk)) == 0) {
+      for (size_t first = 0; first < n; first += chunk) {
+        const size_t cnt = n - first < chunk ? n - first : chunk;
+        const size_t lanes = lanes_for(cnt);
+        KL(KID_LINES, k_lines2s, dim3((unsigned)(lanes / BLS_BLOCK)), dim3(BLS_BLOCK), n, first, cnt, (const uint32_t*)d_pairs, (const int32_t*)d_status, c->lines_ws, lanes, fixed_g2);
+        KL(KID_MILLER2, k_millerf2s, dim3((unsigned)(lanes / BLS_BLOCK)), dim3(BLS_BLOCK), n, first, cnt, (const int32_t*)d_status, (const uint32_t*)c->lines_ws, lanes, d_f);
+      }
+    } else {
+      KL(KID_MILLER2, k_miller2s, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_pairs, d_status, d_f, fixed_g2);
+    }
     KL(KID_FINALEXP, k_finalexps, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_f, d_status);
   }
   HIPCK(hipGetLastError());
@@ -1112,6 +1159,7 @@ static void release_devices() {
       std::lock_guard<std::mutex> lk(c->mu);   // waits for a call in flight on this context
       (void)hipStreamSynchronize(c->stream);
       if (c->arena) (void)hipFree(c->arena);
+      if (c->lines_ws) (void)hipFree(c->lines_ws);
       if (c->ev_host) (void)hipEventDestroy(c->ev_host);
       if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
       if (c->ev_join) (void)hipEventDestroy(c->ev_join);

@@ -37,10 +37,12 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define BLS_FN __device__ __forceinline__
+#define BLS_MFN __device__ __forceinline__   // member functions
 #define BLS_NOINLINE __device__ __noinline__
 #define BLS_CONST __device__ __constant__ const
 #else
 #define BLS_FN static inline
+#define BLS_MFN inline
 #define BLS_NOINLINE static __attribute__((noinline))
 #define BLS_CONST static const
 #endif

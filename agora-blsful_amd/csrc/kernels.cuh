@@ -12,6 +12,7 @@
 #define WS_PAIRS_WORDS (6 * W2)  // P0(2 Fp) Q0(2 Fp2) P1 Q1, affine, internal form
 #define WS_PAIR1_WORDS (3 * W2)  // one (P, Q) pair: the one-pair-per-item workspaces of aggregate verify / pairing products
 #define WS_F_WORDS (6 * W2)      // Fp12
+#define LINE5_WORDS (5 * FP_NL)  // one lane's share of a merged line value (tower.cuh line5_t), see k_lines2s
 #define MILLER1_GROUP 3          // items per Miller loop in the pairing-product kernel (k_miller1s): 262,144 pairs take 29.4 / 28.8 ms with 2 / 3; 4 was measured slower (state of four points spills)
 
 struct dst_arg {
@@ -189,6 +190,8 @@ template <int SG>
 __global__ void k_prepare(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int aug, const uint8_t* msgs,
                           const uint64_t* offs, int single_msg, dst_arg dst, uint32_t* pairs, int32_t* status, int pre_status, int two_lanes);
 __global__ void k_miller2s(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws, int fixed_g2);
+__global__ void k_lines2s(size_t n, size_t first, size_t count, const uint32_t* pairs, const int32_t* status, uint32_t* lines, size_t lanes, int fixed_g2);
+__global__ void k_millerf2s(size_t n, size_t first, size_t count, const int32_t* status, const uint32_t* lines, size_t lanes, uint32_t* fws);
 __global__ void k_finalexps(size_t n, const uint32_t* fws, int32_t* status);
 __global__ void k_miller1s(size_t n, size_t stride, const uint32_t* pairs, const int32_t* skip, uint32_t* fws);
 __global__ void k_finalexp_ones(const uint32_t* fws, size_t stride, int32_t* verdict);
@@ -1071,7 +1074,7 @@ template __global__ void k_prepare_proof<2>(size_t, const uint8_t*, const uint8_
 #endif
 #endif  // BLS_TU_SIGN*
 
-#if defined(BLS_TU_MILLERS) || defined(BLS_TU_FINALEXPS)
+#if defined(BLS_TU_MILLERS) || defined(BLS_TU_FINALEXPS) || defined(BLS_TU_LINES) || defined(BLS_TU_MILLERF)
 // =====================================================================================================
 // lane-split variants (tower_split.cuh): two adjacent lanes per item, 64-thread workgroups = 32 items
 #include "tower_split.cuh"
@@ -1155,6 +1158,174 @@ __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_miller1s(size_t 
   sh_ld_f12(f, acc.sh);
   fp12_conj(f, f);
   ws_st_hfp12(fws, stride, g, f);
+}
+#endif
+
+#if defined(BLS_TU_LINES) || defined(BLS_TU_MILLERF)
+// =====================================================================================================
+// Round 3: the two-pair Miller loop cut in two kernels so that neither holds more state than its registers and LDS take
+// ("The Miller loop in two kernels").  k_lines2s walks the G2 point(s), evaluates the lines, merges the two
+// line values of every step (tower.cuh lines_merge) and streams the five coefficients per step to HBM; k_millerf2s owns nothing
+// but the accumulator f in LDS and multiplies the stream into it: one squaring and ONE semi-sparse product per step.  Both inline
+// everything but the multiplier leaves (BLS_INLINE_MILLER = 1 in their translation units): no operand travels by reference.
+// Line workspace: word w (0..69: c0, c2, c4, c3, c5, fourteen limbs each, this lane's component) of entry e of lane t at
+// lines[((size_t)e * LINE5_WORDS + w) * lanes + t] -- every access a coalesced 256-byte wave access; 68 x 70 x 4 B = 19 KB per
+// lane.  The kernels work on the items [first, first + count) of a batch of n (the host walks large batches in chunks).
+// (the row pointer is wave-uniform and the lane offset 32 bits wide, so that every access is the SGPR-base + VGPR-offset form:
+// with per-lane 64-bit addresses the compiler kept 140 address registers alive across the loop)
+__device__ __forceinline__ void line5_st(uint32_t* lines, size_t lanes, uint32_t t, int e, const line5_t<hfp2>& L) {
+  const fp* c[5] = {&L.c0.v, &L.c2.v, &L.c4.v, &L.c3.v, &L.c5.v};
+  uint32_t* row = lines + (size_t)e * LINE5_WORDS * lanes;
+#pragma unroll
+  for (int j = 0; j < 5; j++)
+#pragma unroll
+    for (int k = 0; k < FP_NL; k++) {
+      row[t] = (uint32_t)c[j]->l[k];
+      row += lanes;
+    }
+}
+__device__ __forceinline__ void line5_ld(line5_t<hfp2>& L, const uint32_t* lines, size_t lanes, uint32_t t, int e) {
+  fp* c[5] = {&L.c0.v, &L.c2.v, &L.c4.v, &L.c3.v, &L.c5.v};
+  const uint32_t* row = lines + (size_t)e * LINE5_WORDS * lanes;
+#pragma unroll
+  for (int j = 0; j < 5; j++)
+#pragma unroll
+    for (int k = 0; k < FP_NL; k++) {
+      c[j]->l[k] = (int32_t)row[t];
+      row += lanes;
+    }
+}
+#endif
+
+#if defined(BLS_TU_LINES)
+// State of the point walk in LDS, one column per lane (word k at sh[k * 64]), unpacked: T = (X, Y, Z) 3 x 14 words, then one Fp
+// of P0 and one of P1 -- the even lane keeps the x coordinates, the odd lane the y coordinates, and the partner's word comes by
+// DPP where the other one is needed.  70 of the 80 dwords a lane may use at two waves per SIMD.
+#define LS_TX 0
+#define LS_TY FP_NL
+#define LS_TZ (2 * FP_NL)
+#define LS_P0 (3 * FP_NL)
+#define LS_P1 (4 * FP_NL)
+#define LS_WORDS (5 * FP_NL)
+__device__ __forceinline__ void ls_ld(fp& r, const lds_u32* sh, int w0) {
+#pragma unroll
+  for (int k = 0; k < FP_NL; k++) r.l[k] = (int32_t)sh[(w0 + k) * BLS_SH_STRIDE];
+}
+__device__ __forceinline__ void ls_st(lds_u32* sh, int w0, const fp& a) {
+#pragma unroll
+  for (int k = 0; k < FP_NL; k++) sh[(w0 + k) * BLS_SH_STRIDE] = (uint32_t)a.l[k];
+}
+// the x (want_y = false) or y coordinate of the point stored split over the lane pair at w0, on both lanes
+__device__ __forceinline__ void ls_ld_coord(fp& r, const lds_u32* sh, int w0, bool want_y) {
+  fp own, other;
+  ls_ld(own, sh, w0);
+  fp_partner(other, own);
+  fp_sel(r, lane_hi() == want_y, own, other);
+}
+struct miller_lds {
+  lds_u32* sh;
+  const uint32_t* pairs;   // the pairs workspace: Q0 is read from it at the five addition steps
+  size_t n, i;
+  BLS_MFN void ld_tx(hfp2& r) const { ls_ld(r.v, sh, LS_TX); }
+  BLS_MFN void ld_ty(hfp2& r) const { ls_ld(r.v, sh, LS_TY); }
+  BLS_MFN void ld_tz(hfp2& r) const { ls_ld(r.v, sh, LS_TZ); }
+  BLS_MFN void st_tx(const hfp2& v) const { ls_st(sh, LS_TX, v.v); }
+  BLS_MFN void st_ty(const hfp2& v) const { ls_st(sh, LS_TY, v.v); }
+  BLS_MFN void st_tz(const hfp2& v) const { ls_st(sh, LS_TZ, v.v); }
+  BLS_MFN void ld_xp(fp& r) const { ls_ld_coord(r, sh, LS_P0, false); }
+  BLS_MFN void ld_yp(fp& r) const { ls_ld_coord(r, sh, LS_P0, true); }
+  BLS_MFN void ld_xq(hfp2& r) const { ws_ld_hfp2(r, pairs, n, i, W2); }
+  BLS_MFN void ld_yq(hfp2& r) const { ws_ld_hfp2(r, pairs, n, i, 2 * W2); }
+};
+// One entry of the loop for a fixed second G2 argument: step, line at P0, the table's line at P1, merge, store.  A function
+// whose arguments are scalars; it keeps nothing in registers between calls (see k_millerf2s about disable_tail_calls).
+template <int ADD>
+static __device__ __noinline__ void lines_step_fn(lds_u32* sh, const uint32_t* pairs, size_t n, size_t i, const uint32_t* row, uint32_t* lines, size_t lanes, uint32_t t,
+                                                  int e) {
+  const miller_lds st = {sh, pairs, n, i};
+  line5_t<hfp2> L;
+  fp x1, y1;
+  hfp2 l0, l2, l3, n0, n2, c;
+  if (ADD) miller_add_step_at(st, l0, l2, l3);
+  else miller_dbl_step_at(st, l0, l2, l3);
+  fp2_load(n0, row);
+  fp2_load(c, row + 2 * FP_NL);
+  ls_ld_coord(x1, sh, LS_P1, false);
+  fp2_mul_fp(n2, c, x1);
+  ls_ld_coord(y1, sh, LS_P1, true);
+  lines_merge_y(L, l0, l2, l3, n0, n2, y1);
+  line5_st(lines, lanes, t, e, L);
+}
+// fixed_g2: 1 / 2 = the second pair's G2 member is -g2 / -[c] g2 (normalised tables of g2neg_lines.cuh)
+__global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) __attribute__((disable_tail_calls))
+k_lines2s(size_t n, size_t first, size_t count, const uint32_t* pairs, const int32_t* status, uint32_t* lines, size_t lanes, int fixed_g2) {
+  const uint32_t t = blockIdx.x * BLS_BLOCK + threadIdx.x;
+  const size_t j = t >> 1;
+  if (j >= count) return;
+  const size_t i = first + j;
+  if (status[i] != BLS_OK) return;
+  __shared__ uint32_t lsh[LS_WORDS * BLS_BLOCK];
+  lds_u32* sh = lds_column(lsh);
+  {
+    hfp2 q;
+    fp p;
+    ws_ld_hfp2(q, pairs, n, i, W2);
+    ls_st(sh, LS_TX, q.v);
+    ws_ld_hfp2(q, pairs, n, i, 2 * W2);
+    ls_st(sh, LS_TY, q.v);
+    fp2_one(q);
+    ls_st(sh, LS_TZ, q.v);
+    ws_ld_fp(p, pairs, n, i, lane_hi() ? W1 : 0);                // P0: x on the even lane, y on the odd lane
+    ls_st(sh, LS_P0, p);
+    ws_ld_fp(p, pairs, n, i, 3 * W2 + (lane_hi() ? W1 : 0));     // P1
+    ls_st(sh, LS_P1, p);
+  }
+  const uint32_t (*rows)[4 * FP_NL] = fixed_g2 == 2 ? G2NEGC_LINES_N : G2NEG_LINES_N;
+  for (int e = 0; e < MILLER_ENTRIES; e++) {
+    if (miller_entry_is_add(e)) lines_step_fn<1>(sh, pairs, n, i, rows[e], lines, lanes, t, e);
+    else lines_step_fn<0>(sh, pairs, n, i, rows[e], lines, lanes, t, e);
+  }
+}
+#endif
+
+#if defined(BLS_TU_MILLERF)
+// The two operations of the accumulator's kernel are FUNCTIONS whose arguments are scalars (LDS column, line pointer): each
+// fits the register file on its own (no spill besides the callee-saved registers it borrows, 32-64 bytes of scratch per lane:
+// L1/L2-resident), whereas inlined into one loop the compiler's allocation left 496 bytes of spill slots per lane -- 65 MB per
+// launch, more than the L2s hold, and a quarter of the waves' time in s_waitcnt (profiles/r03_pmc_millerf_inlined.json).
+static __device__ __noinline__ void f12_sh_sqr_fn(lds_u32* sh) {
+  fp12_t<hfp2> a, r;
+  sh_ld_f12(a, sh);
+  fp12_sqr_body(r, a);
+  sh_st_f12(sh, r);
+}
+static __device__ __noinline__ void f12_sh_mul_line5_fn(lds_u32* sh, const uint32_t* lines, size_t lanes, uint32_t t, int e) {
+  line5_t<hfp2> L;
+  line5_ld(L, lines, lanes, t, e);
+  f12_sh_mul_line5(sh, L);
+}
+// disable_tail_calls: a call the optimiser marks `tail` makes LLVM keep the callee-saved-register convention for its callee (TargetFrameLowering::
+// isSafeForNoCSROpt), and each of the two functions would then save and restore all 112 callee-saved VGPRs on every call
+__global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) __attribute__((disable_tail_calls))
+k_millerf2s(size_t n, size_t first, size_t count, const int32_t* status, const uint32_t* lines, size_t lanes, uint32_t* fws) {
+  const uint32_t t = blockIdx.x * BLS_BLOCK + threadIdx.x;
+  const size_t j = t >> 1;
+  if (j >= count) return;
+  const size_t i = first + j;
+  if (status[i] != BLS_OK) return;
+  __shared__ uint32_t fsh[F12_SH_WORDS * BLS_BLOCK];   // the accumulator, packed (tower_split.cuh)
+  f12_sh acc = {lds_column(fsh)};
+  line5_t<hfp2> L;
+  line5_ld(L, lines, lanes, t, 0);
+  acc_set_line5(acc, L);
+  for (int e = 1; e < MILLER_ENTRIES; e++) {
+    if (!miller_entry_is_add(e)) f12_sh_sqr_fn(acc.sh);
+    f12_sh_mul_line5_fn(acc.sh, lines, lanes, t, e);
+  }
+  fp12_t<hfp2> f;
+  sh_ld_f12(f, acc.sh);
+  fp12_conj(f, f);
+  ws_st_hfp12(fws, n, i, f);
 }
 #endif
 

@@ -8,6 +8,17 @@
 #include "curve.cuh"
 #include "g2neg_lines.cuh"
 
+// BLS_INLINE_MILLER = 1 inlines the Miller steps and the LDS-accumulator operations into their kernel (only the multiplier
+// leaves stay calls): nothing then travels by reference through scratch between them
+#ifndef BLS_INLINE_MILLER
+#define BLS_INLINE_MILLER 0
+#endif
+#if BLS_INLINE_MILLER
+#define BLS_STEP_FN BLS_FN
+#else
+#define BLS_STEP_FN BLS_NOINLINE
+#endif
+
 // homogeneous projective point on the twist, used only inside the Miller loop
 template <class F2>
 struct g2_hom_t {
@@ -19,14 +30,40 @@ typedef g2_hom_t<fp2> g2_hom;
 // fp12_mul_by_line expects).  The small-constant multiples (3b' = 12 (1 + u), 3, 4, 12) are limb-wise additions, so
 // the steps fp_norm / fp_reduce where a chain would pass 2^31 or feed a product with more than 2^29 per limb.
 
+// Where a step finds and leaves its state: the steps below read T, P (and Q for additions) through an accessor, so that the same
+// arithmetic runs on values held in registers (miller_regs: every caller but one) or in LDS (kernels.cuh k_lines2s, whose step
+// functions take no operand by reference).  Every read happens where the value is used and every write as soon as it is known.
+template <class F2>
+struct miller_regs {
+  g2_hom_t<F2>& t;
+  const fp& xp_;
+  const fp& yp_;
+  const F2* xq_;
+  const F2* yq_;
+  BLS_MFN void ld_tx(F2& r) const { r = t.x; }
+  BLS_MFN void ld_ty(F2& r) const { r = t.y; }
+  BLS_MFN void ld_tz(F2& r) const { r = t.z; }
+  BLS_MFN void st_tx(const F2& v) const { t.x = v; }
+  BLS_MFN void st_ty(const F2& v) const { t.y = v; }
+  BLS_MFN void st_tz(const F2& v) const { t.z = v; }
+  BLS_MFN void ld_xp(fp& r) const { r = xp_; }
+  BLS_MFN void ld_yp(fp& r) const { r = yp_; }
+  BLS_MFN void ld_xq(F2& r) const { r = *xq_; }
+  BLS_MFN void ld_yq(F2& r) const { r = *yq_; }
+};
+
 // T <- 2T and the tangent line at T evaluated at P = (xp, yp):
 //   l0 = Y^2 - 3b'Z^2,  l2 = -3X^2 xp,  l3 = 2YZ yp     (coefficients of w^0, w^2, w^3)
-template <class F2>
-BLS_NOINLINE void miller_dbl_step(g2_hom_t<F2>& t, F2& l0, F2& l2, F2& l3, const fp& xp, const fp& yp) {
-  F2 a, b, c, e, f, h, g, s;
-  fp2_mul(a, t.x, t.y);  // XY
-  fp2_sqr(b, t.y);       // B = Y^2
-  fp2_sqr(c, t.z);       // C = Z^2
+template <class F2, class ST>
+BLS_FN void miller_dbl_step_at(const ST& st, F2& l0, F2& l2, F2& l3) {
+  F2 x, y, z, a, b, c, e, f, h, g, s;
+  fp k;
+  st.ld_tx(x);
+  st.ld_ty(y);
+  st.ld_tz(z);
+  fp2_mul(a, x, y);      // XY
+  fp2_sqr(b, y);         // B = Y^2
+  fp2_sqr(c, z);         // C = Z^2
   fp2_mul_xi(e, c);
   fp2_dbl(g, e);
   fp2_add(e, g, e);      // 3 (1 + u) C
@@ -36,27 +73,30 @@ BLS_NOINLINE void miller_dbl_step(g2_hom_t<F2>& t, F2& l0, F2& l2, F2& l3, const
   fp2_norm(e, e);        // E = 3b'C = 12 (1 + u) C
   fp2_dbl(f, e);
   fp2_add(f, f, e);      // F = 3E
-  fp2_add(h, t.y, t.z);
+  fp2_add(h, y, z);
   fp2_norm(h, h);
   fp2_sqr(h, h);
   fp2_sub(h, h, b);
   fp2_sub(h, h, c);      // H = 2YZ
   fp2_norm(h, h);
-  fp2_sqr(s, t.x);       // X^2
+  fp2_sqr(s, x);         // X^2
   // line
   fp2_sub(l0, b, e);
   fp2_norm(l0, l0);
   fp2_dbl(g, s);
   fp2_add(g, g, s);      // 3X^2
   fp2_neg(g, g);
-  fp2_mul_fp(l2, g, xp);
-  fp2_mul_fp(l3, h, yp);
+  st.ld_xp(k);
+  fp2_mul_fp(l2, g, k);
+  st.ld_yp(k);
+  fp2_mul_fp(l3, h, k);
   // point: X3 = 2XY(B - F), Y3 = (B + F)^2 - 12E^2, Z3 = 4BH
   fp2_sub(g, b, f);
   fp2_norm(g, g);
   fp2_mul(g, a, g);
   fp2_dbl(g, g);
-  fp2_reduce(t.x, g);
+  fp2_reduce(g, g);
+  st.st_tx(g);
   fp2_add(g, b, f);
   fp2_norm(g, g);
   fp2_sqr(g, g);
@@ -67,48 +107,76 @@ BLS_NOINLINE void miller_dbl_step(g2_hom_t<F2>& t, F2& l0, F2& l2, F2& l3, const
   fp2_dbl(a, a);
   fp2_dbl(a, a);         // 12E^2
   fp2_sub(g, g, a);
-  fp2_reduce(t.y, g);
+  fp2_reduce(g, g);
+  st.st_ty(g);
   fp2_mul(g, b, h);
   fp2_dbl(g, g);
   fp2_dbl(g, g);
-  fp2_reduce(t.z, g);
+  fp2_reduce(g, g);
+  st.st_tz(g);
+}
+template <class F2>
+BLS_STEP_FN void miller_dbl_step(g2_hom_t<F2>& t, F2& l0, F2& l2, F2& l3, const fp& xp, const fp& yp) {
+  const miller_regs<F2> st = {t, xp, yp, nullptr, nullptr};
+  miller_dbl_step_at(st, l0, l2, l3);
 }
 
 // T <- T + Q and the chord line through T and Q evaluated at P:
 //   l0 = theta xq - lambda yq,  l2 = -theta xp,  l3 = lambda yp
-template <class F2>
-BLS_NOINLINE void miller_add_step(g2_hom_t<F2>& t, F2& l0, F2& l2, F2& l3, const F2& xq, const F2& yq, const fp& xp,
-                                  const fp& yp) {
-  F2 th, la, c, d, e, f, g, h, s;
-  fp2_mul(th, yq, t.z);
-  fp2_sub(th, t.y, th);  // theta = Y - yq Z
-  fp2_mul(la, xq, t.z);
-  fp2_sub(la, t.x, la);  // lambda = X - xq Z
+template <class F2, class ST>
+BLS_FN void miller_add_step_at(const ST& st, F2& l0, F2& l2, F2& l3) {
+  F2 th, la, c, d, e, f, g, h, s, q, z, u;
+  fp k;
+  st.ld_yq(q);
+  st.ld_tz(z);
+  fp2_mul(th, q, z);
+  st.ld_ty(u);
+  fp2_sub(th, u, th);    // theta = Y - yq Z
+  st.ld_xq(q);
+  fp2_mul(la, q, z);
+  st.ld_tx(u);
+  fp2_sub(la, u, la);    // lambda = X - xq Z
   fp2_norm(th, th);
   fp2_norm(la, la);
-  fp2_mul(l0, th, xq);
-  fp2_mul(s, la, yq);
+  fp2_mul(l0, th, q);
+  st.ld_yq(q);
+  fp2_mul(s, la, q);
   fp2_sub(l0, l0, s);
   fp2_norm(l0, l0);
   fp2_neg(s, th);
-  fp2_mul_fp(l2, s, xp);
-  fp2_mul_fp(l3, la, yp);
+  st.ld_xp(k);
+  fp2_mul_fp(l2, s, k);
+  st.ld_yp(k);
+  fp2_mul_fp(l3, la, k);
   fp2_sqr(c, th);
   fp2_sqr(d, la);
   fp2_mul(e, la, d);
-  fp2_mul(f, t.z, c);
-  fp2_mul(g, t.x, d);
+  st.ld_tz(z);
+  fp2_mul(f, z, c);
+  st.ld_tx(u);
+  fp2_mul(g, u, d);
   fp2_add(h, e, f);
   fp2_sub(h, h, g);
   fp2_sub(h, h, g);
   fp2_norm(h, h);
-  fp2_mul(t.x, la, h);
+  fp2_mul(u, la, h);
+  st.st_tx(u);
   fp2_sub(s, g, h);
   fp2_mul(s, th, s);
-  fp2_mul(g, e, t.y);
+  st.ld_ty(u);
+  fp2_mul(g, e, u);
   fp2_sub(s, s, g);
-  fp2_reduce(t.y, s);
-  fp2_mul(t.z, t.z, e);
+  fp2_reduce(s, s);
+  st.st_ty(s);
+  st.ld_tz(z);
+  fp2_mul(z, z, e);
+  st.st_tz(z);
+}
+template <class F2>
+BLS_STEP_FN void miller_add_step(g2_hom_t<F2>& t, F2& l0, F2& l2, F2& l3, const F2& xq, const F2& yq, const fp& xp,
+                                  const fp& yp) {
+  const miller_regs<F2> st = {t, xp, yp, &xq, &yq};
+  miller_add_step_at(st, l0, l2, l3);
 }
 
 // The Miller accumulator is addressed through acc_* so that the same loops run with f in private memory (an fp12_t, below)
@@ -206,6 +274,93 @@ BLS_FN void miller_loop_fixed_g2(ACC& f, const g1_aff& P0, const aff<F2>& Q0, co
       fp2_mul_fp(m3, t, P1.y);
       acc_mul_2lines(f, l0, l2, l3, m0, m2, m3);
       row++;
+    }
+  }
+  acc_finish(f);
+}
+
+// ---- the same product with the two line values of a step MERGED where they are computed (round 3) ------------------------
+// One step of that loop for a fixed second G2 argument given as a normalised table (g2neg_lines.cuh *_LINES_N: rows (l0/h, g/h),
+// the line value is n0 + (n2 x1) w^2 + y1 w^3 with P1 = (x1, y1)): walk T (doubling, or addition of Q0 when add is set), evaluate
+// the chord / tangent at P0 and multiply the two sparse values into five coefficients (tower.cuh lines_merge_y).
+template <class F2, class ST>
+BLS_FN void miller_line5_fixed_at(line5_t<F2>& L, const ST& st, bool add, const fp& x1, const fp& y1, const uint32_t* row) {
+  F2 l0, l2, l3, n0, n2, t;
+  if (add) miller_add_step_at(st, l0, l2, l3);
+  else miller_dbl_step_at(st, l0, l2, l3);
+  fp2_load(n0, row);
+  fp2_load(t, row + 2 * FP_NL);
+  fp2_mul_fp(n2, t, x1);
+  lines_merge_y(L, l0, l2, l3, n0, n2, y1);
+}
+template <class F2>
+BLS_FN void miller_line5_fixed(line5_t<F2>& L, g2_hom_t<F2>& T, bool add, const F2& xq, const F2& yq, const fp& xp, const fp& yp, const fp& x1, const fp& y1,
+                               const uint32_t* row) {
+  const miller_regs<F2> st = {T, xp, yp, &xq, &yq};
+  miller_line5_fixed_at(L, st, add, x1, y1, row);
+}
+// ... and for two general pairs
+template <class F2>
+BLS_FN void miller_line5_pair(line5_t<F2>& L, g2_hom_t<F2>& T0, g2_hom_t<F2>& T1, bool add, const aff<F2>* Q, const g1_aff* P) {
+  F2 l0, l2, l3, m0, m2, m3;
+  if (add) {
+    miller_add_step(T0, l0, l2, l3, Q[0].x, Q[0].y, P[0].x, P[0].y);
+    miller_add_step(T1, m0, m2, m3, Q[1].x, Q[1].y, P[1].x, P[1].y);
+  } else {
+    miller_dbl_step(T0, l0, l2, l3, P[0].x, P[0].y);
+    miller_dbl_step(T1, m0, m2, m3, P[1].x, P[1].y);
+  }
+  lines_merge(L, l0, l2, l3, m0, m2, m3);
+}
+template <class F2>
+BLS_FN void acc_set_line5(fp12_t<F2>& f, const line5_t<F2>& L) { fp12_from_line5(f, L); }
+template <class F2>
+BLS_FN void acc_mul_line5(fp12_t<F2>& f, const line5_t<F2>& L) { fp12_mul_by_line5_body(f, L); }
+// The 68 steps in loop order: entry e is an addition step when bit e of this mask is set (the set bits of |x| below the top one
+// are 62, 60, 57, 48, 16: additions follow the doublings of those iterations)
+#define MILLER_ENTRIES 68
+BLS_FN bool miller_entry_is_add(int e) {
+  // doubling of iteration i = 62 - d sits at entry d + (number of set bits of |x| among 62 .. i + 1); additions right after
+  return e == 1 || e == 4 || e == 8 || e == 18 || e == 51;
+}
+// f <- conj(f_{|x|,Q0}(P0) f_{|x|,Q1}(P1)) up to a factor in Fp2 (killed by the final exponentiation), Q1 the fixed argument of `rows`
+template <class ACC, class F2>
+BLS_FN void miller_loop_fixed_g2_merged(ACC& f, const g1_aff& P0, const aff<F2>& Q0, const g1_aff& P1, const uint32_t (*rows)[4 * FP_NL]) {
+  g2_hom_t<F2> T;
+  T.x = Q0.x;
+  T.y = Q0.y;
+  fp2_one(T.z);
+  line5_t<F2> L;
+  for (int e = 0; e < MILLER_ENTRIES; e++) {
+    const bool add = miller_entry_is_add(e);
+    miller_line5_fixed(L, T, add, Q0.x, Q0.y, P0.x, P0.y, P1.x, P1.y, rows[e]);
+    if (e == 0) {
+      acc_set_line5(f, L);
+    } else {
+      if (!add) acc_sqr(f);
+      acc_mul_line5(f, L);
+    }
+  }
+  acc_finish(f);
+}
+template <class ACC, class F2>
+BLS_FN void miller_loop2_merged(ACC& f, const g1_aff* P, const aff<F2>* Q) {
+  g2_hom_t<F2> T0, T1;
+  T0.x = Q[0].x;
+  T0.y = Q[0].y;
+  fp2_one(T0.z);
+  T1.x = Q[1].x;
+  T1.y = Q[1].y;
+  fp2_one(T1.z);
+  line5_t<F2> L;
+  for (int e = 0; e < MILLER_ENTRIES; e++) {
+    const bool add = miller_entry_is_add(e);
+    miller_line5_pair(L, T0, T1, add, Q, P);
+    if (e == 0) {
+      acc_set_line5(f, L);
+    } else {
+      if (!add) acc_sqr(f);
+      acc_mul_line5(f, L);
     }
   }
   acc_finish(f);

@@ -27,6 +27,10 @@ BLS_FN void fp2_one(fp2& r) {
   fp_one(r.c0);
   fp_zero(r.c1);
 }
+BLS_FN void fp2_from_fp(fp2& r, const fp& k) {   // k + 0 u
+  r.c0 = k;
+  fp_zero(r.c1);
+}
 BLS_FN bool fp2_is_zero(const fp2& a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1); }
 BLS_FN bool fp2_eq(const fp2& a, const fp2& b) { return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1); }
 BLS_FN void fp2_cmov(fp2& r, const fp2& a, bool c) {
@@ -579,48 +583,91 @@ BLS_FN void fp6_mul_by_12(fp6_t<F2>& r, const fp6_t<F2>& x, const F2& y1, const 
   fp2_norm(r.a1, o1);
   fp2_norm(r.a2, o2);
 }
-// f * (a0 + a2 w^2 + a3 w^3)(b0 + b2 w^2 + b3 w^3): the two line values of one Miller step merged first (6 Fp2
-// multiplications; the product has no w^1 term), then ONE Fp12 multiplication with that structure (6 + 5 + 6): 23 Fp2
-// multiplications instead of 2 x 13, and the accumulator is read and written once.
+// ---- merged line values.  (a0 + a2 w^2 + a3 w^3)(b0 + b2 w^2 + b3 w^3) = c0 + c2 w^2 + c3 w^3 + c4 w^4 + c5 w^5: the two line
+// values of one Miller step multiplied together first (6 Fp2 multiplications; the product has no w^1 term), then ONE Fp12
+// multiplication with that structure (6 + 5 + 6): 23 Fp2 multiplications instead of 2 x 13, and the accumulator is read and
+// written once.  The coefficients leave REDUCED (c4 is a plain product): the Karatsuba sums of the Fp12 product double values
+// twice over.  Round 3 splits the two halves between two kernels (kernels.cuh k_lines2s / k_millerf2s): the kernel that walks
+// the G2 point merges the lines and streams the five coefficients through HBM; the accumulator's kernel holds nothing but f.
 template <class F2>
-BLS_FN void fp12_mul_by_2lines_body(fp12_t<F2>& f, const F2& a0, const F2& a2, const F2& a3, const F2& b0, const F2& b2, const F2& b3) {
-  fp6_t<F2> L0, L1s;        // L0 = (c0, c2, c4), L1 = (0, c3, c5)
-  {
-    F2 p00, p22, p33, s, t, m;
-    fp2_mul(p00, a0, b0);
-    fp2_mul(p22, a2, b2);
-    fp2_mul(p33, a3, b3);
-    fp2_mul_xi(m, p33);
-    fp2_add(m, m, p00);
-    fp2_norm(L0.a0, m);      // c0 = a0 b0 + xi a3 b3
-    fp2_add(s, a0, a2);
-    fp2_add(t, b0, b2);
-    fp2_mul(m, s, t);
-    fp2_sub(m, m, p00);
-    fp2_sub(m, m, p22);
-    fp2_norm(L0.a1, m);      // c2 = a0 b2 + a2 b0
-    L0.a2 = p22;             // c4
-    fp2_add(s, a0, a3);
-    fp2_add(t, b0, b3);
-    fp2_mul(m, s, t);
-    fp2_sub(m, m, p00);
-    fp2_sub(m, m, p33);
-    fp2_norm(L1s.a1, m);     // c3 = a0 b3 + a3 b0
-    fp2_add(s, a2, a3);
-    fp2_add(t, b2, b3);
-    fp2_mul(m, s, t);
-    fp2_sub(m, m, p22);
-    fp2_sub(m, m, p33);
-    fp2_norm(L1s.a2, m);     // c5 = a2 b3 + a3 b2
-  }
-  fp6_t<F2> t0, t1, s, m, Ls;
+struct line5_t {
+  F2 c0, c2, c4, c3, c5;
+};
+template <class F2>
+BLS_FN void lines_merge(line5_t<F2>& L, const F2& a0, const F2& a2, const F2& a3, const F2& b0, const F2& b2, const F2& b3) {
+  F2 p00, p22, p33, s, t, m;
+  fp2_mul(p00, a0, b0);
+  fp2_mul(p22, a2, b2);
+  fp2_mul(p33, a3, b3);
+  fp2_mul_xi(m, p33);
+  fp2_add(m, m, p00);
+  fp2_reduce(L.c0, m);       // c0 = a0 b0 + xi a3 b3
+  fp2_add(s, a0, a2);
+  fp2_add(t, b0, b2);
+  fp2_mul(m, s, t);
+  fp2_sub(m, m, p00);
+  fp2_sub(m, m, p22);
+  fp2_reduce(L.c2, m);       // c2 = a0 b2 + a2 b0
+  L.c4 = p22;              // c4
+  fp2_add(s, a0, a3);
+  fp2_add(t, b0, b3);
+  fp2_mul(m, s, t);
+  fp2_sub(m, m, p00);
+  fp2_sub(m, m, p33);
+  fp2_reduce(L.c3, m);       // c3 = a0 b3 + a3 b0
+  fp2_add(s, a2, a3);
+  fp2_add(t, b2, b3);
+  fp2_mul(m, s, t);
+  fp2_sub(m, m, p22);
+  fp2_sub(m, m, p33);
+  fp2_reduce(L.c5, m);       // c5 = a2 b3 + a3 b2
+}
+// the same with b3 = y in Fp (a line of a FIXED G2 argument, scaled so that its w^3 coefficient is yP itself: g2neg_lines.cuh
+// *_LINES_N): a3 b3 is an Fp2-by-Fp product (one product stream per lane instead of two)
+template <class F2>
+BLS_FN void lines_merge_y(line5_t<F2>& L, const F2& a0, const F2& a2, const F2& a3, const F2& b0, const F2& b2, const fp& y) {
+  F2 p00, p22, p33, s, t, m, yy;
+  fp2_from_fp(yy, y);
+  fp2_mul(p00, a0, b0);
+  fp2_mul(p22, a2, b2);
+  fp2_mul_fp(p33, a3, y);
+  fp2_mul_xi(m, p33);
+  fp2_add(m, m, p00);
+  fp2_reduce(L.c0, m);
+  fp2_add(s, a0, a2);
+  fp2_add(t, b0, b2);
+  fp2_mul(m, s, t);
+  fp2_sub(m, m, p00);
+  fp2_sub(m, m, p22);
+  fp2_reduce(L.c2, m);
+  L.c4 = p22;
+  fp2_add(s, a0, a3);
+  fp2_add(t, b0, yy);
+  fp2_mul(m, s, t);
+  fp2_sub(m, m, p00);
+  fp2_sub(m, m, p33);
+  fp2_reduce(L.c3, m);
+  fp2_add(s, a2, a3);
+  fp2_add(t, b2, yy);
+  fp2_mul(m, s, t);
+  fp2_sub(m, m, p22);
+  fp2_sub(m, m, p33);
+  fp2_reduce(L.c5, m);
+}
+// f * (c0 + c2 w^2 + c3 w^3 + c4 w^4 + c5 w^5): L0 = (c0, c2, c4), L1 = (0, c3, c5) in Fp6; 6 + 5 + 6 Fp2 multiplications
+template <class F2>
+BLS_FN void fp12_mul_by_line5_body(fp12_t<F2>& f, const line5_t<F2>& L) {
+  fp6_t<F2> t0, t1, s, m, L0, Ls;
+  L0.a0 = L.c0;
+  L0.a1 = L.c2;
+  L0.a2 = L.c4;
   fp6_mul(t0, f.c0, L0);
-  fp6_mul_by_12(t1, f.c1, L1s.a1, L1s.a2);
+  fp6_mul_by_12(t1, f.c1, L.c3, L.c5);
   fp6_add(s, f.c0, f.c1);
   fp6_norm(s, s);
-  Ls.a0 = L0.a0;
-  fp2_add(Ls.a1, L0.a1, L1s.a1);
-  fp2_add(Ls.a2, L0.a2, L1s.a2);
+  Ls.a0 = L.c0;
+  fp2_add(Ls.a1, L.c2, L.c3);
+  fp2_add(Ls.a2, L.c4, L.c5);
   fp2_norm(Ls.a1, Ls.a1);
   fp2_norm(Ls.a2, Ls.a2);
   fp6_mul(m, s, Ls);
@@ -630,6 +677,22 @@ BLS_FN void fp12_mul_by_2lines_body(fp12_t<F2>& f, const F2& a0, const F2& a2, c
   fp6_mul_v(t1, t1);
   fp6_add(t0, t0, t1);
   fp6_reduce(f.c0, t0);
+}
+template <class F2>
+BLS_FN void fp12_mul_by_2lines_body(fp12_t<F2>& f, const F2& a0, const F2& a2, const F2& a3, const F2& b0, const F2& b2, const F2& b3) {
+  line5_t<F2> L;
+  lines_merge(L, a0, a2, a3, b0, b2, b3);
+  fp12_mul_by_line5_body(f, L);
+}
+// the Fp12 element of a merged line value (the accumulator's first value: 1 * L)
+template <class F2>
+BLS_FN void fp12_from_line5(fp12_t<F2>& f, const line5_t<F2>& L) {
+  f.c0.a0 = L.c0;
+  f.c0.a1 = L.c2;
+  f.c0.a2 = L.c4;
+  fp2_zero(f.c1.a0);
+  f.c1.a1 = L.c3;
+  f.c1.a2 = L.c5;
 }
 template <class F2>
 BLS_NOINLINE void fp12_mul_by_2lines(fp12_t<F2>& f, const F2& a0, const F2& a2, const F2& a3, const F2& b0, const F2& b2, const F2& b3) {

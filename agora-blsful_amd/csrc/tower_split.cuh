@@ -34,6 +34,11 @@ __device__ __forceinline__ void fp2_one(hfp2& r) {
   fp_zero(z);
   fp_sel(r.v, lane_hi(), z, one);
 }
+__device__ __forceinline__ void fp2_from_fp(hfp2& r, const fp& k) {   // k + 0 u: both lanes hold k
+  fp z;
+  fp_zero(z);
+  fp_sel(r.v, lane_hi(), z, k);
+}
 __device__ __forceinline__ void fp2_load(hfp2& r, const uint32_t* c) { fp_load(r.v, c + (lane_hi() ? FP_NL : 0)); }
 __device__ __forceinline__ bool fp2_is_zero(const hfp2& a) {
   int32_t z = fp_is_zero(a.v) ? 1 : 0;
@@ -145,7 +150,7 @@ __device__ __forceinline__ void sh_st_f12(lds_u32* sh, const fp12_t<hfp2>& f) {
   sh_st_fp(sh, 65, f.c1.a2.v);
 }
 // one non-inlined function per step: load the accumulator from LDS, run the inlined body on registers, store it back
-__device__ __noinline__ void f12_sh_sqr(lds_u32* sh) {
+BLS_STEP_FN void f12_sh_sqr(lds_u32* sh) {
   fp12_t<hfp2> a, r;
   sh_ld_f12(a, sh);
   fp12_sqr_body(r, a);
@@ -194,13 +199,13 @@ __device__ __noinline__ void f12_sh_cyclotomic_sqr(lds_u32* sh) {
   cyc_store_plus(sh, 39, t0, z2);
   cyc_store_minus(sh, 26, t2, z3);
 }
-__device__ __noinline__ void f12_sh_mul_line(lds_u32* sh, const hfp2& l0, const hfp2& l2, const hfp2& l3) {
+BLS_STEP_FN void f12_sh_mul_line(lds_u32* sh, const hfp2& l0, const hfp2& l2, const hfp2& l3) {
   fp12_t<hfp2> a;
   sh_ld_f12(a, sh);
   fp12_mul_by_line_body(a, l0, l2, l3);
   sh_st_f12(sh, a);
 }
-__device__ __noinline__ void f12_sh_mul_2lines(lds_u32* sh, const hfp2& a0, const hfp2& a2, const hfp2& a3, const hfp2& b0, const hfp2& b2, const hfp2& b3) {
+BLS_STEP_FN void f12_sh_mul_2lines(lds_u32* sh, const hfp2& a0, const hfp2& a2, const hfp2& a3, const hfp2& b0, const hfp2& b2, const hfp2& b3) {
   fp12_t<hfp2> a;
   sh_ld_f12(a, sh);
   fp12_mul_by_2lines_body(a, a0, a2, a3, b0, b2, b3);
@@ -253,6 +258,42 @@ __device__ __forceinline__ void acc_mul_2lines(f12_sh& f, const hfp2& a0, const 
   f12_sh_mul_line(f.sh, a0, a2, a3);
   f12_sh_mul_line(f.sh, b0, b2, b3);
 #endif
+}
+// accumulator *= merged line value (tower.cuh fp12_mul_by_line5_body) with the accumulator's halves fetched from LDS where they
+// are needed, as f12_sh_mul does
+__device__ __forceinline__ void f12_sh_mul_line5(lds_u32* sh, const line5_t<hfp2>& L) {
+  fp6_t<hfp2> x, y, t0, t1, m, L0, Ls;
+  L0.a0 = L.c0;
+  L0.a1 = L.c2;
+  L0.a2 = L.c4;
+  sh_ld_f6(x, sh, 0);
+  fp6_mul(t0, x, L0);
+  sh_ld_f6(x, sh, 39);
+  fp6_mul_by_12(t1, x, L.c3, L.c5);
+  sh_ld_f6(y, sh, 0);
+  fp6_add(x, x, y);
+  fp6_norm(x, x);
+  Ls.a0 = L.c0;
+  fp2_add(Ls.a1, L.c2, L.c3);
+  fp2_add(Ls.a2, L.c4, L.c5);
+  fp2_norm(Ls.a1, Ls.a1);
+  fp2_norm(Ls.a2, Ls.a2);
+  fp6_mul(m, x, Ls);
+  fp6_sub(m, m, t0);
+  fp6_sub(m, m, t1);
+  fp6_reduce(m, m);
+  sh_st_f6(sh, 39, m);
+  fp6_mul_v(t1, t1);
+  fp6_add(t0, t0, t1);
+  fp6_reduce(t0, t0);
+  sh_st_f6(sh, 0, t0);
+}
+__device__ __forceinline__ void acc_mul_line5(f12_sh& f, const line5_t<hfp2>& L) { f12_sh_mul_line5(f.sh, L); }
+__device__ __forceinline__ void acc_set_line5(f12_sh& f, const line5_t<hfp2>& L) {
+  fp12_t<hfp2> a;
+  fp12_from_line5(a, L);
+  fp12_reduce(a, a);        // only reduced elements pack
+  sh_st_f12(f.sh, a);
 }
 __device__ __forceinline__ void acc_finish(f12_sh&) {}   // the kernel conjugates when it reads the accumulator out (negated limbs do not pack)
 
@@ -356,6 +397,7 @@ struct hfp2 {
 };
 static inline void fp2_zero(hfp2& r) { fp_zero(r.c[0]); fp_zero(r.c[1]); }
 static inline void fp2_one(hfp2& r) { fp_one(r.c[0]); fp_zero(r.c[1]); }
+static inline void fp2_from_fp(hfp2& r, const fp& k) { r.c[0] = k; fp_zero(r.c[1]); }
 static inline void fp2_load(hfp2& r, const uint32_t* c) { fp_load(r.c[0], c); fp_load(r.c[1], c + FP_NL); }
 static inline bool fp2_is_zero(const hfp2& a) { return fp_is_zero(a.c[0]) && fp_is_zero(a.c[1]); }
 static inline bool fp2_eq(const hfp2& a, const hfp2& b) { return fp_eq(a.c[0], b.c[0]) && fp_eq(a.c[1], b.c[1]); }

@@ -156,6 +156,40 @@ int hs_miller_fixed_g2_matches(const uint32_t* p0, const uint32_t* q0, const uin
   store_fp12_plain(wa, a); store_fp12_plain(wb, b);
   return memcmp(wa, wb, sizeof wa) == 0;
 }
+// the merged-line loops (normalised fixed table / two general pairs) against the plain loops: the Miller values differ by a factor
+// in Fp2, the final exponentiations must be equal.  Both tower instantiations.  1 = all equal
+int hs_miller_merged_matches(const uint32_t* p0, const uint32_t* q0, const uint32_t* p1, const uint32_t* q1) {
+  g1_aff P[2]; g2_aff Q[2];
+  fp_from_raw(P[0].x, p0); fp_from_raw(P[0].y, p0 + 12); P[0].inf = false;
+  fp_from_raw(P[1].x, p1); fp_from_raw(P[1].y, p1 + 12); P[1].inf = false;
+  raw_fp2(Q[0].x, q0); raw_fp2(Q[0].y, q0 + 24); Q[0].inf = false;
+  raw_fp2(Q[1].x, q1); raw_fp2(Q[1].y, q1 + 24); Q[1].inf = false;
+  uint32_t wa[144], wb[144];
+  fp12 a, b, ea, eb;
+  // two general pairs
+  miller_loop<2>(a, P, Q);
+  miller_loop2_merged(b, P, Q);
+  final_exponentiation(ea, a); final_exponentiation(eb, b);
+  store_fp12_plain(wa, ea); store_fp12_plain(wb, eb);
+  if (memcmp(wa, wb, sizeof wa)) return -1;
+  // fixed second argument, both tables
+  for (int tb = 0; tb < 2; tb++) {
+    miller_loop_fixed_g2(a, P[0], Q[0], P[1], tb ? G2NEGC_LINES : G2NEG_LINES);
+    miller_loop_fixed_g2_merged(b, P[0], Q[0], P[1], tb ? G2NEGC_LINES_N : G2NEG_LINES_N);
+    final_exponentiation(ea, a); final_exponentiation(eb, b);
+    store_fp12_plain(wa, ea); store_fp12_plain(wb, eb);
+    if (memcmp(wa, wb, sizeof wa)) return -2 - tb;
+  }
+  // the lane-split tower on the fixed form
+  aff<hfp2> QQ; QQ.x.c[0] = Q[0].x.c0; QQ.x.c[1] = Q[0].x.c1; QQ.y.c[0] = Q[0].y.c0; QQ.y.c[1] = Q[0].y.c1; QQ.inf = false;
+  fp12_t<hfp2> fs, es;
+  miller_loop_fixed_g2_merged(fs, P[0], QQ, P[1], G2NEGC_LINES_N);
+  final_exponentiation(es, fs);
+  fp2 chk; chk.c0 = es.c0.a0.c[0]; chk.c1 = es.c0.a0.c[1];
+  if (!fp2_eq(chk, eb.c0.a0)) return -4;
+  chk.c0 = es.c1.a2.c[0]; chk.c1 = es.c1.a2.c[1];
+  return fp2_eq(chk, eb.c1.a2) ? 1 : -5;
+}
 // cyclotomic squaring vs generic squaring on an element of the cyclotomic subgroup
 int hs_cyclotomic_check(int n, const uint32_t* g1s, const uint32_t* g2s) {
   g1_aff P[1]; g2_aff Q[1];
@@ -229,12 +263,19 @@ static void to_split(aff<hfp2>& r, const g2_aff& q) { r.x.c[0] = q.x.c0; r.x.c[1
 // 1 (what the kernels do for Bls12381G1Impl): the message point stays uncleared, pair 1 is (sig, -[c] g2) with its own line table
 // (csrc/g2neg_lines.cuh); 0: the textbook form with the cleared hash and -g2
 int hs_no_clear = 1;
+// 1 (what the lane-split batch kernels do since round 3): the two-kernel Miller loop over merged line values; 0: the one-kernel loop
+int hs_merged_lines = 1;
 static int verdict_split(int sig_group, const g1_aff* P, const g2_aff* Q) {
   aff<hfp2> QQ[2];
   to_split(QQ[0], Q[0]); to_split(QQ[1], Q[1]);
   fp12_t<hfp2> f;
-  if (sig_group == 1) miller_loop_fixed_g2(f, P[0], QQ[0], P[1], hs_no_clear ? G2NEGC_LINES : G2NEG_LINES);
-  else miller_loop<2>(f, P, QQ);
+  if (hs_merged_lines) {   // what k_lines2s + k_millerf2s compute: the two line values of a step merged before they touch f
+    if (sig_group == 1) miller_loop_fixed_g2_merged(f, P[0], QQ[0], P[1], hs_no_clear ? G2NEGC_LINES_N : G2NEG_LINES_N);
+    else miller_loop2_merged(f, P, QQ);
+  } else {
+    if (sig_group == 1) miller_loop_fixed_g2(f, P[0], QQ[0], P[1], hs_no_clear ? G2NEGC_LINES : G2NEG_LINES);
+    else miller_loop<2>(f, P, QQ);
+  }
 #ifdef BLS_COUNT_FPMUL
   hs_phase_marks[1] = g_fpmul_halves;
 #endif

@@ -190,6 +190,9 @@ def test_pairing_values(hs):
     assert hs.hs_pow_x_compressed_check(util.g1_aff_raw(P1), util.g2_aff_raw(Q1)) == 1   # Karabina chain == plain chain
     # the precomputed -g2 line table (tools/gen_g2_lines.py) reproduces the generic loop's Miller value bit for bit
     assert hs.hs_miller_fixed_g2_matches(util.g1_aff_raw(P1), util.g2_aff_raw(Q1), util.g1_aff_raw(P2)) == 1
+    # round 3: the two line values of a step merged before they touch f (k_lines2s / k_millerf2s), fixed lines normalised so that
+    # the w^3 coefficient is yP: same final exponentiation as the plain loops, both tables, both tower instantiations
+    assert hs.hs_miller_merged_matches(util.g1_aff_raw(P1), util.g2_aff_raw(Q1), util.g1_aff_raw(P2), util.g2_aff_raw(Q2)) == 1
 
 
 def test_verify_items(hs):
@@ -207,8 +210,10 @@ def test_verify_items(hs):
     # Bls12381G1Impl twice: as the kernels verify (message point uncleared, second pair (sig, -[c] g2), its own line table) and
     # in the textbook form (cleared hash, -g2): the same verdicts
     no_clear = ctypes.c_int.in_dll(hs, 'hs_no_clear')
-    for C, sg, nc in ((ref.G1Impl, 1, 1), (ref.G1Impl, 1, 0), (ref.G2Impl, 2, 1)):
+    merged = ctypes.c_int.in_dll(hs, 'hs_merged_lines')   # the lane-split leg: 1 = the two-kernel loop over merged lines (default)
+    for C, sg, nc, mg in ((ref.G1Impl, 1, 1, 1), (ref.G1Impl, 1, 0, 1), (ref.G2Impl, 2, 1, 1), (ref.G1Impl, 1, 1, 0), (ref.G2Impl, 2, 1, 0)):
         no_clear.value = nc
+        merged.value = mg
         pkraw, sigraw = (util.g2_raw, util.g1_raw) if sg == 1 else (util.g1_raw, util.g2_raw)
         for sch in (ref.BASIC, ref.AUG, ref.POP):
             sk = ref.keygen_from_hash(bytes([sch + 7 * sg]) * 32)
@@ -223,6 +228,7 @@ def test_verify_items(hs):
             assert hs.hs_verify(sg, pkraw(None), sigraw(sig, rng), aug, m, len(m), d, len(d)) == 3
             assert hs.hs_verify(sg, pkraw(None), sigraw(None), aug, m, len(m), d, len(d)) == 2
     no_clear.value = 1
+    merged.value = 1
 
 
 def test_decompress(hs):
