@@ -517,6 +517,7 @@ int run_pairing2(Ctx* c, size_t n, uint32_t* d_pairs, uint32_t* d_f, int32_t* d_
     // The Miller loop in two kernels (kernels.cuh k_lines2s / k_millerf2s), a chunk of at most miller_chunk_items() items at a
     // time: the chunk's merged line values pass through the context's line workspace.  BLSGPU_MILLER_V1=1, or no memory for
     // that workspace: the one-kernel loop of rounds 1 and 2.
+    static const bool finalexp_v1 = getenv("BLSGPU_FINALEXP_V1") && atoi(getenv("BLSGPU_FINALEXP_V1"));   // A/B: the one-kernel final exponentiation of rounds 1 and 2
     const size_t chunk = !fixed_g2 ? 0 : n < miller_chunk_items() ? n : miller_chunk_items();   // two general pairs: the one-kernel loop
     if (chunk && lines_reserve(c, (size_t)MILLER_ENTRIES * LINE5_WORDS * 4 * lanes_for(chunk)) == 0) {
       for (size_t first = 0; first < n; first += chunk) {
@@ -524,11 +525,14 @@ int run_pairing2(Ctx* c, size_t n, uint32_t* d_pairs, uint32_t* d_f, int32_t* d_
         const size_t lanes = lanes_for(cnt);
         KL(KID_LINES, k_lines2s, dim3((unsigned)(lanes / BLS_BLOCK)), dim3(BLS_BLOCK), n, first, cnt, (const uint32_t*)d_pairs, (const int32_t*)d_status, c->lines_ws, lanes, fixed_g2);
         KL(KID_MILLER2, k_millerf2s, dim3((unsigned)(lanes / BLS_BLOCK)), dim3(BLS_BLOCK), n, first, cnt, (const int32_t*)d_status, (const uint32_t*)c->lines_ws, lanes, d_f);
+        // the chunk's line values are consumed: the same memory is the value store of the final exponentiation (3.4 KB per lane)
+        if (!finalexp_v1) KL(KID_FINALEXP, k_finalexp2s, dim3((unsigned)(lanes / BLS_BLOCK)), dim3(BLS_BLOCK), n, first, cnt, (const uint32_t*)d_f, c->lines_ws, lanes, d_status);
       }
+      if (finalexp_v1) KL(KID_FINALEXP, k_finalexps, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_f, d_status);
     } else {
       KL(KID_MILLER2, k_miller2s, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_pairs, d_status, d_f, fixed_g2);
+      KL(KID_FINALEXP, k_finalexps, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_f, d_status);
     }
-    KL(KID_FINALEXP, k_finalexps, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_f, d_status);
   }
   HIPCK(hipGetLastError());
   return 0;

@@ -192,6 +192,15 @@ BLS_FN bool fp_eq(const fp& a, const fp& b) {
 // signed 64-bit column accumulator; the column sum stays below 2^63 under the limb bounds stated at the top.
 // STREAMS == 0: squaring, r = REDC(a a): the off-diagonal products are taken once against a doubled operand
 // (105 multiply-adds instead of 196 for the product part; same column sums as the general form).
+// Measured and rejected (round 3, tools/ubench/ubench3.hip form 4, profiles/r03_ubench3_leaf_forms.txt): every multiply-add as an
+// opaque instruction in ONE accumulator chain.  The compiler, left to itself, splits the chain into several accumulators and
+// joins them with 64-bit additions (28 v_lshl_add_u64 and 44 moves per fused pass, 113-130 registers); the single chain needs
+// 60 registers and 8 % fewer cycles when two waves keep a SIMD busy all the time (6,069 -> 5,589 cycles per fused pass), but
+// back-to-back dependent v_mad_i64_i32 need wait states (one s_nop per link), a wave that runs alone is 44 % slower (3,470 ->
+// 5,002 cycles), and in the kernels -- where a wave's partner is parked in s_waitcnt 10-15 % of the time -- every kernel lost:
+// k_prepare 1.58 -> 2.25 ms (one wave per SIMD), k_millerf2s 6.80 -> 7.39, k_finalexp2s 9.46 -> 10.09, k_lines2s 3.60 -> 3.85.
+#define FP_MADI(acc, x, y) acc += (int64_t)(x) * (y)
+#define FP_MADU(acc, x, y) acc += (int64_t)(x) * (int32_t)(y)
 template <int STREAMS>
 BLS_FN void fp_redc_products(fp& r, const fp& a, const fp& b, const fp& c, const fp& d) {
 #if defined(BLS_TRACK_BOUNDS) && !defined(__HIPCC__)
@@ -216,21 +225,21 @@ BLS_FN void fp_redc_products(fp& r, const fp& a, const fp& b, const fp& c, const
 #pragma unroll
     for (int i = lo; i <= hi; i++) {
       if (STREAMS == 0) {
-        if (2 * i < k) acc += (int64_t)a.l[i] * a2[k - i];
-        else if (2 * i == k) acc += (int64_t)a.l[i] * a.l[i];
+        if (2 * i < k) FP_MADI(acc, a.l[i], a2[k - i]);
+        else if (2 * i == k) FP_MADI(acc, a.l[i], a.l[i]);
       } else {
-        acc += (int64_t)a.l[i] * b.l[k - i];
-        if (STREAMS == 2) acc += (int64_t)c.l[i] * d.l[k - i];
+        FP_MADI(acc, a.l[i], b.l[k - i]);
+        if (STREAMS == 2) FP_MADI(acc, c.l[i], d.l[k - i]);
       }
     }
 #pragma unroll
     for (int i = lo; i <= hi; i++) {
       if (k < FP_NL && i == k) continue;  // m[k] is not known yet
-      acc += (int64_t)m[i] * (int32_t)FP_P[k - i];
+      FP_MADU(acc, m[i], FP_P[k - i]);
     }
     if (k < FP_NL) {
       m[k] = (int32_t)(((uint32_t)acc * FP_N0INV) & FP_MASK);
-      acc += (int64_t)m[k] * (int32_t)FP_P[0];
+      FP_MADU(acc, m[k], FP_P[0]);
       acc >>= FP_LB;
     } else {
       t[k - FP_NL] = (int32_t)((uint32_t)acc & FP_MASK);

@@ -13,6 +13,7 @@
 #define WS_PAIR1_WORDS (3 * W2)  // one (P, Q) pair: the one-pair-per-item workspaces of aggregate verify / pairing products
 #define WS_F_WORDS (6 * W2)      // Fp12
 #define LINE5_WORDS (5 * FP_NL)  // one lane's share of a merged line value (tower.cuh line5_t), see k_lines2s
+#define FX_STORE_WORDS (10 * 6 * FP_NL)   // one lane's value store of k_finalexp2s (VS_SLOTS slots of an Fp12 share)
 #define MILLER1_GROUP 3          // items per Miller loop in the pairing-product kernel (k_miller1s): 262,144 pairs take 29.4 / 28.8 ms with 2 / 3; 4 was measured slower (state of four points spills)
 
 struct dst_arg {
@@ -192,6 +193,7 @@ __global__ void k_prepare(size_t n, const uint8_t* pks, const uint8_t* sigs, int
 __global__ void k_miller2s(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws, int fixed_g2);
 __global__ void k_lines2s(size_t n, size_t first, size_t count, const uint32_t* pairs, const int32_t* status, uint32_t* lines, size_t lanes, int fixed_g2);
 __global__ void k_millerf2s(size_t n, size_t first, size_t count, const int32_t* status, const uint32_t* lines, size_t lanes, uint32_t* fws);
+__global__ void k_finalexp2s(size_t n, size_t first, size_t count, const uint32_t* fws, uint32_t* vp, size_t lanes, int32_t* status);
 __global__ void k_finalexps(size_t n, const uint32_t* fws, int32_t* status);
 __global__ void k_miller1s(size_t n, size_t stride, const uint32_t* pairs, const int32_t* skip, uint32_t* fws);
 __global__ void k_finalexp_ones(const uint32_t* fws, size_t stride, int32_t* verdict);
@@ -1074,7 +1076,7 @@ template __global__ void k_prepare_proof<2>(size_t, const uint8_t*, const uint8_
 #endif
 #endif  // BLS_TU_SIGN*
 
-#if defined(BLS_TU_MILLERS) || defined(BLS_TU_FINALEXPS) || defined(BLS_TU_LINES) || defined(BLS_TU_MILLERF)
+#if defined(BLS_TU_MILLERS) || defined(BLS_TU_FINALEXPS) || defined(BLS_TU_LINES) || defined(BLS_TU_MILLERF) || defined(BLS_TU_FINALEXP2)
 // =====================================================================================================
 // lane-split variants (tower_split.cuh): two adjacent lanes per item, 64-thread workgroups = 32 items
 #include "tower_split.cuh"
@@ -1345,6 +1347,273 @@ __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_finalexps(size_t
   fp12_t<hfp2> f;
   ws_ld_hfp12(f, fws, n, i);
   int st = pairing_verdict(f);
+  if (!lane_hi()) status[i] = st;
+}
+#endif
+
+#if defined(BLS_TU_FINALEXP2)
+// =====================================================================================================
+// Round 3: the final exponentiation of the lane-split batch path as a sequence of operations on ONE accumulator A in LDS
+// (tower_split.cuh layout: 78 packed words per lane) and a per-lane VALUE STORE in HBM for everything else -- the inputs, the
+// few Fp12 values the exponentiation keeps, the six compressed powers of every a^x and their denominators' prefix products.
+// Every operation is a function whose arguments are scalars (LDS column, store pointer, slot numbers): nothing travels by
+// reference through scratch, nothing stays in registers between operations, and the kernel is marked disable_tail_calls so that
+// no operation saves callee-saved registers (see k_millerf2s).  The arithmetic -- and therefore the bound proof of tests/hostsim --
+// is that of pairing.cuh final_exponentiation / tower_split.cuh fp12_pow_x, operation for operation.
+// Store layout: word w (0..83: six Fp in tower order c0.a0 c0.a1 c0.a2 c1.a0 c1.a1 c1.a2, this lane's component, fourteen limbs
+// each) of slot s of lane t at vs[((size_t)s * VS_WORDS + w) * lanes + t]: coalesced 256-byte wave accesses.
+#define VS_WORDS (6 * FP_NL)
+#define VS_SLOTS 10      // 0: t (inverse, then the running value of the hard part)  1: f (after the easy part)  2: a of the current a^x
+                         // 3..6: the six compressed powers (4 Fp each: two per slot .. packed as 6 x 4 = 24 Fp = 4 slots)  7: prefix products
+struct vs_ref {
+  uint32_t* p;
+  size_t lanes;
+  uint32_t t;
+};
+__device__ __forceinline__ void vs_ld(fp& r, const vs_ref& v, int slot, int j) {
+  const uint32_t* row = v.p + ((size_t)slot * VS_WORDS + (size_t)j * FP_NL) * v.lanes;
+#pragma unroll
+  for (int k = 0; k < FP_NL; k++) {
+    r.l[k] = (int32_t)row[v.t];
+    row += v.lanes;
+  }
+}
+__device__ __forceinline__ void vs_st(const vs_ref& v, int slot, int j, const fp& a) {
+  uint32_t* row = v.p + ((size_t)slot * VS_WORDS + (size_t)j * FP_NL) * v.lanes;
+#pragma unroll
+  for (int k = 0; k < FP_NL; k++) {
+    row[v.t] = (uint32_t)a.l[k];
+    row += v.lanes;
+  }
+}
+__device__ __forceinline__ hfp2& f12_coef(fp12_t<hfp2>& f, int j) {
+  return j == 0 ? f.c0.a0 : j == 1 ? f.c0.a1 : j == 2 ? f.c0.a2 : j == 3 ? f.c1.a0 : j == 4 ? f.c1.a1 : f.c1.a2;
+}
+// operand transforms of fx_load / fx_mul
+#define FX_PLAIN 0
+#define FX_CONJ 1
+#define FX_FROB1 2
+#define FX_FROB2 3
+__device__ __forceinline__ void fx_fetch(fp12_t<hfp2>& b, const vs_ref& v, int slot, int mode) {
+  vs_ld(b.c0.a0.v, v, slot, 0);
+  vs_ld(b.c0.a1.v, v, slot, 1);
+  vs_ld(b.c0.a2.v, v, slot, 2);
+  vs_ld(b.c1.a0.v, v, slot, 3);
+  vs_ld(b.c1.a1.v, v, slot, 4);
+  vs_ld(b.c1.a2.v, v, slot, 5);
+  if (mode == FX_CONJ) {
+    fp12_conj(b, b);
+  } else if (mode == FX_FROB1) {
+    fp12_t<hfp2> r;
+    fp12_frob<1>(r, b);
+    b = r;
+  } else if (mode == FX_FROB2) {
+    fp12_t<hfp2> r;
+    fp12_frob<2>(r, b);
+    b = r;
+  }
+}
+// A <- op(V[slot])
+static __device__ __noinline__ void fx_load(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t, int slot, int mode) {
+  const vs_ref v = {vp, lanes, t};
+  fp12_t<hfp2> b;
+  fx_fetch(b, v, slot, mode);
+  fp12_reduce(b, b);        // only reduced elements pack
+  sh_st_f12(sh, b);
+}
+// V[slot] <- A
+static __device__ __noinline__ void fx_store(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t, int slot) {
+  const vs_ref v = {vp, lanes, t};
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    fp x;
+    sh_ld_fp(x, sh, 13 * j);
+    vs_st(v, slot, j, x);
+  }
+}
+// A <- A * op(V[slot])
+static __device__ __noinline__ void fx_mul(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t, int slot, int mode) {
+  const vs_ref v = {vp, lanes, t};
+  fp12_t<hfp2> b;
+  fx_fetch(b, v, slot, mode);
+  f12_sh_mul_body(sh, b);
+}
+// A <- A^(p^2)
+static __device__ __noinline__ void fx_frob2(lds_u32* sh) {
+  fp12_t<hfp2> a, r;
+  sh_ld_f12(a, sh);
+  fp12_frob<2>(r, a);
+  fp12_reduce(r, r);
+  sh_st_f12(sh, r);
+}
+// A <- 1 / A
+static __device__ __noinline__ void fx_inv(lds_u32* sh) {
+  fp12_t<hfp2> a, r;
+  sh_ld_f12(a, sh);
+  fp12_inv_body(r, a);
+  sh_st_f12(sh, r);         // fp12_inv returns reduced coefficients
+}
+// A <- A^2 for A in the cyclotomic subgroup (Granger-Scott, streamed through LDS)
+static __device__ __noinline__ void fx_cyc_sqr(lds_u32* sh) { f12_sh_cyclotomic_sqr_body(sh); }
+// The compressed part of a^|x| (tower_split.cuh fp12_pow_x): A holds a; 63 compressed squarings of (z2, z3, z4, z5) in their LDS
+// slots, the six powers whose bits are set in |x| saved to the store (power k: Fp j of slot 3 + (4 k + j) / 6 ...).
+__device__ __forceinline__ void cpow_slot(int k, int j, int& slot, int& idx) {   // Fp j (0..3: z2 z3 z4 z5) of saved power k (0..5)
+  const int q = 4 * k + j;
+  slot = 3 + q / 6;
+  idx = q % 6;
+}
+static __device__ __noinline__ void fx_pow_run(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t) {
+  const vs_ref v = {vp, lanes, t};
+  int k = 0;
+  for (int i = 1; i <= 63; i++) {
+    f12_sh_cyc_c_sqr_body(sh);
+    if ((BLS_X_ABS >> i) & 1) {
+      const int w[4] = {39, 26, 13, 65};   // LDS words of z2, z3, z4, z5
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        fp x;
+        int slot, idx;
+        sh_ld_fp(x, sh, w[j]);
+        cpow_slot(k, j, slot, idx);
+        vs_st(v, slot, idx, x);
+      }
+      k++;
+    }
+  }
+}
+// ... and the rest: the six powers decompressed with one shared inversion (Montgomery's trick over the denominators 4 z2) and
+// multiplied into A.  Returns false on the lanes of an item one of whose z2 vanishes (never seen for honest inputs): the caller
+// then runs the plain chain for that item.
+static __device__ __noinline__ bool fx_pow_finish(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t) {
+  const vs_ref v = {vp, lanes, t};
+  hfp2 pre, d, inv, tt;
+  bool ok = true;
+  for (int i = 0; i < 6; i++) {            // prefix products of the denominators -> slot 7
+    int slot, idx;
+    hfp2 z2;
+    cpow_slot(i, 0, slot, idx);
+    vs_ld(z2.v, v, slot, idx);
+    if (fp2_is_zero(z2)) ok = false;
+    fp2_dbl(tt, z2);
+    fp2_dbl(tt, tt);
+    fp2_norm(d, tt);                       // 4 z2
+    if (i == 0) pre = d;
+    else fp2_mul(pre, pre, d);
+    vs_st(v, 7, i, pre.v);
+  }
+  if (!ok) return false;
+  fp2_inv(inv, pre);
+  for (int i = 5; i >= 0; i--) {
+    hfp2 di;
+    cyc_c<hfp2> s;
+    int slot, idx;
+    cpow_slot(i, 0, slot, idx);
+    vs_ld(s.z2.v, v, slot, idx);
+    if (i) {
+      hfp2 pm;
+      vs_ld(pm.v, v, 7, i - 1);
+      fp2_mul(di, inv, pm);                // 1 / d_i
+      fp2_dbl(tt, s.z2);
+      fp2_dbl(tt, tt);
+      fp2_norm(d, tt);
+      fp2_mul(inv, inv, d);
+    } else {
+      di = inv;
+    }
+    cpow_slot(i, 1, slot, idx);
+    vs_ld(s.z3.v, v, slot, idx);
+    cpow_slot(i, 2, slot, idx);
+    vs_ld(s.z4.v, v, slot, idx);
+    cpow_slot(i, 3, slot, idx);
+    vs_ld(s.z5.v, v, slot, idx);
+    fp12_t<hfp2> e;
+    cyc_decompress(e, s, di);
+    if (i == 5) {
+      fp12_reduce(e, e);
+      sh_st_f12(sh, e);
+    } else {
+      f12_sh_mul_body(sh, e);
+    }
+  }
+  return true;
+}
+// the plain chain on A (Granger-Scott squarings, five multiplications by a = V[2]): the fallback of fx_pow_finish
+static __device__ __noinline__ void fx_pow_plain(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t) {
+  fx_load(sh, vp, lanes, t, 2, FX_PLAIN);
+  for (int i = 62; i >= 0; i--) {
+    f12_sh_cyclotomic_sqr_body(sh);
+    if ((BLS_X_ABS >> i) & 1) fx_mul(sh, vp, lanes, t, 2, FX_PLAIN);
+  }
+}
+// A <- conj(A)  (x < 0)
+static __device__ __noinline__ void fx_conj(lds_u32* sh) {
+#pragma unroll
+  for (int j = 3; j < 6; j++) {
+    fp x;
+    sh_ld_fp(x, sh, 13 * j);
+    fp_neg(x, x);
+    fp_reduce(x, x);
+    sh_st_fp(sh, 13 * j, x);
+  }
+}
+// A <- A^x (x < 0), A in the cyclotomic subgroup
+__device__ __forceinline__ void fx_pow_x(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t) {
+  fx_store(sh, vp, lanes, t, 2);           // a: the fallback's operand
+  fx_pow_run(sh, vp, lanes, t);
+  if (!fx_pow_finish(sh, vp, lanes, t)) fx_pow_plain(sh, vp, lanes, t);
+  fx_conj(sh);
+}
+static __device__ __noinline__ int fx_is_one(lds_u32* sh) {
+  fp12_t<hfp2> a;
+  sh_ld_f12(a, sh);
+  return fp12_is_one(a) ? BLS_OK : BLS_ERR_INVALID_SIGNATURE;
+}
+// items [first, first + count) of the Fp12 workspace fws (stride n, as k_millerf2s / k_miller2s leave it)
+__global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) __attribute__((disable_tail_calls))
+k_finalexp2s(size_t n, size_t first, size_t count, const uint32_t* fws, uint32_t* vp, size_t lanes, int32_t* status) {
+  const uint32_t t = blockIdx.x * BLS_BLOCK + threadIdx.x;
+  const size_t j = t >> 1;
+  if (j >= count) return;
+  const size_t i = first + j;
+  if (status[i] != BLS_OK) return;
+  __shared__ uint32_t ash[F12_SH_WORDS * BLS_BLOCK];
+  lds_u32* sh = lds_column(ash);
+  {
+    fp12_t<hfp2> f;
+    ws_ld_hfp12(f, fws, n, i);
+    fp12_reduce(f, f);       // the Miller kernel's conjugate carries negated limbs
+    sh_st_f12(sh, f);
+  }
+  // easy part: f^((p^6 - 1)(p^2 + 1))
+  fx_store(sh, vp, lanes, t, 1);                 // fin
+  fx_inv(sh);
+  fx_store(sh, vp, lanes, t, 0);                 // t = 1 / fin
+  fx_load(sh, vp, lanes, t, 1, FX_CONJ);
+  fx_mul(sh, vp, lanes, t, 0, FX_PLAIN);         // f = conj(fin) / fin
+  fx_store(sh, vp, lanes, t, 1);
+  fx_frob2(sh);
+  fx_mul(sh, vp, lanes, t, 1, FX_PLAIN);         // f = f^(p^2) f
+  fx_store(sh, vp, lanes, t, 1);                 // slot 1: f for the rest of the kernel
+  // hard part: (x-1)^2 (x+p) (x^2+p^2-1) + 3
+  fx_pow_x(sh, vp, lanes, t);
+  fx_mul(sh, vp, lanes, t, 1, FX_CONJ);          // t = f^(x-1)
+  fx_store(sh, vp, lanes, t, 0);
+  fx_pow_x(sh, vp, lanes, t);
+  fx_mul(sh, vp, lanes, t, 0, FX_CONJ);          // t = t^(x-1)
+  fx_store(sh, vp, lanes, t, 0);
+  fx_pow_x(sh, vp, lanes, t);
+  fx_mul(sh, vp, lanes, t, 0, FX_FROB1);         // t = t^(x+p)
+  fx_store(sh, vp, lanes, t, 0);
+  fx_pow_x(sh, vp, lanes, t);
+  fx_pow_x(sh, vp, lanes, t);                    // t^(x^2)
+  fx_mul(sh, vp, lanes, t, 0, FX_FROB2);
+  fx_mul(sh, vp, lanes, t, 0, FX_CONJ);          // t = t^(x^2+p^2-1)
+  fx_store(sh, vp, lanes, t, 0);
+  fx_load(sh, vp, lanes, t, 1, FX_PLAIN);
+  fx_cyc_sqr(sh);
+  fx_mul(sh, vp, lanes, t, 1, FX_PLAIN);         // f^3
+  fx_mul(sh, vp, lanes, t, 0, FX_PLAIN);
+  const int st = fx_is_one(sh);
   if (!lane_hi()) status[i] = st;
 }
 #endif

@@ -407,7 +407,7 @@ BLS_NOINLINE void fp12_sqr(fp12_t<F2>& r, const fp12_t<F2>& a) {
   fp12_sqr_body(r, a);
 }
 template <class F2>
-BLS_NOINLINE void fp12_inv(fp12_t<F2>& r, const fp12_t<F2>& a) {
+BLS_FN void fp12_inv_body(fp12_t<F2>& r, const fp12_t<F2>& a) {
   fp6_t<F2> t0, t1;
   fp6_mul(t0, a.c0, a.c0);
   fp6_mul(t1, a.c1, a.c1);
@@ -421,6 +421,10 @@ BLS_NOINLINE void fp12_inv(fp12_t<F2>& r, const fp12_t<F2>& a) {
   fp6_mul(t1, a.c1, t0);
   fp6_neg(t1, t1);
   fp6_reduce(r.c1, t1);
+}
+template <class F2>
+BLS_NOINLINE void fp12_inv(fp12_t<F2>& r, const fp12_t<F2>& a) {
+  fp12_inv_body(r, a);
 }
 // a^(p^J), J = 1 or 2:  coefficient of w^k -> conj^J(c_k) * FROBJ[k]
 template <int J, class F2>

@@ -175,7 +175,7 @@ __device__ __forceinline__ void cyc_store_plus(lds_u32* sh, int w0, const hfp2& 
   fp2_reduce(r, r);
   sh_st_fp(sh, w0, r.v);
 }
-__device__ __noinline__ void f12_sh_cyclotomic_sqr(lds_u32* sh) {
+__device__ __forceinline__ void f12_sh_cyclotomic_sqr_body(lds_u32* sh) {
   hfp2 t0, t1;
   {
     hfp2 z0, z1;
@@ -199,6 +199,7 @@ __device__ __noinline__ void f12_sh_cyclotomic_sqr(lds_u32* sh) {
   cyc_store_plus(sh, 39, t0, z2);
   cyc_store_minus(sh, 26, t2, z3);
 }
+__device__ __noinline__ void f12_sh_cyclotomic_sqr(lds_u32* sh) { f12_sh_cyclotomic_sqr_body(sh); }
 BLS_STEP_FN void f12_sh_mul_line(lds_u32* sh, const hfp2& l0, const hfp2& l2, const hfp2& l3) {
   fp12_t<hfp2> a;
   sh_ld_f12(a, sh);
@@ -223,7 +224,7 @@ __device__ __forceinline__ void sh_st_f6(lds_u32* sh, int w0, const fp6_t<hfp2>&
 }
 // accumulator *= b: the Karatsuba product of fp12_mul_body with the accumulator's halves fetched from LDS where they are
 // needed (and fetched again for the sum) instead of held across the three Fp6 products
-__device__ __noinline__ void f12_sh_mul(lds_u32* sh, const fp12_t<hfp2>& b) {
+__device__ __forceinline__ void f12_sh_mul_body(lds_u32* sh, const fp12_t<hfp2>& b) {
   fp6_t<hfp2> x, y, t0, t1, m;
   sh_ld_f6(x, sh, 0);
   fp6_mul(t0, x, b.c0);
@@ -244,6 +245,7 @@ __device__ __noinline__ void f12_sh_mul(lds_u32* sh, const fp12_t<hfp2>& b) {
   fp6_reduce(t0, t0);
   sh_st_f6(sh, 0, t0);
 }
+__device__ __noinline__ void f12_sh_mul(lds_u32* sh, const fp12_t<hfp2>& b) { f12_sh_mul_body(sh, b); }
 __device__ __forceinline__ void acc_one(f12_sh& f) {
   fp12_t<hfp2> one;
   fp12_one(one);
@@ -298,7 +300,7 @@ __device__ __forceinline__ void acc_set_line5(f12_sh& f, const line5_t<hfp2>& L)
 __device__ __forceinline__ void acc_finish(f12_sh&) {}   // the kernel conjugates when it reads the accumulator out (negated limbs do not pack)
 
 // compressed squaring (pairing.cuh cyc_c_sqr) on the LDS slots of z2, z3, z4, z5: the last two thirds of the function above
-__device__ __noinline__ void f12_sh_cyc_c_sqr(lds_u32* sh) {
+__device__ __forceinline__ void f12_sh_cyc_c_sqr_body(lds_u32* sh) {
   hfp2 t0, t1, z2, z3, z4, z5, t2, t3;
   sh_ld_fp(z2.v, sh, 39);
   sh_ld_fp(z3.v, sh, 26);
@@ -313,6 +315,7 @@ __device__ __noinline__ void f12_sh_cyc_c_sqr(lds_u32* sh) {
   cyc_store_plus(sh, 39, t0, z2);
   cyc_store_minus(sh, 26, t2, z3);
 }
+__device__ __noinline__ void f12_sh_cyc_c_sqr(lds_u32* sh) { f12_sh_cyc_c_sqr_body(sh); }
 // the plain chain (Granger-Scott squarings, five multiplications) with the running power in LDS: fallback of fp12_pow_x
 __device__ __noinline__ void fp12_pow_x_plain_sh(fp12_t<hfp2>& r, const fp12_t<hfp2>& a, lds_u32* sh) {
   fp12_t<hfp2> acc;

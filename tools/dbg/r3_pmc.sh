@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes of the bench command (lane-split kernels): instruction counts, wait shares, busy cycles, memory instructions
 set -o pipefail
-OUT=gpurun_out/r3/pmc
+OUT=gpurun_out/r3/pmc3
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 rocprofv3 -L > $OUT/counters.txt 2>&1 || true
@@ -11,6 +11,6 @@ for c in "SQ_WAVES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY S
   rocprofv3 --pmc $c --output-format csv -d $OUT/p$i -- python3 bench.py --steps 2 --warmup 1 --no-extras > /dev/null 2> $OUT/p$i.err || { echo "pass $i failed"; tail -5 $OUT/p$i.err; }
   echo "pass $i done"
 done
-python3 tools/pmc_summary.py $OUT/p* > gpurun_out/r3/pmc_v2.json
+python3 tools/pmc_summary.py $OUT/p* > gpurun_out/r3/pmc_v3.json
 find $OUT -name "*.csv" -size +2M -delete
-cat gpurun_out/r3/pmc_v2.json | head -80
+cat gpurun_out/r3/pmc_v3.json | head -80

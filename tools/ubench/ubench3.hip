@@ -110,8 +110,46 @@ static const int32_t P28_H[NL] = {0xfffaaab, 0xfefffff, 0x3ffffb9, 0xfffeb15, 0x
 // F = 1: product scanning, the two product streams and the reduction stream in three accumulators, summed at the column's end
 // F = 2: operand scanning: 15 independent 64-bit column accumulators, row i adds a_i b + c_i d + m_i p
 // F = 3: product scanning with the products of column k + 1 issued in a second accumulator while column k's reduction chain runs
+#if defined(__HIP_DEVICE_COMPILE__)
+// F = 4: one accumulator chain, every multiply-add an opaque instruction (the compiler cannot split the chain into several
+// accumulators that it then joins with 64-bit additions), the reduction's products unsigned
+#define MADI(acc, a, b) do { uint64_t cy_; asm volatile("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy_) : "v"(a), "v"(b)); } while (0)
+#define MADU(acc, a, b) do { uint64_t cy_; asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy_) : "v"(a), "s"(b)); } while (0)
+__device__ __forceinline__ void fused_asm(fp28& r, const fp28& a, const fp28& b, const fp28& c, const fp28& d, const int32_t* P) {
+  int64_t acc = 0;
+  int32_t m[NL];
+  fp28 t;
+#pragma unroll
+  for (int k = 0; k < 2 * NL - 1; k++) {
+    const int lo = k > NL - 1 ? k - (NL - 1) : 0, hi = k < NL - 1 ? k : NL - 1;
+#pragma unroll
+    for (int i = lo; i <= hi; i++) {
+      MADI(acc, a.l[i], b.l[k - i]);
+      MADI(acc, c.l[i], d.l[k - i]);
+    }
+#pragma unroll
+    for (int i = lo; i <= hi; i++) {
+      if (k < NL && i == k) continue;
+      MADU(acc, m[i], P[k - i]);
+    }
+    if (k < NL) {
+      m[k] = (int32_t)(((uint32_t)acc * N0INV28) & MASK28);
+      MADU(acc, m[k], P[0]);
+      acc >>= 28;
+    } else {
+      t.l[k - NL] = (int32_t)((uint32_t)acc & MASK28);
+      acc >>= 28;
+    }
+  }
+  t.l[NL - 1] = (int32_t)acc;
+  r = t;
+}
+#endif
 template <int F>
 HD void fused(fp28& r, const fp28& a_, const fp28& b_, const fp28& c_, const fp28& d_, const int32_t* P) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (F == 4) { fused_asm(r, a_, b_, c_, d_, P); return; }
+#endif
   fp28 a = a_, b = b_, c = c_, d = d_;
   for (int i = 0; i < NL; i++) { OPAQUE(a.l[i]); OPAQUE(b.l[i]); OPAQUE(c.l[i]); OPAQUE(d.l[i]); }
   fp28 t;
@@ -245,6 +283,8 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  const bool leaf_only = argc > 1 && !strcmp(argv[1], "leaf");
+  if (!leaf_only) {
   all_rates<A_8ACC_SAME>(dcy, dsink);
   all_rates<A_8ACC_DIST>(dcy, dsink);
   all_rates<A_1ACC_DIST>(dcy, dsink);
@@ -253,6 +293,7 @@ int main(int argc, char** argv) {
   all_rates<A_8ACC_SGPR>(dcy, dsink);
   all_rates<A_ASHR64>(dcy, dsink);
   all_rates<A_MAD3_ADD1>(dcy, dsink);
+  }
   std::vector<int32_t> hin(NL * 1024);
   srand(7);
   for (int i = 0; i < 1024; i++) {
@@ -264,12 +305,15 @@ int main(int argc, char** argv) {
     run_mul<0, 1>(wps, dout, din, dcy, hin);
     run_mul<1, 1>(wps, dout, din, dcy, hin);
     run_mul<2, 1>(wps, dout, din, dcy, hin);
+    run_mul<4, 1>(wps, dout, din, dcy, hin);
   }
+  for (int wps = 5; wps <= 8; wps++) run_mul<4, 1>(wps, dout, din, dcy, hin);   // 60 VGPRs: up to eight waves per SIMD
   // the same with the register budget of four waves per SIMD forced
   for (int wps = 2; wps <= 4; wps += 2) {
     run_mul<0, 4>(wps, dout, din, dcy, hin);
     run_mul<1, 4>(wps, dout, din, dcy, hin);
     run_mul<2, 4>(wps, dout, din, dcy, hin);
+    run_mul<4, 4>(wps, dout, din, dcy, hin);
   }
   return 0;
 }
