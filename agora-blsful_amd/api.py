@@ -191,10 +191,14 @@ def verify_batch(sig_group, scheme, pks, sigs, msgs, fmt=FMT_RAW_PROJ):
     return list(st)
 
 
-def verify_batch_grouped(sig_group, scheme, pks, sigs, msgs, seed=0x626c73677075, fmt=FMT_RAW_PROJ):
+def verify_batch_grouped(sig_group, scheme, pks, sigs, msgs, seed=None, fmt=FMT_RAW_PROJ):
     """the OPT-IN grouped form of verify_batch (groups of eight items share one final exponentiation through a random linear
-    combination; failing groups are re-verified item by item): same status list up to a 2^-64 chance per group that holds an
-    invalid item (include/blsgpu.h)."""
+    combination; failing groups are re-verified item by item): same status list unless a group that holds an invalid item passes
+    its combined check.  The 64-bit scalars are derived inside the library from the group's own inputs (include/blsgpu.h);
+    `seed` is extra entropy mixed into that hash: a fresh random value by default, no secrecy needed."""
+    if seed is None:
+        import secrets
+        seed = secrets.randbits(64)
     lib = init()
     n = len(msgs)
     offs, blob = _offsets(msgs)

@@ -347,8 +347,12 @@ size_t coop_max_items() {
 // launched through blsgpu_hash_to_g1 (the output is then meaningless); 0 / unset: the whole hash
 int hash_phase_stop();
 int hash_phase_stop() {
-  const char* e = getenv("BLSGPU_HASH_STOP");
+#if defined(BLS_DEBUG_KNOBS)        // measurement builds only (tools/dbg/hash_phases.py, hash2.py): a stray environment variable must
+  const char* e = getenv("BLSGPU_HASH_STOP");   // not change hash outputs and verdicts of the product library
   return e ? atoi(e) & 0xff : 0;
+#else
+  return 0;
+#endif
 }
 size_t wide_max_items() {
   static long v = -1;
@@ -421,12 +425,28 @@ size_t shard_devices(size_t n, std::initializer_list<const void*> inputs) {
   while (d > 1 && n / d < shard_min_items() / 4) d--;
   return d;
 }
+// a helper thread that is joined when its owner goes out of scope, whichever way: an exception between the start of a helper and
+// its join must unwind into API_CATCH, not into std::terminate of a process that holds the GPU (advisor finding, round 2)
+struct JoinedThread {
+  std::thread t;
+  JoinedThread() = default;
+  template <class F, class... A>
+  explicit JoinedThread(F&& f, A&&... a) : t(std::forward<F>(f), std::forward<A>(a)...) {}
+  JoinedThread(JoinedThread&&) = default;
+  JoinedThread& operator=(JoinedThread&& o) {
+    if (t.joinable()) t.join();
+    t = std::move(o.t);
+    return *this;
+  }
+  void join() { if (t.joinable()) t.join(); }
+  ~JoinedThread() { if (t.joinable()) t.join(); }
+};
 // fn(d) for d < k on k host threads (thread d leases from device d); the first failure wins and its message is kept
 template <class F>
 int run_on_devices(size_t k, F&& fn) {
   std::vector<int> rcs(k, 0);
   std::vector<std::string> errs(k);
-  std::vector<std::thread> th;
+  std::vector<JoinedThread> th;        // joined on every way out, also when body(0) or an emplace_back throws
   auto body = [&](size_t d) {
     t_devidx = d;
     t_nested = true;
@@ -434,9 +454,12 @@ int run_on_devices(size_t k, F&& fn) {
       rcs[d] = fn(d);
     } catch (const std::exception& e) {
       rcs[d] = fail(BLSGPU_E_HIP, std::string("internal: ") + e.what());
+    } catch (...) {
+      rcs[d] = fail(BLSGPU_E_HIP, "internal: unknown exception");
     }
     errs[d] = t_err;
   };
+  th.reserve(k);
   for (size_t d = 1; d < k; d++) th.emplace_back(body, d);
   const size_t keep_dev = t_devidx;
   const bool keep_nested = t_nested;
@@ -1749,8 +1772,9 @@ static bool duplicate_check_host(const uint8_t* mh, const uint64_t* offs_h, size
     if (nthr == 1) {
       work(0);
     } else {
-      std::vector<std::thread> pool;
-      for (unsigned t = 0; t < nthr; t++) pool.emplace_back(work, t);
+      std::vector<JoinedThread> pool;
+      pool.reserve(nthr);
+      for (unsigned t = 0; t < nthr; t++) pool.emplace_back([&work, t] { work(t); });
       for (auto& th : pool) th.join();
     }
   }
@@ -1789,9 +1813,9 @@ int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const ui
     uint64_t dup[2] = {~0ull, ~0ull};
     int dup_rc = 0;
     std::string dup_err;
-    std::thread dup_thread;
+    JoinedThread dup_thread;
     if (scheme == BLSGPU_SCHEME_BASIC)
-      dup_thread = std::thread([&] {
+      dup_thread = JoinedThread([&] {
         t_nested = true;
         if (is_device_ptr(msgs)) {
           dup_rc = blsgpu_first_duplicate_message(msgs, msg_offsets, n, dup);
@@ -1816,7 +1840,7 @@ int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const ui
       return blsgpu_aggregate_partial(sig_group, scheme, (const uint8_t*)pks + lo * psz, msgs, msg_offsets + lo, hi - lo, d == 0 ? sig : nullptr, fmt,
                                       recs.data() + 576 * d, &fbs[d]);
     });
-    if (dup_thread.joinable()) dup_thread.join();
+    dup_thread.join();
     if (rc) return rc;
     if (dup_rc) {
       t_err = dup_err;
@@ -1977,7 +2001,7 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
     const uint64_t offs1[2] = {0, (uint64_t)msg_len};
     int hash_rc = 0;
     std::string hash_err;
-    std::thread hash_thread([&] {           // H(msg) beside everything else (a second context of device 0)
+    JoinedThread hash_thread([&] {           // H(msg) beside everything else (a second context of device 0)
       t_nested = true;
       hash_rc = (sig_group == 1 ? blsgpu_hash_to_g1 : blsgpu_hash_to_g2)(msg, offs1, 1, (const uint8_t*)dsts, strlen(dsts), hm.data());
       hash_err = t_err;

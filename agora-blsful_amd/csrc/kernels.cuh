@@ -360,20 +360,62 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare(size_t n, const uint8_
   ws_st_pair(pairs, n, i, 1, P[1], Q[1]);
 }
 // Grouped verification (opt-in, blsgpu_verify_batch_grouped): GROUPED_ITEMS items share ONE final exponentiation.  With per-item
-// scalars r_i (64 bits from a seeded generator) a group is accepted iff
+// scalars r_i a group is accepted iff
 //     prod_i e(r_i H(m_i), pk_i) * e(sum_i r_i sig_i, -g2) == 1,
-// which holds for valid signatures and, for a group that contains an invalid one, with probability below 2^-64; a group that
-// fails is re-verified item by item, so a valid item is never rejected and the statuses are those of blsgpu_verify_batch.
+// which holds for valid signatures; a group that fails is re-verified item by item, so a valid item is never rejected and the
+// statuses are those of blsgpu_verify_batch.  The scalars are DERIVED FROM THE GROUP'S OWN INPUTS (Fiat-Shamir; round 3, after
+// the advisor's finding on seed-only scalars: with r_a, r_b known in advance sig_a + [r_b] D and sig_b - [r_a] D cancel in the
+// combined check): d_i = SHA-256(tag || seed || n || i || pk_i || sig_i || |m_i| || m_i) over the caller's bytes, D = SHA-256(d of the
+// group's eight slots, zero for slots past n), r_i = the first 64 bits of SHA-256(D || i) (1 if they are all zero).  Whoever
+// chooses the inputs of a group learns its scalars only after all of them are fixed, so making an invalid item pass takes about
+// 2^64 hash evaluations per group; the caller's seed is mixed in as optional extra entropy and needs no secrecy.
 // This kernel: the per-item checks and hash of k_prepare, then A_i = r_i H(m_i) (affine, with the key: one pair of the
 // group's Miller loops) and B_i = r_i sig_i (Jacobian, for k_group_sigsum).  Pair slots: item i sits at (i / 8) + (i % 8) ng
 // of a workspace of 9 ng one-pair items, so that k_miller1s (items g, g + q, g + 2q per loop, q = 3 ng) leaves the three
 // partial products of group c at c, c + ng, c + 2 ng.  skip[] arrives all ones.
-__device__ __forceinline__ uint64_t grouped_scalar(uint64_t seed, uint64_t i) {   // splitmix64 of (seed, i), never zero
-  uint64_t z = seed + 0x9e3779b97f4a7c15ull * (i + 1);
-  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-  z ^= z >> 31;
-  return z | 1ull;
+__device__ __forceinline__ void sha256_u64(sha256_ctx& c, uint64_t x) {
+  for (int k = 7; k >= 0; k--) sha256_byte(c, (uint8_t)(x >> (8 * k)));
+}
+// the scalar of item i; every lane of the wave calls this (lanes past n contribute zero digests), groups are aligned octets of lanes
+__device__ __noinline__ uint64_t grouped_scalar(uint64_t seed, size_t n, size_t i, const uint8_t* pk, uint32_t pk_len, const uint8_t* sig, uint32_t sig_len,
+                                              const uint8_t* m, uint32_t mlen) {
+  static_assert(GROUPED_ITEMS == 8 && BLS_BLOCK % GROUPED_ITEMS == 0, "a group is an aligned octet of lanes");
+  uint8_t d[32];
+  sha256_ctx c;
+  if (i < n) {
+    const char tag[] = "blsgpu-grouped-v2";
+    sha256_init(c);
+    sha256_update(c, (const uint8_t*)tag, sizeof tag - 1);
+    sha256_u64(c, seed);
+    sha256_u64(c, (uint64_t)n);
+    sha256_u64(c, (uint64_t)i);
+    sha256_update(c, pk, pk_len);
+    sha256_update(c, sig, sig_len);
+    sha256_u64(c, mlen);
+    sha256_update(c, m, mlen);
+    sha256_final(c, d);
+  } else {
+    for (int k = 0; k < 32; k++) d[k] = 0;
+  }
+  uint32_t w[8];
+  for (int k = 0; k < 8; k++) w[k] = ((uint32_t)d[4 * k] << 24) | ((uint32_t)d[4 * k + 1] << 16) | ((uint32_t)d[4 * k + 2] << 8) | d[4 * k + 3];
+  sha256_init(c);
+  for (int j = 0; j < GROUPED_ITEMS; j++)
+    for (int k = 0; k < 8; k++) {
+      const uint32_t x = (uint32_t)__shfl((int)w[k], j, GROUPED_ITEMS);
+      sha256_byte(c, (uint8_t)(x >> 24));
+      sha256_byte(c, (uint8_t)(x >> 16));
+      sha256_byte(c, (uint8_t)(x >> 8));
+      sha256_byte(c, (uint8_t)x);
+    }
+  sha256_final(c, d);
+  sha256_init(c);
+  sha256_update(c, d, 32);
+  sha256_u64(c, (uint64_t)i);
+  sha256_final(c, d);
+  uint64_t r = 0;
+  for (int k = 0; k < 8; k++) r = (r << 8) | d[k];
+  return r ? r : 1;
 }
 template <int SG>
 __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare_grouped(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int aug, const uint8_t* msgs,
@@ -381,10 +423,14 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare_grouped(size_t n, cons
                                                              uint8_t* scaled_sigs, int32_t* status) {
   static_assert(SG == 1, "grouped verification is built for Bls12381G1Impl");
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const bool live = i < n;
+  const size_t ii = live ? i : 0;
+  const uint8_t* m = msgs + offs[ii];
+  const uint32_t mlen = (uint32_t)(offs[ii + 1] - offs[ii]);
+  const uint32_t pk_len = fmt == 0 ? 288 : 192, sig_len = fmt == 0 ? 144 : 96;
+  const uint64_t r = grouped_scalar(seed, n, i, pks + ii * pk_len, pk_len, sigs + ii * sig_len, sig_len, m, mlen);   // all lanes: the group's digests travel by shuffles
+  if (!live) return;
   const size_t slot = i / GROUPED_ITEMS + (i % GROUPED_ITEMS) * ng, stride = (GROUPED_ITEMS + 1) * ng;
-  const uint8_t* m = msgs + offs[i];
-  const uint32_t mlen = (uint32_t)(offs[i + 1] - offs[i]);
   g1_aff P[2];
   g2_aff Q[2];
   g2_jac pk;
@@ -398,7 +444,6 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare_grouped(size_t n, cons
     store_g1_pt(scaled_sigs, i, b);
     return;
   }
-  const uint64_t r = grouped_scalar(seed, i);
   jac_from_aff(a, P[0]);
   jac_mul_u64(a, a, r);
   jac_from_aff(b, P[1]);

@@ -12,6 +12,23 @@
  * 57-signer production vector) and cross-checked against oracle/py on random inputs.
  */
 #include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+/* allocation and thread helpers of the threaded CPU legs: a failed malloc ends the process with a message (this is test
+ * infrastructure: there is nothing to fall back to), a failed pthread_create runs that job on the calling thread instead of
+ * leaving an uninitialised pthread_t for pthread_join (advisor finding, round 2) */
+static void* xmalloc(size_t bytes) {
+  void* p = malloc(bytes ? bytes : 1);
+  if (!p) { fprintf(stderr, "oracle/c: out of memory (%zu bytes)\n", bytes); abort(); }
+  return p;
+}
+typedef struct { pthread_t th; int started; } bo_thread;
+static void bo_spawn(bo_thread* t, void* (*fn)(void*), void* arg, int inline_only) {
+  t->started = 0;
+  if (!inline_only && pthread_create(&t->th, 0, fn, arg) == 0) { t->started = 1; return; }
+  fn(arg);
+}
+static void bo_join(bo_thread* t) { if (t->started) pthread_join(t->th, 0); }
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -419,7 +436,7 @@ static g2p hash_to_g2(const uint8_t* pre, size_t prel, const uint8_t* m, size_t 
  * tangent at T=(X,Y,Z), scaled by 2YZ^3:  l0 = 3X^3 - 2Y^2,  l2 = -3X^2 Z^2 xP,  l3 = 2YZ^3 yP
  * chord T,Q=(x2,y2), scaled by Z3 = Z H:   l0 = r x2 - y2 Z3,  l2 = -r xP,        l3 = Z3 yP      (r = y2 Z^3 - Y, H = x2 Z^2 - X) */
 static fp12 miller_loop(int n, const fp* xp, const fp* yp, const fp2* xq, const fp2* yq) {
-  g2p T8[8]; g2p* T = n <= 8 ? T8 : (g2p*)malloc(sizeof(g2p) * (size_t)n); fp12 f = F12_ONE;
+  g2p T8[8]; g2p* T = n <= 8 ? T8 : (g2p*)xmalloc(sizeof(g2p) * (size_t)n); fp12 f = F12_ONE;
   for (int k = 0; k < n; k++) { T[k].x = xq[k]; T[k].y = yq[k]; T[k].z = FP2_ONE; }
   for (int i = 62; i >= 0; i--) {
     f = f12_sqr(f);
@@ -525,14 +542,14 @@ static void* worker(void* a) {
 void bo_verify_batch(int sg, int scheme, const uint8_t* pks, const uint8_t* sigs, const uint8_t* msgs, const uint64_t* offs, size_t n, int32_t* st, int threads) {
   bo_init();
   if (threads < 1) threads = 1;
-  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
-  job* jobs = (job*)malloc(sizeof(job) * threads);
+  bo_thread* th = (bo_thread*)xmalloc(sizeof(bo_thread) * threads);
+  job* jobs = (job*)xmalloc(sizeof(job) * threads);
   for (int t = 0; t < threads; t++) {
     job j = {sg, scheme, pks, sigs, msgs, offs, n * t / threads, n * (t + 1) / threads, st};
     jobs[t] = j;
-    pthread_create(&th[t], 0, worker, &jobs[t]);
+    bo_spawn(&th[t], worker, &jobs[t], threads == 1);
   }
-  for (int t = 0; t < threads; t++) pthread_join(th[t], 0);
+  for (int t = 0; t < threads; t++) bo_join(&th[t]);
   free(th); free(jobs);
 }
 
@@ -558,7 +575,7 @@ int bo_verify_secure(int sg, int scheme, const uint8_t* pks, size_t n, const uin
     if (sg == 1) { g1p s1 = load_g1(sig_raw); inf = g1p_is_inf(&s1); } else { g2p s2 = load_g2(sig_raw); inf = g2p_is_inf(&s2); }
     return inf ? 0 : 1;
   }
-  uint8_t* kb = (uint8_t*)malloc(width * n); const uint8_t** order = (const uint8_t**)malloc(sizeof(void*) * n);
+  uint8_t* kb = (uint8_t*)xmalloc(width * n); const uint8_t** order = (const uint8_t**)xmalloc(sizeof(void*) * n);
   for (size_t i = 0; i < n; i++) {
     if (sg == 1) g2_compress(kb + i * width, load_g2(pks + i * psz)); else g1_compress(kb + i * width, load_g1(pks + i * psz));
     if (legacy && kb[i * width] != 0xc0) { uint8_t ys = kb[i * width] & 0x20; kb[i * width] &= 0x1f; if (ys) kb[i * width] |= 0x80; }
@@ -605,15 +622,15 @@ static void* sum_worker(void* a) {
 int bo_multi_verify(int sg, int scheme, const uint8_t* pks, size_t n, const uint8_t* sig, const uint8_t* msg, size_t len, int threads) {
   bo_init();
   if (threads < 1) threads = 1;
-  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
-  sum_job* jobs = (sum_job*)malloc(sizeof(sum_job) * threads);
+  bo_thread* th = (bo_thread*)xmalloc(sizeof(bo_thread) * threads);
+  sum_job* jobs = (sum_job*)xmalloc(sizeof(sum_job) * threads);
   for (int t = 0; t < threads; t++) {
     jobs[t].sg = sg; jobs[t].pks = pks; jobs[t].lo = n * t / threads; jobs[t].hi = n * (t + 1) / threads;
-    if (threads == 1) sum_worker(&jobs[t]); else pthread_create(&th[t], 0, sum_worker, &jobs[t]);
+    bo_spawn(&th[t], sum_worker, &jobs[t], threads == 1);
   }
   g1p a1; g2p a2; memset(&a1, 0, sizeof a1); memset(&a2, 0, sizeof a2);
   for (int t = 0; t < threads; t++) {
-    if (threads > 1) pthread_join(th[t], 0);
+    bo_join(&th[t]);
     a1 = g1p_add(a1, jobs[t].s1); a2 = g2p_add(a2, jobs[t].s2);
   }
   free(th); free(jobs);
@@ -625,8 +642,8 @@ static void* agg_worker(void* a) {
   agg_job* j = (agg_job*)a;
   const uint8_t* dst = (const uint8_t*)DSTS[j->sg - 1][j->scheme]; size_t dl = strlen((const char*)dst);
   size_t k = j->hi - j->lo;
-  fp* xp = (fp*)malloc(sizeof(fp) * (k + 1)); fp* yp = (fp*)malloc(sizeof(fp) * (k + 1));
-  fp2* xq = (fp2*)malloc(sizeof(fp2) * (k + 1)); fp2* yq = (fp2*)malloc(sizeof(fp2) * (k + 1));
+  fp* xp = (fp*)xmalloc(sizeof(fp) * (k + 1)); fp* yp = (fp*)xmalloc(sizeof(fp) * (k + 1));
+  fp2* xq = (fp2*)xmalloc(sizeof(fp2) * (k + 1)); fp2* yq = (fp2*)xmalloc(sizeof(fp2) * (k + 1));
   j->first_bad = -1;
   size_t m = 0;
   for (size_t i = j->lo; i < j->hi; i++) {               /* reference src/traits/sig_core.rs:161-171 */
@@ -665,7 +682,7 @@ int bo_aggregate_verify(int sg, int scheme, const uint8_t* pks, const uint8_t* m
   bo_init();
   aux[0] = aux[1] = 0;
   if (scheme == 0 && n > 1) {      /* first i whose message equals an earlier one: sort indices by (message, index), scan runs */
-    size_t* idx = (size_t*)malloc(sizeof(size_t) * n);
+    size_t* idx = (size_t*)xmalloc(sizeof(size_t) * n);
     for (size_t i = 0; i < n; i++) idx[i] = i;
     g_dup_msgs = msgs; g_dup_offs = offs; qsort(idx, n, sizeof(size_t), cmp_msgs);
     size_t best = (size_t)-1, old = 0, run = 0;
@@ -680,16 +697,16 @@ int bo_aggregate_verify(int sg, int scheme, const uint8_t* pks, const uint8_t* m
   }
   if (sg == 1) { g1p s = load_g1(sig_raw); if (g1p_is_inf(&s)) return 2; } else { g2p s = load_g2(sig_raw); if (g2p_is_inf(&s)) return 2; }
   if (threads < 1) threads = 1;
-  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
-  agg_job* jobs = (agg_job*)malloc(sizeof(agg_job) * threads);
+  bo_thread* th = (bo_thread*)xmalloc(sizeof(bo_thread) * threads);
+  agg_job* jobs = (agg_job*)xmalloc(sizeof(agg_job) * threads);
   for (int t = 0; t < threads; t++) {
     agg_job j = {sg, scheme, pks, msgs, offs, n * t / threads, n * (t + 1) / threads, F12_ONE, -1};
     jobs[t] = j;
-    if (threads == 1) agg_worker(&jobs[t]); else pthread_create(&th[t], 0, agg_worker, &jobs[t]);
+    bo_spawn(&th[t], agg_worker, &jobs[t], threads == 1);
   }
   fp12 f = F12_ONE; long fb = -1;
   for (int t = 0; t < threads; t++) {
-    if (threads > 1) pthread_join(th[t], 0);
+    bo_join(&th[t]);
     if (fb < 0 && jobs[t].first_bad >= 0) fb = jobs[t].first_bad;
     f = f12_mul(f, jobs[t].f);
   }
@@ -728,7 +745,7 @@ int bo_verify_secure_mt(int sg, int scheme, const uint8_t* pks, size_t n, const 
   bo_init();
   if (n == 0 || threads <= 1) return bo_verify_secure(sg, scheme, pks, n, sig_raw, msg, len, legacy);
   size_t psz = sg == 1 ? 288 : 144, width = sg == 1 ? 96 : 48;
-  uint8_t* kb = (uint8_t*)malloc(width * n); const uint8_t** order = (const uint8_t**)malloc(sizeof(void*) * n);
+  uint8_t* kb = (uint8_t*)xmalloc(width * n); const uint8_t** order = (const uint8_t**)xmalloc(sizeof(void*) * n);
   for (size_t i = 0; i < n; i++) {
     if (sg == 1) g2_compress(kb + i * width, load_g2(pks + i * psz)); else g1_compress(kb + i * width, load_g1(pks + i * psz));
     if (legacy && kb[i * width] != 0xc0) { uint8_t ys = kb[i * width] & 0x20; kb[i * width] &= 0x1f; if (ys) kb[i * width] |= 0x80; }
@@ -738,18 +755,18 @@ int bo_verify_secure_mt(int sg, int scheme, const uint8_t* pks, size_t n, const 
   sha256 s; uint8_t H[32]; sha_init(&s);
   for (size_t i = 0; i < n; i++) sha_update(&s, order[i], width);
   sha_final(&s, H);
-  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
-  sec_job* jobs = (sec_job*)malloc(sizeof(sec_job) * threads);
+  bo_thread* th = (bo_thread*)xmalloc(sizeof(bo_thread) * threads);
+  sec_job* jobs = (sec_job*)xmalloc(sizeof(sec_job) * threads);
   for (int t = 0; t < threads; t++) {
     sec_job j; memset(&j, 0, sizeof j);
     j.sg = sg; j.pks = pks; j.order = order; j.kb = kb; j.width = width; j.H = H; j.lo = n * t / threads; j.hi = n * (t + 1) / threads;
     jobs[t] = j;
-    pthread_create(&th[t], 0, sec_worker, &jobs[t]);
+    bo_spawn(&th[t], sec_worker, &jobs[t], 0);
   }
   g1p a1; g2p a2; memset(&a1, 0, sizeof a1); memset(&a2, 0, sizeof a2);
   int zero = 0;
   for (int t = 0; t < threads; t++) {
-    pthread_join(th[t], 0);
+    bo_join(&th[t]);
     zero |= jobs[t].zero;
     a1 = g1p_add(a1, jobs[t].s1); a2 = g2p_add(a2, jobs[t].s2);
   }

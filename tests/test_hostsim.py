@@ -227,6 +227,29 @@ def test_verify_items(hs):
             assert hs.hs_verify(sg, pkraw(pk, rng), sigraw(None), aug, m, len(m), d, len(d)) == 2
             assert hs.hs_verify(sg, pkraw(None), sigraw(sig, rng), aug, m, len(m), d, len(d)) == 3
             assert hs.hs_verify(sg, pkraw(None), sigraw(None), aug, m, len(m), d, len(d)) == 2
+    # a RAW signature with a cofactor-torsion component (T1 = [r] R1 lies in r E1(Fp), where the reduced pairing is trivial): the same
+    # verdict in the cleared form (pair (sig, -g2)) and in the uncleared one the kernels run (pair (sig, -[c] g2)); a RAW key outside G2
+    # is never accepted (advisor's low finding / VERDICT r2 weak #1; the GPU twin is tests/test_gpu_round2.py)
+    C = ref.G1Impl
+    while True:
+        x = rng.randrange(P)
+        y = c.fp_sqrt(c.E1.rhs(x))
+        T1 = c.E1.mul((x, y), c.R) if y is not None else None
+        if T1 is not None:
+            break
+    while True:
+        x = (rng.randrange(P), rng.randrange(P))
+        y = c.f2_sqrt(c.E2.rhs(x))
+        T2 = c.E2.mul((x, y), c.R) if y is not None else None
+        if T2 is not None:
+            break
+    sk, m, d = 424242, b'torsion', C.DST[ref.POP]
+    pk, sig = ref.public_key(C, sk), ref.sign(C, ref.POP, sk, m)
+    for nc in (1, 0):
+        for mg in (1, 0):
+            no_clear.value, merged.value = nc, mg
+            assert hs.hs_verify(1, util.g2_raw(pk, rng), util.g1_raw(c.E1.add(sig, T1), rng), 0, m, len(m), d, len(d)) == 0
+            assert hs.hs_verify(1, util.g2_raw(c.E2.add(pk, T2), rng), util.g1_raw(sig, rng), 0, m, len(m), d, len(d)) == 1
     no_clear.value = 1
     merged.value = 1
 
@@ -319,3 +342,17 @@ def test_msm2_per_item_functions(hs):
         for W in (9, 10, 13, 22):           # window counts that divide the bits evenly and unevenly (widths differ by one)
             hs.hs_msm2_small(group, n, blob, sb, W, o1)
             assert o1.raw[:48 * group] == comp(want), (group, W)
+
+
+def test_device_headers_under_ubsan(tmp_path):
+    """The device arithmetic headers as host C++ once more with -fsanitize=undefined -fno-sanitize-recover (signed overflow of the
+    lazy limbs, shifts, misaligned accesses): the pairing and verification tests of this file in a child process on that build."""
+    import subprocess
+    import sys
+    so = str(tmp_path / 'libhostsim_ubsan.so')
+    subprocess.check_call(['g++', '-O1', '-g', '-DBLS_TRACK_BOUNDS', '-fsanitize=undefined', '-fno-sanitize-recover=undefined', '-shared', '-fPIC', '-o', so,
+                           os.path.join(util.ROOT, 'tests', 'hostsim', 'hostsim.cpp')])
+    env = dict(os.environ, BLS_HOSTSIM_SO=so)
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(util.ROOT, 'tests', 'test_hostsim.py'), '-q', '-x', '-p', 'no:cacheprovider',
+                        '-k', 'fp_ops or fp12_ops or pairing_values or verify_items or g2_split or msm2'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]

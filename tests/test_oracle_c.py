@@ -145,3 +145,21 @@ def test_c_oracle_config_legs_vs_python_oracle(bo):
             for th in (1, 3):
                 assert bo.bo_verify_secure_mt(sg, 0, V(praw), n, V(sagg), m1, len(m1), mode, th) == 0
                 assert bo.bo_verify_secure_mt(sg, 0, V(praw), n - 1, V(sagg), m1, len(m1), mode, th) == 1
+
+
+def test_c_oracle_threaded_legs_under_sanitizers(tmp_path):
+    """oracle/c/san_driver.c: the threaded CPU legs (config 4's 16,384-pair bo_aggregate_verify on 16 threads and on one, its error
+    precedence, bo_multi_verify, bo_verify_secure[_mt] incl. the legacy transcode, a threaded bo_verify_batch) built with
+    -fsanitize=address,undefined -fno-sanitize-recover: no finding, and the expected status codes.  Added after a round-2 run of
+    tools/bench_configs.py dumped core in its config-4 section without an explanation: not reproducible --
+    the committed code is clean at the sizes of that run; the 1-thread leg at the full 16,384 pairs (2 minutes under ASan) was
+    run by hand with the same result."""
+    exe = str(tmp_path / 'san_driver')
+    src = os.path.join(util.ROOT, 'oracle', 'c', 'san_driver.c')
+    subprocess.check_call(['gcc', '-O1', '-g', '-fsanitize=address,undefined', '-fno-sanitize-recover=undefined', '-Wall', '-Wno-unused-function',
+                           '-o', exe, src, '-lpthread'])
+    r = subprocess.run([exe, '16384', '16'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'san_driver ok' in r.stdout
+    r = subprocess.run([exe, '512', '1'], capture_output=True, text=True, timeout=600)       # the same legs inline on the calling thread
+    assert r.returncode == 0, r.stdout + r.stderr
