@@ -13,9 +13,12 @@ over ranks.
   3  MultiSignature::verify, 1,048,576 G2 public keys, one message
   4  AggregateSignature::verify, 262,144 distinct (pk, msg) pairs, Basic scheme (duplicate-message rule on)
   5  verify_secure, 65,536 public keys (--variant g1m | g2m | g2l: Bls12381G1Impl Modern, Bls12381G2Impl Modern / Legacy)
-The default run also times a few steps of configs 3-5 AFTER the headline measurement and reports them under
-"other_configs" of the same JSON line (--no-extras switches that off), so that a multi-GPU launch of the default command
-yields hardware numbers for the sharded configs too.
+The default run also times a few steps of configs 3-5 (and of config 2 for Bls12381G2Impl) AFTER the headline measurement and
+reports them under "other_configs" of the same JSON line (--no-extras switches that off) AT EVERY N: the driver's
+`torch.distributed.run ... bench.py --gpus 8` therefore measures BASELINE's 8-GPU configs (4 and 5) over RCCL too.  After each
+of those entries the ranks agree on its outcome through the rendezvous store before anybody enters the next collective; a
+failure ends the ride-along and every rank exits non-zero (--fail-extra rehearses that; --backend gloo rehearses the N > 1
+control flow with several ranks on one card).
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
   roofline      the dominant kernel's algorithmic HBM bytes / its HIP-event-measured duration vs 8 TB/s (and vs 6.29 TB/s)
@@ -41,8 +44,9 @@ FIXED_MSG = hashlib.sha256(SEED + b'fixed').digest()
 ALG_BYTES_PER_VERIFY = 468          # pk 288 + sig 144 + msg 32 + status 4
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_MEASURED_GBS = 6290.0           # same guide: measured copy bandwidth (BASELINE.md section 4 asks for both)
-FPMUL_PEAK_G = 66.6                 # profiles/ubench_r01_fp28.txt: best measured Fp-multiplication-equivalent rate of the 28-bit-limb
-                                    # multiplier chip-wide (fused two-product pass, 2-4 waves/SIMD): the integer-VALU roofline
+FPMUL_PEAK_G = 74.0                 # profiles/r03_ubench3_mad_rates.txt: the fused two-product multiplier pass alone, chip-wide, 2-4 waves/SIMD
+                                    # (72-76 G multiplication-equivalents/s over runs and boxes; round 1 measured 66.6 with lazy signed limbs)
+FPMUL_MAD_ONLY_G = 85.0             # the same pipe with nothing but multiply-adds: 33.5 T lane-MAD/s / 392 per multiplication
 CONFIG_SIZES = {3: 1048576, 4: 262144, 5: 65536}
 VARIANTS = {'g1m': (1, 0, 'Bls12381G1Impl/Modern'), 'g2m': (2, 0, 'Bls12381G2Impl/Modern'), 'g2l': (2, 1, 'Bls12381G2Impl/Legacy')}
 
@@ -115,14 +119,22 @@ class Harness:
         self.world = int(os.environ.get('WORLD_SIZE', '1'))
         assert self.world == args.gpus, 'launch with torch.distributed.run --nproc-per-node == --gpus'
         assert torch.cuda.is_available(), 'bench.py needs a GPU: the product has no CPU path'
-        torch.cuda.set_device(self.local_rank)
-        self.dev = torch.device('cuda', self.local_rank)
+        # --backend gloo rehearses the N > 1 control flow on a box with fewer cards than ranks (ranks then share cards)
+        ndev = torch.cuda.device_count()
+        assert args.backend == 'gloo' or self.local_rank < ndev, 'one GPU per rank with --backend nccl'
+        torch.cuda.set_device(self.local_rank % ndev)
+        self.dev = torch.device('cuda', self.local_rank % ndev)
+        self.backend = args.backend
         self.dist = None
-        if self.world > 1 or 'RANK' in os.environ:      # under torch.distributed.run: RCCL init / barrier / collectives
+        self.store = None
+        if self.world > 1 or 'RANK' in os.environ:      # under torch.distributed.run: RCCL (or gloo) init / barrier / collectives
             import torch.distributed as dist_mod
             self.dist = dist_mod
             # a bounded timeout: a rank that fails outside a collective must not leave the others waiting for ever
-            self.dist.init_process_group('nccl', device_id=self.dev, timeout=datetime.timedelta(seconds=180))
+            kw = {'device_id': self.dev} if args.backend == 'nccl' else {}
+            self.dist.init_process_group(args.backend, timeout=datetime.timedelta(seconds=args.pg_timeout), **kw)
+            self.store = dist_mod.distributed_c10d._get_default_store()
+        self.pg_timeout = args.pg_timeout
         import __graft_entry__ as ge
         self.pkg = ge.import_pkg()
         self.api = self.pkg.api
@@ -141,6 +153,23 @@ class Harness:
             self.dist.barrier()
             self.torch.cuda.synchronize()
 
+    def rccl_ranks(self):
+        """what the process group itself reports (1 without one): recorded in every result entry"""
+        return self.dist.get_world_size() if self.dist is not None else 1
+
+    def agree(self, tag, error):
+        """Error agreement after a unit of work that contains collectives: every rank posts its outcome in the rendezvous STORE
+        (TCP key-value, independent of the collective backend's state) and reads everybody's.  Returns the list of error
+        strings (empty: all ranks succeeded).  A rank that never posts (dead, or stuck in a collective past the process-group
+        timeout) makes the wait raise: the caller exits non-zero instead of hanging."""
+        if self.store is None:
+            return [error] if error else []
+        self.store.set('agree/%s/%d' % (tag, self.rank), error or 'ok')
+        keys = ['agree/%s/%d' % (tag, r) for r in range(self.world)]
+        self.store.wait(keys, datetime.timedelta(seconds=self.pg_timeout + 30))
+        vals = [self.store.get(k).decode() for k in keys]
+        return ['rank %d: %s' % (r, v) for r, v in enumerate(vals) if v != 'ok']
+
     def timed(self, step, steps, warmup, after_warmup=None):
         """warmup untimed steps, then exactly `steps` steps between fences; (seconds = max over ranks, kernel profile)."""
         for _ in range(warmup):
@@ -158,7 +187,7 @@ class Harness:
         prof = self.api.profile_read()
         self.api.profile_enable(False)
         if self.dist is not None:
-            t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev)
+            t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev if self.backend == 'nccl' else 'cpu')
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, prof
@@ -371,13 +400,18 @@ def run_config2_grouped(h, steps, warmup, n, tampered_every):
 
 
 # ------------------------------------------------------------------------------------------------- config 2 (headline)
-def run_config2(h, args):
+def run_config2(h, args, sg=1, steps=None, warmup=None, headline=True):
+    """n independent Signature::verify items per GPU.  sg = 1: Bls12381G1Impl (BASELINE configs[1], the headline); sg = 2: the same
+    batch for Bls12381G2Impl (keys in G1, signatures in G2: the orientation Dash and the reference's KATs use; reference
+    src/impls/g2.rs:15-17,36-38) -- an other_configs entry.  headline: with roofline traffic, census fraction and the CPU leg."""
     torch, api, lib = h.torch, h.api, h.lib
     n, rank, world, dev = args.n, h.rank, h.world, h.dev
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     P = h.P
     # ---- synthetic inputs, signed on the device, left resident in HBM
     _, msgs = gen_inputs(n, rank * n)
-    d_pks, d_sigs, d_msgs, d_offs = h.sign(1, api.POP, n, rank * n, b''.join(msgs), 32)
+    d_pks, d_sigs, d_msgs, d_offs = h.sign(sg, api.POP, n, rank * n, b''.join(msgs), 32)
     d_status = torch.full((n,), -7, dtype=torch.int32, device=dev)
     # negative controls: flip one bit of the message of 1 % of the items after signing
     bad = torch.arange(37, n, 100, device=dev)
@@ -387,44 +421,50 @@ def run_config2(h, args):
     torch.cuda.synchronize()
 
     def step():
-        api._check(lib.blsgpu_verify_batch(1, api.POP, P(d_pks), P(d_sigs), P(d_msgs), P(d_offs), n, api.FMT_RAW_PROJ, P(d_status)))
+        api._check(lib.blsgpu_verify_batch(sg, api.POP, P(d_pks), P(d_sigs), P(d_msgs), P(d_offs), n, api.FMT_RAW_PROJ, P(d_status)))
 
     def check():
         assert torch.equal(d_status, expect), 'verdict vector differs from the expected one'
 
-    dt, prof = h.timed(step, args.steps, args.warmup, after_warmup=check)
+    dt, prof = h.timed(step, steps, warmup, after_warmup=check)
     check()
     out = None
     if rank == 0:
+        impl = 'Bls12381G1Impl' if sg == 1 else 'Bls12381G2Impl'
         dom = max(prof.items(), key=lambda kv: kv[1][0])
-        rl = roofline_of(prof, ALG_BYTES_PER_VERIFY * n)
-        rl['note'] = 'integer-VALU bound path: see valu_roofline; traffic is scratch (by-reference Fp12 operands), not input data'
+        alg = ALG_BYTES_PER_VERIFY if sg == 1 else 144 + 288 + 32 + 4
+        rl = roofline_of(prof, alg * n)
+        rl['note'] = 'integer-VALU bound path: see valu_roofline; the traffic beyond the input bytes is the merged line values streamed between the two Miller kernels'
         out = {
-            'metric': 'BLS12-381 sig verifications/sec (batch)', 'value': world * n * args.steps / dt, 'unit': 'verifications/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'metric': 'BLS12-381 sig verifications/sec (batch)', 'value': world * n * steps / dt, 'unit': 'verifications/s',
+            'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': dt / steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u32', 'data': 'synthetic',
-            'config': {'workload': 'configs[1]: %d independent Signature<Bls12381G1Impl>::verify items per GPU, 32-byte messages, '
-                                   'PoP scheme, RAW_PROJ inputs resident in HBM, 1%% tampered' % n,
+            'config': {'workload': 'configs[1]: %d independent Signature<%s>::verify items per GPU, 32-byte messages, '
+                                   'PoP scheme, RAW_PROJ inputs resident in HBM, 1%% tampered' % (n, impl),
                        'items_per_gpu': n, 'sharding': 'independent batches per rank, no collective'},
+            'rccl_ranks': h.rccl_ranks(), 'collective_ms_per_step': 0.0,
             'roofline': rl,
             'kernel_ms': {k: round(v[0] / v[1], 3) for k, v in prof.items()},
         }
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(pmc):
+        if headline and os.path.exists(pmc):
             # HBM-side bytes per launch of the dominant kernel from rocprofv3 --pmc passes of this same command
             # (FETCH_SIZE and WRITE_SIZE in separate passes, KB units; FETCH_SIZE doubled: on gfx950 it tallies
-            # 128-byte requests as 64 B -- MI355X_MICROARCH.md, HBM section).  Recorded by tools/pmc_traffic.py.
+            # 128-byte requests as 64 B -- MI355X_MICROARCH.md, HBM section).  Recorded by tools/profile_round.sh.
             t = json.load(open(pmc)).get(dom[0])
             if t:
                 out['roofline']['traffic'] = (2 * t['FETCH_SIZE'] + t['WRITE_SIZE']) * 1024.0
                 out['roofline']['traffic_source'] = t.get('source', 'profiles/pmc_traffic.json')
         fpm = os.path.join(ROOT, 'profiles', 'fpmul_counts.json')
         if os.path.exists(fpm):
-            cnt = json.load(open(fpm))['verify_g1impl_fp_mul_equiv']
-            rate = cnt * world * n * args.steps / dt / 1e9
-            out['valu_roofline'] = {'fp_mul_per_verify': cnt, 'achieved_per_gpu': rate / world, 'peak': FPMUL_PEAK_G, 'unit': 'G fp_mul/s',
-                                    'frac': rate / world / FPMUL_PEAK_G}
-        if world == 1:
+            cnt = json.load(open(fpm))['verify_g1impl_fp_mul_equiv' if sg == 1 else 'verify_g2impl_fp_mul_equiv']
+            rate = cnt * world * n * steps / dt / 1e9
+            out['valu_roofline'] = {'fp_mul_per_verify': cnt, 'achieved_per_gpu': rate / world, 'unit': 'G fp_mul/s',
+                                    'peak': FPMUL_PEAK_G, 'frac': rate / world / FPMUL_PEAK_G,
+                                    'peak_note': 'the fused multiplier pass alone at 2-4 waves per SIMD (profiles/r03_ubench3_mad_rates.txt)',
+                                    'peak_mad_only': FPMUL_MAD_ONLY_G, 'frac_of_mad_only': rate / world / FPMUL_MAD_ONLY_G,
+                                    'peak_mad_only_note': 'v_mad_i64_i32 alone: 33.5 T lane-MAD/s / 392 multiply-adds per multiplication'}
+        if headline and world == 1:
             sample = min(args.cpu_sample, n)
             msgs_tampered = list(msgs)
             for i in range(37, n, 100):
@@ -442,7 +482,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--n', type=int, default=65536, help='items per GPU (config 2)')
+    ap.add_argument('--n', '--items', dest='n', type=int, default=65536,
+                    help='items per GPU (config 2); under torch.distributed.run spell it --items: the launcher reads a bare --n as an abbreviation of its own options')
     ap.add_argument('--cpu-sample', type=int, default=4096)
     ap.add_argument('--config', type=int, default=2, choices=[2, 3, 4, 5])
     ap.add_argument('--variant', default='g1m', choices=sorted(VARIANTS))
@@ -450,33 +491,53 @@ def main():
     ap.add_argument('--keys-as-deserialised', action='store_true', help='config 3: feed keys with Z = 1 (what a verifier holds after decoding the wire bytes)')
     ap.add_argument('--grouped', type=int, default=None, metavar='K', help='config 2 through the opt-in grouped entry with every K-th item tampered (0: all valid); not the headline')
     ap.add_argument('--no-extras', action='store_true', help='config 2 only: do not time configs 3-5 after the headline measurement')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend; gloo rehearses the N > 1 control flow with ranks sharing a card')
+    ap.add_argument('--pg-timeout', type=int, default=180, help='process-group timeout in seconds')
+    ap.add_argument('--fail-extra', default=None, metavar='NAME[:RANK]', help='test aid: make that other_configs entry raise on that rank (default 0) before its collectives')
     args = ap.parse_args()
     h = Harness(args)
     common = {'n_gpus': h.world, 'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': True, 'vs_baseline': None, 'dtype': 'u32',
               'data': 'synthetic'}
+    exit_code = 0
     if args.config == 2 and args.grouped is not None:
         out = run_config2_grouped(h, args.steps, args.warmup, args.n, args.grouped)
         out.update(common)
     elif args.config == 2:
         out = run_config2(h, args)
-        # the other configs ride along only in the one-GPU run: at N > 1 they are collectives over RCCL, and a rank that fails
-        # inside one would leave the others waiting -- the scaling run measures the headline only (use --config 3|4|5 --gpus N)
-        if not args.no_extras and h.world == 1:
+        if not args.no_extras:
+            # The other BASELINE configs ride along at every N: at N > 1 they are collectives over RCCL, so after each one the
+            # ranks AGREE on its outcome through the rendezvous store (Harness.agree) before anybody enters the next collective.
+            # An entry that failed on some rank is recorded as an error and ends the ride-along: the headline line is still
+            # printed, every rank then exits non-zero (a collective that lost a rank ends at the process-group timeout).
             extras = {}
             k = max(1, min(args.steps, 3))
-            for name, fn in (('config3_multi_verify_1048576', lambda: run_config3(h, k, 1)),
-                             ('config4_aggregate_verify_262144', lambda: run_config4(h, k, 1)),
-                             ('config5_verify_secure_65536_g1impl_modern', lambda: run_config5(h, k, 1, 'g1m')),
-                             ('config5_verify_secure_65536_g2impl_modern', lambda: run_config5(h, k, 1, 'g2m')),
-                             ('config5_verify_secure_65536_g2impl_legacy', lambda: run_config5(h, k, 1, 'g2l')),
-                             ('config2_grouped_optin_1pct_tampered', lambda: run_config2_grouped(h, k, 1, args.n, 100)),
-                             ('config2_grouped_optin_all_valid', lambda: run_config2_grouped(h, k, 1, args.n, 0))):
+            size = lambda c: min(CONFIG_SIZES[c], args.size) if args.size else None  # noqa: E731
+            plan = [('config3_multi_verify_1048576', lambda: run_config3(h, k, 1, size(3))),
+                    ('config4_aggregate_verify_262144', lambda: run_config4(h, k, 1, size(4))),
+                    ('config5_verify_secure_65536_g1impl_modern', lambda: run_config5(h, k, 1, 'g1m', size(5))),
+                    ('config5_verify_secure_65536_g2impl_modern', lambda: run_config5(h, k, 1, 'g2m', size(5))),
+                    ('config5_verify_secure_65536_g2impl_legacy', lambda: run_config5(h, k, 1, 'g2l', size(5))),
+                    ('config2_g2impl_65536', lambda: run_config2(h, args, sg=2, steps=k, warmup=1, headline=False)),
+                    ('config2_grouped_optin_1pct_tampered', lambda: run_config2_grouped(h, k, 1, args.n, 100)),
+                    ('config2_grouped_optin_all_valid', lambda: run_config2_grouped(h, k, 1, args.n, 0))]
+            fail_name, _, fail_rank = (args.fail_extra or '').partition(':')
+            for name, fn in plan:
+                err, r = None, None
                 try:
+                    if fail_name == name and h.rank == int(fail_rank or 0):
+                        raise RuntimeError('--fail-extra: deliberate failure before the collectives of this entry')
                     r = fn()
-                    r.update({'n_gpus': h.world, 'steps': k, 'warmup': 1})
-                    extras[name] = r
                 except Exception as e:  # noqa: BLE001 -- the headline line must survive a failing extra
-                    extras[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+                    err = '%s: %s' % (type(e).__name__, e)
+                errs = h.agree(name, err)
+                if errs:
+                    extras[name] = {'error': '; '.join(errs)}
+                    exit_code = 3
+                    break
+                if r is not None:
+                    r.update({'n_gpus': h.world, 'steps': k, 'warmup': 1, 'rccl_ranks': h.rccl_ranks()})
+                    r.setdefault('collective_ms_per_step', 0.0)
+                    extras[name] = r
                 h.torch.cuda.empty_cache()
             if out is not None:
                 out['other_configs'] = extras
@@ -488,8 +549,14 @@ def main():
         else:
             out = run_config5(h, args.steps, args.warmup, args.variant, args.size)
         out.update(common)
+        out['rccl_ranks'] = h.rccl_ranks()
     if h.rank == 0:
         os.write(RESULT_FD, (json.dumps(out) + '\n').encode())
+    if exit_code:
+        # ranks may be stuck in (or have timed out of) a collective: no orderly teardown, just leave -- non-zero, all of them
+        sys.stderr.write('bench.py rank %d: an other_configs entry failed on some rank, exiting %d\n' % (h.rank, exit_code))
+        sys.stderr.flush()
+        os._exit(exit_code)
     if h.dist is not None:
         h.dist.destroy_process_group()
 
