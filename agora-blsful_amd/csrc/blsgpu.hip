@@ -47,6 +47,8 @@ struct Ctx {
   size_t hpin_cap = 0;
   uint8_t* hsmall = nullptr;      // pinned 64 KiB for the small host <-> device records of a call (offsets, flags, verdicts):
   size_t hsmall_off = 0;          // they outlive every early return, unlike stack variables
+  hipStream_t tail = nullptr;     // the leftover items of a pairing product (run_miller_product) run here beside the main chunks
+  hipEvent_t ev_tail_fork = nullptr, ev_tail_join = nullptr;
   uint32_t* lines_ws = nullptr;   // merged line values on their way from k_lines2s to k_millerf2s (kernels.cuh): 19 KB per lane
   size_t lines_cap = 0;           // bytes; grown on demand, kept between calls
   // optional per-kernel timing with HIP events on `stream` (blsgpu_profile_*)
@@ -89,6 +91,10 @@ struct Lease {
     if (c->side2 && hipStreamQuery(c->side2) != hipSuccess) {
       (void)hipGetLastError();
       (void)hipStreamSynchronize(c->side2);
+    }
+    if (c->tail && hipStreamQuery(c->tail) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipStreamSynchronize(c->tail);
     }
   }
 };
@@ -495,6 +501,18 @@ size_t miller_chunk_items() {
   return (size_t)v;
 }
 size_t lanes_for(size_t items) { return (2 * items + BLS_BLOCK - 1) / BLS_BLOCK * BLS_BLOCK; }
+// Row stride (in words) of the line workspace and the value store for that many lanes: NOT a power of two -- consecutive rows of
+// a lane are a stride apart, and with 2^k-byte strides the 70 rows a wave touches per step camp on the same HBM channels
+// (measured on the 262,144-lane chunks of config 4: BLSGPU_ROW_PAD=0 restores the bare stride for A/B runs)
+size_t row_stride(size_t lanes) {
+  static long pad = -1;
+  if (pad < 0) {
+    const char* e = getenv("BLSGPU_ROW_PAD");
+    pad = e ? atol(e) : 192;
+    if (pad < 0) pad = 0;
+  }
+  return lanes + (size_t)pad;
+}
 // the context's line workspace; 0 on success, non-zero (and no error recorded) when the device has no room for it
 int lines_reserve(Ctx* c, size_t bytes) {
   if (bytes <= c->lines_cap) return 0;
@@ -541,15 +559,23 @@ int run_pairing2(Ctx* c, size_t n, uint32_t* d_pairs, uint32_t* d_f, int32_t* d_
     // time: the chunk's merged line values pass through the context's line workspace.  BLSGPU_MILLER_V1=1, or no memory for
     // that workspace: the one-kernel loop of rounds 1 and 2.
     static const bool finalexp_v1 = getenv("BLSGPU_FINALEXP_V1") && atoi(getenv("BLSGPU_FINALEXP_V1"));   // A/B: the one-kernel final exponentiation of rounds 1 and 2
-    const size_t chunk = !fixed_g2 ? 0 : n < miller_chunk_items() ? n : miller_chunk_items();   // two general pairs: the one-kernel loop
-    if (chunk && lines_reserve(c, (size_t)MILLER_ENTRIES * LINE5_WORDS * 4 * lanes_for(chunk)) == 0) {
+    const size_t chunk = n < miller_chunk_items() ? n : miller_chunk_items();
+    const size_t words_per_lane = (size_t)MILLER_ENTRIES * (LINE5_WORDS + (fixed_g2 ? 0 : LINE3_WORDS_H));   // two general pairs: pair 0's plain lines too
+    if (chunk && lines_reserve(c, words_per_lane * 4 * row_stride(lanes_for(chunk))) == 0) {
       for (size_t first = 0; first < n; first += chunk) {
         const size_t cnt = n - first < chunk ? n - first : chunk;
-        const size_t lanes = lanes_for(cnt);
-        KL(KID_LINES, k_lines2s, dim3((unsigned)(lanes / BLS_BLOCK)), dim3(BLS_BLOCK), n, first, cnt, (const uint32_t*)d_pairs, (const int32_t*)d_status, c->lines_ws, lanes, fixed_g2);
-        KL(KID_MILLER2, k_millerf2s, dim3((unsigned)(lanes / BLS_BLOCK)), dim3(BLS_BLOCK), n, first, cnt, (const int32_t*)d_status, (const uint32_t*)c->lines_ws, lanes, d_f);
+        const size_t nlanes = lanes_for(cnt), lanes = row_stride(nlanes);       // `lanes` below: the row stride the kernels index with
+        uint32_t* lines3 = c->lines_ws + (size_t)MILLER_ENTRIES * LINE5_WORDS * lanes;
+        const dim3 grid((unsigned)(nlanes / BLS_BLOCK));
+        if (fixed_g2) {
+          KL(KID_LINES, k_lines2s, grid, dim3(BLS_BLOCK), n, first, cnt, (const uint32_t*)d_pairs, (const int32_t*)d_status, c->lines_ws, lines3, lanes, fixed_g2, 0);
+        } else {
+          KL(KID_LINES, k_lines2s, grid, dim3(BLS_BLOCK), n, first, cnt, (const uint32_t*)d_pairs, (const int32_t*)d_status, c->lines_ws, lines3, lanes, 0, 1);
+          KL(KID_LINES, k_lines2s, grid, dim3(BLS_BLOCK), n, first, cnt, (const uint32_t*)d_pairs, (const int32_t*)d_status, c->lines_ws, lines3, lanes, 0, 2);
+        }
+        KL(KID_MILLER2, k_millerf2s, grid, dim3(BLS_BLOCK), n, first, cnt, (const int32_t*)d_status, (const uint32_t*)c->lines_ws, lanes, d_f);
         // the chunk's line values are consumed: the same memory is the value store of the final exponentiation (3.4 KB per lane)
-        if (!finalexp_v1) KL(KID_FINALEXP, k_finalexp2s, dim3((unsigned)(lanes / BLS_BLOCK)), dim3(BLS_BLOCK), n, first, cnt, (const uint32_t*)d_f, c->lines_ws, lanes, d_status);
+        if (!finalexp_v1) KL(KID_FINALEXP, k_finalexp2s, grid, dim3(BLS_BLOCK), n, first, cnt, (const uint32_t*)d_f, c->lines_ws, lanes, d_status);
       }
       if (finalexp_v1) KL(KID_FINALEXP, k_finalexps, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_f, d_status);
     } else {
@@ -708,6 +734,86 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
   else
     KL(KID_PREPARE, k_prepare<2>, dim3(nb), dim3(BLS_BLOCK), n, d_pks, d_sigs, fmt, aug, d_msgs, d_offs, single_msg, dst, d_pairs, d_status, pre_status, two_lanes);
   return run_pairing2(c, n, d_pairs, d_f, d_status, sg == 1 ? 2 : 0);
+}
+
+// Miller loops of a pairing product over mm one-pair items (workspace stride given; flagged items contribute 1): leaves *outputs
+// partial products at the start of the Fp12 workspace.  Round 3: two items share a merged line value (k_linesp, two passes),
+// and one accumulator takes the values of `group` such pairs per step (k_millerfp).  The items are cut into chunks of 2 cnt
+// items whose lane-pair counts fill whole workgroups -- and whole machine rounds (65,536 lane pairs) when there are that many:
+// a single extra wave after a full round costs a lone wave's latency, ~7 ms -- and what is left (< 1,024 items: 262,145 pairs
+// leave one) goes through k_miller1s on the context's tail stream BESIDE the chunks.  BLSGPU_MILLER_V1=1, fewer than 4,096
+// items, or no memory for the line workspace: k_miller1s for everything.
+int run_miller_product(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs, int32_t* d_bad, uint32_t* d_f, size_t* outputs) {
+  const size_t chunk_max = 2 * miller_chunk_items(), round = 65536;
+  const size_t words_per_lane = (size_t)MILLER_ENTRIES * (LINE5_WORDS + LINE3_WORDS_H);
+  auto nice = [&](size_t pairs) {          // virtual items of the next chunk when `pairs` virtual items could still be formed
+    if (pairs > chunk_max) pairs = chunk_max;
+    return pairs >= round ? pairs / round * round : pairs / 32 * 32;
+  };
+  const size_t first_cnt = mm >= 4096 && chunk_max ? nice(mm / 2) : 0;
+  if (first_cnt == 0 || lines_reserve(c, words_per_lane * 4 * row_stride(lanes_for(first_cnt))) != 0) {
+    MILLER1_LAUNCH(mm, stride, d_pairs, d_bad, d_f);
+    HIPCK(hipGetLastError());
+    *outputs = MILLER1_OUTPUTS(mm);
+    return 0;
+  }
+  // the plan: chunks [lo, lo + 2 cnt) until fewer than 1,024 items are left
+  struct Chunk { size_t lo, cnt; };
+  std::vector<Chunk> plan;
+  size_t lo = 0;
+  while (mm - lo >= 1024) {
+    const size_t cnt = nice((mm - lo) / 2);
+    plan.push_back({lo, cnt});
+    lo += 2 * cnt;
+  }
+  size_t out0 = 0;
+  for (const Chunk& ch : plan) {
+    int group = (int)(ch.cnt / round);              // one machine round of accumulators when the chunk has several rounds of line values
+    if (group < 1) group = 1;
+    if (group > 4) group = 4;
+    out0 += (ch.cnt + group - 1) / group;
+  }
+  const size_t left = mm - lo, left_out0 = out0;
+  if (left) {                                       // first in time: a few waves whose latency hides under the chunks
+    if (!c->tail) {
+      HIPCK(hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking));
+      HIPCK(hipEventCreateWithFlags(&c->ev_tail_fork, hipEventDisableTiming));
+      HIPCK(hipEventCreateWithFlags(&c->ev_tail_join, hipEventDisableTiming));
+    }
+    HIPCK(hipEventRecord(c->ev_tail_fork, c->stream));
+    HIPCK(hipStreamWaitEvent(c->tail, c->ev_tail_fork, 0));
+    hipLaunchKernelGGL(k_miller1s, dim3(blocks_for(2 * MILLER1_OUTPUTS(left))), dim3(BLS_BLOCK), 0, c->tail, left, stride, (const uint32_t*)(d_pairs + lo),
+                       (const int32_t*)(d_bad + lo), d_f + left_out0);
+    const hipError_t e1 = hipGetLastError(), e2 = hipEventRecord(c->ev_tail_join, c->tail);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+      (void)hipStreamSynchronize(c->tail);
+      return fail(BLSGPU_E_HIP, "tail-stream launch failed");
+    }
+  }
+  out0 = 0;
+  for (const Chunk& ch : plan) {
+    const size_t nlanes = lanes_for(ch.cnt), lanes = row_stride(nlanes);
+    uint32_t* lines3 = c->lines_ws + (size_t)MILLER_ENTRIES * LINE5_WORDS * lanes;
+    int group = (int)(ch.cnt / round);
+    if (group < 1) group = 1;
+    if (group > 4) group = 4;
+    const size_t q = (ch.cnt + group - 1) / group;
+    const dim3 grid((unsigned)(nlanes / BLS_BLOCK));
+    // the chunk's items as a workspace of its own: item v pairs with item v + cnt
+    const uint32_t* pw = d_pairs + ch.lo;
+    const int32_t* bw = d_bad + ch.lo;
+    KL(KID_LINES, k_linesp, grid, dim3(BLS_BLOCK), 2 * ch.cnt, ch.cnt, stride, pw, bw, c->lines_ws, lines3, lanes, (size_t)0, ch.cnt, 1);
+    KL(KID_LINES, k_linesp, grid, dim3(BLS_BLOCK), 2 * ch.cnt, ch.cnt, stride, pw, bw, c->lines_ws, lines3, lanes, (size_t)0, ch.cnt, 2);
+    KL(KID_MILLER1, k_millerfp, dim3(blocks_for(2 * q)), dim3(BLS_BLOCK), ch.cnt, q, group, (const uint32_t*)c->lines_ws, lanes, d_f, stride, out0);
+    out0 += q;
+  }
+  if (left) {
+    HIPCK(hipStreamWaitEvent(c->stream, c->ev_tail_join, 0));
+    out0 += MILLER1_OUTPUTS(left);
+  }
+  HIPCK(hipGetLastError());
+  *outputs = out0;
+  return 0;
 }
 
 // product of m Fp12 values in a workspace (stride given) folded into item 0
@@ -1187,6 +1293,9 @@ static void release_devices() {
       (void)hipStreamSynchronize(c->stream);
       if (c->arena) (void)hipFree(c->arena);
       if (c->lines_ws) (void)hipFree(c->lines_ws);
+      if (c->ev_tail_fork) (void)hipEventDestroy(c->ev_tail_fork);
+      if (c->ev_tail_join) (void)hipEventDestroy(c->ev_tail_join);
+      if (c->tail) (void)hipStreamDestroy(c->tail);
       if (c->ev_host) (void)hipEventDestroy(c->ev_host);
       if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
       if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -1729,11 +1838,12 @@ static int aggregate_enqueue(Ctx* c, int sig_group, int scheme, const uint8_t* d
     if (d_verdict) HIPCK(hipMemsetAsync(d_verdict, 0, 4, c->stream));   // the empty product is one
     return 0;
   }
-  MILLER1_LAUNCH(mm, m, d_pairs, d_bad, d_f);
+  size_t outputs = 0;
+  if ((rc = run_miller_product(c, mm, m, d_pairs, d_bad, d_f, &outputs))) return rc;
   if (d_verdict) {
-    if ((rc = run_f12_product_verdict(c, d_f, MILLER1_OUTPUTS(mm), m, d_verdict))) return rc;
+    if ((rc = run_f12_product_verdict(c, d_f, outputs, m, d_verdict))) return rc;
   } else {
-    if ((rc = run_f12_fold(c, d_f, MILLER1_OUTPUTS(mm), m))) return rc;
+    if ((rc = run_f12_fold(c, d_f, outputs, m))) return rc;
     KL(KID_F12_IO, k_f12_export, dim3(1), dim3(BLS_BLOCK), d_f, m, d_rec);
     HIPCK(hipGetLastError());
   }

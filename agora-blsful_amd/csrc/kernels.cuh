@@ -13,6 +13,7 @@
 #define WS_PAIR1_WORDS (3 * W2)  // one (P, Q) pair: the one-pair-per-item workspaces of aggregate verify / pairing products
 #define WS_F_WORDS (6 * W2)      // Fp12
 #define LINE5_WORDS (5 * FP_NL)  // one lane's share of a merged line value (tower.cuh line5_t), see k_lines2s
+#define LINE3_WORDS_H (3 * FP_NL) // ... and of one pair's plain line value (two general pairs: first pass of k_lines2s)
 #define FX_STORE_WORDS (10 * 6 * FP_NL)   // one lane's value store of k_finalexp2s (VS_SLOTS slots of an Fp12 share)
 #define MILLER1_GROUP 3          // items per Miller loop in the pairing-product kernel (k_miller1s): 262,144 pairs take 29.4 / 28.8 ms with 2 / 3; 4 was measured slower (state of four points spills)
 
@@ -191,9 +192,11 @@ template <int SG>
 __global__ void k_prepare(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int aug, const uint8_t* msgs,
                           const uint64_t* offs, int single_msg, dst_arg dst, uint32_t* pairs, int32_t* status, int pre_status, int two_lanes);
 __global__ void k_miller2s(size_t n, const uint32_t* pairs, const int32_t* status, uint32_t* fws, int fixed_g2);
-__global__ void k_lines2s(size_t n, size_t first, size_t count, const uint32_t* pairs, const int32_t* status, uint32_t* lines, size_t lanes, int fixed_g2);
+__global__ void k_lines2s(size_t n, size_t first, size_t count, const uint32_t* pairs, const int32_t* status, uint32_t* lines, uint32_t* lines3, size_t lanes, int fixed_g2, int pass);
 __global__ void k_millerf2s(size_t n, size_t first, size_t count, const int32_t* status, const uint32_t* lines, size_t lanes, uint32_t* fws);
 __global__ void k_finalexp2s(size_t n, size_t first, size_t count, const uint32_t* fws, uint32_t* vp, size_t lanes, int32_t* status);
+__global__ void k_linesp(size_t mm, size_t half, size_t stride, const uint32_t* pairs, const int32_t* bad, uint32_t* lines, uint32_t* lines3, size_t lanes, size_t first_v, size_t count_v, int pass);
+__global__ void k_millerfp(size_t count_v, size_t q, int group, const uint32_t* lines, size_t lanes, uint32_t* fws, size_t stride, size_t out0);
 __global__ void k_finalexps(size_t n, const uint32_t* fws, int32_t* status);
 __global__ void k_miller1s(size_t n, size_t stride, const uint32_t* pairs, const int32_t* skip, uint32_t* fws);
 __global__ void k_finalexp_ones(const uint32_t* fws, size_t stride, int32_t* verdict);
@@ -1284,28 +1287,87 @@ struct miller_lds {
   BLS_MFN void ld_xq(hfp2& r) const { ws_ld_hfp2(r, pairs, n, i, W2); }
   BLS_MFN void ld_yq(hfp2& r) const { ws_ld_hfp2(r, pairs, n, i, 2 * W2); }
 };
-// One entry of the loop for a fixed second G2 argument: step, line at P0, the table's line at P1, merge, store.  A function
-// whose arguments are scalars; it keeps nothing in registers between calls (see k_millerf2s about disable_tail_calls).
-template <int ADD>
-static __device__ __noinline__ void lines_step_fn(lds_u32* sh, const uint32_t* pairs, size_t n, size_t i, const uint32_t* row, uint32_t* lines, size_t lanes, uint32_t t,
-                                                  int e) {
+// One entry of the loop: walk this kernel's point (doubling or addition), evaluate the line at its G1 point, then
+//   SRC_TABLE  merge with the line of a FIXED second G2 argument (normalised table row at P1) and store the five coefficients;
+//   SRC_NONE   store the three line coefficients as they are (first pass over two general pairs: pair 0);
+//   SRC_LINES  merge with the line the first pass stored for this entry (second pass: pair 1) and store the five coefficients.
+// A function whose arguments are scalars; it keeps nothing in registers between calls (see k_millerf2s about disable_tail_calls).
+#define SRC_TABLE 0
+#define SRC_NONE 1
+#define SRC_LINES 2
+#define LINE3_WORDS (3 * FP_NL)
+__device__ __forceinline__ void line3_st(uint32_t* lines3, size_t lanes, uint32_t t, int e, const hfp2& l0, const hfp2& l2, const hfp2& l3) {
+  const fp* c[3] = {&l0.v, &l2.v, &l3.v};
+  uint32_t* row = lines3 + (size_t)e * LINE3_WORDS * lanes;
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+#pragma unroll
+    for (int k = 0; k < FP_NL; k++) {
+      row[t] = (uint32_t)c[j]->l[k];
+      row += lanes;
+    }
+}
+__device__ __forceinline__ void line3_ld(hfp2& l0, hfp2& l2, hfp2& l3, const uint32_t* lines3, size_t lanes, uint32_t t, int e) {
+  fp* c[3] = {&l0.v, &l2.v, &l3.v};
+  const uint32_t* row = lines3 + (size_t)e * LINE3_WORDS * lanes;
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+#pragma unroll
+    for (int k = 0; k < FP_NL; k++) {
+      c[j]->l[k] = (int32_t)row[t];
+      row += lanes;
+    }
+}
+template <int ADD, int SRC>
+static __device__ __noinline__ void lines_step_fn(lds_u32* sh, const uint32_t* pairs, size_t n, size_t i, const uint32_t* row, uint32_t* lines, uint32_t* lines3,
+                                                  size_t lanes, uint32_t t, int e, int skip_a = 0, int skip_b = 0) {
   const miller_lds st = {sh, pairs, n, i};
-  line5_t<hfp2> L;
-  fp x1, y1;
-  hfp2 l0, l2, l3, n0, n2, c;
+  hfp2 l0, l2, l3;
   if (ADD) miller_add_step_at(st, l0, l2, l3);
   else miller_dbl_step_at(st, l0, l2, l3);
-  fp2_load(n0, row);
-  fp2_load(c, row + 2 * FP_NL);
-  ls_ld_coord(x1, sh, LS_P1, false);
-  fp2_mul_fp(n2, c, x1);
-  ls_ld_coord(y1, sh, LS_P1, true);
-  lines_merge_y(L, l0, l2, l3, n0, n2, y1);
+  if (SRC == SRC_NONE) {
+    line3_st(lines3, lanes, t, e, l0, l2, l3);
+    return;
+  }
+  line5_t<hfp2> L;
+  if (SRC == SRC_TABLE) {
+    fp x1, y1;
+    hfp2 n0, n2, c;
+    fp2_load(n0, row);
+    fp2_load(c, row + 2 * FP_NL);
+    ls_ld_coord(x1, sh, LS_P1, false);
+    fp2_mul_fp(n2, c, x1);
+    ls_ld_coord(y1, sh, LS_P1, true);
+    lines_merge_y(L, l0, l2, l3, n0, n2, y1);
+  } else {
+    hfp2 m0, m2, m3;
+    line3_ld(m0, m2, m3, lines3, lanes, t, e);
+    lines_merge(L, m0, m2, m3, l0, l2, l3);        // pair 0's line first, as miller_line5_pair does
+    if (skip_a | skip_b) {                         // pairing products: a pair that contributes 1 leaves the other's line, or 1
+      hfp2 z, one;
+      fp2_zero(z);
+      fp2_one(one);
+      const hfp2& s0 = skip_a ? l0 : m0;
+      const hfp2& s2 = skip_a ? l2 : m2;
+      const hfp2& s3 = skip_a ? l3 : m3;
+      const bool both = skip_a && skip_b;
+      fp2_reduce(L.c0, s0);
+      fp2_reduce(L.c2, s2);
+      fp2_reduce(L.c3, s3);
+      fp2_cmov(L.c0, one, both);
+      fp2_cmov(L.c2, z, both);
+      fp2_cmov(L.c3, z, both);
+      L.c4 = z;
+      L.c5 = z;
+    }
+  }
   line5_st(lines, lanes, t, e, L);
 }
-// fixed_g2: 1 / 2 = the second pair's G2 member is -g2 / -[c] g2 (normalised tables of g2neg_lines.cuh)
+// fixed_g2: 1 / 2 = the second pair's G2 member is -g2 / -[c] g2 (normalised tables of g2neg_lines.cuh): one launch, pass = 0.
+// fixed_g2 = 0, two general pairs: two launches -- pass 1 walks pair 0 and stores its lines (lines3), pass 2 walks pair 1, merges
+// and stores the five coefficients -- because two points do not fit the 80 LDS dwords a lane has at two waves per SIMD.
 __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) __attribute__((disable_tail_calls))
-k_lines2s(size_t n, size_t first, size_t count, const uint32_t* pairs, const int32_t* status, uint32_t* lines, size_t lanes, int fixed_g2) {
+k_lines2s(size_t n, size_t first, size_t count, const uint32_t* pairs, const int32_t* status, uint32_t* lines, uint32_t* lines3, size_t lanes, int fixed_g2, int pass) {
   const uint32_t t = blockIdx.x * BLS_BLOCK + threadIdx.x;
   const size_t j = t >> 1;
   if (j >= count) return;
@@ -1313,24 +1375,80 @@ k_lines2s(size_t n, size_t first, size_t count, const uint32_t* pairs, const int
   if (status[i] != BLS_OK) return;
   __shared__ uint32_t lsh[LS_WORDS * BLS_BLOCK];
   lds_u32* sh = lds_column(lsh);
+  const int pair = pass == 2 ? 1 : 0;                  // which (P, Q) of the workspace this launch walks
+  const uint32_t* pw = pairs + (size_t)pair * 3 * W2 * n;   // the accessors read Q at word offsets W2 and 2 W2 of the pair they are given
   {
     hfp2 q;
     fp p;
-    ws_ld_hfp2(q, pairs, n, i, W2);
+    ws_ld_hfp2(q, pw, n, i, W2);
     ls_st(sh, LS_TX, q.v);
-    ws_ld_hfp2(q, pairs, n, i, 2 * W2);
+    ws_ld_hfp2(q, pw, n, i, 2 * W2);
     ls_st(sh, LS_TY, q.v);
     fp2_one(q);
     ls_st(sh, LS_TZ, q.v);
-    ws_ld_fp(p, pairs, n, i, lane_hi() ? W1 : 0);                // P0: x on the even lane, y on the odd lane
+    ws_ld_fp(p, pw, n, i, lane_hi() ? W1 : 0);                   // this pair's G1 point: x on the even lane, y on the odd lane
     ls_st(sh, LS_P0, p);
-    ws_ld_fp(p, pairs, n, i, 3 * W2 + (lane_hi() ? W1 : 0));     // P1
+    ws_ld_fp(p, pairs, n, i, 3 * W2 + (lane_hi() ? W1 : 0));     // P1 (used by the table form only)
     ls_st(sh, LS_P1, p);
   }
-  const uint32_t (*rows)[4 * FP_NL] = fixed_g2 == 2 ? G2NEGC_LINES_N : G2NEG_LINES_N;
+  if (pass == 0) {
+    const uint32_t (*rows)[4 * FP_NL] = fixed_g2 == 2 ? G2NEGC_LINES_N : G2NEG_LINES_N;
+    for (int e = 0; e < MILLER_ENTRIES; e++) {
+      if (miller_entry_is_add(e)) lines_step_fn<1, SRC_TABLE>(sh, pw, n, i, rows[e], lines, lines3, lanes, t, e);
+      else lines_step_fn<0, SRC_TABLE>(sh, pw, n, i, rows[e], lines, lines3, lanes, t, e);
+    }
+  } else if (pass == 1) {
+    for (int e = 0; e < MILLER_ENTRIES; e++) {
+      if (miller_entry_is_add(e)) lines_step_fn<1, SRC_NONE>(sh, pw, n, i, nullptr, lines, lines3, lanes, t, e);
+      else lines_step_fn<0, SRC_NONE>(sh, pw, n, i, nullptr, lines, lines3, lanes, t, e);
+    }
+  } else {
+    for (int e = 0; e < MILLER_ENTRIES; e++) {
+      if (miller_entry_is_add(e)) lines_step_fn<1, SRC_LINES>(sh, pw, n, i, nullptr, lines, lines3, lanes, t, e);
+      else lines_step_fn<0, SRC_LINES>(sh, pw, n, i, nullptr, lines, lines3, lanes, t, e);
+    }
+  }
+}
+#endif
+
+#if defined(BLS_TU_LINES)
+// Pairing PRODUCTS (aggregate verify: reference src/traits/sig_core.rs:149-178): mm one-pair items in a workspace of stride
+// `stride`, flagged items contribute 1.  Two items share a merged line value: virtual item v pairs item v with item v + half
+// (half = ceil(mm / 2)).  pass 1 walks item v and stores its lines, pass 2 walks item v + half, merges and stores the five
+// coefficients (the two-pass form of k_lines2s); this launch covers the virtual items [first_v, first_v + count_v).
+__global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) __attribute__((disable_tail_calls))
+k_linesp(size_t mm, size_t half, size_t stride, const uint32_t* pairs, const int32_t* bad, uint32_t* lines, uint32_t* lines3, size_t lanes, size_t first_v,
+         size_t count_v, int pass) {
+  const uint32_t t = blockIdx.x * BLS_BLOCK + threadIdx.x;
+  const size_t j = t >> 1;
+  if (j >= count_v) return;
+  const size_t v = first_v + j, ib = v + half;
+  const bool have_b = ib < mm;
+  const int skip_a = bad[v] != 0, skip_b = !have_b || bad[ib] != 0;
+  if (pass == 1 && skip_a) return;                          // nobody reads a skipped item's lines
+  const size_t i = pass == 1 || !have_b ? v : ib;           // (an absent partner: walk item v again, its result is discarded)
+  __shared__ uint32_t lsh[LS_WORDS * BLS_BLOCK];
+  lds_u32* sh = lds_column(lsh);
+  {
+    hfp2 q;
+    fp p;
+    ws_ld_hfp2(q, pairs, stride, i, W2);
+    ls_st(sh, LS_TX, q.v);
+    ws_ld_hfp2(q, pairs, stride, i, 2 * W2);
+    ls_st(sh, LS_TY, q.v);
+    fp2_one(q);
+    ls_st(sh, LS_TZ, q.v);
+    ws_ld_fp(p, pairs, stride, i, lane_hi() ? W1 : 0);
+    ls_st(sh, LS_P0, p);
+  }
   for (int e = 0; e < MILLER_ENTRIES; e++) {
-    if (miller_entry_is_add(e)) lines_step_fn<1>(sh, pairs, n, i, rows[e], lines, lanes, t, e);
-    else lines_step_fn<0>(sh, pairs, n, i, rows[e], lines, lanes, t, e);
+    if (pass == 1) {
+      if (miller_entry_is_add(e)) lines_step_fn<1, SRC_NONE>(sh, pairs, stride, i, nullptr, lines, lines3, lanes, t, e);
+      else lines_step_fn<0, SRC_NONE>(sh, pairs, stride, i, nullptr, lines, lines3, lanes, t, e);
+    } else {
+      if (miller_entry_is_add(e)) lines_step_fn<1, SRC_LINES>(sh, pairs, stride, i, nullptr, lines, lines3, lanes, t, e, skip_a, skip_b);
+      else lines_step_fn<0, SRC_LINES>(sh, pairs, stride, i, nullptr, lines, lines3, lanes, t, e, skip_a, skip_b);
+    }
   }
 }
 #endif
@@ -1393,6 +1511,38 @@ __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_finalexps(size_t
   ws_ld_hfp12(f, fws, n, i);
   int st = pairing_verdict(f);
   if (!lane_hi()) status[i] = st;
+}
+#endif
+
+#if defined(BLS_TU_MILLERF)
+// ... and the accumulator's kernel of a pairing product: lane pair g multiplies the merged line values of the virtual items
+// g, g + q, g + 2q, ... (group of them) into ONE accumulator -- one squaring per entry for all of them -- and leaves partial
+// product g at item `out0 + g` of the Fp12 workspace (stride as given).  lines: the chunk's line workspace, virtual item j of
+// the chunk at lanes 2 j, 2 j + 1.
+__global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) __attribute__((disable_tail_calls))
+k_millerfp(size_t count_v, size_t q, int group, const uint32_t* lines, size_t lanes, uint32_t* fws, size_t stride, size_t out0) {
+  const uint32_t t = blockIdx.x * BLS_BLOCK + threadIdx.x;
+  const size_t g = t >> 1;
+  if (g >= q) return;
+  const uint32_t hi = t & 1u;
+  __shared__ uint32_t fsh[F12_SH_WORDS * BLS_BLOCK];
+  f12_sh acc = {lds_column(fsh)};
+  {
+    line5_t<hfp2> L;
+    line5_ld(L, lines, lanes, (uint32_t)(2 * g) + hi, 0);
+    acc_set_line5(acc, L);
+  }
+  for (int e = 0; e < MILLER_ENTRIES; e++) {
+    if (e > 0 && !miller_entry_is_add(e)) f12_sh_sqr_fn(acc.sh);
+    for (int k = e == 0 ? 1 : 0; k < group; k++) {
+      const size_t v = g + (size_t)k * q;
+      if (v < count_v) f12_sh_mul_line5_fn(acc.sh, lines, lanes, (uint32_t)(2 * v) + hi, e);
+    }
+  }
+  fp12_t<hfp2> f;
+  sh_ld_f12(f, acc.sh);
+  fp12_conj(f, f);
+  ws_st_hfp12(fws, stride, out0 + g, f);
 }
 #endif
 
