@@ -27,10 +27,10 @@ thread_local bool t_nested = false;  // inside a sharded call: the per-device su
 
 enum {
   KID_PREPARE, KID_MILLER2, KID_FINALEXP, KID_PREPARE_AGG, KID_PAIRS_AFF, KID_MILLER1, KID_F12_FOLD, KID_FINALEXP_ONE,
-  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_F12_IO, KID_MSM_SORT, KID_MSM_BUCKET, KID_MSM_CHUNK, KID_DECOMPRESS, KID_PAIRING_COOP, KID_KEY_SORT, KID_COEFF, KID_DUP, KID_FIRST_BAD, KID_MSM_PREP, KID_MSM_NORM, KID_MSM_MERGE, KID_WIDE, KID_LINES, KID_COUNT
+  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_F12_IO, KID_MSM_SORT, KID_MSM_BUCKET, KID_MSM_CHUNK, KID_DECOMPRESS, KID_PAIRING_COOP, KID_KEY_SORT, KID_COEFF, KID_DUP, KID_FIRST_BAD, KID_MSM_PREP, KID_MSM_NORM, KID_MSM_MERGE, KID_WIDE, KID_LINES, KID_CYCRUN, KID_COUNT
 };
 const char* KID_NAMES[KID_COUNT] = {"k_prepare", "k_miller2", "k_finalexp", "k_prepare_agg", "k_pairs_to_affine", "k_miller1", "k_f12_fold",
-                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign", "k_f12_io", "k_msm_sort", "k_msm_bucket", "k_msm_chunk", "k_decompress", "k_pairing_coop", "k_key_sort", "k_sha256_coeff", "k_duplicate_rule", "k_first_identity", "k_msm_prep", "k_normalize", "k_msm_merge", "k_wide", "k_lines2"};
+                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign", "k_f12_io", "k_msm_sort", "k_msm_bucket", "k_msm_chunk", "k_decompress", "k_pairing_coop", "k_key_sort", "k_sha256_coeff", "k_duplicate_rule", "k_first_identity", "k_msm_prep", "k_normalize", "k_msm_merge", "k_wide", "k_lines2", "k_cyc_run4"};
 
 struct Ctx {
   int dev = -1;
@@ -558,6 +558,10 @@ int run_pairing2(Ctx* c, size_t n, uint32_t* d_pairs, uint32_t* d_f, int32_t* d_
     // The Miller loop in two kernels (kernels.cuh k_lines2s / k_millerf2s), a chunk of at most miller_chunk_items() items at a
     // time: the chunk's merged line values pass through the context's line workspace.  BLSGPU_MILLER_V1=1, or no memory for
     // that workspace: the one-kernel loop of rounds 1 and 2.
+    // BLSGPU_FINALEXP_SEG=1: the final exponentiation in six segments with the 63 compressed squarings of every a^x on FOUR lanes per
+    // item at four waves per SIMD between them (k_cyc_run4).  Measured and not adopted (profiles/r03_pmc_finalexp_segments_cycrun4.json):
+    // the squarings take 5.27 ms instead of ~5.6 ms inside k_finalexp2s, the six segments 4.28 ms: 9.55 ms against 9.49 ms for the one kernel.
+    static const bool finalexp_seg = getenv("BLSGPU_FINALEXP_SEG") && atoi(getenv("BLSGPU_FINALEXP_SEG"));
     static const bool finalexp_v1 = getenv("BLSGPU_FINALEXP_V1") && atoi(getenv("BLSGPU_FINALEXP_V1"));   // A/B: the one-kernel final exponentiation of rounds 1 and 2
     const size_t chunk = n < miller_chunk_items() ? n : miller_chunk_items();
     const size_t words_per_lane = (size_t)MILLER_ENTRIES * (LINE5_WORDS + (fixed_g2 ? 0 : LINE3_WORDS_H));   // two general pairs: pair 0's plain lines too
@@ -575,7 +579,16 @@ int run_pairing2(Ctx* c, size_t n, uint32_t* d_pairs, uint32_t* d_f, int32_t* d_
         }
         KL(KID_MILLER2, k_millerf2s, grid, dim3(BLS_BLOCK), n, first, cnt, (const int32_t*)d_status, (const uint32_t*)c->lines_ws, lanes, d_f);
         // the chunk's line values are consumed: the same memory is the value store of the final exponentiation (3.4 KB per lane)
-        if (!finalexp_v1) KL(KID_FINALEXP, k_finalexp2s, grid, dim3(BLS_BLOCK), n, first, cnt, (const uint32_t*)d_f, c->lines_ws, lanes, d_status);
+        if (!finalexp_v1 && finalexp_seg) {
+          // in segments, the compressed squarings of each a^x on four lanes per item at four waves per SIMD (k_cyc_run4)
+          const dim3 grid4(blocks_for(4 * cnt));
+          for (int seg = 0; seg <= 5; seg++) {
+            KL(KID_FINALEXP, k_finalexp_seg, grid, dim3(BLS_BLOCK), seg, n, first, cnt, (const uint32_t*)d_f, c->lines_ws, lanes, d_status);
+            if (seg < 5) KL(KID_CYCRUN, k_cyc_run4, grid4, dim3(BLS_BLOCK), cnt, c->lines_ws, lanes, (const int32_t*)d_status, first);
+          }
+        } else if (!finalexp_v1) {
+          KL(KID_FINALEXP, k_finalexp2s, grid, dim3(BLS_BLOCK), n, first, cnt, (const uint32_t*)d_f, c->lines_ws, lanes, d_status);
+        }
       }
       if (finalexp_v1) KL(KID_FINALEXP, k_finalexps, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_f, d_status);
     } else {
@@ -724,7 +737,10 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
   // two lanes per item (the two SSWU maps side by side, G2 point arithmetic on the lane-split tower): always for
   // Bls12381G2Impl, whose hash-to-G2 halves its per-lane work that way; for Bls12381G1Impl only in latency mode (the
   // Fp-only remainder would run redundantly and a full batch is faster with one lane per item -- both measured)
-  const int two_lanes = (sg == 2 || n <= coop_max_items()) ? 1 : 0;
+  static const int force_lanes = getenv("BLSGPU_PREPARE_LANES") ? atoi(getenv("BLSGPU_PREPARE_LANES")) : 0;   // A/B aid: 1 or 2 lanes per item in k_prepare<1>
+  // two lanes per item also for full Bls12381G1Impl batches since round 3: 1.69 against 1.80 ms at 65,536 items (k_prepare is a one-wave-per-SIMD kernel
+  // otherwise, and a lone wave issues a multiply-add every 8.8 cycles where two waves share the pipe at 4.4)
+  const int two_lanes = force_lanes == 1 && sg == 1 ? 0 : 1;
   unsigned nb = blocks_for(two_lanes ? 2 * n : n);
   // Bls12381G1Impl: the message points stay UNCLEARED (a third of the hash) and the second pair is (sig, -[c] g2), c = h_eff^-1
   // mod r, whose line table is as constant as -g2's: e(h P', pk) e(sig, -g2) = 1  <=>  e(P', pk) e(sig, -[c] g2) = 1

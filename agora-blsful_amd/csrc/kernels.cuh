@@ -195,6 +195,8 @@ __global__ void k_miller2s(size_t n, const uint32_t* pairs, const int32_t* statu
 __global__ void k_lines2s(size_t n, size_t first, size_t count, const uint32_t* pairs, const int32_t* status, uint32_t* lines, uint32_t* lines3, size_t lanes, int fixed_g2, int pass);
 __global__ void k_millerf2s(size_t n, size_t first, size_t count, const int32_t* status, const uint32_t* lines, size_t lanes, uint32_t* fws);
 __global__ void k_finalexp2s(size_t n, size_t first, size_t count, const uint32_t* fws, uint32_t* vp, size_t lanes, int32_t* status);
+__global__ void k_finalexp_seg(int seg, size_t n, size_t first, size_t count, const uint32_t* fws, uint32_t* vp, size_t lanes, int32_t* status);
+__global__ void k_cyc_run4(size_t count, uint32_t* vp, size_t lanes, const int32_t* status, size_t first);
 __global__ void k_linesp(size_t mm, size_t half, size_t stride, const uint32_t* pairs, const int32_t* bad, uint32_t* lines, uint32_t* lines3, size_t lanes, size_t first_v, size_t count_v, int pass);
 __global__ void k_millerfp(size_t count_v, size_t q, int group, const uint32_t* lines, size_t lanes, uint32_t* fws, size_t stride, size_t out0);
 __global__ void k_finalexps(size_t n, const uint32_t* fws, int32_t* status);
@@ -1124,7 +1126,7 @@ template __global__ void k_prepare_proof<2>(size_t, const uint8_t*, const uint8_
 #endif
 #endif  // BLS_TU_SIGN*
 
-#if defined(BLS_TU_MILLERS) || defined(BLS_TU_FINALEXPS) || defined(BLS_TU_LINES) || defined(BLS_TU_MILLERF) || defined(BLS_TU_FINALEXP2)
+#if defined(BLS_TU_MILLERS) || defined(BLS_TU_FINALEXPS) || defined(BLS_TU_LINES) || defined(BLS_TU_MILLERF) || defined(BLS_TU_FINALEXP2) || defined(BLS_TU_CYCRUN4)
 // =====================================================================================================
 // lane-split variants (tower_split.cuh): two adjacent lanes per item, 64-thread workgroups = 32 items
 #include "tower_split.cuh"
@@ -1810,6 +1812,159 @@ k_finalexp2s(size_t n, size_t first, size_t count, const uint32_t* fws, uint32_t
   fx_mul(sh, vp, lanes, t, 0, FX_PLAIN);
   const int st = fx_is_one(sh);
   if (!lane_hi()) status[i] = st;
+}
+// The same final exponentiation in SEGMENTS between which k_cyc_run4 (four lanes per item, four waves per SIMD) runs the 63
+// compressed squarings of each a^x: segment s ends by leaving a in slot 2, segment s + 1 starts by decompressing and multiplying
+// the six saved powers (fx_pow_finish; the plain chain on the lanes of an item with a vanishing z2) and conjugating.
+//   0: easy part, f -> slot 1, a = f          1: t = f^x conj(f) -> slot 0, a = t        2: t = t^x conj(t) -> slot 0, a = t
+//   3: t = t^x t^p -> slot 0, a = t           4: a = t^x                                 5: t^(x^2) t^(p^2) conj(t) f^3 == 1 ?
+__device__ __forceinline__ void fx_pow_end(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t) {
+  if (!fx_pow_finish(sh, vp, lanes, t)) fx_pow_plain(sh, vp, lanes, t);
+  fx_conj(sh);
+}
+__global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) __attribute__((disable_tail_calls))
+k_finalexp_seg(int seg, size_t n, size_t first, size_t count, const uint32_t* fws, uint32_t* vp, size_t lanes, int32_t* status) {
+  const uint32_t t = blockIdx.x * BLS_BLOCK + threadIdx.x;
+  const size_t j = t >> 1;
+  if (j >= count) return;
+  const size_t i = first + j;
+  if (status[i] != BLS_OK) return;
+  __shared__ uint32_t ash[F12_SH_WORDS * BLS_BLOCK];
+  lds_u32* sh = lds_column(ash);
+  if (seg == 0) {
+    {
+      fp12_t<hfp2> f;
+      ws_ld_hfp12(f, fws, n, i);
+      fp12_reduce(f, f);       // the Miller kernel's conjugate carries negated limbs
+      sh_st_f12(sh, f);
+    }
+    fx_store(sh, vp, lanes, t, 1);                 // fin
+    fx_inv(sh);
+    fx_store(sh, vp, lanes, t, 0);                 // 1 / fin
+    fx_load(sh, vp, lanes, t, 1, FX_CONJ);
+    fx_mul(sh, vp, lanes, t, 0, FX_PLAIN);         // conj(fin) / fin
+    fx_store(sh, vp, lanes, t, 1);
+    fx_frob2(sh);
+    fx_mul(sh, vp, lanes, t, 1, FX_PLAIN);         // f = f^(p^2) f
+    fx_store(sh, vp, lanes, t, 1);                 // slot 1: f for the rest
+    fx_store(sh, vp, lanes, t, 2);                 // a of the first a^x
+    return;
+  }
+  fx_pow_end(sh, vp, lanes, t);
+  if (seg == 1 || seg == 2) {
+    fx_mul(sh, vp, lanes, t, seg == 1 ? 1 : 0, FX_CONJ);
+  } else if (seg == 3) {
+    fx_mul(sh, vp, lanes, t, 0, FX_FROB1);
+  } else if (seg == 5) {
+    fx_mul(sh, vp, lanes, t, 0, FX_FROB2);
+    fx_mul(sh, vp, lanes, t, 0, FX_CONJ);          // t^(x^2+p^2-1)
+    fx_store(sh, vp, lanes, t, 0);
+    fx_load(sh, vp, lanes, t, 1, FX_PLAIN);
+    fx_cyc_sqr(sh);
+    fx_mul(sh, vp, lanes, t, 1, FX_PLAIN);         // f^3
+    fx_mul(sh, vp, lanes, t, 0, FX_PLAIN);
+    const int st = fx_is_one(sh);
+    if (!lane_hi()) status[i] = st;
+    return;
+  }
+  if (seg != 4) fx_store(sh, vp, lanes, t, 0);
+  fx_store(sh, vp, lanes, t, 2);
+}
+#endif
+
+#if defined(BLS_TU_CYCRUN4)
+// =====================================================================================================
+// The 63 compressed squarings of an a^x with FOUR lanes per item (round 3).  The running element is four Fp2 values
+// (z2, z3, z4, z5) whose update is two independent Fp4 squarings (pairing.cuh cyc_c_sqr): lanes 0, 1 of a quad hold (z2, z3) --
+// real parts on the even lane, imaginary parts on the odd lane, as everywhere in tower_split.cuh -- lanes 2, 3 hold (z4, z5);
+// each pair squares its own Fp4 element and the results cross once per squaring by DPP quad_perm [2,3,0,1].  A lane's state is
+// two Fp (26 packed LDS words) and three multiplier calls per squaring, so the kernel runs at FOUR waves per SIMD (128
+// registers, 106 KB of LDS per CU): the multiply-add pipe is then saturated and the plain instructions between the multiplier
+// calls issue at full rate, which two waves per SIMD cannot do (profiles/r03_ubench3_mad_rates.txt).  This loop is 60 % of the
+// final exponentiation's instructions; nothing else on the path has a state this small.
+// Store layout: as k_finalexp2s (value store, two lanes per item); a: slot 2, the six saved powers: cpow_slot().
+#if !defined(BLS_TU_FINALEXP2)
+#define VS_WORDS (6 * FP_NL)
+__device__ __forceinline__ void cpow_slot(int k, int j, int& slot, int& idx) {   // Fp j (0..3: z2 z3 z4 z5) of saved power k (0..5)
+  const int q = 4 * k + j;
+  slot = 3 + q / 6;
+  idx = q % 6;
+}
+#endif
+__device__ __forceinline__ int32_t dpp_cross(int32_t x) { return __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true); }   // quad_perm [2,3,0,1]
+__device__ __forceinline__ void fp_cross(fp& r, const fp& a) {
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) r.l[i] = dpp_cross(a.l[i]);
+}
+// 3 u + 2 z (plus) or 3 u - 2 z, reduced, into LDS word w0 -- tower_split.cuh cyc_store_plus / cyc_store_minus with the sign a lane value
+__device__ __forceinline__ void cyc_store_signed(lds_u32* sh, int w0, const hfp2& u, const hfp2& z, bool plus) {
+  hfp2 zz, nz, r;
+  fp2_neg(nz, z);
+  fp_sel(zz.v, plus, z.v, nz.v);
+  fp2_add(r, u, zz);
+  fp2_dbl(r, r);
+  fp2_add(r, r, u);
+  fp2_reduce(r, r);
+  sh_st_fp(sh, w0, r.v);
+}
+// one compressed squaring on the two LDS values (words 0 and 13) of this lane; pair_b: this lane belongs to the (z4, z5) pair
+static __device__ __noinline__ void cyc4_sqr_fn(lds_u32* sh, bool pair_b) {
+  hfp2 a, b, t0, t1, r0, r1, x, u0, u1;
+  sh_ld_fp(a.v, sh, 0);
+  sh_ld_fp(b.v, sh, 13);
+  fp4_sqr(t0, t1, a, b);
+  fp_cross(r0.v, t0.v);                    // the other pair's (t_first, t_second)
+  fp_cross(r1.v, t1.v);
+  fp2_mul_xi(x, r1);                       // pair A needs xi t3 (pair B computes it too and drops it)
+  fp2_norm(x, x);
+  //   pair A (z2, z3):  z2' = 3 xi t3 + 2 z2,  z3' = 3 t2 - 2 z3         pair B (z4, z5):  z4' = 3 t0 - 2 z4,  z5' = 3 t1 + 2 z5
+  fp_sel(u0.v, pair_b, r0.v, x.v);
+  fp_sel(u1.v, pair_b, r1.v, r0.v);
+  cyc_store_signed(sh, 0, u0, a, !pair_b);
+  cyc_store_signed(sh, 13, u1, b, pair_b);
+}
+__global__ void __launch_bounds__(BLS_BLOCK, 4) __attribute__((disable_tail_calls))
+k_cyc_run4(size_t count, uint32_t* vp, size_t lanes, const int32_t* status, size_t first) {
+  const uint32_t t4 = blockIdx.x * BLS_BLOCK + threadIdx.x;
+  const size_t j = t4 >> 2;
+  if (j >= count) return;
+  if (status[first + j] != BLS_OK) return;
+  const bool pair_b = (t4 & 2u) != 0;
+  const uint32_t t = (uint32_t)(2 * j) + (t4 & 1u);          // this lane's column of the (two lanes per item) value store
+  __shared__ uint32_t csh[26 * BLS_BLOCK];
+  lds_u32* sh = lds_column(csh);
+  // tower order in a slot: c0.a0 c0.a1 c0.a2 c1.a0 c1.a1 c1.a2; z2 = c1.a0 (3), z3 = c0.a2 (2), z4 = c0.a1 (1), z5 = c1.a2 (5)
+  const int i0 = pair_b ? 1 : 3, i1 = pair_b ? 5 : 2;
+  {
+    fp x;
+    const uint32_t* row = vp + ((size_t)2 * VS_WORDS + (size_t)i0 * FP_NL) * lanes;
+#pragma unroll
+    for (int k = 0; k < FP_NL; k++) { x.l[k] = (int32_t)row[t]; row += lanes; }
+    fp_reduce(x, x);
+    sh_st_fp(sh, 0, x);
+    row = vp + ((size_t)2 * VS_WORDS + (size_t)i1 * FP_NL) * lanes;
+#pragma unroll
+    for (int k = 0; k < FP_NL; k++) { x.l[k] = (int32_t)row[t]; row += lanes; }
+    fp_reduce(x, x);
+    sh_st_fp(sh, 13, x);
+  }
+  int saved = 0;
+  for (int i = 1; i <= 63; i++) {
+    cyc4_sqr_fn(sh, pair_b);
+    if ((BLS_X_ABS >> i) & 1) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        fp x;
+        int slot, idx;
+        sh_ld_fp(x, sh, 13 * h);
+        cpow_slot(saved, (pair_b ? 2 : 0) + h, slot, idx);
+        uint32_t* row = vp + ((size_t)slot * VS_WORDS + (size_t)idx * FP_NL) * lanes;
+#pragma unroll
+        for (int k = 0; k < FP_NL; k++) { row[t] = (uint32_t)x.l[k]; row += lanes; }
+      }
+      saved++;
+    }
+  }
 }
 #endif
 

@@ -3,6 +3,7 @@ Basic's duplicate-message rule, the first-identity reduction and the neutral rec
 scalars >= r in the MSM, the context pool.  Everything goes through the C ABI and is compared with the oracle or with a
 plain Python restatement of the reference's loop."""
 import ctypes
+import os
 import hashlib
 import random
 
@@ -543,3 +544,37 @@ def test_randomised_campaign_short(api):
         kind = kinds[k % 4] if k < 8 else rng.choices(kinds, (5, 2, 2, 3))[0]
         line = []
         assert kind(api, bo, rng, line.append), (k, line)
+
+@pytest.mark.gpu
+def test_segmented_final_exponentiation_and_one_kernel_miller_loop_agree():
+    """The A/B forms kept beside the defaults -- BLSGPU_FINALEXP_SEG=1 (six segments + the four-lanes-per-item compressed squarings of
+    k_cyc_run4), BLSGPU_FINALEXP_V1=1 and BLSGPU_MILLER_V1=1 (rounds 1-2's one-kernel final exponentiation / Miller loop) -- return the
+    default path's verdict vector on a lane-split batch with tampered items and identities (child processes: the switches are read once)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, random; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge, util\n"
+        "api = ge.import_pkg().api; api.init()\n"
+        "n = 6400; rng = random.Random(5)\n"
+        "sks = [1000 + i for i in range(n)]; msgs = [b'seg-%%d' %% i for i in range(n)]\n"
+        "out = []\n"
+        "for sg in (1, 2):\n"
+        "    pks, sigs = api.sign_batch(sg, api.POP, sks, msgs)\n"
+        "    pks, sigs, ms = list(pks), list(sigs), list(msgs)\n"
+        "    for i in range(0, n, 37): ms[i] = ms[i] + b'!'\n"
+        "    sigs[11] = util.g1_raw(None) if sg == 1 else util.g2_raw(None)\n"
+        "    out.append(api.verify_batch(sg, api.POP, pks, sigs, ms))\n"
+        "print(repr(out))\n") % (util.ROOT, os.path.join(util.ROOT, 'tests'))
+    res = {}
+    for name, env in (('default', {}), ('seg', {'BLSGPU_FINALEXP_SEG': '1'}), ('fe_v1', {'BLSGPU_FINALEXP_V1': '1'}), ('miller_v1', {'BLSGPU_MILLER_V1': '1'})):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        res[name] = eval(r.stdout.strip().splitlines()[-1])
+    want = res['default']
+    for sg_idx in (0, 1):
+        exp = [1 if i % 37 == 0 else 0 for i in range(6400)]
+        exp[11] = 2
+        assert want[sg_idx] == exp
+    for name in ('seg', 'fe_v1', 'miller_v1'):
+        assert res[name] == want, name

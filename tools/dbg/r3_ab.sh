@@ -7,7 +7,7 @@ tail -2 gpurun_out/r3/t_api.log
 python -m pytest tests/test_gpu_fullsize.py -x -q -k config2 > gpurun_out/r3/t_full.log 2>&1 || { tail -30 gpurun_out/r3/t_full.log; exit 1; }
 tail -2 gpurun_out/r3/t_full.log
 python bench.py --steps 10 --warmup 3 --no-extras > gpurun_out/r3/bench_v2.json 2> gpurun_out/r3/bench_v2.err || { tail -20 gpurun_out/r3/bench_v2.err; exit 1; }
-BLSGPU_FINALEXP_V1=1 python bench.py --steps 10 --warmup 3 --no-extras > gpurun_out/r3/bench_v1.json 2> gpurun_out/r3/bench_v1.err
+BLSGPU_FINALEXP_SEG=0 python bench.py --steps 10 --warmup 3 --no-extras > gpurun_out/r3/bench_v1.json 2> gpurun_out/r3/bench_v1.err
 python - <<'PY'
 import json
 for f in ('v2', 'v1'):

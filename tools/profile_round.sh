@@ -1,38 +1,44 @@
 #!/bin/bash
 # Round profiles on the GPU box (run through gpurun from the repo root): rocprofv3 kernel statistics of the bench command and
-# of all configs, PMC passes (HBM traffic, wait share, VALU count) for the default build and for the 1-wave-per-SIMD build
-# of the lane-split kernels (BLS_SPLIT_WAVES=1, agora-blsful_amd/libblsgpu_w1.so: build it first with tools/build_w1.py; skipped
-# when the file is absent), and the CPU legs of configs 1/3/4/5 (SKIP_CPU_LEGS=1 skips them).
-# Outputs under gpurun_out/prof_r02/; tools/pmc_summary.py turns the PMC directories into JSON.
+# of all configs, PMC passes (HBM traffic, wait shares, instruction counts) of the bench command, the dominant kernels' HBM-side
+# traffic as bench.py reads it (pmc_traffic.json), and the CPU legs of configs 1/3/4/5 (SKIP_CPU_LEGS=1 skips them).
+# Outputs under gpurun_out/prof_$ROUND/ (ROUND defaults to r03); copy the summaries into profiles/ with the round's prefix.
 set -e -o pipefail
-OUT=gpurun_out/prof_r02
+ROUND=${ROUND:-r03}
+OUT=gpurun_out/prof_$ROUND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-R=$PWD
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bench -- python3 bench.py --steps 5 --warmup 2 --no-extras > $OUT/bench_noextras.json 2> $OUT/bench_noextras.err
 echo "stats bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_all -- python3 bench.py --steps 3 --warmup 1 > $OUT/bench_all.json 2> $OUT/bench_all.err
 echo "stats all done"
-for c in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES"; do
-  d=$OUT/pmc_default_$(echo $c | tr ' ' '_' | cut -c1-20)
+i=0
+for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+  i=$((i+1))
+  d=$OUT/pmc_$i
   rocprofv3 --pmc $c --output-format csv -d $d -- python3 bench.py --steps 2 --warmup 1 --no-extras > /dev/null 2> $d.err
-  echo "pmc default $c done"
+  echo "pmc pass $i ($c) done"
 done
-if [ -f $R/agora-blsful_amd/libblsgpu_w1.so ]; then
-export BLSGPU_LIB=$R/agora-blsful_amd/libblsgpu_w1.so
-for c in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES"; do
-  d=$OUT/pmc_w1_$(echo $c | tr ' ' '_' | cut -c1-20)
-  rocprofv3 --pmc $c --output-format csv -d $d -- python3 bench.py --steps 2 --warmup 1 --no-extras > /dev/null 2> $d.err
-  echo "pmc w1 $c done"
-done
-unset BLSGPU_LIB
-python3 tools/pmc_summary.py $OUT/pmc_w1_* > $OUT/pmc_w1.json
-fi
-python3 tools/pmc_summary.py $OUT/pmc_default_* > $OUT/pmc_default.json
+python3 tools/pmc_summary.py $OUT/pmc_* > $OUT/pmc_default.json
+# what bench.py reads for roofline.traffic: FETCH_SIZE / WRITE_SIZE (KB) per launch, keyed by the library's profile names
+python3 - $OUT $ROUND <<'PY'
+import json, sys
+out, rnd = sys.argv[1], sys.argv[2]
+d = json.load(open(out + '/pmc_default.json'))
+names = {'k_finalexp2s': 'k_finalexp', 'k_millerf2s': 'k_miller2', 'k_lines2s': 'k_lines2', 'k_prepare<1>': 'k_prepare', 'k_finalexps': 'k_finalexp', 'k_miller2s': 'k_miller2'}
+res = {}
+for k, v in d.items():
+    if k in names and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v and names[k] not in res:
+        res[names[k]] = {'FETCH_SIZE': v['FETCH_SIZE'], 'WRITE_SIZE': v['WRITE_SIZE'], 'kernel': k,
+                         'source': 'profiles/%s_pmc_default.json (rocprofv3 --pmc passes of bench.py --steps 2 --no-extras, n=65536; tools/profile_round.sh)' % rnd}
+json.dump(res, open(out + '/pmc_traffic.json', 'w'), indent=1)
+print(json.dumps(res, indent=1))
+PY
 if [ -z "$SKIP_CPU_LEGS" ]; then
   python3 tools/bench_configs.py --cpu-seconds 6 > $OUT/configs_cpu_legs.jsonl 2> $OUT/configs_cpu_legs.err
   echo "cpu legs done"
 fi
 # keep only the summaries (the raw traces are large)
 find $OUT -name "*_kernel_trace.csv" -delete
+find $OUT -name "*counter_collection.csv" -size +1M -delete
 du -sh $OUT
