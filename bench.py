@@ -493,6 +493,7 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help='config 2 only: do not time configs 3-5 after the headline measurement')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend; gloo rehearses the N > 1 control flow with ranks sharing a card')
     ap.add_argument('--pg-timeout', type=int, default=180, help='process-group timeout in seconds')
+    ap.add_argument('--extras-timeout', type=int, default=150, help='seconds the whole other_configs ride-along may take before the headline line is printed without the rest')
     ap.add_argument('--fail-extra', default=None, metavar='NAME[:RANK]', help='test aid: make that other_configs entry raise on that rank (default 0) before its collectives')
     args = ap.parse_args()
     h = Harness(args)
@@ -521,10 +522,31 @@ def main():
                     ('config2_grouped_optin_1pct_tampered', lambda: run_config2_grouped(h, k, 1, args.n, 100)),
                     ('config2_grouped_optin_all_valid', lambda: run_config2_grouped(h, k, 1, args.n, 0))]
             fail_name, _, fail_rank = (args.fail_extra or '').partition(':')
+            # A watchdog over the whole ride-along: whatever happens in there (a collective that never returns, a backend that
+            # aborts the process at ITS timeout), the headline line gets printed -- with the entries finished so far -- before
+            # this process leaves.  Every rank runs the same timer, so all of them exit.
+            import threading
+            state = {'current': None}
+
+            def expire():
+                if out is not None and h.rank == 0:
+                    done = dict(extras)
+                    done[state['current'] or 'ride-along'] = {'error': 'timeout: the other_configs ride-along exceeded %d s' % args.extras_timeout}
+                    out['other_configs'] = done
+                    os.write(RESULT_FD, (json.dumps(out) + '\n').encode())
+                sys.stderr.write('bench.py rank %d: other_configs watchdog fired, exiting 3\n' % h.rank)
+                sys.stderr.flush()
+                os._exit(3)
+            dog = threading.Timer(args.extras_timeout, expire)
+            dog.daemon = True
+            dog.start()
             for name, fn in plan:
+                state['current'] = name
                 err, r = None, None
                 try:
-                    if fail_name == name and h.rank == int(fail_rank or 0):
+                    if fail_name == name and h.rank == int((fail_rank or '0').split(':')[0]):
+                        if fail_rank.endswith(':hang'):
+                            time.sleep(10 ** 6)
                         raise RuntimeError('--fail-extra: deliberate failure before the collectives of this entry')
                     r = fn()
                 except Exception as e:  # noqa: BLE001 -- the headline line must survive a failing extra
@@ -539,6 +561,7 @@ def main():
                     r.setdefault('collective_ms_per_step', 0.0)
                     extras[name] = r
                 h.torch.cuda.empty_cache()
+            dog.cancel()
             if out is not None:
                 out['other_configs'] = extras
     else:

@@ -50,3 +50,15 @@ def test_bench_failing_extra_exits_nonzero_on_every_rank(api):
     assert 'error' not in oc['config3_multi_verify_1048576']
     assert 'deliberate failure' in oc['config4_aggregate_verify_262144']['error']
     assert 'config5_verify_secure_65536_g1impl_modern' not in oc                      # the ride-along ends at the failure
+
+
+@pytest.mark.gpu
+def test_bench_hanging_extra_still_prints_the_headline(api):
+    """one rank never reaches an entry's collectives: the watchdog over the ride-along prints the headline line (with the entries that
+    finished) and every rank leaves -- before the process group's own timeout can take the process down without a line"""
+    rc, out, dt, err = launch(['--fail-extra', 'config4_aggregate_verify_262144:1:hang', '--pg-timeout', '300', '--extras-timeout', '45'], 600)
+    assert rc != 0 and dt < 300
+    assert out is not None and out['value'] > 0
+    oc = out['other_configs']
+    assert 'error' not in oc['config3_multi_verify_1048576']
+    assert 'timeout' in oc['config4_aggregate_verify_262144']['error']
