@@ -419,7 +419,7 @@ BLS_FN void fp_to_raw(uint32_t* w, const fp& a) {
 // a^e for a public exponent given as little-endian 32-bit words (same for every lane: no divergence).
 // Sliding windows of up to POW_WINDOW bits that end in a set bit, over the odd powers a, a^3 .. a^(2^W - 1): for the 379-bit
 // (p-3)/4 that is 375 squarings + 78 multiplications + 8 for the table (fixed 4-bit digits: 376 + 92 + 14).
-#define POW_WINDOW 4
+#define POW_WINDOW 4   // fp_pow's switch over the table assumes 2^(POW_WINDOW - 1) = 8 entries
 // bits of a little-endian exponent through a 64-bit view of words cw and cw - 1: one load per word instead of one per bit (the
 // scan is uniform scalar code, but a load per bit costs as much as the multiplications the windows save)
 struct pow_bits {
@@ -458,13 +458,32 @@ BLS_NOINLINE void fp_pow(fp& r, const fp& a, const uint32_t* e, int nbits) {
     }
     uint32_t v;
     const int j = pow_window(x, i, POW_WINDOW, v);
+    // the window value is the same on every lane (a public exponent): a uniform switch over STATIC table indices keeps the eight
+    // odd powers in registers -- indexed with a run-time value the table lived in scratch, 14 loads per multiplication, and
+    // k_prepare (two square-root chains per message) spent 30 % of its waves' time waiting for them
+#define POW_PICK(op)                  \
+  switch (v >> 1) {                   \
+    case 0: op(tbl[0]); break;        \
+    case 1: op(tbl[1]); break;        \
+    case 2: op(tbl[2]); break;        \
+    case 3: op(tbl[3]); break;        \
+    case 4: op(tbl[4]); break;        \
+    case 5: op(tbl[5]); break;        \
+    case 6: op(tbl[6]); break;        \
+    default: op(tbl[7]); break;       \
+  }
+#define POW_MUL(t) fp_mul(acc, acc, t)
+#define POW_SET(t) acc = t
     if (started) {
       for (int k = i; k >= j; k--) fp_sqr(acc, acc);
-      fp_mul(acc, acc, tbl[v >> 1]);
+      POW_PICK(POW_MUL)
     } else {
-      acc = tbl[v >> 1];
+      POW_PICK(POW_SET)
       started = true;
     }
+#undef POW_MUL
+#undef POW_SET
+#undef POW_PICK
     i = j - 1;
   }
   if (!started) fp_one(acc);
