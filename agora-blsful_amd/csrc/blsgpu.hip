@@ -49,6 +49,7 @@ struct Ctx {
   size_t hsmall_off = 0;          // they outlive every early return, unlike stack variables
   hipStream_t tail = nullptr;     // the leftover items of a pairing product (run_miller_product) run here beside the main chunks
   hipEvent_t ev_tail_fork = nullptr, ev_tail_join = nullptr;
+  uint32_t* fold_ws = nullptr;    // two small ping-pong buffers of the engine levels of an Fp12 fold tree (run_f12_fold)
   uint32_t* lines_ws = nullptr;   // merged line values on their way from k_lines2s to k_millerf2s (kernels.cuh): 19 KB per lane
   size_t lines_cap = 0;           // bytes; grown on demand, kept between calls
   // optional per-kernel timing with HIP events on `stream` (blsgpu_profile_*)
@@ -766,6 +767,38 @@ int run_miller_product(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs, int3
     if (pairs > chunk_max) pairs = chunk_max;
     return pairs >= round ? pairs / round * round : pairs / 32 * 32;
   };
+  if (mm >= 64 && mm <= round + 1023 && chunk_max) {
+    // at most one machine round of lane pairs: one item per accumulator slot, plain lines (k_linesp pass 1, k_millerfp3); up to 1,023
+    // items beyond the round go through k_miller1s on the tail stream beside them
+    const size_t cnt = mm >= round ? round : mm, left = mm - cnt;      // below a round: every item gets a lane pair (the last workgroup may be partly idle)
+    const size_t nlanes = lanes_for(cnt), lanes = row_stride(nlanes);
+    if (lines_reserve(c, (size_t)MILLER_ENTRIES * LINE3_WORDS_H * 4 * lanes) == 0) {
+      if (left) {
+        if (!c->tail) {
+          HIPCK(hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking));
+          HIPCK(hipEventCreateWithFlags(&c->ev_tail_fork, hipEventDisableTiming));
+          HIPCK(hipEventCreateWithFlags(&c->ev_tail_join, hipEventDisableTiming));
+        }
+        HIPCK(hipEventRecord(c->ev_tail_fork, c->stream));
+        HIPCK(hipStreamWaitEvent(c->tail, c->ev_tail_fork, 0));
+        hipLaunchKernelGGL(k_miller1s, dim3(blocks_for(2 * MILLER1_OUTPUTS(left))), dim3(BLS_BLOCK), 0, c->tail, left, stride, (const uint32_t*)(d_pairs + cnt),
+                           (const int32_t*)(d_bad + cnt), d_f + cnt);
+        const hipError_t e1 = hipGetLastError(), e2 = hipEventRecord(c->ev_tail_join, c->tail);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+          (void)hipStreamSynchronize(c->tail);
+          return fail(BLSGPU_E_HIP, "tail-stream launch failed");
+        }
+      }
+      const dim3 grid((unsigned)(nlanes / BLS_BLOCK));
+      // k_linesp pass 1 on a "chunk" whose partners do not exist (half = cnt): every lane pair walks its own item and stores its lines
+      KL(KID_LINES, k_linesp, grid, dim3(BLS_BLOCK), cnt, cnt, stride, (const uint32_t*)d_pairs, (const int32_t*)d_bad, c->lines_ws, c->lines_ws, lanes, (size_t)0, cnt, 1);
+      KL(KID_MILLER1, k_millerfp3, grid, dim3(BLS_BLOCK), cnt, cnt, 1, (const int32_t*)d_bad, (const uint32_t*)c->lines_ws, lanes, d_f, stride, (size_t)0);
+      if (left) HIPCK(hipStreamWaitEvent(c->stream, c->ev_tail_join, 0));
+      HIPCK(hipGetLastError());
+      *outputs = cnt + (left ? MILLER1_OUTPUTS(left) : 0);
+      return 0;
+    }
+  }
   const size_t first_cnt = mm >= 4096 && chunk_max ? nice(mm / 2) : 0;
   if (first_cnt == 0 || lines_reserve(c, words_per_lane * 4 * row_stride(lanes_for(first_cnt))) != 0) {
     MILLER1_LAUNCH(mm, stride, d_pairs, d_bad, d_f);
@@ -834,11 +867,32 @@ int run_miller_product(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs, int3
 
 // product of m Fp12 values in a workspace (stride given) folded into item 0
 int run_f12_fold(Ctx* c, uint32_t* d_f, size_t m, size_t stride) {
+  // halvings on lane pairs while there are thousands of values (parallel work, 0.15 ms per launch), then sixteen-way products on
+  // the engine (k_f12_tree_wide, ~50 us per launch): 65,536 values are one value after 4 + 3 launches instead of 16
+  const bool engine = wide_max_items() > 0 && coop_max_items() > 0;
+  const size_t ENGINE_FROM = 4096;
   size_t cur = m;
-  while (cur > 1) {
+  while (cur > (engine ? ENGINE_FROM : 1)) {
     size_t half = (cur + 1) / 2;
     KL(KID_F12_FOLD, k_f12_fold, dim3(blocks_for(half)), dim3(BLS_BLOCK), cur, half, d_f, stride);
     cur = half;
+  }
+  if (cur > 1) {
+    const size_t cap = ENGINE_FROM / 16;                      // items per ping-pong buffer
+    if (!c->fold_ws) HIPCK(hipMalloc((void**)&c->fold_ws, 2 * cap * (size_t)WS_F_WORDS * 4));
+    const uint32_t* src = d_f;
+    size_t sstride = stride;
+    int which = 0;
+    while (cur > 1) {
+      const size_t outn = (cur + 15) / 16;
+      uint32_t* dst = outn == 1 ? d_f : c->fold_ws + (size_t)which * cap * WS_F_WORDS;
+      const size_t dstride = outn == 1 ? stride : cap;
+      KL(KID_F12_FOLD, k_f12_tree_wide, dim3((unsigned)outn), dim3(WIDE_ENGINE_BLOCK), cur, src, sstride, dst, dstride);
+      src = dst;
+      sstride = dstride;
+      which ^= 1;
+      cur = outn;
+    }
   }
   HIPCK(hipGetLastError());
   return 0;
@@ -1309,6 +1363,7 @@ static void release_devices() {
       (void)hipStreamSynchronize(c->stream);
       if (c->arena) (void)hipFree(c->arena);
       if (c->lines_ws) (void)hipFree(c->lines_ws);
+      if (c->fold_ws) (void)hipFree(c->fold_ws);
       if (c->ev_tail_fork) (void)hipEventDestroy(c->ev_tail_fork);
       if (c->ev_tail_join) (void)hipEventDestroy(c->ev_tail_join);
       if (c->tail) (void)hipStreamDestroy(c->tail);

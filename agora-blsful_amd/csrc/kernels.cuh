@@ -199,6 +199,7 @@ __global__ void k_finalexp_seg(int seg, size_t n, size_t first, size_t count, co
 __global__ void k_cyc_run4(size_t count, uint32_t* vp, size_t lanes, const int32_t* status, size_t first);
 __global__ void k_linesp(size_t mm, size_t half, size_t stride, const uint32_t* pairs, const int32_t* bad, uint32_t* lines, uint32_t* lines3, size_t lanes, size_t first_v, size_t count_v, int pass);
 __global__ void k_millerfp(size_t count_v, size_t q, int group, const uint32_t* lines, size_t lanes, uint32_t* fws, size_t stride, size_t out0);
+__global__ void k_millerfp3(size_t count, size_t q, int group, const int32_t* bad, const uint32_t* lines3, size_t lanes, uint32_t* fws, size_t stride, size_t out0);
 __global__ void k_finalexps(size_t n, const uint32_t* fws, int32_t* status);
 __global__ void k_miller1s(size_t n, size_t stride, const uint32_t* pairs, const int32_t* skip, uint32_t* fws);
 __global__ void k_finalexp_ones(const uint32_t* fws, size_t stride, int32_t* verdict);
@@ -286,6 +287,7 @@ __global__ void k_wide_mul_test(size_t n, const uint8_t* a, const uint8_t* b, ui
 __global__ void k_pairing_coop_easy(size_t n, const uint32_t* pairs, const int32_t* status, int fixed_g2, uint32_t* easy);
 __global__ void k_finalexp_wide(size_t n, const uint32_t* easy, int32_t* status);
 __global__ void k_finalexp_wide_ws(const uint32_t* fws, size_t stride, int32_t* verdict);
+__global__ void k_f12_tree_wide(size_t m, const uint32_t* fin, size_t sin, uint32_t* fout, size_t sout);
 __global__ void k_wide_prog_test(const uint32_t* prog, int len, int reps, const uint8_t* fin, uint8_t* tout);
 bool wide_prog_is_fp12(const uint32_t* prog, size_t len);   // host: what k_wide_prog_test may be given
 __global__ void k_pairing_wide(size_t n, const uint32_t* pairs, int32_t* status, int fixed_g2);
@@ -1548,6 +1550,47 @@ k_millerfp(size_t count_v, size_t q, int group, const uint32_t* lines, size_t la
 }
 #endif
 
+#if defined(BLS_TU_MILLERF)
+// ... and for shards of at most one machine round of lane pairs (65,536 items): ONE item per accumulator slot and its plain line
+// values (pass 1 of k_linesp only; the 13-product sparse multiplication), `group` items per accumulator.  Below a machine round
+// every kernel costs a whole round whatever its size (a wave's time does not depend on how many SIMDs are busy), so the merge --
+// one more pass of line kernels for fewer products here -- does not pay: 11 against 14-16 ms for 32,768-65,536 pairs.
+static __device__ __noinline__ void f12_sh_mul_line3_fn(lds_u32* sh, const uint32_t* lines3, size_t lanes, uint32_t t, int e) {
+  hfp2 l0, l2, l3;
+  fp* c[3] = {&l0.v, &l2.v, &l3.v};
+  const uint32_t* row = lines3 + (size_t)e * (3 * FP_NL) * lanes;
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+#pragma unroll
+    for (int k = 0; k < FP_NL; k++) {
+      c[j]->l[k] = (int32_t)row[t];
+      row += lanes;
+    }
+  f12_sh_mul_line3(sh, l0, l2, l3);
+}
+__global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) __attribute__((disable_tail_calls))
+k_millerfp3(size_t count, size_t q, int group, const int32_t* bad, const uint32_t* lines3, size_t lanes, uint32_t* fws, size_t stride, size_t out0) {
+  const uint32_t t = blockIdx.x * BLS_BLOCK + threadIdx.x;
+  const size_t g = t >> 1;
+  if (g >= q) return;
+  const uint32_t hi = t & 1u;
+  __shared__ uint32_t fsh[F12_SH_WORDS * BLS_BLOCK];
+  f12_sh acc = {lds_column(fsh)};
+  acc_one(acc);
+  for (int e = 0; e < MILLER_ENTRIES; e++) {
+    if (e > 0 && !miller_entry_is_add(e)) f12_sh_sqr_fn(acc.sh);
+    for (int k = 0; k < group; k++) {
+      const size_t v = g + (size_t)k * q;
+      if (v < count && bad[v] == 0) f12_sh_mul_line3_fn(acc.sh, lines3, lanes, (uint32_t)(2 * v) + hi, e);
+    }
+  }
+  fp12_t<hfp2> f;
+  sh_ld_f12(f, acc.sh);
+  fp12_conj(f, f);
+  ws_st_hfp12(fws, stride, out0 + g, f);
+}
+#endif
+
 #if defined(BLS_TU_FINALEXP2)
 // =====================================================================================================
 // Round 3: the final exponentiation of the lane-split batch path as a sequence of operations on ONE accumulator A in LDS
@@ -2790,6 +2833,35 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_finalexp_wide_ws(const ui
   }
   __syncthreads();
   if (threadIdx.x == 0) *verdict = S.flag ? BLS_OK : BLS_ERR_INVALID_SIGNATURE;
+}
+// The last levels of a pairing product's fold tree on the engine (round 3): workgroup b <- the product of the Fp12 items
+// [16 b, 16 b + 16) of a workspace (absent ones count as 1), written as item b of another workspace.  Fifteen general products of
+// ~2.8 us against one 0.15 ms launch per halving with the lane-pair kernel (k_f12_fold): 65,536 partial products took 16 launches,
+// 2.4 ms -- 8 % of AggregateSignature::verify over 262,144 pairs.  fin and fout must not overlap (workgroups read what others write).
+__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_f12_tree_wide(size_t m, const uint32_t* fin, size_t sin, uint32_t* fout, size_t sout) {
+  __shared__ wide_lds_t<wide_tb_f12> S;
+  const size_t base = (size_t)blockIdx.x * 16;
+  if (base >= m) return;
+  wide_consts K;
+  wide_init(K);
+  wide_stage(S, WIDE_PROG_F12_TREE16, WIDE_PROG_F12_TREE16_LEN);
+  const int l = (int)(threadIdx.x & 15u);
+  for (int u = (int)(threadIdx.x >> 4); u < 16 * 12; u += WIDE_TABLE_ROWS) {      // u = 12 j + v: value v of item j
+    const int j = u / 12, v = u % 12, k = v >> 1, pw = k < 3 ? 2 * k : 2 * (k - 3) + 1;   // tower order -> powers of w, as k_finalexp_wide_ws
+    uint32_t x = 0;
+    if (base + j < m) {
+      if (l < FP_NL) x = fin[(size_t)(W1 * v + l) * sin + base + j];
+    } else if (v == 0 && l < FP_NL) {
+      x = FP_ONE[l];
+    }
+    S.V[WV_L + 12 * j + 2 * pw + (v & 1)][l] = x;
+  }
+  __syncthreads();
+  wide_exec(S, WIDE_PROG_F12_TREE16_LEN, K);
+  for (int v = (int)(threadIdx.x >> 4); v < 12; v += WIDE_TABLE_ROWS) {
+    const int k = v >> 1, pw = k < 3 ? 2 * k : 2 * (k - 3) + 1;
+    if (l < FP_NL) fout[(size_t)(W1 * v + l) * sout + blockIdx.x] = S.V[WV_L + 2 * pw + (v & 1)][l];
+  }
 }
 // The cut check, early parts.  blockIdx.y + first_part = 0: the key's line coefficients (program PRE_LINES: needs the key only);
 // 1: the Miller function of the (signature, -g2) pair (PRE_F1: needs the signature only).  Both leave their result in the

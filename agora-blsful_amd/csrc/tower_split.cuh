@@ -261,6 +261,50 @@ __device__ __forceinline__ void acc_mul_2lines(f12_sh& f, const hfp2& a0, const 
   f12_sh_mul_line(f.sh, b0, b2, b3);
 #endif
 }
+// (x0, x1, x2) * (y0 + y1 v): the sparse Fp6 product of tower.cuh fp12_mul_by_line_body (Karatsuba on the two non-zero coefficients, 5 products)
+__device__ __forceinline__ void fp6_mul_by_01(fp6_t<hfp2>& r, const fp6_t<hfp2>& a, const hfp2& y0, const hfp2& y1) {
+  hfp2 v0, v1, x, y, z;
+  fp2_mul(v0, a.a0, y0);
+  fp2_mul(v1, a.a1, y1);
+  fp2_mul(x, a.a2, y1);
+  fp2_mul_xi(x, x);
+  fp2_add(r.a0, v0, x);
+  fp2_add(y, a.a0, a.a1);
+  fp2_add(z, y0, y1);
+  fp2_mul(y, y, z);
+  fp2_sub(y, y, v0);
+  fp2_sub(r.a1, y, v1);
+  fp2_mul(z, a.a2, y0);
+  fp2_add(r.a2, z, v1);
+}
+// accumulator *= (l0 + l2 w^2 + l3 w^3), the plain sparse line value: fp12_mul_by_line_body with the accumulator's halves fetched
+// from LDS where they are needed (k_millerfp3: one item per accumulator, no merge)
+__device__ __forceinline__ void f12_sh_mul_line3(lds_u32* sh, const hfp2& l0, const hfp2& l2, const hfp2& l3) {
+  fp6_t<hfp2> x, y, t0, t1, m;
+  hfp2 l23, u;
+  sh_ld_f6(x, sh, 0);
+  fp6_mul_by_01(t0, x, l0, l2);
+  fp6_norm(t0, t0);
+  sh_ld_f6(x, sh, 39);
+  fp2_mul(u, x.a2, l3);
+  fp2_mul_xi(t1.a0, u);
+  fp2_mul(t1.a1, x.a0, l3);
+  fp2_mul(t1.a2, x.a1, l3);
+  sh_ld_f6(y, sh, 0);
+  fp6_add(x, y, x);
+  fp6_norm(x, x);
+  fp2_add(l23, l2, l3);
+  fp2_norm(l23, l23);
+  fp6_mul_by_01(m, x, l0, l23);
+  fp6_sub(m, m, t0);
+  fp6_sub(m, m, t1);
+  fp6_reduce(m, m);
+  sh_st_f6(sh, 39, m);
+  fp6_mul_v(t1, t1);
+  fp6_add(t0, t0, t1);
+  fp6_reduce(t0, t0);
+  sh_st_f6(sh, 0, t0);
+}
 // accumulator *= merged line value (tower.cuh fp12_mul_by_line5_body) with the accumulator's halves fetched from LDS where they
 // are needed, as f12_sh_mul does
 __device__ __forceinline__ void f12_sh_mul_line5(lds_u32* sh, const line5_t<hfp2>& L) {

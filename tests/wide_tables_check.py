@@ -184,6 +184,16 @@ def check_programs():
         V3[B['W']:B['W'] + 12] = V2[B['F']:B['F'] + 12]
         sim_program(OPS, lay, dict(PROGRAMS)['POST'], V3)
         assert unflat(V3[B['T']:B['T'] + 12]) == want, 'cut pairing programs'
+    # the fold tree's sixteen-way product
+    vals = [tuple((rng.randrange(P), rng.randrange(P)) for _ in range(6)) for _ in range(16)]
+    Vt = [0] * lay.count
+    for j, x in enumerate(vals):
+        Vt[B['L'] + 12 * j:B['L'] + 12 * j + 12] = flat(x)
+    sim_program(OPS, lay, dict(PROGRAMS)['F12_TREE16'], Vt)
+    want = vals[0]
+    for x in vals[1:]:
+        want = c.f12_mul(want, x)
+    assert unflat(Vt[B['L']:B['L'] + 12]) == want, 'F12_TREE16'
     return lay
 
 

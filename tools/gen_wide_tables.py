@@ -956,6 +956,16 @@ def prog_easy():
     return [('CONJ', 'U', 'F', 'F')] + prog_f12_inv() + [('MUL', 'F', 'U', 'T'), ('FROB2', 'T', 'F', 'F'), ('MUL', 'F', 'T', 'F')]
 
 
+def prog_f12_tree16():
+    """L[0..11] <- the product of the sixteen Fp12 values L[12 j .. 12 j + 11], j < 16 (the line array doubles as the input store):
+    the last levels of a pairing product's fold tree (kernels.cuh k_f12_tree_wide), fifteen general products"""
+    st, d = [], 1
+    while d < 16:
+        st += [('MUL', ('L', 12 * j), ('L', 12 * j), ('L', 12 * (j + d))) for j in range(0, 16, 2 * d)]
+        d *= 2
+    return st
+
+
 CONJ_F = [('CONJ', 'F', 'F', 'F')]                 # x < 0: the Miller function of |x| is conjugated once, after the product
 PROGRAMS = [('FINAL_HARD', prog_final_hard()),
             ('FINAL', prog_easy() + prog_final_hard()),              # the whole final exponentiation of a Miller product (aggregate verify)
@@ -968,7 +978,8 @@ PROGRAMS = [('FINAL_HARD', prog_final_hard()),
             ('PRE_F1', prog_pprep((1,)) + prog_miller((1,))),
             # Bls12381G2Impl: pair 1 is (-g1, signature): its lines come from the signature, then the same Miller function
             ('PRE_F1G', prog_key_lines(1) + prog_pprep((1,)) + prog_miller((1,))),
-            ('POST', prog_pprep((0,)) + prog_miller((0,)) + [('MUL', 'F', 'F', 'W')] + CONJ_F + prog_easy() + prog_final_hard())]
+            ('POST', prog_pprep((0,)) + prog_miller((0,)) + [('MUL', 'F', 'F', 'W')] + CONJ_F + prog_easy() + prog_final_hard()),
+            ('F12_TREE16', prog_f12_tree16())]
 
 
 def layout_f12():
