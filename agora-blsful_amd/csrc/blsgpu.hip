@@ -342,7 +342,8 @@ size_t coop_max_items() {
   static long v = -1;
   if (v < 0) {
     const char* e = getenv("BLSGPU_COOP_MAX");
-    v = e ? atol(e) : 6144;   // measured crossover with the lane-split kernels: 11.9 vs 13.7 ms at 6,144 items, 14.9 vs 13.8 ms at 8,192
+    v = e ? atol(e) : 4096;   // measured crossover with the lane-split kernels (tools/dbg/mid3.py, round 3: whole calls from host lists): 11.4 vs 12.0 ms at
+                              // 3,072 items, 12.1 vs 12.1 at 4,096, 17.4 vs 12.5 at 6,144 (rounds 1-2, the one-kernel Miller loop: 6,144)
     if (v < 0) v = 0;
   }
   return (size_t)v;

@@ -1,5 +1,5 @@
 """Randomised differential campaign on the GPU box: the C ABI against oracle/c (test infrastructure, the checker) on inputs no
-fixed test holds -- random batch sizes on both sides of every path boundary (1 / 128 / 512 / 1,024 / 6,144 items), random
+fixed test holds -- random batch sizes on both sides of every path boundary (1 / 128 / 512 / 1,024 / 4,096 items), random
 message lengths, random tampering (swapped signatures, flipped message bytes, identity points), all three schemes, both
 groups; hash-to-curve of random messages; MultiSignature::verify, verify_secure and AggregateSignature::verify of random key sets.  Not collected by pytest
 (minutes, not seconds): python tests/stress_parity.py --seconds 480 [--seed S].  Prints one line per round and a summary; exits
@@ -18,7 +18,7 @@ import util  # noqa: E402
 from util import c  # noqa: E402
 
 V = lambda x: ctypes.cast(x, ctypes.c_void_p)  # noqa: E731
-SIZES = [1, 2, 3, 17, 64, 127, 128, 129, 255, 256, 257, 511, 512, 513, 700, 1023, 1024, 1025, 2000, 6144, 6145, 9000]
+SIZES = [1, 2, 3, 17, 64, 127, 128, 129, 255, 256, 257, 511, 512, 513, 700, 1023, 1024, 1025, 2000, 4096, 4097, 6145, 9000]
 
 
 def oracle_statuses(bo, sg, scheme, pks, sigs, msgs):

@@ -409,7 +409,7 @@ def test_verify_batch_vs_c_oracle(api, sg, path):
 def test_verify_batch_ragged_sizes(api, sg):
     """Batch sizes around the wave (32 items) and workgroup boundaries and on both sides of the cooperative / lane-split
     threshold (6,144 items), empty batch included: one tampered item per batch, exact verdict vectors, both orientations."""
-    sizes = (0, 1, 2, 31, 32, 33, 63, 65, 255, 257, 511, 512, 513, 1023, 1024, 1025, 1057, 6144, 6145, 6177) if sg == 1 else (0, 1, 33, 511, 513, 1025, 6145)
+    sizes = (0, 1, 2, 31, 32, 33, 63, 65, 255, 257, 511, 512, 513, 1023, 1024, 1025, 1057, 4096, 4097, 4129, 6145) if sg == 1 else (0, 1, 33, 511, 513, 1025, 4097)
     nmax = max(sizes)
     sks = [0x5151 + 3 * i for i in range(nmax)]
     msgs = [hashlib.sha256(b'ragged%d' % i).digest() for i in range(nmax)]
