@@ -143,3 +143,27 @@ def test_config2_verify_batch_65536(api, gpu):
     V = lambda x: ctypes.cast(x, ctypes.c_void_p)  # noqa: E731
     bo.bo_verify_batch(1, 2, V(ctypes.c_char_p(pks_h)), V(ctypes.c_char_p(sigs_h)), V(ctypes.c_char_p(blob)), V(offs), sample, V(st), 16)
     assert list(st) == d_st[:sample].cpu().tolist()
+
+
+@pytest.mark.parametrize('sg', [1, 2])
+def test_verify_batch_beyond_one_chunk(api, gpu, sg):
+    """More items than one pass of the two-kernel Miller loop takes (65,536): a second, ragged chunk (70,001 items; Bls12381G2Impl: the
+    two-pass line kernel), tampered items on both sides of the chunk boundary and in the last workgroup, identities in the second chunk:
+    the exact verdict vector."""
+    torch, lib, P = gpu['torch'], gpu['lib'], gpu['P']
+    n = 70001
+    pksz, sgsz = (288, 144) if sg == 1 else (144, 288)
+    msgs = [hashlib.sha256(SEED + b'chunks' + i.to_bytes(8, 'little')).digest() for i in range(n)]
+    d_pks, d_sigs, d_msgs, d_offs = gpu['sign'](sg, api.POP, [(S0 + 77 + i) % R for i in range(n)], msgs)
+    bad = torch.tensor(sorted(set(list(range(11, n, 911)) + [65535, 65536, 65537, 69999, 70000])), device=gpu['dev'])
+    d_msgs[bad * 32] ^= 1
+    expect = torch.zeros(n, dtype=torch.int32, device=gpu['dev'])
+    expect[bad] = api.INVALID_SIGNATURE
+    d_sigs.view(n, sgsz)[66000, 2 * sgsz // 3:] = 0                 # Z = 0: identity signature in the second chunk
+    expect[66000] = api.SIG_IDENTITY
+    d_pks.view(n, pksz)[66001, 2 * pksz // 3:] = 0                  # identity key
+    expect[66001] = api.PK_IDENTITY
+    d_st = torch.full((n,), -7, dtype=torch.int32, device=gpu['dev'])
+    api._check(lib.blsgpu_verify_batch(sg, api.POP, P(d_pks), P(d_sigs), P(d_msgs), P(d_offs), n, api.FMT_RAW_PROJ, P(d_st)))
+    diff = torch.nonzero(d_st != expect).view(-1)
+    assert diff.numel() == 0, diff[:10].tolist()
