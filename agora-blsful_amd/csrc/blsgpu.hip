@@ -754,6 +754,121 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
   return run_pairing2(c, n, d_pairs, d_f, d_status, sg == 1 ? 2 : 0);
 }
 
+// Pairing products, second form (round 3): the product over the items entry by entry, then one Horner chain (kernels.cuh
+// k_line_quad).  Chunks of one machine round of lane pairs walk their G2 points (k_linesp pass 1: the plain line values of every
+// item and entry), k_line_quad multiplies four items' values per entry into an Fp12 value, k_f12_fold4 folds each entry's values
+// four to one -- chunk by chunk while a level still fills the machine, then over all chunks' values together -- the engine takes
+// the last sixteen per entry (k_f12_tree_seg) and runs the Horner chain over the 68 products (k_f12_horner_wide).  What is
+// left beyond whole rounds (< 1,024 items) is a small chunk of its own on the tail stream, beside the others.  Leaves the
+// Miller product as item 0 of d_f (*outputs = 1).  *done = false: not applicable (too few items,
+// no engine, no memory, BLSGPU_PRODUCT_TREE=0) -- the caller falls back to the accumulator kernels.
+int run_miller_product_tree(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs, int32_t* d_bad, uint32_t* d_f, size_t* outputs, bool* done) {
+  *done = false;
+  static const int enabled = getenv("BLSGPU_PRODUCT_TREE") ? atoi(getenv("BLSGPU_PRODUCT_TREE")) : 1;
+  static const long local_env = getenv("BLSGPU_TREE_LOCAL") ? atol(getenv("BLSGPU_TREE_LOCAL")) : 0;
+  if (!enabled || mm < 64 || !miller_chunk_items() || !(wide_max_items() > 0 && coop_max_items() > 0)) return 0;
+  const size_t round = 65536, E = MILLER_ENTRIES;
+  const size_t LOCAL = local_env > 16 ? (size_t)local_env : 1024;    // 68 x 1,024 lane pairs: one machine round
+  const size_t rem = mm % round;
+  const size_t left = mm >= round && rem < 1024 ? rem : 0, body = mm - left;
+  const size_t nch = (body + round - 1) / round;
+  auto chunk_cnt = [&](size_t k) { return k + 1 < nch ? round : body - k * round; };
+  auto quarter = [](size_t q) { return (q + 3) / 4; };
+  auto local_out = [&](size_t cnt) {
+    size_t q = quarter(cnt);
+    while (q > LOCAL) q = quarter(q);
+    return q;
+  };
+  size_t Qc = left ? quarter(left) : 0;
+  for (size_t k = 0; k < nch; k++) Qc += local_out(chunk_cnt(k));
+  const size_t q0max = quarter(chunk_cnt(0));
+  const size_t capA = E * (q0max > quarter(Qc) ? q0max : quarter(Qc)), capB = E * (quarter(q0max) > quarter(quarter(Qc)) ? quarter(q0max) : quarter(quarter(Qc)));
+  const size_t lanes_max = row_stride(lanes_for(chunk_cnt(0))), lanes_left = left ? row_stride(lanes_for(left)) : 0;
+  const size_t T_STRIDE = 128;
+  if ((capA + E * Qc) * W1 >= ((size_t)1 << 30)) return 0;      // the fold kernels' 32-bit lane offsets (kernels.cuh wsu_ld_hfp6)
+  const size_t words = E * LINE3_WORDS_H * (lanes_max + lanes_left) + (size_t)WS_F_WORDS * (capA + capB + E * Qc + T_STRIDE);
+  if (lines_reserve(c, words * 4) != 0) return 0;
+  uint32_t* lines3 = c->lines_ws;
+  uint32_t* lines3_left = lines3 + E * LINE3_WORDS_H * lanes_max;
+  uint32_t* bufA = lines3_left + E * LINE3_WORDS_H * lanes_left;
+  uint32_t* bufB = bufA + (size_t)WS_F_WORDS * capA;
+  uint32_t* comb = bufB + (size_t)WS_F_WORDS * capB;
+  uint32_t* t68 = comb + (size_t)WS_F_WORDS * E * Qc;
+  const size_t comb_stride = E * Qc;
+  size_t comb_off = 0;
+  for (size_t k = 0; k < nch; k++) {
+    const size_t lo = k * round, cnt = chunk_cnt(k);
+    const size_t nlanes = lanes_for(cnt), lanes = row_stride(nlanes);
+    const uint32_t* pw = d_pairs + lo;
+    const int32_t* bw = d_bad + lo;
+    KL(KID_LINES, k_linesp, dim3((unsigned)(nlanes / BLS_BLOCK)), dim3(BLS_BLOCK), cnt, cnt, stride, pw, bw, lines3, lines3, lanes, (size_t)0, cnt, 1);
+    if (k == 0 && left) {
+      // the leftover items: a chunk of their own on the tail stream, its values straight into the combined level.  It starts when
+      // the first chunk's line kernel is through -- beside that kernel, which fills every wave slot of the machine exactly, a
+      // few extra waves would make some of its workgroups wait for a whole round (measured: 2.97 against 2.1 ms) -- and its 68-step
+      // latency hides beside the short tasks of the chunk's product kernels
+      if (!c->tail) {
+        HIPCK(hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking));
+        HIPCK(hipEventCreateWithFlags(&c->ev_tail_fork, hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&c->ev_tail_join, hipEventDisableTiming));
+      }
+      HIPCK(hipEventRecord(c->ev_tail_fork, c->stream));
+      HIPCK(hipStreamWaitEvent(c->tail, c->ev_tail_fork, 0));
+      const size_t nl = lanes_for(left), ql = quarter(left);
+      hipLaunchKernelGGL(k_linesp, dim3((unsigned)(nl / BLS_BLOCK)), dim3(BLS_BLOCK), 0, c->tail, left, left, stride, (const uint32_t*)(d_pairs + body),
+                         (const int32_t*)(d_bad + body), lines3_left, lines3_left, lanes_left, (size_t)0, left, 1);
+      hipLaunchKernelGGL(k_line_quad, dim3(blocks_for(2 * ql), (unsigned)E), dim3(BLS_BLOCK), 0, c->tail, left, ql, (const int32_t*)(d_bad + body),
+                         (const uint32_t*)lines3_left, lanes_left, comb, comb_stride, Qc, Qc - ql);
+      const hipError_t e1 = hipGetLastError(), e2 = hipEventRecord(c->ev_tail_join, c->tail);
+      if (e1 != hipSuccess || e2 != hipSuccess) {
+        (void)hipStreamSynchronize(c->tail);
+        return fail(BLSGPU_E_HIP, "tail-stream launch failed");
+      }
+    }
+    size_t q = quarter(cnt);
+    if (q <= LOCAL) {
+      KL(KID_MILLER1, k_line_quad, dim3(blocks_for(2 * q), (unsigned)E), dim3(BLS_BLOCK), cnt, q, bw, (const uint32_t*)lines3, lanes, comb, comb_stride, Qc, comb_off);
+    } else {
+      KL(KID_MILLER1, k_line_quad, dim3(blocks_for(2 * q), (unsigned)E), dim3(BLS_BLOCK), cnt, q, bw, (const uint32_t*)lines3, lanes, bufA, E * q, q, (size_t)0);
+      uint32_t *src = bufA, *dst = bufB;
+      while (q > LOCAL) {
+        const size_t qo = quarter(q);
+        if (qo <= LOCAL)
+          KL(KID_F12_FOLD, k_f12_fold4, dim3(blocks_for(2 * qo), (unsigned)E), dim3(BLS_BLOCK), q, qo, (const uint32_t*)src, E * q, q, comb, comb_stride, Qc, comb_off);
+        else
+          KL(KID_F12_FOLD, k_f12_fold4, dim3(blocks_for(2 * qo), (unsigned)E), dim3(BLS_BLOCK), q, qo, (const uint32_t*)src, E * q, q, dst, E * qo, qo, (size_t)0);
+        uint32_t* t = src;
+        src = dst;
+        dst = t;
+        q = qo;
+      }
+    }
+    comb_off += q;
+  }
+  if (left) HIPCK(hipStreamWaitEvent(c->stream, c->ev_tail_join, 0));
+  // all chunks' values together
+  {
+    const uint32_t* src = comb;
+    size_t q = Qc;
+    uint32_t *dst = bufA, *other = bufB;
+    while (q > 16) {
+      const size_t qo = quarter(q);
+      KL(KID_F12_FOLD, k_f12_fold4, dim3(blocks_for(2 * qo), (unsigned)E), dim3(BLS_BLOCK), q, qo, src, E * q, q, dst, E * qo, qo, (size_t)0);
+      src = dst;
+      uint32_t* t = dst;
+      dst = other;
+      other = t;
+      q = qo;
+    }
+    KL(KID_F12_FOLD, k_f12_tree_seg, dim3((unsigned)E), dim3(WIDE_ENGINE_BLOCK), q, src, E * q, q, t68, T_STRIDE);
+    KL(KID_F12_FOLD, k_f12_horner_wide, dim3(1), dim3(WIDE_ENGINE_BLOCK), (const uint32_t*)t68, T_STRIDE, d_f, stride);
+  }
+  HIPCK(hipGetLastError());
+  *outputs = 1;
+  *done = true;
+  return 0;
+}
+
 // Miller loops of a pairing product over mm one-pair items (workspace stride given; flagged items contribute 1): leaves *outputs
 // partial products at the start of the Fp12 workspace.  Round 3: two items share a merged line value (k_linesp, two passes),
 // and one accumulator takes the values of `group` such pairs per step (k_millerfp).  The items are cut into chunks of 2 cnt
@@ -762,6 +877,11 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
 // leave one) goes through k_miller1s on the context's tail stream BESIDE the chunks.  BLSGPU_MILLER_V1=1, fewer than 4,096
 // items, or no memory for the line workspace: k_miller1s for everything.
 int run_miller_product(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs, int32_t* d_bad, uint32_t* d_f, size_t* outputs) {
+  {
+    bool done = false;
+    if (int rc = run_miller_product_tree(c, mm, stride, d_pairs, d_bad, d_f, outputs, &done)) return rc;
+    if (done) return 0;
+  }
   const size_t chunk_max = 2 * miller_chunk_items(), round = 65536;
   const size_t words_per_lane = (size_t)MILLER_ENTRIES * (LINE5_WORDS + LINE3_WORDS_H);
   auto nice = [&](size_t pairs) {          // virtual items of the next chunk when `pairs` virtual items could still be formed

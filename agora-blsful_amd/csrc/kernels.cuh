@@ -200,6 +200,8 @@ __global__ void k_cyc_run4(size_t count, uint32_t* vp, size_t lanes, const int32
 __global__ void k_linesp(size_t mm, size_t half, size_t stride, const uint32_t* pairs, const int32_t* bad, uint32_t* lines, uint32_t* lines3, size_t lanes, size_t first_v, size_t count_v, int pass);
 __global__ void k_millerfp(size_t count_v, size_t q, int group, const uint32_t* lines, size_t lanes, uint32_t* fws, size_t stride, size_t out0);
 __global__ void k_millerfp3(size_t count, size_t q, int group, const int32_t* bad, const uint32_t* lines3, size_t lanes, uint32_t* fws, size_t stride, size_t out0);
+__global__ void k_line_quad(size_t count, size_t q, const int32_t* bad, const uint32_t* lines3, size_t lanes, uint32_t* fout, size_t sout, size_t rout, size_t oout);
+__global__ void k_f12_fold4(size_t qin, size_t qout, const uint32_t* fin, size_t sin, size_t rin, uint32_t* fout, size_t sout, size_t rout, size_t oout);
 __global__ void k_finalexps(size_t n, const uint32_t* fws, int32_t* status);
 __global__ void k_miller1s(size_t n, size_t stride, const uint32_t* pairs, const int32_t* skip, uint32_t* fws);
 __global__ void k_finalexp_ones(const uint32_t* fws, size_t stride, int32_t* verdict);
@@ -288,6 +290,8 @@ __global__ void k_pairing_coop_easy(size_t n, const uint32_t* pairs, const int32
 __global__ void k_finalexp_wide(size_t n, const uint32_t* easy, int32_t* status);
 __global__ void k_finalexp_wide_ws(const uint32_t* fws, size_t stride, int32_t* verdict);
 __global__ void k_f12_tree_wide(size_t m, const uint32_t* fin, size_t sin, uint32_t* fout, size_t sout);
+__global__ void k_f12_tree_seg(size_t qin, const uint32_t* fin, size_t sin, size_t rin, uint32_t* fout, size_t sout);
+__global__ void k_f12_horner_wide(const uint32_t* fin, size_t sin, uint32_t* fout, size_t sout);
 __global__ void k_wide_prog_test(const uint32_t* prog, int len, int reps, const uint8_t* fin, uint8_t* tout);
 bool wide_prog_is_fp12(const uint32_t* prog, size_t len);   // host: what k_wide_prog_test may be given
 __global__ void k_pairing_wide(size_t n, const uint32_t* pairs, int32_t* status, int fixed_g2);
@@ -1591,6 +1595,153 @@ k_millerfp3(size_t count, size_t q, int group, const int32_t* bad, const uint32_
 }
 #endif
 
+#if defined(BLS_TU_MILLERF)
+// ---- pairing products, second form (round 3): the product over the ITEMS first, entry by entry, then ONE Horner chain ----------
+// The Miller function of item i is f_i = (..((l_i0)^2 l_i1)^2 ..) over the 68 entries (no squaring before the five addition entries),
+// and squaring is multiplicative: prod_i f_i = (..((P_0)^2 P_1)^2 ..) with P_e = prod_i l_ie.  So a pairing product needs 68
+// independent products over the items' sparse line values -- short independent tasks, any number of them in flight, no
+// 68-step accumulator chain per lane pair -- and 63 squarings IN ALL (the engine's Horner program, k_f12_horner_wide) instead of 63
+// per accumulator.  Per line value: 3 (merge of two lines) + 4.25 (two merged values -> a full Fp12 value) + 4.5 (the fold tree)
+// = 11.75 Fp2 multiplications, against 13 + 12 for one item per accumulator (k_millerfp3).
+// k_line_quad: grid (q / 32, 68).  Lane pair j of entry e = blockIdx.y takes the line values (k_linesp pass 1) of the chunk's items
+// j, j + q, j + 2 q, j + 3 q (absent or flagged ones count as the line 1), merges them two by two and leaves the product of the
+// two merged values at position e * rout + oout + j of the Fp12 workspace fout (stride sout).
+static __device__ __noinline__ void f12_sh_st_ws_fn(lds_u32* sh, uint32_t* ws, size_t stride, uint32_t off);
+__device__ __forceinline__ void quad_line_ld(hfp2& l0, hfp2& l2, hfp2& l3, size_t count, const int32_t* bad, const uint32_t* row, size_t lanes, size_t x, uint32_t hi) {
+  if (x < count && bad[x] == 0) {
+    fp* c[3] = {&l0.v, &l2.v, &l3.v};
+    const uint32_t t = (uint32_t)(2 * x) + hi;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+      for (int k = 0; k < FP_NL; k++) {
+        c[j]->l[k] = (int32_t)row[t];
+        row += lanes;
+      }
+  } else {
+    fp2_one(l0);
+    fp2_zero(l2);
+    fp2_zero(l3);
+  }
+}
+template <int FIRST>
+static __device__ __noinline__ void quad_merge_fn(lds_u32* sh, size_t count, const int32_t* bad, const uint32_t* row, size_t lanes, size_t xa, size_t xb, uint32_t hi) {
+  hfp2 a0, a2, a3, b0, b2, b3;
+  quad_line_ld(a0, a2, a3, count, bad, row, lanes, xa, hi);
+  quad_line_ld(b0, b2, b3, count, bad, row, lanes, xb, hi);
+  line5_t<hfp2> L;
+  lines_merge(L, a0, a2, a3, b0, b2, b3);
+  if (FIRST) {
+    f12_sh acc = {sh};
+    acc_set_line5(acc, L);
+  } else {
+    f12_sh_mul_line5(sh, L);
+  }
+}
+__global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) __attribute__((disable_tail_calls))
+k_line_quad(size_t count, size_t q, const int32_t* bad, const uint32_t* lines3, size_t lanes, uint32_t* fout, size_t sout, size_t rout, size_t oout) {
+  const uint32_t t = blockIdx.x * BLS_BLOCK + threadIdx.x;
+  const size_t j = t >> 1;
+  if (j >= q) return;
+  const uint32_t hi = t & 1u;
+  const int e = (int)blockIdx.y;
+  __shared__ uint32_t fsh[F12_SH_WORDS * BLS_BLOCK];
+  lds_u32* sh = lds_column(fsh);
+  const uint32_t* row = lines3 + (size_t)e * (3 * FP_NL) * lanes;
+  quad_merge_fn<1>(sh, count, bad, row, lanes, j, j + q, hi);
+  quad_merge_fn<0>(sh, count, bad, row, lanes, j + 2 * q, j + 3 * q, hi);
+  f12_sh_st_ws_fn(sh, fout + (size_t)e * rout + oout, sout, (uint32_t)j + hi * (uint32_t)(W1 * sout));
+}
+// k_f12_fold4: one level of the 68 fold trees.  grid (qout / 32, 68): lane pair j of entry e multiplies the values at positions
+// e * rin + j + k qout (k < 4, j + k qout < qin) of fin and leaves the product at position e * rout + oout + j of fout.  fin and
+// fout must not overlap.
+// (the factor streams in from the workspace half by half, its first half twice: with all of it held beside the three Fp6 products
+// the function spilled 700 bytes per lane; and every access is wave-uniform row pointer + 32-bit lane offset, see line5_st)
+// wsu_*: `ws` points at word 0 of a wave-uniform position of an Fp12 workspace, `off` = this lane's item offset from there plus
+// W1 * stride on the odd lane (the imaginary parts' rows); the host keeps W1 * stride + items below 2^30 words
+__device__ __forceinline__ void wsu_ld_hfp6(fp6_t<hfp2>& r, const uint32_t* ws, size_t stride, uint32_t off, int half) {
+  fp* c[3] = {&r.a0.v, &r.a1.v, &r.a2.v};
+  const uint32_t* row = ws + (size_t)(3 * W2 * half) * stride;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+#pragma unroll
+    for (int k = 0; k < FP_NL; k++) {
+      c[j]->l[k] = (int32_t)row[off];
+      row += stride;
+    }
+    row += (size_t)(W2 - FP_NL) * stride;
+  }
+}
+__device__ __forceinline__ void wsu_st_hfp6(uint32_t* ws, size_t stride, uint32_t off, int half, const fp6_t<hfp2>& a) {
+  const fp* c[3] = {&a.a0.v, &a.a1.v, &a.a2.v};
+  uint32_t* row = ws + (size_t)(3 * W2 * half) * stride;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+#pragma unroll
+    for (int k = 0; k < FP_NL; k++) {
+      row[off] = (uint32_t)c[j]->l[k];
+      row += stride;
+    }
+    row += (size_t)(W2 - FP_NL) * stride;
+  }
+}
+static __device__ __noinline__ void f12_sh_mul_ws_fn(lds_u32* sh, const uint32_t* ws, size_t stride, uint32_t off) {
+  fp6_t<hfp2> x, y, t0, t1, m;
+  sh_ld_f6(x, sh, 0);
+  wsu_ld_hfp6(y, ws, stride, off, 0);
+  fp6_mul(t0, x, y);
+  sh_ld_f6(x, sh, 39);
+  wsu_ld_hfp6(y, ws, stride, off, 1);
+  fp6_mul(t1, x, y);
+  sh_ld_f6(m, sh, 0);
+  fp6_add(x, x, m);
+  fp6_norm(x, x);
+  wsu_ld_hfp6(m, ws, stride, off, 0);
+  fp6_add(y, y, m);
+  fp6_norm(y, y);
+  fp6_mul(m, x, y);
+  fp6_sub(m, m, t0);
+  fp6_sub(m, m, t1);
+  fp6_reduce(m, m);
+  sh_st_f6(sh, 39, m);
+  fp6_mul_v(t1, t1);
+  fp6_add(t0, t0, t1);
+  fp6_reduce(t0, t0);
+  sh_st_f6(sh, 0, t0);
+}
+static __device__ __noinline__ void f12_sh_ld_ws_fn(lds_u32* sh, const uint32_t* ws, size_t stride, uint32_t off) {
+  fp6_t<hfp2> x;
+  wsu_ld_hfp6(x, ws, stride, off, 0);      // stored from the packed form: reduced
+  sh_st_f6(sh, 0, x);
+  wsu_ld_hfp6(x, ws, stride, off, 1);
+  sh_st_f6(sh, 39, x);
+}
+static __device__ __noinline__ void f12_sh_st_ws_fn(lds_u32* sh, uint32_t* ws, size_t stride, uint32_t off) {
+  fp6_t<hfp2> x;
+  sh_ld_f6(x, sh, 0);
+  wsu_st_hfp6(ws, stride, off, 0, x);
+  sh_ld_f6(x, sh, 39);
+  wsu_st_hfp6(ws, stride, off, 1, x);
+}
+__global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) __attribute__((disable_tail_calls))
+k_f12_fold4(size_t qin, size_t qout, const uint32_t* fin, size_t sin, size_t rin, uint32_t* fout, size_t sout, size_t rout, size_t oout) {
+  const uint32_t t = blockIdx.x * BLS_BLOCK + threadIdx.x;
+  const uint32_t j = t >> 1;
+  if (j >= qout) return;
+  const uint32_t hi = t & 1u;
+  const uint32_t* in = fin + (size_t)blockIdx.y * rin;
+  const uint32_t off_in = j + hi * (uint32_t)(W1 * sin);
+  __shared__ uint32_t fsh[F12_SH_WORDS * BLS_BLOCK];
+  lds_u32* sh = lds_column(fsh);
+  f12_sh_ld_ws_fn(sh, in, sin, off_in);
+  for (int k = 1; k < 4; k++) {
+    const size_t x = j + (size_t)k * qout;
+    if (x < qin) f12_sh_mul_ws_fn(sh, in + (size_t)k * qout, sin, off_in);
+  }
+  f12_sh_st_ws_fn(sh, fout + (size_t)blockIdx.y * rout + oout, sout, j + hi * (uint32_t)(W1 * sout));
+}
+#endif
+
 #if defined(BLS_TU_FINALEXP2)
 // =====================================================================================================
 // Round 3: the final exponentiation of the lane-split batch path as a sequence of operations on ONE accumulator A in LDS
@@ -2861,6 +3012,52 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_f12_tree_wide(size_t m, c
   for (int v = (int)(threadIdx.x >> 4); v < 12; v += WIDE_TABLE_ROWS) {
     const int k = v >> 1, pw = k < 3 ? 2 * k : 2 * (k - 3) + 1;
     if (l < FP_NL) fout[(size_t)(W1 * v + l) * sout + blockIdx.x] = S.V[WV_L + 2 * pw + (v & 1)][l];
+  }
+}
+// ... the same for the fold trees of a pairing product's 68 entries (k_line_quad / k_f12_fold4): workgroup e <- the product of the
+// qin <= 16 values at positions e * rin + j, written as item e of fout
+__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_f12_tree_seg(size_t qin, const uint32_t* fin, size_t sin, size_t rin, uint32_t* fout, size_t sout) {
+  __shared__ wide_lds_t<wide_tb_f12> S;
+  const size_t base = (size_t)blockIdx.x * rin;
+  wide_consts K;
+  wide_init(K);
+  wide_stage(S, WIDE_PROG_F12_TREE16, WIDE_PROG_F12_TREE16_LEN);
+  const int l = (int)(threadIdx.x & 15u);
+  for (int u = (int)(threadIdx.x >> 4); u < 16 * 12; u += WIDE_TABLE_ROWS) {
+    const int j = u / 12, v = u % 12, k = v >> 1, pw = k < 3 ? 2 * k : 2 * (k - 3) + 1;
+    uint32_t x = 0;
+    if ((size_t)j < qin) {
+      if (l < FP_NL) x = fin[(size_t)(W1 * v + l) * sin + base + j];
+    } else if (v == 0 && l < FP_NL) {
+      x = FP_ONE[l];
+    }
+    S.V[WV_L + 12 * j + 2 * pw + (v & 1)][l] = x;
+  }
+  __syncthreads();
+  wide_exec(S, WIDE_PROG_F12_TREE16_LEN, K);
+  for (int v = (int)(threadIdx.x >> 4); v < 12; v += WIDE_TABLE_ROWS) {
+    const int k = v >> 1, pw = k < 3 ? 2 * k : 2 * (k - 3) + 1;
+    if (l < FP_NL) fout[(size_t)(W1 * v + l) * sout + blockIdx.x] = S.V[WV_L + 2 * pw + (v & 1)][l];
+  }
+}
+// ... and the Horner chain over the 68 per-entry products (items 0..67 of fin): program HORNER on one workgroup, 63 squarings and
+// 67 products, the conjugated result (x < 0) as item 0 of fout -- the Miller product of all the items whose lines went in
+__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_f12_horner_wide(const uint32_t* fin, size_t sin, uint32_t* fout, size_t sout) {
+  __shared__ wide_lds_t<wide_tb_f12> S;
+  if (blockIdx.x != 0) return;
+  wide_consts K;
+  wide_init(K);
+  wide_stage(S, WIDE_PROG_HORNER, WIDE_PROG_HORNER_LEN);
+  const int l = (int)(threadIdx.x & 15u);
+  for (int u = (int)(threadIdx.x >> 4); u < WIDE_STEPS * 12; u += WIDE_TABLE_ROWS) {
+    const int j = u / 12, v = u % 12, k = v >> 1, pw = k < 3 ? 2 * k : 2 * (k - 3) + 1;
+    S.V[WV_L + 12 * j + 2 * pw + (v & 1)][l] = l < FP_NL ? fin[(size_t)(W1 * v + l) * sin + j] : 0u;
+  }
+  __syncthreads();
+  wide_exec(S, WIDE_PROG_HORNER_LEN, K);
+  for (int v = (int)(threadIdx.x >> 4); v < 12; v += WIDE_TABLE_ROWS) {
+    const int k = v >> 1, pw = k < 3 ? 2 * k : 2 * (k - 3) + 1;
+    if (l < FP_NL) fout[(size_t)(W1 * v + l) * sout] = S.V[WV_F + 2 * pw + (v & 1)][l];
   }
 }
 // The cut check, early parts.  blockIdx.y + first_part = 0: the key's line coefficients (program PRE_LINES: needs the key only);

@@ -578,3 +578,45 @@ def test_segmented_final_exponentiation_and_one_kernel_miller_loop_agree():
         assert want[sg_idx] == exp
     for name in ('seg', 'fe_v1', 'miller_v1'):
         assert res[name] == want, name
+
+
+@pytest.mark.gpu
+def test_pairing_product_tree_and_accumulator_forms_agree():
+    """AggregateSignature::verify's pairing product in its two forms -- the per-entry products over the items with one Horner chain
+    (k_line_quad / k_f12_fold4 / k_f12_horner_wide, the default from 64 pairs) and one accumulator per item or pair of items
+    (BLSGPU_PRODUCT_TREE=0: k_millerfp3 / k_millerfp) -- give the same verdicts AND the same 576-byte Miller-product records
+    (blsgpu_aggregate_partial: shards of either form fold together) at sizes around the form's lower bound, the fold levels'
+    fan-in (4, 16) and with flagged (identity) keys, tampered messages and a missing signature pair (child processes: the switch is read once)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge, util\n"
+        "api = ge.import_pkg().api; api.init()\n"
+        "out = []\n"
+        "for sg in (1, 2):\n"
+        "    nmax = 4200\n"
+        "    sks = [0x9000 + 3 * i for i in range(nmax)]; msgs = [hashlib.sha256(b'tree%%d' %% i).digest() for i in range(nmax)]\n"
+        "    pks, sigs = api.sign_batch(sg, api.BASIC, sks, msgs)\n"
+        "    for n in (62, 63, 64, 65, 67, 255, 256, 257, 1030, 4100):\n"
+        "        agg = api.point_sum(sg, sigs[:n])\n"
+        "        out.append(api.aggregate_verify(sg, api.BASIC, pks[:n], msgs[:n], agg))\n"
+        "        bad = list(msgs[:n]); bad[n // 3] = b'tampered'\n"
+        "        out.append(api.aggregate_verify(sg, api.BASIC, pks[:n], bad, agg))\n"
+        "        ident = list(pks[:n]); ident[n - 2] = util.g2_raw(None) if sg == 1 else util.g1_raw(None)\n"
+        "        out.append(api.aggregate_verify(sg, api.BASIC, ident, msgs[:n], agg))\n"
+        "        out.append(api.aggregate_partial(sg, api.BASIC, pks[:n], msgs[:n], agg))\n"
+        "        out.append(api.aggregate_partial(sg, api.BASIC, ident, msgs[:n], None))\n"
+        "print(repr(out))\n") % (util.ROOT, os.path.join(util.ROOT, 'tests'))
+    res = {}
+    for name, env in (('tree', {}), ('acc', {'BLSGPU_PRODUCT_TREE': '0'})):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        res[name] = eval(r.stdout.strip().splitlines()[-1])
+    assert len(res['tree']) == 2 * 10 * 5
+    for k in range(0, len(res['tree']), 5):
+        ok, tampered, ident, rec, rec_ident = res['tree'][k:k + 5]
+        assert ok[0] == 0 and tampered[0] == 1, k
+        assert ident[0] != 0, k                      # an identity key is an error of its own (reference src/traits/sig_core.rs:149-178)
+        assert len(rec[0]) == 576 and rec[1] == -1 and rec_ident[1] >= 0, k
+    assert res['acc'] == res['tree']

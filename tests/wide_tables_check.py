@@ -194,6 +194,18 @@ def check_programs():
     for x in vals[1:]:
         want = c.f12_mul(want, x)
     assert unflat(Vt[B['L']:B['L'] + 12]) == want, 'F12_TREE16'
+    # the Horner chain of a pairing product's per-entry line products: entries 1, 4, 8, 18, 51 are the addition steps (no squaring)
+    vals = [tuple((rng.randrange(P), rng.randrange(P)) for _ in range(6)) for _ in range(NSTEPS)]
+    Vh = [0] * lay.count
+    for j, x in enumerate(vals):
+        Vh[B['L'] + 12 * j:B['L'] + 12 * j + 12] = flat(x)
+    sim_program(OPS, lay, dict(PROGRAMS)['HORNER'], Vh)
+    want = vals[0]
+    for e in range(1, NSTEPS):
+        if e not in (1, 4, 8, 18, 51):
+            want = c.f12_mul(want, want)
+        want = c.f12_mul(want, vals[e])
+    assert unflat(Vh[B['F']:B['F'] + 12]) == c.f12_conj(want), 'HORNER'
     return lay
 
 

@@ -966,6 +966,21 @@ def prog_f12_tree16():
     return st
 
 
+def prog_horner():
+    """F <- conj of the Horner chain over the 68 Fp12 values L[12 e .. 12 e + 11]: F = P_0, then per Miller entry e >= 1 a squaring
+    (doubling entries only) and F <- F P_e.  With P_e = the product over the items of a pairing product of their line values at
+    entry e this is the product of the items' Miller functions (squaring is multiplicative): kernels.cuh k_f12_horner_wide"""
+    st, step = [], 0
+    for i in range(62, -1, -1):
+        if i != 62:
+            st.append(('SQR', 'F', 'F', 'F'))
+        for _ in range(2 if (X_ABS >> i) & 1 else 1):
+            st.append(('COPY', 'F', ('L', 0), ('L', 0)) if step == 0 else ('MUL', 'F', 'F', ('L', 12 * step)))
+            step += 1
+    assert step == NSTEPS
+    return st + [('CONJ', 'F', 'F', 'F')]
+
+
 CONJ_F = [('CONJ', 'F', 'F', 'F')]                 # x < 0: the Miller function of |x| is conjugated once, after the product
 PROGRAMS = [('FINAL_HARD', prog_final_hard()),
             ('FINAL', prog_easy() + prog_final_hard()),              # the whole final exponentiation of a Miller product (aggregate verify)
@@ -979,7 +994,8 @@ PROGRAMS = [('FINAL_HARD', prog_final_hard()),
             # Bls12381G2Impl: pair 1 is (-g1, signature): its lines come from the signature, then the same Miller function
             ('PRE_F1G', prog_key_lines(1) + prog_pprep((1,)) + prog_miller((1,))),
             ('POST', prog_pprep((0,)) + prog_miller((0,)) + [('MUL', 'F', 'F', 'W')] + CONJ_F + prog_easy() + prog_final_hard()),
-            ('F12_TREE16', prog_f12_tree16())]
+            ('F12_TREE16', prog_f12_tree16()),
+            ('HORNER', prog_horner())]
 
 
 def layout_f12():
