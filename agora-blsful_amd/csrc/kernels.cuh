@@ -1142,6 +1142,20 @@ __device__ __forceinline__ void ws_ld_hfp2(hfp2& r, const uint32_t* ws, size_t s
 __device__ __forceinline__ void ws_st_hfp2(uint32_t* ws, size_t stride, size_t i, int w0, const hfp2& a) {
   ws_st_fp(ws, stride, i, w0 + (lane_hi() ? W1 : 0), a.v);
 }
+// Wave-uniform arguments of the non-inlined operation functions.  A function's arguments arrive in VECTOR registers and its pointers
+// are generic: left alone, every row access of a workspace becomes a flat load through a 64-bit per-lane address (two 64-bit vector
+// additions per row: 139 of them per call of the accumulator's line product, and their spill slots when a row is read twice).
+// The workspace pointers, strides, entry and slot numbers ARE wave-uniform, so the functions say so: v_readfirstlane makes them
+// scalars, the pointer becomes a global (address space 1) pointer, and an access is global_load saddr + this lane's 32-bit offset.
+typedef __attribute__((address_space(1))) uint32_t g_u32;
+typedef __attribute__((address_space(1))) const uint32_t gc_u32;
+__device__ __forceinline__ uint32_t uni_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ size_t uni_sz(size_t v) { return ((size_t)uni_u32((uint32_t)(v >> 32)) << 32) | uni_u32((uint32_t)v); }
+__device__ __forceinline__ g_u32* uni_global(uint32_t* p) { return (g_u32*)uni_sz((size_t)p); }
+__device__ __forceinline__ gc_u32* uni_global(const uint32_t* p) { return (gc_u32*)uni_sz((size_t)p); }
+// word `w` (a lane offset whose BYTE offset fits 32 bits: the hosts keep rows below 2^30 words) of a uniform row
+__device__ __forceinline__ uint32_t g_ld(gc_u32* row, uint32_t w) { return *(gc_u32*)((__attribute__((address_space(1))) const char*)row + (w << 2)); }
+__device__ __forceinline__ void g_st(g_u32* row, uint32_t w, uint32_t x) { *(g_u32*)((__attribute__((address_space(1))) char*)row + (w << 2)) = x; }
 __device__ __forceinline__ void ws_ld_hfp12(fp12_t<hfp2>& f, const uint32_t* ws, size_t stride, size_t i) {
   ws_ld_hfp2(f.c0.a0, ws, stride, i, 0);
   ws_ld_hfp2(f.c0.a1, ws, stride, i, W2);
@@ -1233,23 +1247,25 @@ __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_miller1s(size_t 
 // with per-lane 64-bit addresses the compiler kept 140 address registers alive across the loop)
 __device__ __forceinline__ void line5_st(uint32_t* lines, size_t lanes, uint32_t t, int e, const line5_t<hfp2>& L) {
   const fp* c[5] = {&L.c0.v, &L.c2.v, &L.c4.v, &L.c3.v, &L.c5.v};
-  uint32_t* row = lines + (size_t)e * LINE5_WORDS * lanes;
+  lanes = uni_sz(lanes);
+  g_u32* row = uni_global(lines) + (size_t)uni_u32((uint32_t)e) * LINE5_WORDS * lanes;
 #pragma unroll
   for (int j = 0; j < 5; j++)
 #pragma unroll
     for (int k = 0; k < FP_NL; k++) {
-      row[t] = (uint32_t)c[j]->l[k];
+      g_st(row, t, (uint32_t)c[j]->l[k]);
       row += lanes;
     }
 }
 __device__ __forceinline__ void line5_ld(line5_t<hfp2>& L, const uint32_t* lines, size_t lanes, uint32_t t, int e) {
   fp* c[5] = {&L.c0.v, &L.c2.v, &L.c4.v, &L.c3.v, &L.c5.v};
-  const uint32_t* row = lines + (size_t)e * LINE5_WORDS * lanes;
+  lanes = uni_sz(lanes);
+  gc_u32* row = uni_global(lines) + (size_t)uni_u32((uint32_t)e) * LINE5_WORDS * lanes;
 #pragma unroll
   for (int j = 0; j < 5; j++)
 #pragma unroll
     for (int k = 0; k < FP_NL; k++) {
-      c[j]->l[k] = (int32_t)row[t];
+      c[j]->l[k] = (int32_t)g_ld(row, t);
       row += lanes;
     }
 }
@@ -1306,23 +1322,25 @@ struct miller_lds {
 #define LINE3_WORDS (3 * FP_NL)
 __device__ __forceinline__ void line3_st(uint32_t* lines3, size_t lanes, uint32_t t, int e, const hfp2& l0, const hfp2& l2, const hfp2& l3) {
   const fp* c[3] = {&l0.v, &l2.v, &l3.v};
-  uint32_t* row = lines3 + (size_t)e * LINE3_WORDS * lanes;
+  lanes = uni_sz(lanes);
+  g_u32* row = uni_global(lines3) + (size_t)uni_u32((uint32_t)e) * LINE3_WORDS * lanes;
 #pragma unroll
   for (int j = 0; j < 3; j++)
 #pragma unroll
     for (int k = 0; k < FP_NL; k++) {
-      row[t] = (uint32_t)c[j]->l[k];
+      g_st(row, t, (uint32_t)c[j]->l[k]);
       row += lanes;
     }
 }
 __device__ __forceinline__ void line3_ld(hfp2& l0, hfp2& l2, hfp2& l3, const uint32_t* lines3, size_t lanes, uint32_t t, int e) {
   fp* c[3] = {&l0.v, &l2.v, &l3.v};
-  const uint32_t* row = lines3 + (size_t)e * LINE3_WORDS * lanes;
+  lanes = uni_sz(lanes);
+  gc_u32* row = uni_global(lines3) + (size_t)uni_u32((uint32_t)e) * LINE3_WORDS * lanes;
 #pragma unroll
   for (int j = 0; j < 3; j++)
 #pragma unroll
     for (int k = 0; k < FP_NL; k++) {
-      c[j]->l[k] = (int32_t)row[t];
+      c[j]->l[k] = (int32_t)g_ld(row, t);
       row += lanes;
     }
 }
@@ -1341,8 +1359,15 @@ static __device__ __noinline__ void lines_step_fn(lds_u32* sh, const uint32_t* p
   if (SRC == SRC_TABLE) {
     fp x1, y1;
     hfp2 n0, n2, c;
-    fp2_load(n0, row);
-    fp2_load(c, row + 2 * FP_NL);
+    {                                              // this lane's components of the table row (a wave-uniform pointer: see uni_global)
+      gc_u32* tr = uni_global(row);
+      const uint32_t o = lane_hi() ? FP_NL : 0;
+#pragma unroll
+      for (int k = 0; k < FP_NL; k++) {
+        n0.v.l[k] = (int32_t)g_ld(tr, o + k);
+        c.v.l[k] = (int32_t)g_ld(tr, o + 2 * FP_NL + k);
+      }
+    }
     ls_ld_coord(x1, sh, LS_P1, false);
     fp2_mul_fp(n2, c, x1);
     ls_ld_coord(y1, sh, LS_P1, true);
@@ -1562,12 +1587,13 @@ k_millerfp(size_t count_v, size_t q, int group, const uint32_t* lines, size_t la
 static __device__ __noinline__ void f12_sh_mul_line3_fn(lds_u32* sh, const uint32_t* lines3, size_t lanes, uint32_t t, int e) {
   hfp2 l0, l2, l3;
   fp* c[3] = {&l0.v, &l2.v, &l3.v};
-  const uint32_t* row = lines3 + (size_t)e * (3 * FP_NL) * lanes;
+  lanes = uni_sz(lanes);
+  gc_u32* row = uni_global(lines3) + (size_t)uni_u32((uint32_t)e) * (3 * FP_NL) * lanes;
 #pragma unroll
   for (int j = 0; j < 3; j++)
 #pragma unroll
     for (int k = 0; k < FP_NL; k++) {
-      c[j]->l[k] = (int32_t)row[t];
+      c[j]->l[k] = (int32_t)g_ld(row, t);
       row += lanes;
     }
   f12_sh_mul_line3(sh, l0, l2, l3);
@@ -1607,7 +1633,7 @@ k_millerfp3(size_t count, size_t q, int group, const int32_t* bad, const uint32_
 // j, j + q, j + 2 q, j + 3 q (absent or flagged ones count as the line 1), merges them two by two and leaves the product of the
 // two merged values at position e * rout + oout + j of the Fp12 workspace fout (stride sout).
 static __device__ __noinline__ void f12_sh_st_ws_fn(lds_u32* sh, uint32_t* ws, size_t stride, uint32_t off);
-__device__ __forceinline__ void quad_line_ld(hfp2& l0, hfp2& l2, hfp2& l3, size_t count, const int32_t* bad, const uint32_t* row, size_t lanes, size_t x, uint32_t hi) {
+__device__ __forceinline__ void quad_line_ld(hfp2& l0, hfp2& l2, hfp2& l3, size_t count, const int32_t* bad, gc_u32* row, size_t lanes, size_t x, uint32_t hi) {
   if (x < count && bad[x] == 0) {
     fp* c[3] = {&l0.v, &l2.v, &l3.v};
     const uint32_t t = (uint32_t)(2 * x) + hi;
@@ -1615,7 +1641,7 @@ __device__ __forceinline__ void quad_line_ld(hfp2& l0, hfp2& l2, hfp2& l3, size_
     for (int j = 0; j < 3; j++)
 #pragma unroll
       for (int k = 0; k < FP_NL; k++) {
-        c[j]->l[k] = (int32_t)row[t];
+        c[j]->l[k] = (int32_t)g_ld(row, t);
         row += lanes;
       }
   } else {
@@ -1625,8 +1651,10 @@ __device__ __forceinline__ void quad_line_ld(hfp2& l0, hfp2& l2, hfp2& l3, size_
   }
 }
 template <int FIRST>
-static __device__ __noinline__ void quad_merge_fn(lds_u32* sh, size_t count, const int32_t* bad, const uint32_t* row, size_t lanes, size_t xa, size_t xb, uint32_t hi) {
+static __device__ __noinline__ void quad_merge_fn(lds_u32* sh, size_t count, const int32_t* bad, const uint32_t* row_, size_t lanes, size_t xa, size_t xb, uint32_t hi) {
   hfp2 a0, a2, a3, b0, b2, b3;
+  gc_u32* row = uni_global(row_);
+  lanes = uni_sz(lanes);
   quad_line_ld(a0, a2, a3, count, bad, row, lanes, xa, hi);
   quad_line_ld(b0, b2, b3, count, bad, row, lanes, xb, hi);
   line5_t<hfp2> L;
@@ -1661,12 +1689,13 @@ k_line_quad(size_t count, size_t q, const int32_t* bad, const uint32_t* lines3, 
 // W1 * stride on the odd lane (the imaginary parts' rows); the host keeps W1 * stride + items below 2^30 words
 __device__ __forceinline__ void wsu_ld_hfp6(fp6_t<hfp2>& r, const uint32_t* ws, size_t stride, uint32_t off, int half) {
   fp* c[3] = {&r.a0.v, &r.a1.v, &r.a2.v};
-  const uint32_t* row = ws + (size_t)(3 * W2 * half) * stride;
+  stride = uni_sz(stride);
+  gc_u32* row = uni_global(ws) + (size_t)(3 * W2 * half) * stride;
 #pragma unroll
   for (int j = 0; j < 3; j++) {
 #pragma unroll
     for (int k = 0; k < FP_NL; k++) {
-      c[j]->l[k] = (int32_t)row[off];
+      c[j]->l[k] = (int32_t)g_ld(row, off);
       row += stride;
     }
     row += (size_t)(W2 - FP_NL) * stride;
@@ -1674,12 +1703,13 @@ __device__ __forceinline__ void wsu_ld_hfp6(fp6_t<hfp2>& r, const uint32_t* ws, 
 }
 __device__ __forceinline__ void wsu_st_hfp6(uint32_t* ws, size_t stride, uint32_t off, int half, const fp6_t<hfp2>& a) {
   const fp* c[3] = {&a.a0.v, &a.a1.v, &a.a2.v};
-  uint32_t* row = ws + (size_t)(3 * W2 * half) * stride;
+  stride = uni_sz(stride);
+  g_u32* row = uni_global(ws) + (size_t)(3 * W2 * half) * stride;
 #pragma unroll
   for (int j = 0; j < 3; j++) {
 #pragma unroll
     for (int k = 0; k < FP_NL; k++) {
-      row[off] = (uint32_t)c[j]->l[k];
+      g_st(row, off, (uint32_t)c[j]->l[k]);
       row += stride;
     }
     row += (size_t)(W2 - FP_NL) * stride;
@@ -1689,25 +1719,32 @@ static __device__ __noinline__ void f12_sh_mul_ws_fn(lds_u32* sh, const uint32_t
   fp6_t<hfp2> x, y, t0, t1, m;
   sh_ld_f6(x, sh, 0);
   wsu_ld_hfp6(y, ws, stride, off, 0);
-  fp6_mul(t0, x, y);
-  sh_ld_f6(x, sh, 39);
-  wsu_ld_hfp6(y, ws, stride, off, 1);
-  fp6_mul(t1, x, y);
-  sh_ld_f6(m, sh, 0);
+  fp6_mul(t0, x, y);                    // a0 b0
+  __builtin_amdgcn_sched_barrier(0);
+  sh_ld_f6(m, sh, 39);
   fp6_add(x, x, m);
-  fp6_norm(x, x);
-  wsu_ld_hfp6(m, ws, stride, off, 0);
-  fp6_add(y, y, m);
+  fp6_reduce(x, x);
+  sh_st_f6(sh, 0, x);                   // slot 0 <- a0 + a1 (a0 is used up)
+  wsu_ld_hfp6(y, ws, stride, off, 1);
+  fp6_mul(t1, m, y);                    // a1 b1
+  __builtin_amdgcn_sched_barrier(0);
+  fp6_mul_v(m, t1);
+  fp6_add(m, t0, m);
+  fp6_reduce(m, m);
+  sh_st_f6(sh, 39, m);                  // slot 1 <- c0 = a0 b0 + v a1 b1, parked (a1 is used up)
+  fp6_add(t0, t0, t1);
+  fp6_norm(t0, t0);
+  __builtin_amdgcn_sched_barrier(0);
+  sh_ld_f6(x, sh, 0);
+  wsu_ld_hfp6(t1, ws, stride, off, 0);
+  fp6_add(y, y, t1);
   fp6_norm(y, y);
   fp6_mul(m, x, y);
   fp6_sub(m, m, t0);
-  fp6_sub(m, m, t1);
-  fp6_reduce(m, m);
+  fp6_reduce(m, m);                     // c1 = (a0 + a1)(b0 + b1) - a0 b0 - a1 b1
+  sh_ld_f6(x, sh, 39);
+  sh_st_f6(sh, 0, x);
   sh_st_f6(sh, 39, m);
-  fp6_mul_v(t1, t1);
-  fp6_add(t0, t0, t1);
-  fp6_reduce(t0, t0);
-  sh_st_f6(sh, 0, t0);
 }
 static __device__ __noinline__ void f12_sh_ld_ws_fn(lds_u32* sh, const uint32_t* ws, size_t stride, uint32_t off) {
   fp6_t<hfp2> x;
@@ -1762,19 +1799,21 @@ struct vs_ref {
   uint32_t t;
 };
 __device__ __forceinline__ void vs_ld(fp& r, const vs_ref& v, int slot, int j) {
-  const uint32_t* row = v.p + ((size_t)slot * VS_WORDS + (size_t)j * FP_NL) * v.lanes;
+  const size_t lanes = uni_sz(v.lanes);
+  gc_u32* row = uni_global((const uint32_t*)v.p) + ((size_t)uni_u32((uint32_t)slot) * VS_WORDS + (size_t)j * FP_NL) * lanes;
 #pragma unroll
   for (int k = 0; k < FP_NL; k++) {
-    r.l[k] = (int32_t)row[v.t];
-    row += v.lanes;
+    r.l[k] = (int32_t)g_ld(row, v.t);
+    row += lanes;
   }
 }
 __device__ __forceinline__ void vs_st(const vs_ref& v, int slot, int j, const fp& a) {
-  uint32_t* row = v.p + ((size_t)slot * VS_WORDS + (size_t)j * FP_NL) * v.lanes;
+  const size_t lanes = uni_sz(v.lanes);
+  g_u32* row = uni_global(v.p) + ((size_t)uni_u32((uint32_t)slot) * VS_WORDS + (size_t)j * FP_NL) * lanes;
 #pragma unroll
   for (int k = 0; k < FP_NL; k++) {
-    row[v.t] = (uint32_t)a.l[k];
-    row += v.lanes;
+    g_st(row, v.t, (uint32_t)a.l[k]);
+    row += lanes;
   }
 }
 __device__ __forceinline__ hfp2& f12_coef(fp12_t<hfp2>& f, int j) {
