@@ -2746,8 +2746,9 @@ int blsgpu_pairing_product_is_one(const void* g1s, const void* g2s, size_t n, in
     uint32_t* d_f = (uint32_t*)arena_take(c, (size_t)WS_F_WORDS * 4 * n);
     if (!d_skip || !d_pairs || !d_f) return fail(BLSGPU_E_HIP, "internal: arena too small");
     KL(KID_PAIRS_AFF, k_pairs_to_affine, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d1, (const uint8_t*)d2, fmt, d_pairs, d_skip);
-    MILLER1_LAUNCH(n, n, d_pairs, d_skip, d_f);
-    if ((rc = run_f12_product_verdict(c, d_f, MILLER1_OUTPUTS(n), n, d_skip + n))) return rc;
+    size_t outputs = 0;
+    if ((rc = run_miller_product(c, n, n, d_pairs, d_skip, d_f, &outputs))) return rc;
+    if ((rc = run_f12_product_verdict(c, d_f, outputs, n, d_skip + n))) return rc;
     HIPCK(hipMemcpyAsync(&verdict, d_skip + n, 4, hipMemcpyDeviceToHost, c->stream));
     SYNC_FLUSH(c);
   }

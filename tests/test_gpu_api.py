@@ -103,6 +103,18 @@ def test_pairing_product(api):
     ks = [rng.randrange(c.R) for _ in range(4)]
     ks.append(-sum(ks) % c.R)
     assert api.pairing_product_is_one([util.g1_raw(c.E1.mul(c.G1_GEN, k), rng) for k in ks], [util.g2_raw(c.G2_GEN, rng)] * 5)
+    # 70 and 300 pairs (from 64 pairs on the product is taken entry by entry over the items, blsgpu.hip run_miller_product_tree):
+    # e(k_i G1, m_i G2) with sum k_i m_i = 0, identities sprinkled in on either side; one k off by one must fail
+    for n in (70, 300):
+        ms = [rng.randrange(1, 50) for _ in range(n)]
+        ks = [rng.randrange(c.R) for _ in range(n - 1)]
+        ks.append(-sum(k * m for k, m in zip(ks, ms)) * pow(ms[-1], -1, c.R) % c.R)
+        g2s = {m: c.E2.mul(c.G2_GEN, m) for m in set(ms)}
+        p1 = [util.g1_raw(c.E1.mul(c.G1_GEN, k), rng) for k in ks] + [util.g1_raw(None), util.g1_raw(c.G1_GEN, rng)]
+        p2 = [util.g2_raw(g2s[m], rng) for m in ms] + [util.g2_raw(c.G2_GEN, rng), util.g2_raw(None)]
+        assert api.pairing_product_is_one(p1, p2), n
+        p1[n // 2] = util.g1_raw(c.E1.mul(c.G1_GEN, (ks[n // 2] + 1) % c.R), rng)
+        assert not api.pairing_product_is_one(p1, p2), n
 
 
 @pytest.mark.parametrize('C,sg', IMPLS, ids=['g1', 'g2'])
