@@ -834,9 +834,9 @@ int run_miller_product_tree(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs,
       while (q > LOCAL) {
         const size_t qo = quarter(q);
         if (qo <= LOCAL)
-          KL(KID_F12_FOLD, k_f12_fold4, dim3(blocks_for(2 * qo), (unsigned)E), dim3(BLS_BLOCK), q, qo, (const uint32_t*)src, E * q, q, comb, comb_stride, Qc, comb_off);
+          KL(KID_F12_FOLD, k_f12_fold4, dim3(blocks_for(2 * qo), (unsigned)E), dim3(BLS_BLOCK), q, qo, 4, (const uint32_t*)src, E * q, q, comb, comb_stride, Qc, comb_off);
         else
-          KL(KID_F12_FOLD, k_f12_fold4, dim3(blocks_for(2 * qo), (unsigned)E), dim3(BLS_BLOCK), q, qo, (const uint32_t*)src, E * q, q, dst, E * qo, qo, (size_t)0);
+          KL(KID_F12_FOLD, k_f12_fold4, dim3(blocks_for(2 * qo), (unsigned)E), dim3(BLS_BLOCK), q, qo, 4, (const uint32_t*)src, E * q, q, dst, E * qo, qo, (size_t)0);
         uint32_t* t = src;
         src = dst;
         dst = t;
@@ -851,9 +851,21 @@ int run_miller_product_tree(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs,
     const uint32_t* src = comb;
     size_t q = Qc;
     uint32_t *dst = bufA, *other = bufB;
+    // levels down to the engine's sixteen per entry: as few as fan-ins of at most five allow (each level is a launch and a chain of
+    // fan - 1 products, ~0.13 ms when it no longer fills the machine; 1,025 values -- a round of pairs and the signature's -- are
+    // 205, 41, 9 instead of 257, 65, 17, 5)
+    int levels = 0;
+    for (size_t cap = 16; cap < q; cap *= 5) levels++;
     while (q > 16) {
-      const size_t qo = quarter(q);
-      KL(KID_F12_FOLD, k_f12_fold4, dim3(blocks_for(2 * qo), (unsigned)E), dim3(BLS_BLOCK), q, qo, src, E * q, q, dst, E * qo, qo, (size_t)0);
+      size_t fan = 2;
+      {
+        size_t reach = 16;
+        for (int l = 1; l < levels; l++) reach *= 4;          // what the remaining levels can take at fan-in four
+        while (fan < 5 && (q + fan - 1) / fan > reach) fan++;  // (five always suffices: `levels` was counted for fan-in five)
+      }
+      levels--;
+      const size_t qo = (q + fan - 1) / fan;
+      KL(KID_F12_FOLD, k_f12_fold4, dim3(blocks_for(2 * qo), (unsigned)E), dim3(BLS_BLOCK), q, qo, (int)fan, src, E * q, q, dst, E * qo, qo, (size_t)0);
       src = dst;
       uint32_t* t = dst;
       dst = other;

@@ -201,7 +201,7 @@ __global__ void k_linesp(size_t mm, size_t half, size_t stride, const uint32_t* 
 __global__ void k_millerfp(size_t count_v, size_t q, int group, const uint32_t* lines, size_t lanes, uint32_t* fws, size_t stride, size_t out0);
 __global__ void k_millerfp3(size_t count, size_t q, int group, const int32_t* bad, const uint32_t* lines3, size_t lanes, uint32_t* fws, size_t stride, size_t out0);
 __global__ void k_line_quad(size_t count, size_t q, const int32_t* bad, const uint32_t* lines3, size_t lanes, uint32_t* fout, size_t sout, size_t rout, size_t oout);
-__global__ void k_f12_fold4(size_t qin, size_t qout, const uint32_t* fin, size_t sin, size_t rin, uint32_t* fout, size_t sout, size_t rout, size_t oout);
+__global__ void k_f12_fold4(size_t qin, size_t qout, int fan, const uint32_t* fin, size_t sin, size_t rin, uint32_t* fout, size_t sout, size_t rout, size_t oout);
 __global__ void k_finalexps(size_t n, const uint32_t* fws, int32_t* status);
 __global__ void k_miller1s(size_t n, size_t stride, const uint32_t* pairs, const int32_t* skip, uint32_t* fws);
 __global__ void k_finalexp_ones(const uint32_t* fws, size_t stride, int32_t* verdict);
@@ -1681,8 +1681,8 @@ k_line_quad(size_t count, size_t q, const int32_t* bad, const uint32_t* lines3, 
   f12_sh_st_ws_fn(sh, fout + (size_t)e * rout + oout, sout, (uint32_t)j + hi * (uint32_t)(W1 * sout));
 }
 // k_f12_fold4: one level of the 68 fold trees.  grid (qout / 32, 68): lane pair j of entry e multiplies the values at positions
-// e * rin + j + k qout (k < 4, j + k qout < qin) of fin and leaves the product at position e * rout + oout + j of fout.  fin and
-// fout must not overlap.
+// e * rin + j + k qout (k < fan -- four, or five where that saves a level --, j + k qout < qin) of fin and leaves the product at
+// position e * rout + oout + j of fout.  fin and fout must not overlap.
 // (the factor streams in from the workspace half by half, its first half twice: with all of it held beside the three Fp6 products
 // the function spilled 700 bytes per lane; and every access is wave-uniform row pointer + 32-bit lane offset, see line5_st)
 // wsu_*: `ws` points at word 0 of a wave-uniform position of an Fp12 workspace, `off` = this lane's item offset from there plus
@@ -1761,7 +1761,7 @@ static __device__ __noinline__ void f12_sh_st_ws_fn(lds_u32* sh, uint32_t* ws, s
   wsu_st_hfp6(ws, stride, off, 1, x);
 }
 __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) __attribute__((disable_tail_calls))
-k_f12_fold4(size_t qin, size_t qout, const uint32_t* fin, size_t sin, size_t rin, uint32_t* fout, size_t sout, size_t rout, size_t oout) {
+k_f12_fold4(size_t qin, size_t qout, int fan, const uint32_t* fin, size_t sin, size_t rin, uint32_t* fout, size_t sout, size_t rout, size_t oout) {
   const uint32_t t = blockIdx.x * BLS_BLOCK + threadIdx.x;
   const uint32_t j = t >> 1;
   if (j >= qout) return;
@@ -1771,7 +1771,7 @@ k_f12_fold4(size_t qin, size_t qout, const uint32_t* fin, size_t sin, size_t rin
   __shared__ uint32_t fsh[F12_SH_WORDS * BLS_BLOCK];
   lds_u32* sh = lds_column(fsh);
   f12_sh_ld_ws_fn(sh, in, sin, off_in);
-  for (int k = 1; k < 4; k++) {
+  for (int k = 1; k < fan; k++) {
     const size_t x = j + (size_t)k * qout;
     if (x < qin) f12_sh_mul_ws_fn(sh, in + (size_t)k * qout, sin, off_in);
   }
