@@ -82,6 +82,38 @@ def test_config4_aggregate_verify_262144_pairs(api, gpu):
     assert (int(st.item()), aux.tolist()) == (api.DUPLICATE_MESSAGE, [7, 200001])
 
 
+@pytest.mark.parametrize('sg', [1, 2])
+def test_aggregate_verify_around_the_chunk_boundaries(api, gpu, sg):
+    """The per-entry product form of the pairing product (blsgpu.hip run_miller_product_tree) at the sizes where its plan changes:
+    n + 1 pairs = one machine round of lane pairs exactly (65,535 + the signature's), a round and a leftover chunk on the tail
+    stream (65,536 + 1; 66,000 + 1: 465 leftovers), a round and a second chunk (70,000 + 1).  Each size: the valid aggregate,
+    a tampered message in the LAST chunk and in the first, an identity key in the leftover (its pair enters as the line 1, its
+    index comes back).  Both signature groups."""
+    g = gpu
+    lib, P, torch = g['lib'], g['P'], g['torch']
+    nmax = 70000
+    msgs = [hashlib.sha256(SEED + b'chunk' + i.to_bytes(8, 'little')).digest() for i in range(nmax)]
+    d_pks, d_sigs, d_msgs, d_offs = g['sign'](sg, api.POP, [(S0 + 3 * i) % R or 1 for i in range(nmax)], msgs)
+    pk_sz, sig_sz = (288, 144) if sg == 1 else (144, 288)
+    st = _i32(g)
+    aux = torch.zeros(2, dtype=torch.int64, device=g['dev'])
+    d_agg = torch.empty(sig_sz, dtype=torch.uint8, device=g['dev'])
+    for n in (65535, 65536, 66000, 70000):
+        api._check((lib.blsgpu_sum_g1 if sg == 1 else lib.blsgpu_sum_g2)(P(d_sigs), n, api.FMT_RAW_PROJ, P(d_agg)))
+        api._check(lib.blsgpu_aggregate_verify(sg, api.POP, P(d_pks), P(d_msgs), P(d_offs), n, P(d_agg), api.FMT_RAW_PROJ, P(st), P(aux)))
+        assert int(st.item()) == api.OK, n
+        for j in (n - 1, 5):
+            d_msgs[32 * j + 3] ^= 1
+            api._check(lib.blsgpu_aggregate_verify(sg, api.POP, P(d_pks), P(d_msgs), P(d_offs), n, P(d_agg), api.FMT_RAW_PROJ, P(st), P(aux)))
+            assert int(st.item()) == api.INVALID_SIGNATURE, (n, j)
+            d_msgs[32 * j + 3] ^= 1
+        keep = d_pks[pk_sz * (n - 1):pk_sz * n].clone()
+        d_pks[pk_sz * (n - 1):pk_sz * n] = 0                       # RAW_PROJ identity: Z = 0
+        api._check(lib.blsgpu_aggregate_verify(sg, api.POP, P(d_pks), P(d_msgs), P(d_offs), n, P(d_agg), api.FMT_RAW_PROJ, P(st), P(aux)))
+        assert int(st.item()) == api.PK_IDENTITY and int(aux[0].item()) == n, n      # 1-based index of the first identity key
+        d_pks[pk_sz * (n - 1):pk_sz * n] = keep
+
+
 @pytest.mark.parametrize('sg,mode', [(1, 0), (2, 0), (2, 1)])
 def test_config5_verify_secure_65536_keys(api, gpu, sg, mode):
     """verify_secure over 65,536 keys: the library's own coefficients t_i give the valid secure aggregate
