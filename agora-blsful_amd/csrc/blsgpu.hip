@@ -782,7 +782,9 @@ int run_miller_product_tree(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs,
   size_t Qc = left ? quarter(left) : 0;
   for (size_t k = 0; k < nch; k++) Qc += local_out(chunk_cnt(k));
   const size_t q0max = quarter(chunk_cnt(0));
-  const size_t capA = E * (q0max > quarter(Qc) ? q0max : quarter(Qc)), capB = E * (quarter(q0max) > quarter(quarter(Qc)) ? quarter(q0max) : quarter(quarter(Qc)));
+  // two ping-pong buffers: the first takes a chunk's quads and the first level over all chunks' values (fan-in >= 2), the second the levels after them
+  const size_t half_qc = (Qc + 1) / 2;
+  const size_t capA = E * (q0max > half_qc ? q0max : half_qc), capB = E * (quarter(q0max) > quarter(Qc) + 16 ? quarter(q0max) : quarter(Qc) + 16);
   const size_t lanes_max = row_stride(lanes_for(chunk_cnt(0))), lanes_left = left ? row_stride(lanes_for(left)) : 0;
   const size_t T_STRIDE = 128;
   if ((capA + E * Qc) * W1 >= ((size_t)1 << 30)) return 0;      // the fold kernels' 32-bit lane offsets (kernels.cuh wsu_ld_hfp6)
@@ -851,18 +853,18 @@ int run_miller_product_tree(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs,
     const uint32_t* src = comb;
     size_t q = Qc;
     uint32_t *dst = bufA, *other = bufB;
-    // levels down to the engine's sixteen per entry: as few as fan-ins of at most five allow (each level is a launch and a chain of
-    // fan - 1 products, ~0.13 ms when it no longer fills the machine; 1,025 values -- a round of pairs and the signature's -- are
-    // 205, 41, 9 instead of 257, 65, 17, 5)
+    // Levels that fill the machine on lane pairs (fan-in four, or five where that saves a level), down to at most ENGINE_FROM values
+    // per entry; the rest on the engine, sixteen values per workgroup (two launches for up to 256 values): a product there takes
+    // 3.7 us against 43 on a lane pair, and a lane-pair level of a few hundred tasks is nothing but its chain of fan - 1 products
+    // (~0.13 ms).  1,025 values per entry -- a round of pairs and the signature's -- go 205, 52 on lane pairs, then 4, 1 on the engine.
+    static const long engine_from_env = getenv("BLSGPU_TREE_ENGINE_FROM") ? atol(getenv("BLSGPU_TREE_ENGINE_FROM")) : 0;
+    const size_t ENGINE_FROM = engine_from_env >= 16 && engine_from_env <= 256 ? (size_t)engine_from_env : 128;
     int levels = 0;
-    for (size_t cap = 16; cap < q; cap *= 5) levels++;
-    while (q > 16) {
-      size_t fan = 2;
-      {
-        size_t reach = 16;
-        for (int l = 1; l < levels; l++) reach *= 4;          // what the remaining levels can take at fan-in four
-        while (fan < 5 && (q + fan - 1) / fan > reach) fan++;  // (five always suffices: `levels` was counted for fan-in five)
-      }
+    for (size_t cap = ENGINE_FROM; cap < q; cap *= 5) levels++;
+    while (q > ENGINE_FROM) {
+      size_t fan = 2, reach = ENGINE_FROM;
+      for (int l = 1; l < levels; l++) reach *= 4;            // what the remaining levels can take at fan-in four
+      while (fan < 5 && (q + fan - 1) / fan > reach) fan++;    // (five always suffices: `levels` was counted for fan-in five)
       levels--;
       const size_t qo = (q + fan - 1) / fan;
       KL(KID_F12_FOLD, k_f12_fold4, dim3(blocks_for(2 * qo), (unsigned)E), dim3(BLS_BLOCK), q, qo, (int)fan, src, E * q, q, dst, E * qo, qo, (size_t)0);
@@ -872,7 +874,13 @@ int run_miller_product_tree(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs,
       other = t;
       q = qo;
     }
-    KL(KID_F12_FOLD, k_f12_tree_seg, dim3((unsigned)E), dim3(WIDE_ENGINE_BLOCK), q, src, E * q, q, t68, T_STRIDE);
+    if (q > 16) {
+      const size_t qo = (q + 15) / 16;
+      KL(KID_F12_FOLD, k_f12_tree_seg, dim3((unsigned)qo, (unsigned)E), dim3(WIDE_ENGINE_BLOCK), q, src, E * q, q, dst, E * qo, qo);
+      src = dst;
+      q = qo;
+    }
+    KL(KID_F12_FOLD, k_f12_tree_seg, dim3(1, (unsigned)E), dim3(WIDE_ENGINE_BLOCK), q, src, E * q, q, t68, T_STRIDE, (size_t)1);
     KL(KID_F12_FOLD, k_f12_horner_wide, dim3(1), dim3(WIDE_ENGINE_BLOCK), (const uint32_t*)t68, T_STRIDE, d_f, stride);
   }
   HIPCK(hipGetLastError());
@@ -2021,11 +2029,16 @@ static int aggregate_enqueue(Ctx* c, int sig_group, int scheme, const uint8_t* d
   // Bls12381G1Impl: the messages are hashed to E1(Fp) WITHOUT the cofactor clearing (a third of the hash) and the signature's
   // pair is (sig, -[c] g2) instead of (sig, -g2): the same verdict (csrc/g2neg_lines.cuh), also shard by shard -- only the
   // product of all records is ever exponentiated
-  const int agg_flags = sig_group == 1 ? 2 : 1;
+  // ... on two lanes per item (the two SSWU maps of the hash side by side) while that fits one machine round of lanes: the kernel is a
+  // latency chain there (1.75 -> 1.1 ms at 32,768 pairs, 1.63 -> 0.96 at 4,096); beyond a round the redundant rest of the two-lane form costs more
+  // than the shorter chains save (5.9 against 5.3 ms at 262,144).  BLSGPU_AGG_LANES=1 / 2 forces a form (A/B)
+  static const int agg_lanes_env = getenv("BLSGPU_AGG_LANES") ? atoi(getenv("BLSGPU_AGG_LANES")) : 0;
+  const int agg_one_lane = agg_lanes_env == 1 || (agg_lanes_env != 2 && mm > 65536 + 1024);
+  const int agg_flags = sig_group == 1 ? (agg_one_lane ? 2 : 3) : 1;
   if (mm > 0) {
     // the workspace stride is always n + 1 (k_prepare_agg's layout); without a signature lane n stays idle
     if (sig_group == 1)
-      KL(KID_PREPARE_AGG, k_prepare_agg<1>, dim3(blocks_for(mm)), dim3(BLS_BLOCK), n, d_pks, d_sig, fmt, aug, d_msgs, d_offs, dst, d_pairs, d_bad, agg_flags, has_sig);
+      KL(KID_PREPARE_AGG, k_prepare_agg<1>, dim3(blocks_for(agg_one_lane ? mm : 2 * mm)), dim3(BLS_BLOCK), n, d_pks, d_sig, fmt, aug, d_msgs, d_offs, dst, d_pairs, d_bad, agg_flags, has_sig);
     else
       KL(KID_PREPARE_AGG, k_prepare_agg<2>, dim3(blocks_for(2 * mm)), dim3(BLS_BLOCK), n, d_pks, d_sig, fmt, aug, d_msgs, d_offs, dst, d_pairs, d_bad, agg_flags, has_sig);
     if (n) KL(KID_FIRST_BAD, k_first_bad, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const int32_t*)d_bad, d_min);

@@ -290,7 +290,7 @@ __global__ void k_pairing_coop_easy(size_t n, const uint32_t* pairs, const int32
 __global__ void k_finalexp_wide(size_t n, const uint32_t* easy, int32_t* status);
 __global__ void k_finalexp_wide_ws(const uint32_t* fws, size_t stride, int32_t* verdict);
 __global__ void k_f12_tree_wide(size_t m, const uint32_t* fin, size_t sin, uint32_t* fout, size_t sout);
-__global__ void k_f12_tree_seg(size_t qin, const uint32_t* fin, size_t sin, size_t rin, uint32_t* fout, size_t sout);
+__global__ void k_f12_tree_seg(size_t qin, const uint32_t* fin, size_t sin, size_t rin, uint32_t* fout, size_t sout, size_t rout);
 __global__ void k_f12_horner_wide(const uint32_t* fin, size_t sin, uint32_t* fout, size_t sout);
 __global__ void k_wide_prog_test(const uint32_t* prog, int len, int reps, const uint8_t* fin, uint8_t* tout);
 bool wide_prog_is_fp12(const uint32_t* prog, size_t len);   // host: what k_wide_prog_test may be given
@@ -3053,11 +3053,14 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_f12_tree_wide(size_t m, c
     if (l < FP_NL) fout[(size_t)(W1 * v + l) * sout + blockIdx.x] = S.V[WV_L + 2 * pw + (v & 1)][l];
   }
 }
-// ... the same for the fold trees of a pairing product's 68 entries (k_line_quad / k_f12_fold4): workgroup e <- the product of the
-// qin <= 16 values at positions e * rin + j, written as item e of fout
-__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_f12_tree_seg(size_t qin, const uint32_t* fin, size_t sin, size_t rin, uint32_t* fout, size_t sout) {
+// ... the same for the fold trees of a pairing product's 68 entries (k_line_quad / k_f12_fold4), grid (ceil(qin / 16), 68): workgroup
+// (b, e) <- the product of the values at positions e * rin + 16 b + j (j < 16, 16 b + j < qin), written at position e * rout + b of fout
+// (a product on the engine takes 3.7 us against 43 on a lane pair: the levels that no longer fill the machine belong here)
+__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_f12_tree_seg(size_t qin, const uint32_t* fin, size_t sin, size_t rin, uint32_t* fout, size_t sout, size_t rout) {
   __shared__ wide_lds_t<wide_tb_f12> S;
-  const size_t base = (size_t)blockIdx.x * rin;
+  const size_t first = (size_t)blockIdx.x * 16;
+  if (first >= qin) return;
+  const size_t base = (size_t)blockIdx.y * rin + first, have = qin - first;
   wide_consts K;
   wide_init(K);
   wide_stage(S, WIDE_PROG_F12_TREE16, WIDE_PROG_F12_TREE16_LEN);
@@ -3065,7 +3068,7 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_f12_tree_seg(size_t qin, 
   for (int u = (int)(threadIdx.x >> 4); u < 16 * 12; u += WIDE_TABLE_ROWS) {
     const int j = u / 12, v = u % 12, k = v >> 1, pw = k < 3 ? 2 * k : 2 * (k - 3) + 1;
     uint32_t x = 0;
-    if ((size_t)j < qin) {
+    if ((size_t)j < have) {
       if (l < FP_NL) x = fin[(size_t)(W1 * v + l) * sin + base + j];
     } else if (v == 0 && l < FP_NL) {
       x = FP_ONE[l];
@@ -3076,7 +3079,7 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_f12_tree_seg(size_t qin, 
   wide_exec(S, WIDE_PROG_F12_TREE16_LEN, K);
   for (int v = (int)(threadIdx.x >> 4); v < 12; v += WIDE_TABLE_ROWS) {
     const int k = v >> 1, pw = k < 3 ? 2 * k : 2 * (k - 3) + 1;
-    if (l < FP_NL) fout[(size_t)(W1 * v + l) * sout + blockIdx.x] = S.V[WV_L + 2 * pw + (v & 1)][l];
+    if (l < FP_NL) fout[(size_t)(W1 * v + l) * sout + (size_t)blockIdx.y * rout + blockIdx.x] = S.V[WV_L + 2 * pw + (v & 1)][l];
   }
 }
 // ... and the Horner chain over the 68 per-entry products (items 0..67 of fin): program HORNER on one workgroup, 63 squarings and
