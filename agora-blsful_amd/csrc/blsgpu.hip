@@ -762,15 +762,30 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
 // left beyond whole rounds (< 1,024 items) is a small chunk of its own on the tail stream, beside the others.  Leaves the
 // Miller product as item 0 of d_f (*outputs = 1).  *done = false: not applicable (too few items,
 // no engine, no memory, BLSGPU_PRODUCT_TREE=0) -- the caller falls back to the accumulator kernels.
-int run_miller_product_tree(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs, int32_t* d_bad, uint32_t* d_f, size_t* outputs, bool* done) {
+// last_mode: what item mm - 1 is.  0: an item like the others.  1 / 2: (P, -g2) / (P, -[c] g2), the signature's pair of an
+// aggregate verification of Bls12381G1Impl: its line values come from the fixed argument's table (k_lines_fixed), no point walk.
+// 3: the signature's pair of Bls12381G2Impl, a general pair.  The pairs proper of an aggregate are counts like 32,768 or 65,536, and
+// the line kernels have cliffs exactly there (the 1,025th wave puts two waves on one SIMD, which then take 1.7 times as long; the
+// 2,049th runs alone after the others): in modes 1 - 3 the signature's pair is a one-item chunk of its own on the tail stream.
+int run_miller_product_tree(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs, int32_t* d_bad, uint32_t* d_f, size_t* outputs, bool* done, int last_mode) {
   *done = false;
   static const int enabled = getenv("BLSGPU_PRODUCT_TREE") ? atoi(getenv("BLSGPU_PRODUCT_TREE")) : 1;
   static const long local_env = getenv("BLSGPU_TREE_LOCAL") ? atol(getenv("BLSGPU_TREE_LOCAL")) : 0;
+  static const long lines4_env = getenv("BLSGPU_LINES4_MAX") ? atol(getenv("BLSGPU_LINES4_MAX")) : -1;   // A/B: 0 = the two-lane line kernel everywhere
   if (!enabled || mm < 64 || !miller_chunk_items() || !(wide_max_items() > 0 && coop_max_items() > 0)) return 0;
   const size_t round = 65536, E = MILLER_ENTRIES;
   const size_t LOCAL = local_env > 16 ? (size_t)local_env : 1024;    // 68 x 1,024 lane pairs: one machine round
-  const size_t rem = mm % round;
-  const size_t left = mm >= round && rem < 1024 ? rem : 0, body = mm - left;
+  // The line kernel of a chunk.  Four lanes per item (k_linesp4: the doubling step shared by two lane pairs, six multiplier passes
+  // on the critical path instead of eleven) while its waves have a SIMD each (16,384 items = 1,024 waves: 0.75 ms against 1.1);
+  // two lanes per item beyond (1.2 ms up to 32,768 items = 1,024 waves, 2.05 ms up to 65,536 = two waves per SIMD; the four-lane
+  // kernel with two waves per SIMD takes 1.4 ms).  Measured, tools/dbg/r3_agg5.sh.
+  const size_t lines4_max = lines4_env >= 0 ? (size_t)lines4_env : 16384;
+  // the signature's pair apart?  Always when its lines come from a table; a general one only where it would cost a cliff
+  const size_t G = last_mode ? mm - 1 : mm;
+  const bool extra = last_mode == 1 || last_mode == 2 || (last_mode == 3 && G % 16384 == 0);
+  const size_t M = extra ? G : mm;                                   // items of the chunks proper
+  const size_t rem = M % round;
+  const size_t left = M >= round && rem < 1024 ? rem : 0, body = M - left;
   const size_t nch = (body + round - 1) / round;
   auto chunk_cnt = [&](size_t k) { return k + 1 < nch ? round : body - k * round; };
   auto quarter = [](size_t q) { return (q + 3) / 4; };
@@ -779,20 +794,23 @@ int run_miller_product_tree(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs,
     while (q > LOCAL) q = quarter(q);
     return q;
   };
-  size_t Qc = left ? quarter(left) : 0;
-  for (size_t k = 0; k < nch; k++) Qc += local_out(chunk_cnt(k));
+  const size_t ql = left ? quarter(left) : 0, qx = extra ? 1 : 0;
+  size_t Qmain = 0;
+  for (size_t k = 0; k < nch; k++) Qmain += local_out(chunk_cnt(k));
+  const size_t Qc = Qmain + ql + qx;
   const size_t q0max = quarter(chunk_cnt(0));
   // two ping-pong buffers: the first takes a chunk's quads and the first level over all chunks' values (fan-in >= 2), the second the levels after them
   const size_t half_qc = (Qc + 1) / 2;
   const size_t capA = E * (q0max > half_qc ? q0max : half_qc), capB = E * (quarter(q0max) > quarter(Qc) + 16 ? quarter(q0max) : quarter(Qc) + 16);
-  const size_t lanes_max = row_stride(lanes_for(chunk_cnt(0))), lanes_left = left ? row_stride(lanes_for(left)) : 0;
+  const size_t lanes_max = row_stride(lanes_for(chunk_cnt(0))), lanes_left = left ? row_stride(lanes_for(left)) : 0, lanes_x = extra ? row_stride(lanes_for(1)) : 0;
   const size_t T_STRIDE = 128;
   if ((capA + E * Qc) * W1 >= ((size_t)1 << 30)) return 0;      // the fold kernels' 32-bit lane offsets (kernels.cuh wsu_ld_hfp6)
-  const size_t words = E * LINE3_WORDS_H * (lanes_max + lanes_left) + (size_t)WS_F_WORDS * (capA + capB + E * Qc + T_STRIDE);
+  const size_t words = E * LINE3_WORDS_H * (lanes_max + lanes_left + lanes_x) + (size_t)WS_F_WORDS * (capA + capB + E * Qc + T_STRIDE);
   if (lines_reserve(c, words * 4) != 0) return 0;
   uint32_t* lines3 = c->lines_ws;
   uint32_t* lines3_left = lines3 + E * LINE3_WORDS_H * lanes_max;
-  uint32_t* bufA = lines3_left + E * LINE3_WORDS_H * lanes_left;
+  uint32_t* lines3_x = lines3_left + E * LINE3_WORDS_H * lanes_left;
+  uint32_t* bufA = lines3_x + E * LINE3_WORDS_H * lanes_x;
   uint32_t* bufB = bufA + (size_t)WS_F_WORDS * capA;
   uint32_t* comb = bufB + (size_t)WS_F_WORDS * capB;
   uint32_t* t68 = comb + (size_t)WS_F_WORDS * E * Qc;
@@ -803,12 +821,15 @@ int run_miller_product_tree(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs,
     const size_t nlanes = lanes_for(cnt), lanes = row_stride(nlanes);
     const uint32_t* pw = d_pairs + lo;
     const int32_t* bw = d_bad + lo;
-    KL(KID_LINES, k_linesp, dim3((unsigned)(nlanes / BLS_BLOCK)), dim3(BLS_BLOCK), cnt, cnt, stride, pw, bw, lines3, lines3, lanes, (size_t)0, cnt, 1);
-    if (k == 0 && left) {
-      // the leftover items: a chunk of their own on the tail stream, its values straight into the combined level.  It starts when
-      // the first chunk's line kernel is through -- beside that kernel, which fills every wave slot of the machine exactly, a
-      // few extra waves would make some of its workgroups wait for a whole round (measured: 2.97 against 2.1 ms) -- and its 68-step
-      // latency hides beside the short tasks of the chunk's product kernels
+    if (cnt <= lines4_max)
+      KL(KID_LINES, k_linesp4, dim3(blocks_for(4 * cnt)), dim3(BLS_BLOCK), cnt, stride, pw, bw, lines3, lanes);
+    else
+      KL(KID_LINES, k_linesp, dim3((unsigned)(nlanes / BLS_BLOCK)), dim3(BLS_BLOCK), cnt, cnt, stride, pw, bw, lines3, lines3, lanes, (size_t)0, cnt, 1);
+    if (k == 0 && (left || extra)) {
+      // the leftover items and the signature's pair: chunks of their own on the tail stream, their values straight into the
+      // combined level.  They start when the first chunk's line kernel is through -- beside that kernel, whose waves fill the
+      // machine's slots exactly, a few extra waves cost a whole chain's time (above) -- and their own chains hide beside the short
+      // tasks of the chunk's product kernels
       if (!c->tail) {
         HIPCK(hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking));
         HIPCK(hipEventCreateWithFlags(&c->ev_tail_fork, hipEventDisableTiming));
@@ -816,11 +837,20 @@ int run_miller_product_tree(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs,
       }
       HIPCK(hipEventRecord(c->ev_tail_fork, c->stream));
       HIPCK(hipStreamWaitEvent(c->tail, c->ev_tail_fork, 0));
-      const size_t nl = lanes_for(left), ql = quarter(left);
-      hipLaunchKernelGGL(k_linesp, dim3((unsigned)(nl / BLS_BLOCK)), dim3(BLS_BLOCK), 0, c->tail, left, left, stride, (const uint32_t*)(d_pairs + body),
-                         (const int32_t*)(d_bad + body), lines3_left, lines3_left, lanes_left, (size_t)0, left, 1);
-      hipLaunchKernelGGL(k_line_quad, dim3(blocks_for(2 * ql), (unsigned)E), dim3(BLS_BLOCK), 0, c->tail, left, ql, (const int32_t*)(d_bad + body),
-                         (const uint32_t*)lines3_left, lanes_left, comb, comb_stride, Qc, Qc - ql);
+      if (extra) {
+        const uint32_t* px = d_pairs + (mm - 1);
+        const int32_t* bx = d_bad + (mm - 1);
+        if (last_mode == 3) hipLaunchKernelGGL(k_linesp4, dim3(1), dim3(BLS_BLOCK), 0, c->tail, (size_t)1, stride, px, bx, lines3_x, lanes_x);
+        else hipLaunchKernelGGL(k_lines_fixed, dim3(1), dim3(BLS_BLOCK), 0, c->tail, stride, px, bx, lines3_x, lanes_x, last_mode);
+        hipLaunchKernelGGL(k_line_quad, dim3(1, (unsigned)E), dim3(BLS_BLOCK), 0, c->tail, (size_t)1, (size_t)1, bx, (const uint32_t*)lines3_x, lanes_x, comb, comb_stride, Qc,
+                           Qmain + ql);
+      }
+      if (left) {
+        hipLaunchKernelGGL(k_linesp4, dim3(blocks_for(4 * left)), dim3(BLS_BLOCK), 0, c->tail, left, stride, (const uint32_t*)(d_pairs + body),
+                           (const int32_t*)(d_bad + body), lines3_left, lanes_left);
+        hipLaunchKernelGGL(k_line_quad, dim3(blocks_for(2 * ql), (unsigned)E), dim3(BLS_BLOCK), 0, c->tail, left, ql, (const int32_t*)(d_bad + body),
+                           (const uint32_t*)lines3_left, lanes_left, comb, comb_stride, Qc, Qmain);
+      }
       const hipError_t e1 = hipGetLastError(), e2 = hipEventRecord(c->ev_tail_join, c->tail);
       if (e1 != hipSuccess || e2 != hipSuccess) {
         (void)hipStreamSynchronize(c->tail);
@@ -847,7 +877,7 @@ int run_miller_product_tree(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs,
     }
     comb_off += q;
   }
-  if (left) HIPCK(hipStreamWaitEvent(c->stream, c->ev_tail_join, 0));
+  if (left || extra) HIPCK(hipStreamWaitEvent(c->stream, c->ev_tail_join, 0));
   // all chunks' values together
   {
     const uint32_t* src = comb;
@@ -896,10 +926,10 @@ int run_miller_product_tree(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs,
 // a single extra wave after a full round costs a lone wave's latency, ~7 ms -- and what is left (< 1,024 items: 262,145 pairs
 // leave one) goes through k_miller1s on the context's tail stream BESIDE the chunks.  BLSGPU_MILLER_V1=1, fewer than 4,096
 // items, or no memory for the line workspace: k_miller1s for everything.
-int run_miller_product(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs, int32_t* d_bad, uint32_t* d_f, size_t* outputs) {
+int run_miller_product(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs, int32_t* d_bad, uint32_t* d_f, size_t* outputs, int last_mode = 0) {
   {
     bool done = false;
-    if (int rc = run_miller_product_tree(c, mm, stride, d_pairs, d_bad, d_f, outputs, &done)) return rc;
+    if (int rc = run_miller_product_tree(c, mm, stride, d_pairs, d_bad, d_f, outputs, &done, last_mode)) return rc;
     if (done) return 0;
   }
   const size_t chunk_max = 2 * miller_chunk_items(), round = 65536;
@@ -2056,7 +2086,8 @@ static int aggregate_enqueue(Ctx* c, int sig_group, int scheme, const uint8_t* d
     return 0;
   }
   size_t outputs = 0;
-  if ((rc = run_miller_product(c, mm, m, d_pairs, d_bad, d_f, &outputs))) return rc;
+  // the signature's pair (item n, when present): its G2 member is the constant -[c] g2 for Bls12381G1Impl, the signature itself otherwise
+  if ((rc = run_miller_product(c, mm, m, d_pairs, d_bad, d_f, &outputs, has_sig ? (sig_group == 1 ? ((agg_flags & 2) ? 2 : 1) : 3) : 0))) return rc;
   if (d_verdict) {
     if ((rc = run_f12_product_verdict(c, d_f, outputs, m, d_verdict))) return rc;
   } else {

@@ -198,6 +198,8 @@ __global__ void k_finalexp2s(size_t n, size_t first, size_t count, const uint32_
 __global__ void k_finalexp_seg(int seg, size_t n, size_t first, size_t count, const uint32_t* fws, uint32_t* vp, size_t lanes, int32_t* status);
 __global__ void k_cyc_run4(size_t count, uint32_t* vp, size_t lanes, const int32_t* status, size_t first);
 __global__ void k_linesp(size_t mm, size_t half, size_t stride, const uint32_t* pairs, const int32_t* bad, uint32_t* lines, uint32_t* lines3, size_t lanes, size_t first_v, size_t count_v, int pass);
+__global__ void k_linesp4(size_t cnt, size_t stride, const uint32_t* pairs, const int32_t* bad, uint32_t* lines3, size_t lanes);
+__global__ void k_lines_fixed(size_t stride, const uint32_t* pairs, const int32_t* bad, uint32_t* lines3, size_t lanes, int fixed_g2);
 __global__ void k_millerfp(size_t count_v, size_t q, int group, const uint32_t* lines, size_t lanes, uint32_t* fws, size_t stride, size_t out0);
 __global__ void k_millerfp3(size_t count, size_t q, int group, const int32_t* bad, const uint32_t* lines3, size_t lanes, uint32_t* fws, size_t stride, size_t out0);
 __global__ void k_line_quad(size_t count, size_t q, const int32_t* bad, const uint32_t* lines3, size_t lanes, uint32_t* fout, size_t sout, size_t rout, size_t oout);
@@ -1482,6 +1484,196 @@ k_linesp(size_t mm, size_t half, size_t stride, const uint32_t* pairs, const int
       if (miller_entry_is_add(e)) lines_step_fn<1, SRC_LINES>(sh, pairs, stride, i, nullptr, lines, lines3, lanes, t, e, skip_a, skip_b);
       else lines_step_fn<0, SRC_LINES>(sh, pairs, stride, i, nullptr, lines, lines3, lanes, t, e, skip_a, skip_b);
     }
+  }
+}
+#endif
+
+#if defined(BLS_TU_LINES)
+// ---- k_linesp4: the plain line values of a pairing product's items (what k_linesp pass 1 stores) on FOUR lanes per item -- two lane
+// pairs A (lanes 0, 1 of a quad) and B (lanes 2, 3) that share the doubling step: for shards of at most 32,768 items, where the
+// two-lane kernel leaves one wave per SIMD issuing at half rate and its 68-step chain sets the time (2.0 ms for 32,768 items as for
+// 65,536).  Lanes of a wave run ONE instruction stream, so the step is a sequence of slots in each of which both pairs do the same
+// kind of product on operands of their own:
+//     slot 1 (product)   A: X Y            B: Z Z
+//     slot 2 (squaring)  A: Y^2 = B_       B: (Y + Z)^2
+//     slot 3 (squaring)  A: X^2            B: E^2            (E = 12 (1 + u) Z^2 is B's after slot 1)
+//       exchange (DPP quad_perm [2,3,0,1]):  A gets E, B gets B_
+//     slot 4 (product)   A: X Y (B_ - 3E)  B: B_ H          (H = (Y + Z)^2 - B_ - Z^2)   -> X3 = 2 ., Z3 = 4 .
+//     slot 5 (squaring)  B: (B_ + 3E)^2    (A: the same, unused)                         -> Y3 = . - 12 E^2 on B;  exchange: A gets Y3
+//     slot 6 (by Fp)     A: -3 X^2 xP      B: H yP                                       -> the line's w^2 and w^3 coefficients
+// i.e. six multiplier passes (2 x 588 + 4 x 392 multiply-adds per lane) on the critical path instead of eleven (3 x 588 + 8 x 392):
+// the arithmetic of pairing.cuh miller_dbl_step_at operation for operation, so the stored values are the same field elements.
+// A holds X, Y and B holds Y, Z in their LDS columns; the five addition steps exchange what is missing and run the whole step
+// (miller_add_step_at) redundantly on both pairs.  Line workspace and lane numbering as k_linesp: item j at lanes 2 j, 2 j + 1.
+#define L4_X 0
+#define L4_Y FP_NL
+#define L4_Z (2 * FP_NL)
+#define L4_PX (3 * FP_NL)
+#define L4_PY (4 * FP_NL)
+#define L4_WORDS (5 * FP_NL)
+__device__ __forceinline__ void fp_cross4(fp& r, const fp& a) {   // the other pair's lane of the same parity
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) r.l[i] = __builtin_amdgcn_mov_dpp(a.l[i], 0x4E, 0xF, 0xF, true);
+}
+__device__ __forceinline__ void fp2_sel(hfp2& r, bool c, const hfp2& a, const hfp2& b) { fp_sel(r.v, c, a.v, b.v); }
+struct miller_lds4 {
+  lds_u32* sh;
+  const uint32_t* pairs;
+  size_t n, i;
+  BLS_MFN void ld_tx(hfp2& r) const { ls_ld(r.v, sh, L4_X); }
+  BLS_MFN void ld_ty(hfp2& r) const { ls_ld(r.v, sh, L4_Y); }
+  BLS_MFN void ld_tz(hfp2& r) const { ls_ld(r.v, sh, L4_Z); }
+  BLS_MFN void st_tx(const hfp2& v) const { ls_st(sh, L4_X, v.v); }
+  BLS_MFN void st_ty(const hfp2& v) const { ls_st(sh, L4_Y, v.v); }
+  BLS_MFN void st_tz(const hfp2& v) const { ls_st(sh, L4_Z, v.v); }
+  BLS_MFN void ld_xp(fp& r) const { ls_ld(r, sh, L4_PX); }
+  BLS_MFN void ld_yp(fp& r) const { ls_ld(r, sh, L4_PY); }
+  BLS_MFN void ld_xq(hfp2& r) const { ws_ld_hfp2(r, pairs, n, i, W2); }
+  BLS_MFN void ld_yq(hfp2& r) const { ws_ld_hfp2(r, pairs, n, i, 2 * W2); }
+};
+// A stores l0 and l2 (words 0..27 of the entry), B stores l3 (words 28..41): t2 = this lane's lane number in the line workspace
+__device__ __forceinline__ void line3_st4(uint32_t* lines3, size_t lanes, uint32_t t2, int e, bool pr, const hfp2& l0, const hfp2& l2, const hfp2& l3) {
+  lanes = uni_sz(lanes);
+  g_u32* row = uni_global(lines3) + (size_t)uni_u32((uint32_t)e) * LINE3_WORDS * lanes;
+  hfp2 first;
+  fp2_sel(first, pr, l3, l0);
+  const uint32_t w = t2 + (pr ? (uint32_t)(2 * FP_NL) * (uint32_t)lanes : 0u);
+#pragma unroll
+  for (int k = 0; k < FP_NL; k++) {
+    g_st(row, w, (uint32_t)first.v.l[k]);
+    row += lanes;
+  }
+  if (!pr) {
+#pragma unroll
+    for (int k = 0; k < FP_NL; k++) {
+      g_st(row, t2, (uint32_t)l2.v.l[k]);
+      row += lanes;
+    }
+  }
+}
+static __device__ __noinline__ void lines4_dbl_fn(lds_u32* sh, uint32_t* lines3, size_t lanes, uint32_t t2, int e, bool pr) {
+  hfp2 r0, r1, u, w, m1, s2, s3, E, g, f, b, h, l0, m4, s5, snd, rcv;
+  const lds_u32* c0 = sh + (pr ? L4_Y : L4_X) * BLS_SH_STRIDE;     // A: X, Y    B: Y, Z
+  ls_ld(r0.v, c0, 0);
+  ls_ld(r1.v, c0, FP_NL);
+  fp2_sel(u, pr, r1, r0);
+  fp2_mul(m1, u, r1);              // slot 1   A: a = X Y        B: c = Z^2
+  fp2_add(w, r0, r1);
+  fp2_norm(w, w);
+  fp2_sel(w, pr, w, r1);
+  fp2_sqr(s2, w);                  // slot 2   A: B_ = Y^2       B: (Y + Z)^2
+  fp2_mul_xi(E, m1);
+  fp2_dbl(g, E);
+  fp2_add(E, g, E);
+  fp2_reduce(E, E);
+  fp2_dbl(E, E);
+  fp2_dbl(E, E);
+  fp2_norm(E, E);                  // B: E = 3 b' Z^2 = 12 (1 + u) Z^2
+  fp2_sel(w, pr, E, r0);
+  fp2_sqr(s3, w);                  // slot 3   A: X^2            B: E^2
+  fp2_sel(snd, pr, E, s2);
+  fp_cross4(rcv.v, snd.v);
+  fp2_sel(b, pr, rcv, s2);         // B_ on both pairs
+  fp2_sel(E, pr, E, rcv);          // E on both pairs
+  fp2_dbl(f, E);
+  fp2_add(f, f, E);                // F = 3E
+  fp2_sub(h, s2, b);
+  fp2_sub(h, h, m1);
+  fp2_norm(h, h);                  // B: H = 2 Y Z
+  fp2_sub(l0, b, E);
+  fp2_norm(l0, l0);                // the line's constant coefficient (A stores it)
+  fp2_sub(g, b, f);
+  fp2_norm(g, g);
+  fp2_sel(u, pr, b, m1);
+  fp2_sel(w, pr, h, g);
+  fp2_mul(m4, u, w);               // slot 4   A: X Y (B_ - F)   B: B_ H
+  fp2_dbl(g, m4);
+  fp2_dbl(w, g);
+  fp2_sel(g, pr, w, g);
+  fp2_reduce(g, g);
+  ls_st(sh, pr ? L4_Z : L4_X, g.v);   // A: X3 = 2 X Y (B_ - F)    B: Z3 = 4 B_ H
+  fp2_add(g, b, f);
+  fp2_norm(g, g);
+  fp2_sqr(s5, g);                  // slot 5   (B_ + F)^2
+  fp2_dbl(g, s3);
+  fp2_add(g, g, s3);               // B: 3 E^2        A: 3 X^2
+  hfp2 n3;
+  fp2_neg(n3, g);                  // A: -3 X^2
+  fp2_norm(g, g);
+  fp2_dbl(g, g);
+  fp2_dbl(g, g);                   // B: 12 E^2
+  fp2_sub(g, s5, g);
+  fp2_reduce(g, g);                // B: Y3
+  fp_cross4(rcv.v, g.v);
+  fp2_sel(g, pr, g, rcv);
+  ls_st(sh, L4_Y, g.v);            // Y3 on both pairs
+  fp k;
+  ls_ld(k, sh, pr ? L4_PY : L4_PX);
+  fp2_sel(u, pr, h, n3);
+  hfp2 l23;
+  fp2_mul_fp(l23, u, k);           // slot 6   A: l2 = -3 X^2 xP    B: l3 = H yP
+  line3_st4(lines3, lanes, t2, e, pr, l0, l23, l23);
+}
+static __device__ __noinline__ void lines4_add_fn(lds_u32* sh, const uint32_t* pairs, size_t n, size_t i, uint32_t* lines3, size_t lanes, uint32_t t2, int e, bool pr) {
+  {                                // A lacks Z, B lacks X: one exchange completes both columns
+    fp snd, rcv;
+    ls_ld(snd, sh, pr ? L4_Z : L4_X);
+    fp_cross4(rcv, snd);
+    ls_st(sh, pr ? L4_X : L4_Z, rcv);
+  }
+  const miller_lds4 st = {sh, pairs, n, i};
+  hfp2 l0, l2, l3;
+  miller_add_step_at(st, l0, l2, l3);   // both pairs, the same operands: X3, Y3, Z3 in both columns
+  line3_st4(lines3, lanes, t2, e, pr, l0, l2, l3);
+}
+// The line values of ONE item whose G2 member is the fixed -g2 (fixed_g2 = 1) or -[c] g2 (2) -- the signature's pair of an
+// aggregate verification of Bls12381G1Impl -- in k_linesp's format, as item 0 of a line workspace: no point walk, the normalised
+// table row of every entry (g2neg_lines.cuh *_LINES_N) evaluated at the pair's G1 point: n0 + (n2 x1) w^2 + y1 w^3.  One lane pair.
+__global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) k_lines_fixed(size_t stride, const uint32_t* pairs, const int32_t* bad, uint32_t* lines3, size_t lanes, int fixed_g2) {
+  if (blockIdx.x != 0 || threadIdx.x >= 2) return;
+  if (bad[0] != 0) return;
+  const uint32_t hi = threadIdx.x & 1u;
+  fp x1, y1;
+  ws_ld_fp(x1, pairs, stride, 0, 0);
+  ws_ld_fp(y1, pairs, stride, 0, W1);
+  const uint32_t (*rows)[4 * FP_NL] = fixed_g2 == 2 ? G2NEGC_LINES_N : G2NEG_LINES_N;
+  hfp2 l3;
+  fp2_from_fp(l3, y1);
+  for (int e = 0; e < MILLER_ENTRIES; e++) {
+    hfp2 n0, c, l2;
+    fp2_load(n0, rows[e]);
+    fp2_load(c, rows[e] + 2 * FP_NL);
+    fp2_mul_fp(l2, c, x1);
+    line3_st(lines3, lanes, hi, e, n0, l2, l3);
+  }
+}
+__global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) __attribute__((disable_tail_calls))
+k_linesp4(size_t cnt, size_t stride, const uint32_t* pairs, const int32_t* bad, uint32_t* lines3, size_t lanes) {
+  const uint32_t t = blockIdx.x * BLS_BLOCK + threadIdx.x;
+  const size_t j = t >> 2;
+  if (j >= cnt) return;
+  if (bad[j] != 0) return;                                  // (the four lanes of an item together)
+  const bool pr = ((t >> 1) & 1u) != 0;
+  const uint32_t t2 = (uint32_t)(2 * j) + (t & 1u);
+  __shared__ uint32_t lsh[L4_WORDS * BLS_BLOCK];
+  lds_u32* sh = lds_column(lsh);
+  {
+    hfp2 q;
+    fp p;
+    ws_ld_hfp2(q, pairs, stride, j, W2);
+    ls_st(sh, L4_X, q.v);
+    ws_ld_hfp2(q, pairs, stride, j, 2 * W2);
+    ls_st(sh, L4_Y, q.v);
+    fp2_one(q);
+    ls_st(sh, L4_Z, q.v);
+    ws_ld_fp(p, pairs, stride, j, 0);
+    ls_st(sh, L4_PX, p);
+    ws_ld_fp(p, pairs, stride, j, W1);
+    ls_st(sh, L4_PY, p);
+  }
+  for (int e = 0; e < MILLER_ENTRIES; e++) {
+    if (miller_entry_is_add(e)) lines4_add_fn(sh, pairs, stride, j, lines3, lanes, t2, e, pr);
+    else lines4_dbl_fn(sh, lines3, lanes, t2, e, pr);
   }
 }
 #endif

@@ -581,11 +581,11 @@ def test_segmented_final_exponentiation_and_one_kernel_miller_loop_agree():
 
 
 @pytest.mark.gpu
-def test_pairing_product_tree_and_accumulator_forms_agree():
+def test_pairing_product_tree_and_accumulator_forms_agree(api):
     """AggregateSignature::verify's pairing product in its two forms -- the per-entry products over the items with one Horner chain
     (k_line_quad / k_f12_fold4 / k_f12_horner_wide, the default from 64 pairs) and one accumulator per item or pair of items
-    (BLSGPU_PRODUCT_TREE=0: k_millerfp3 / k_millerfp) -- give the same verdicts AND the same 576-byte Miller-product records
-    (blsgpu_aggregate_partial: shards of either form fold together) at sizes around the form's lower bound, the fold levels'
+    (BLSGPU_PRODUCT_TREE=0: k_millerfp3 / k_millerfp) -- give the same verdicts, the same 576-byte Miller-product records for shards
+    without the signature's pair and records that fold together for shards with it (blsgpu_aggregate_partial) at sizes around the form's lower bound, the fold levels'
     fan-in (4, 16) and with flagged (identity) keys, tampered messages and a missing signature pair (child processes: the switch is read once)."""
     import subprocess
     import sys
@@ -615,8 +615,17 @@ def test_pairing_product_tree_and_accumulator_forms_agree():
         res[name] = eval(r.stdout.strip().splitlines()[-1])
     assert len(res['tree']) == 2 * 10 * 5
     for k in range(0, len(res['tree']), 5):
-        ok, tampered, ident, rec, rec_ident = res['tree'][k:k + 5]
-        assert ok[0] == 0 and tampered[0] == 1, k
-        assert ident[0] != 0, k                      # an identity key is an error of its own (reference src/traits/sig_core.rs:149-178)
-        assert len(rec[0]) == 576 and rec[1] == -1 and rec_ident[1] >= 0, k
-    assert res['acc'] == res['tree']
+        for name in ('tree', 'acc'):
+            ok, tampered, ident, rec, rec_ident = res[name][k:k + 5]
+            assert ok[0] == 0 and tampered[0] == 1, (name, k)
+            assert ident[0] != 0, (name, k)          # an identity key is an error of its own (reference src/traits/sig_core.rs:149-178)
+            assert len(rec[0]) == 576 and rec[1] == -1 and rec_ident[1] >= 0, (name, k)
+            # the record of the whole valid aggregate (signature's pair included) is a Miller product whose final exponentiation is 1:
+            # checked HERE, by this process's library, for the records of both children
+            assert api.fp12_product_is_one([rec[0]]), (name, k)
+            assert not api.fp12_product_is_one([rec_ident[0]]), (name, k)
+        # without the signature's pair the two forms multiply the same line values: byte-identical records.  With it the per-entry
+        # form takes that pair's lines from the NORMALISED table of the fixed argument (every row divided by a factor in Fp2, which
+        # the final exponentiation removes): the records differ by such a factor and fold together all the same (above)
+        assert res['acc'][k + 4] == res['tree'][k + 4], k
+        assert [r[0] for r in res['acc'][k:k + 3]] == [r[0] for r in res['tree'][k:k + 3]], k
