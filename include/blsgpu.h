@@ -223,7 +223,9 @@ int blsgpu_signatures_to_tagged(int sig_group, const uint8_t* schemes, const voi
  * (src/traits/sig_core.rs:149-178).  out_f12 (576 B) = an Fp12 value whose final exponentiation is the product of the pairings
  * of the shard's (H(m_i), pk_i) pairs [times (sig, -g) when sig != NULL] -- a product of Miller values (for Bls12381G1Impl
  * taken at the message points before their cofactor clearing, the signature's at -[c] g2, c = h_eff^-1 mod r: the same
- * verdict); only products of such records and their final exponentiation are meaningful; *first_bad = local index of the first identity
+ * verdict); only products of such records and their final exponentiation are meaningful -- a record is defined up to factors that
+ * the final exponentiation removes (the line values are scaled by elements of Fp2, differently from one library build to another), so
+ * compare verdicts, never record bytes, and fold only records that ranks of ONE library build produced; *first_bad = local index of the first identity
  * key, n when the signature is the identity, -1 otherwise (identity pairs contribute 1 to the record, so it can always be
  * folded).  out_f12 and first_bad may be device pointers: then nothing crosses to the host and the caller hands them to
  * RCCL as they are.  Ranks exchange the records (all-gather) and finish with blsgpu_fp12_product_is_one.
