@@ -1,3 +1,4 @@
+#include <vector>
 // TEST-ONLY harness: compiles the device arithmetic headers (agora-blsful_amd/csrc/*.cuh) as plain host C++ so that
 // the `-m "not gpu"` suite can check every per-item device function against the oracle without a GPU.
 // It is never linked into libblsgpu.so and is not a CPU fallback: the product library has no host compute path.
@@ -189,6 +190,98 @@ int hs_miller_merged_matches(const uint32_t* p0, const uint32_t* q0, const uint3
   if (!fp2_eq(chk, eb.c0.a0)) return -4;
   chk.c0 = es.c1.a2.c[0]; chk.c1 = es.c1.a2.c[1];
   return fp2_eq(chk, eb.c1.a2) ? 1 : -5;
+}
+// Pairing products as the kernels of run_miller_product_tree take them (kernels.cuh k_linesp / k_line_quad / k_f12_fold4 / program
+// HORNER): the plain line values of every item and entry; per entry the product over the items -- four items' values merged two by
+// two and multiplied (lines_merge, fp12_from_line5, fp12_mul_by_line5_body), the quads' values folded with general products;
+// then ONE Horner chain over the 68 entry products.  Lane-split tower, bound tracker on.  fixed_last: the last pair's G2 member is
+// -[c] g2 and its line values come from the normalised table (k_lines_fixed).  Compared after the final exponentiation with the
+// product of the plain Miller loops.  1 = equal
+int hs_product_tree_matches(int n, const uint32_t* g1s, const uint32_t* g2s, int fixed_last) {
+  typedef hfp2 F2;
+  std::vector<g1_aff> P(n);
+  std::vector<g2_aff> Q(n);
+  for (int i = 0; i < n; i++) {
+    fp_from_raw(P[i].x, g1s + 24 * i); fp_from_raw(P[i].y, g1s + 24 * i + 12); P[i].inf = false;
+    raw_fp2(Q[i].x, g2s + 48 * i); raw_fp2(Q[i].y, g2s + 48 * i + 24); Q[i].inf = false;
+  }
+  // reference: one plain Miller loop per pair (the last pair's G2 member as given: the caller passes -[c] g2 there when fixed_last)
+  fp12 ref, one_pair, eref;
+  for (int i = 0; i < n; i++) {
+    miller_loop<1>(one_pair, &P[i], &Q[i]);
+    if (i == 0) ref = one_pair;
+    else fp12_mul(ref, ref, one_pair);
+  }
+  final_exponentiation(eref, ref);
+  // the items' line values
+  struct line3 { F2 l0, l2, l3; };
+  std::vector<std::vector<line3> > L(n, std::vector<line3>(MILLER_ENTRIES));
+  for (int i = 0; i < n; i++) {
+    if (fixed_last && i == n - 1) {
+      for (int e = 0; e < MILLER_ENTRIES; e++) {
+        F2 c;
+        fp2_load(L[i][e].l0, G2NEGC_LINES_N[e]);
+        fp2_load(c, G2NEGC_LINES_N[e] + 2 * FP_NL);
+        fp2_mul_fp(L[i][e].l2, c, P[i].x);
+        fp2_from_fp(L[i][e].l3, P[i].y);
+      }
+      continue;
+    }
+    aff<F2> QQ;
+    QQ.x.c[0] = Q[i].x.c0; QQ.x.c[1] = Q[i].x.c1; QQ.y.c[0] = Q[i].y.c0; QQ.y.c[1] = Q[i].y.c1; QQ.inf = false;
+    g2_hom_t<F2> T;
+    T.x = QQ.x; T.y = QQ.y; fp2_one(T.z);
+    for (int e = 0; e < MILLER_ENTRIES; e++) {
+      if (miller_entry_is_add(e)) miller_add_step(T, L[i][e].l0, L[i][e].l2, L[i][e].l3, QQ.x, QQ.y, P[i].x, P[i].y);
+      else miller_dbl_step(T, L[i][e].l0, L[i][e].l2, L[i][e].l3, P[i].x, P[i].y);
+    }
+  }
+  // per entry: quads, then a fold by fours
+  line3 neutral;
+  fp2_one(neutral.l0); fp2_zero(neutral.l2); fp2_zero(neutral.l3);
+  const int q = (n + 3) / 4;
+  fp12_t<F2> F;
+  for (int e = 0; e < MILLER_ENTRIES; e++) {
+    std::vector<fp12_t<F2> > v(q);
+    for (int j = 0; j < q; j++) {
+      const line3& a = L[j][e];
+      const line3& b = j + q < n ? L[j + q][e] : neutral;
+      const line3& c = j + 2 * q < n ? L[j + 2 * q][e] : neutral;
+      const line3& d = j + 3 * q < n ? L[j + 3 * q][e] : neutral;
+      line5_t<F2> M;
+      lines_merge(M, a.l0, a.l2, a.l3, b.l0, b.l2, b.l3);
+      fp12_from_line5(v[j], M);
+      fp12_reduce(v[j], v[j]);
+      lines_merge(M, c.l0, c.l2, c.l3, d.l0, d.l2, d.l3);
+      fp12_mul_by_line5_body(v[j], M);
+    }
+    int m = q;
+    while (m > 1) {
+      const int mo = (m + 3) / 4;
+      for (int j = 0; j < mo; j++)
+        for (int k = 1; k < 4; k++)
+          if (j + k * mo < m) fp12_mul(v[j], v[j], v[j + k * mo]);
+      m = mo;
+    }
+    if (e == 0) {
+      F = v[0];
+    } else {
+      if (!miller_entry_is_add(e)) fp12_sqr(F, F);
+      fp12_mul(F, F, v[0]);
+    }
+  }
+  fp12_t<F2> Fc, es;
+  fp12_conj(Fc, F);
+  final_exponentiation(es, Fc);
+  fp2 chk;
+  const F2* got[6] = {&es.c0.a0, &es.c0.a1, &es.c0.a2, &es.c1.a0, &es.c1.a1, &es.c1.a2};
+  const fp2* want[6] = {&eref.c0.a0, &eref.c0.a1, &eref.c0.a2, &eref.c1.a0, &eref.c1.a1, &eref.c1.a2};
+  for (int k = 0; k < 6; k++) {
+    chk.c0 = got[k]->c[0];
+    chk.c1 = got[k]->c[1];
+    if (!fp2_eq(chk, *want[k])) return -1 - k;
+  }
+  return 1;
 }
 // cyclotomic squaring vs generic squaring on an element of the cyclotomic subgroup
 int hs_cyclotomic_check(int n, const uint32_t* g1s, const uint32_t* g2s) {

@@ -195,6 +195,25 @@ def test_pairing_values(hs):
     assert hs.hs_miller_merged_matches(util.g1_aff_raw(P1), util.g2_aff_raw(Q1), util.g1_aff_raw(P2), util.g2_aff_raw(Q2)) == 1
 
 
+def test_pairing_product_by_entries_and_horner_chain(hs):
+    """The pairing product as run_miller_product_tree takes it (csrc/kernels.cuh k_linesp / k_line_quad / k_f12_fold4, engine program
+    HORNER): per Miller entry the product over the items of their line values (four items merged two by two and multiplied, then folds
+    by fours), ONE Horner chain over the 68 entry products -- on the lane-split tower with the bound tracker on, against the product
+    of the plain Miller loops after the final exponentiation.  Item counts that leave quads and fold levels partly empty (absent
+    items enter as the line 1); with the last pair's line values from the normalised table of -[c] g2 (k_lines_fixed)."""
+    rng = random.Random(11)
+    cinv = pow(c.H_EFF_G1, -1, c.R)
+    negc = c.E2.neg(c.E2.mul(c.G2_GEN, cinv))
+    for n, fixed in ((1, 0), (4, 0), (5, 1), (6, 0), (17, 1), (21, 0)):
+        ps = [c.E1.mul(c.G1_GEN, rng.randrange(1, c.R)) for _ in range(n)]
+        qs = [c.E2.mul(c.G2_GEN, rng.randrange(1, c.R)) for _ in range(n)]
+        if fixed:
+            qs[-1] = negc
+        g1 = b''.join(util.g1_aff_raw(p) for p in ps)
+        g2 = b''.join(util.g2_aff_raw(q) for q in qs)
+        assert hs.hs_product_tree_matches(n, g1, g2, fixed) == 1, (n, fixed)
+
+
 def test_verify_items(hs):
     """core_verify per item (reference src/traits/sig_core.rs:120-146): verdicts and error precedence, both backends,
     all schemes, plus the C++ known-answer signatures (tests/cpp_integration_test.rs:54-82)."""
