@@ -152,6 +152,35 @@ BLS_FN void fp_reduce(fp& r, const fp& a) {
   FP_TRK(r.lb = FP_LB_N; r.vb = 0.52;)
 }
 
+// The value reduction of ka a + kb b (small integer coefficients, e.g. 3 t - 2 z of a compressed squaring) in ONE pass: the
+// combination is formed on 64 bits inside the carry chain, so the caller needs neither the limb-wise doublings and additions nor a
+// carry pass to keep them within 32 bits.  Same result contract as fp_reduce.  Inputs: |ka| a.lb + |kb| b.lb below 2^35 (the carry
+// into the top limb then moves the quotient estimate by less than 128 units of p / 106,514), |ka| a.vb + |kb| b.vb <= 120.
+BLS_FN void fp_reduce_lin2(fp& r, const fp& a, int ka, const fp& b, int kb) {
+  FP_TRK(const double tlb = (ka < 0 ? -ka : ka) * a.lb + (kb < 0 ? -kb : kb) * b.lb, tvb = (ka < 0 ? -ka : ka) * a.vb + (kb < 0 ? -kb : kb) * b.vb;
+         if (tlb >= 34359738368.0) fp_trk_fail("fp_reduce_lin2 |limb| < 2^35", tlb, 0); if (tvb > 120.0) fp_trk_fail("fp_reduce_lin2 |value| < 120 p", tvb, 0);)
+  const int32_t k = (int32_t)rintf((float)(ka * a.l[FP_NL - 1] + kb * b.l[FP_NL - 1]) * FP_PTOP_INV);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the coefficients as opaque scalars: three multiply-adds per limb; left to itself the compiler strength-reduces 3 a and 2 b into
+  // 64-bit shifts, additions and borrow chains (seven instructions per limb instead of three)
+  asm volatile("" : "+s"(ka));
+  asm volatile("" : "+s"(kb));
+#endif
+  const int32_t nk = -k;
+  int64_t c = 0;                                  // (the carry stays on 64 bits: it is the addend of the next limb's multiply-add chain)
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) {
+    const int64_t x = (int64_t)a.l[i] * ka + ((int64_t)b.l[i] * kb + ((int64_t)nk * (int32_t)FP_P[i] + c));
+    if (i < FP_NL - 1) {
+      r.l[i] = (int32_t)((uint32_t)x & FP_MASK);
+      c = x >> FP_LB;
+    } else {
+      r.l[i] = (int32_t)x;
+    }
+  }
+  FP_TRK(r.lb = FP_LB_N; r.vb = 0.52;)
+}
+
 // The representative in [0, p) with exact limbs.
 BLS_FN void fp_canon(fp& r, const fp& a) {
   fp t;

@@ -2086,16 +2086,26 @@ __device__ __forceinline__ void cpow_slot(int k, int j, int& slot, int& idx) {  
 }
 static __device__ __noinline__ void fx_pow_run(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t) {
   const vs_ref v = {vp, lanes, t};
+  {                                        // the four coordinates out of A's packed slots into the unpacked layout of the loop (A is dead from here:
+    fp z2, z3, z4, z5;                     // fx_pow_finish rebuilds it from the saved powers, the fallback from V[2])
+    sh_ld_fp(z2, sh, 39);
+    sh_ld_fp(z3, sh, 26);
+    sh_ld_fp(z4, sh, 13);
+    sh_ld_fp(z5, sh, 65);
+    shu_st_fp(sh, CYCU_Z2, z2);
+    shu_st_fp(sh, CYCU_Z3, z3);
+    shu_st_fp(sh, CYCU_Z4, z4);
+    shu_st_fp(sh, CYCU_Z5, z5);
+  }
   int k = 0;
   for (int i = 1; i <= 63; i++) {
-    f12_sh_cyc_c_sqr_body(sh);
+    f12_sh_cyc_c_sqr_unpacked_body(sh);
     if ((BLS_X_ABS >> i) & 1) {
-      const int w[4] = {39, 26, 13, 65};   // LDS words of z2, z3, z4, z5
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
+      for (int j = 0; j < 4; j++) {        // z2, z3, z4, z5
         fp x;
         int slot, idx;
-        sh_ld_fp(x, sh, w[j]);
+        shu_ld_fp(x, sh, j * FP_NL);
         cpow_slot(k, j, slot, idx);
         vs_st(v, slot, idx, x);
       }

@@ -407,18 +407,19 @@ BLS_FN void cyc_out(F2& r, const F2& t, const F2& z, bool plus) {   // 3 t +- 2 
   fp2_add(u, u, t);
   fp2_reduce(r, u);
 }
+// (the Fp4 squarings leave their outputs as plain sums and every new coordinate 3 t +- 2 z is ONE reduction pass that forms the
+// combination on 64 bits, fp_reduce_lin2: no doublings, additions or carry passes in between -- round 3)
 template <class F2>
 BLS_FN void cyc_c_sqr(cyc_c<F2>& r, const cyc_c<F2>& a) {
   F2 t0, t1, t2, t3, x;
-  fp4_sqr(t0, t1, a.z2, a.z3);
-  fp4_sqr(t2, t3, a.z4, a.z5);
+  fp4_sqr_lazy(t0, t1, a.z2, a.z3);
+  fp4_sqr_lazy(t2, t3, a.z4, a.z5);
   cyc_c<F2> o;
-  cyc_out(o.z4, t0, a.z4, false);
-  cyc_out(o.z5, t1, a.z5, true);
+  fp2_reduce_lin2(o.z4, t0, 3, a.z4, -2);
+  fp2_reduce_lin2(o.z5, t1, 3, a.z5, 2);
   fp2_mul_xi(x, t3);
-  fp2_norm(x, x);
-  cyc_out(o.z2, x, a.z2, true);
-  cyc_out(o.z3, t2, a.z3, false);
+  fp2_reduce_lin2(o.z2, x, 3, a.z2, 2);
+  fp2_reduce_lin2(o.z3, t2, 3, a.z3, -2);
   r = o;
 }
 // f = the cyclotomic element whose compressed form is c, given inv4z2 = 1 / (4 z2)

@@ -27,6 +27,10 @@ BLS_FN void fp2_one(fp2& r) {
   fp_one(r.c0);
   fp_zero(r.c1);
 }
+BLS_FN void fp2_reduce_lin2(fp2& r, const fp2& a, int ka, const fp2& b, int kb) {
+  fp_reduce_lin2(r.c0, a.c0, ka, b.c0, kb);
+  fp_reduce_lin2(r.c1, a.c1, ka, b.c1, kb);
+}
 BLS_FN void fp2_from_fp(fp2& r, const fp& k) {   // k + 0 u
   r.c0 = k;
   fp_zero(r.c1);
@@ -462,6 +466,21 @@ BLS_FN void fp4_sqr(F2& c0, F2& c1, const F2& a, const F2& b) {
   fp2_sub(t2, t2, t0);
   fp2_sub(t2, t2, t1);
   fp2_norm(c1, t2);
+}
+// ... with the two outputs left as the sums they are (limbs up to three products' worth): for callers that feed them to
+// fp2_reduce_lin2 (the compressed squarings: 3 c +- 2 z in one pass)
+template <class F2>
+BLS_FN void fp4_sqr_lazy(F2& c0, F2& c1, const F2& a, const F2& b) {
+  F2 t0, t1, t2;
+  fp2_sqr(t0, a);
+  fp2_sqr(t1, b);
+  fp2_mul_xi(t2, t1);
+  fp2_add(c0, t2, t0);
+  fp2_add(t2, a, b);
+  fp2_norm(t2, t2);
+  fp2_sqr(t2, t2);
+  fp2_sub(t2, t2, t0);
+  fp2_sub(c1, t2, t1);
 }
 template <class F2>
 BLS_FN void fp12_cyclotomic_sqr_body(fp12_t<F2>& r, const fp12_t<F2>& f) {

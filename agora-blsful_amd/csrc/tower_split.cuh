@@ -55,6 +55,7 @@ __device__ __forceinline__ void fp2_neg(hfp2& r, const hfp2& a) { fp_neg(r.v, a.
 __device__ __forceinline__ void fp2_dbl(hfp2& r, const hfp2& a) { fp_dbl(r.v, a.v); }
 __device__ __forceinline__ void fp2_norm(hfp2& r, const hfp2& a) { fp_norm(r.v, a.v); }
 __device__ __forceinline__ void fp2_reduce(hfp2& r, const hfp2& a) { fp_reduce(r.v, a.v); }
+__device__ __forceinline__ void fp2_reduce_lin2(hfp2& r, const hfp2& a, int ka, const hfp2& b, int kb) { fp_reduce_lin2(r.v, a.v, ka, b.v, kb); }
 __device__ __forceinline__ void fp2_conj(hfp2& r, const hfp2& a) {
   fp n;
   fp_neg(n, a.v);
@@ -345,19 +346,54 @@ __device__ __forceinline__ void acc_finish(f12_sh&) {}   // the kernel conjugate
 
 // compressed squaring (pairing.cuh cyc_c_sqr) on the LDS slots of z2, z3, z4, z5: the last two thirds of the function above
 __device__ __forceinline__ void f12_sh_cyc_c_sqr_body(lds_u32* sh) {
-  hfp2 t0, t1, z2, z3, z4, z5, t2, t3;
+  hfp2 t0, t1, z2, z3, z4, z5, t2, t3, o;
   sh_ld_fp(z2.v, sh, 39);
   sh_ld_fp(z3.v, sh, 26);
-  fp4_sqr(t0, t1, z2, z3);
+  fp4_sqr_lazy(t0, t1, z2, z3);
   sh_ld_fp(z4.v, sh, 13);
   sh_ld_fp(z5.v, sh, 65);
-  fp4_sqr(t2, t3, z4, z5);
-  cyc_store_minus(sh, 13, t0, z4);
-  cyc_store_plus(sh, 65, t1, z5);
+  fp4_sqr_lazy(t2, t3, z4, z5);
+  fp2_reduce_lin2(o, t0, 3, z4, -2);
+  sh_st_fp(sh, 13, o.v);
+  fp2_reduce_lin2(o, t1, 3, z5, 2);
+  sh_st_fp(sh, 65, o.v);
   fp2_mul_xi(t0, t3);
-  fp2_norm(t0, t0);
-  cyc_store_plus(sh, 39, t0, z2);
-  cyc_store_minus(sh, 26, t2, z3);
+  fp2_reduce_lin2(o, t0, 3, z2, 2);
+  sh_st_fp(sh, 39, o.v);
+  fp2_reduce_lin2(o, t2, 3, z3, -2);
+  sh_st_fp(sh, 26, o.v);
+}
+// The same with the four coordinates UNPACKED in LDS (fourteen words each at words 0, 14, 28, 42 of the lane's column: z2, z3, z4, z5):
+// the loop of an a^x touches nothing else of the accumulator, whose packed form it may overwrite (k_finalexp2s fx_pow_run)
+#define CYCU_Z2 0
+#define CYCU_Z3 FP_NL
+#define CYCU_Z4 (2 * FP_NL)
+#define CYCU_Z5 (3 * FP_NL)
+__device__ __forceinline__ void shu_ld_fp(fp& r, const lds_u32* sh, int w0) {
+#pragma unroll
+  for (int k = 0; k < FP_NL; k++) r.l[k] = (int32_t)sh[(w0 + k) * BLS_SH_STRIDE];
+}
+__device__ __forceinline__ void shu_st_fp(lds_u32* sh, int w0, const fp& a) {
+#pragma unroll
+  for (int k = 0; k < FP_NL; k++) sh[(w0 + k) * BLS_SH_STRIDE] = (uint32_t)a.l[k];
+}
+__device__ __forceinline__ void f12_sh_cyc_c_sqr_unpacked_body(lds_u32* sh) {
+  hfp2 t0, t1, z2, z3, z4, z5, t2, t3, o;
+  shu_ld_fp(z2.v, sh, CYCU_Z2);
+  shu_ld_fp(z3.v, sh, CYCU_Z3);
+  fp4_sqr_lazy(t0, t1, z2, z3);
+  shu_ld_fp(z4.v, sh, CYCU_Z4);
+  shu_ld_fp(z5.v, sh, CYCU_Z5);
+  fp4_sqr_lazy(t2, t3, z4, z5);
+  fp2_reduce_lin2(o, t0, 3, z4, -2);
+  shu_st_fp(sh, CYCU_Z4, o.v);
+  fp2_reduce_lin2(o, t1, 3, z5, 2);
+  shu_st_fp(sh, CYCU_Z5, o.v);
+  fp2_mul_xi(t0, t3);
+  fp2_reduce_lin2(o, t0, 3, z2, 2);
+  shu_st_fp(sh, CYCU_Z2, o.v);
+  fp2_reduce_lin2(o, t2, 3, z3, -2);
+  shu_st_fp(sh, CYCU_Z3, o.v);
 }
 __device__ __noinline__ void f12_sh_cyc_c_sqr(lds_u32* sh) { f12_sh_cyc_c_sqr_body(sh); }
 // the plain chain (Granger-Scott squarings, five multiplications) with the running power in LDS: fallback of fp12_pow_x
@@ -455,6 +491,10 @@ static inline void fp2_neg(hfp2& r, const hfp2& a) { fp_neg(r.c[0], a.c[0]); fp_
 static inline void fp2_dbl(hfp2& r, const hfp2& a) { fp_dbl(r.c[0], a.c[0]); fp_dbl(r.c[1], a.c[1]); }
 static inline void fp2_norm(hfp2& r, const hfp2& a) { fp_norm(r.c[0], a.c[0]); fp_norm(r.c[1], a.c[1]); }
 static inline void fp2_reduce(hfp2& r, const hfp2& a) { fp_reduce(r.c[0], a.c[0]); fp_reduce(r.c[1], a.c[1]); }
+static inline void fp2_reduce_lin2(hfp2& r, const hfp2& a, int ka, const hfp2& b, int kb) {
+  fp_reduce_lin2(r.c[0], a.c[0], ka, b.c[0], kb);
+  fp_reduce_lin2(r.c[1], a.c[1], ka, b.c[1], kb);
+}
 static inline void fp2_conj(hfp2& r, const hfp2& a) { r.c[0] = a.c[0]; fp_neg(r.c[1], a.c[1]); }
 static inline void fp2_mul(hfp2& r, const hfp2& a, const hfp2& b) {
   fp na1, c0, c1;
