@@ -107,7 +107,7 @@ def round_multi(api, bo, rng, log):
 def round_aggregate(api, bo, rng, log):
     """AggregateSignature::verify: n (key, message) pairs under one summed signature; valid, a changed message, an identity key,
     a repeated message (an error for Basic, fine for the others), an identity signature"""
-    sg, scheme, n = rng.choice((1, 2)), rng.choice((0, 1, 2)), rng.choice((1, 2, 3, 4, 50, 191, 192, 193, 1000, 5000))
+    sg, scheme, n = rng.choice((1, 2)), rng.choice((0, 1, 2)), rng.choice((1, 2, 3, 4, 50, 63, 64, 65, 67, 191, 192, 193, 1000, 1027, 5000, 16384, 16385, 20000))   # 64: the per-entry product form starts; 16,384 / 16,385 pairs proper: four / two lanes per item in the line kernel
     sks = [rng.randrange(1, c.R) for _ in range(n)]
     msgs = [i.to_bytes(4, 'big') + rng.randbytes(rng.choice((0, 28, 60))) for i in range(n)]
     pks, sigs = api.sign_batch(sg, scheme, sks, msgs)
