@@ -609,7 +609,12 @@ def test_pairing_product_tree_and_accumulator_forms_agree(api):
         "        out.append(api.aggregate_partial(sg, api.BASIC, ident, msgs[:n], None))\n"
         "print(repr(out))\n") % (util.ROOT, os.path.join(util.ROOT, 'tests'))
     res = {}
-    for name, env in (('tree', {}), ('acc', {'BLSGPU_PRODUCT_TREE': '0'})):
+    variants = (('tree', {}), ('acc', {'BLSGPU_PRODUCT_TREE': '0'}),
+                # the per-entry form's own switches: the two-lane line kernel everywhere; chunk-local fold levels from 64 values on and
+                # the engine only for the last sixteen; k_prepare_agg on one lane per item
+                ('lines2', {'BLSGPU_LINES4_MAX': '0'}), ('levels', {'BLSGPU_TREE_LOCAL': '64', 'BLSGPU_TREE_ENGINE_FROM': '16'}),
+                ('agg1', {'BLSGPU_AGG_LANES': '1'}))
+    for name, env in variants:
         r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, (name, r.stderr[-2000:])
         res[name] = eval(r.stdout.strip().splitlines()[-1])
@@ -629,3 +634,8 @@ def test_pairing_product_tree_and_accumulator_forms_agree(api):
         # the final exponentiation removes): the records differ by such a factor and fold together all the same (above)
         assert res['acc'][k + 4] == res['tree'][k + 4], k
         assert [r[0] for r in res['acc'][k:k + 3]] == [r[0] for r in res['tree'][k:k + 3]], k
+    # the switches of the per-entry form change its plan, never a result
+    for name in ('lines2', 'levels', 'agg1'):
+        assert [r[0] for r in res[name]] == [r[0] for r in res['tree']], name
+        for k in range(3, len(res['tree']), 5):
+            assert api.fp12_product_is_one([res[name][k][0]]) and res[name][k + 1] == res['tree'][k + 1], (name, k)
