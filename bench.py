@@ -480,8 +480,8 @@ RESULT_FD = 1          # where the result line goes (__main__ moves stdout prope
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)      # with no flags: 25 steps of ~21 ms + the ride-along configs (at most 3 steps each): a few seconds
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--n', '--items', dest='n', type=int, default=65536,
                     help='items per GPU (config 2); under torch.distributed.run spell it --items: the launcher reads a bare --n as an abbreviation of its own options')
     ap.add_argument('--cpu-sample', type=int, default=4096)
