@@ -120,6 +120,25 @@ __device__ __forceinline__ void load_g2_pt(g2_jac& p, const uint8_t* base, size_
     }
   }
 }
+// the Z coordinate alone (1 for a finite affine point): what the identity checks need
+__device__ __forceinline__ void load_g1_z(fp& z, const uint8_t* base, size_t i, int fmt) {
+  if (fmt == 0) {
+    fp_from_raw(z, (const uint32_t*)(base + i * 144) + 24);
+  } else if (words_all_zero((const uint32_t*)(base + i * 96), 24)) {
+    fp_zero(z);
+  } else {
+    fp_one(z);
+  }
+}
+__device__ __forceinline__ void load_g2_z(fp2& z, const uint8_t* base, size_t i, int fmt) {
+  if (fmt == 0) {
+    fp2_from_raw(z, (const uint32_t*)(base + i * 288) + 48);
+  } else if (words_all_zero((const uint32_t*)(base + i * 192), 48)) {
+    fp2_zero(z);
+  } else {
+    fp2_one(z);
+  }
+}
 __device__ __forceinline__ void store_g1_pt(uint8_t* base, size_t i, const g1_jac& p) {
   uint32_t* w = (uint32_t*)(base + i * 144);
   fp_to_raw(w, p.x);
@@ -353,7 +372,32 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare(size_t n, const uint8_
   g1_aff P[2];
   g2_aff Q[2];
   int st;
-  if (SG == 1) {
+  if (SG == 1 && !aug) {
+    // Key and signature are not needed before the hash is through (nothing of them enters it): only their Z coordinates are read
+    // first, for the identity checks in the reference's order, and the points themselves after the hash -- held from the start they
+    // were 126 dwords parked in scratch across the whole hash (a store and a load each, at scratch latency)
+    fp zs;
+    fp2 zp;
+    load_g1_z(zs, sigs, i, fmt);
+    load_g2_z(zp, pks, i, fmt);
+    if (fp_is_zero(zs)) {
+      st = BLS_ERR_SIG_IDENTITY;
+    } else if (fp2_is_zero(zp)) {
+      st = BLS_ERR_PK_IDENTITY;
+    } else {
+      const bool no_clear = (two_lanes & 2) != 0;
+      g1_jac h;
+      hash_to_g1(h, nullptr, 0, m, mlen, dst.b, dst.len, lane2, no_clear);
+      g2_jac pk;
+      g1_jac sig;
+      load_g2_pt(pk, pks, i, fmt);
+      load_g1_pt(sig, sigs, i, fmt);
+      prepare_g1impl_tail(P, Q, pk, sig, h);
+      if (no_clear) g2_negc_gen(Q[1]);
+      else g2_neg_gen(Q[1]);
+      st = BLS_OK;
+    }
+  } else if (SG == 1) {
     g2_jac pk;
     g1_jac sig;
     load_g2_pt(pk, pks, i, fmt);

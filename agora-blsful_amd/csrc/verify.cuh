@@ -106,6 +106,20 @@ BLS_FN void g2_neg_gen(g2_aff& r) {
 //       2 = proof of possession (the message IS the key bytes, reference src/traits/sig_pop.rs:67-70)
 // no_clear: P[0] is the message point BEFORE its cofactor clearing and Q[1] = -[c] g2 instead of -g2 (same verdict, a third
 // of the hash saved; see g2_negc_gen)
+// the part after the hash (no augmentation): sig, H(m) and pk to affine with ONE shared inversion
+BLS_FN void prepare_g1impl_tail(g1_aff* P, g2_aff* Q, const g2_jac& pk, const g1_jac& sig, const g1_jac& h) {
+  if (jac_is_inf(h)) {              // cannot happen for a hash output in practice; keep the generic path correct
+    g1g2_to_aff(P[1], Q[0], sig, pk);
+    jac_to_aff(P[0], h);
+  } else {
+    fp zs = sig.z, zh = h.z, n;
+    fp2_norm_sq(n, pk.z);
+    fp_inv3(zs, zh, n);
+    g1_apply_zinv(P[1], sig, zs);
+    g1_apply_zinv(P[0], h, zh);
+    g2_apply_ninv(Q[0], pk, n);
+  }
+}
 BLS_FN int prepare_g1impl(g1_aff* P, g2_aff* Q, const g2_jac& pk, const g1_jac& sig, int mode, const uint8_t* msg,
                           uint32_t msg_len, const uint8_t* dst, uint32_t dst_len, int lane2 = -1, bool no_clear = false) {
   if (jac_is_inf(sig)) return BLS_ERR_SIG_IDENTITY;
@@ -120,17 +134,7 @@ BLS_FN int prepare_g1impl(g1_aff* P, g2_aff* Q, const g2_jac& pk, const g1_jac& 
     jac_to_aff(P[0], h);
   } else {
     hash_to_g1(h, nullptr, 0, msg, msg_len, dst, dst_len, lane2, no_clear);
-    if (jac_is_inf(h)) {            // cannot happen for a hash output in practice; keep the generic path correct
-      g1g2_to_aff(P[1], Q[0], sig, pk);
-      jac_to_aff(P[0], h);
-    } else {
-      fp zs = sig.z, zh = h.z, n;
-      fp2_norm_sq(n, pk.z);
-      fp_inv3(zs, zh, n);
-      g1_apply_zinv(P[1], sig, zs);
-      g1_apply_zinv(P[0], h, zh);
-      g2_apply_ninv(Q[0], pk, n);
-    }
+    prepare_g1impl_tail(P, Q, pk, sig, h);
   }
   if (no_clear) g2_negc_gen(Q[1]);
   else g2_neg_gen(Q[1]);
