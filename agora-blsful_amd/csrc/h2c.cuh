@@ -29,7 +29,7 @@ BLS_CONST uint32_t SHA256_K[64] = {
 
 BLS_FN uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
 
-BLS_NOINLINE void sha256_compress(uint32_t* h, const uint32_t* wsrc) {
+BLS_FN void sha256_rounds(uint32_t* h, const uint32_t* wsrc) {
   uint32_t w[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) w[i] = wsrc[i];
@@ -56,6 +56,7 @@ BLS_NOINLINE void sha256_compress(uint32_t* h, const uint32_t* wsrc) {
   }
   h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
 }
+BLS_NOINLINE void sha256_compress(uint32_t* h, const uint32_t* wsrc) { sha256_rounds(h, wsrc); }
 
 BLS_FN void sha256_init(sha256_ctx& c) {
   c.h[0] = 0x6a09e667; c.h[1] = 0xbb67ae85; c.h[2] = 0x3c6ef372; c.h[3] = 0xa54ff53a;
@@ -121,6 +122,148 @@ BLS_FN void expand_message_xmd(uint8_t* out, const uint8_t* pre, uint32_t pre_le
     sha256_final(c, bi);
     for (int i = 0; i < 32; i++) out[32 * (blk - 1) + i] = bi[i];
   }
+}
+
+// ---- the same in WORDS, for the lane kernels (round 3).  The byte-streaming form above costs a lone wave 0.36 ms per message where its
+// instructions are worth 0.05: every byte of the inputs, of b_0 ^ b_(i-1), of the output and of the 64-byte field inputs is a
+// memory access of its own (a private byte array or a generic pointer), waited for one at a time.  Here the chaining values are the
+// hash state's words, a block is assembled in sixteen registers (a shift register: the block is complete after sixteen words
+// whatever it started with), the compression takes and returns its operands BY VALUE (device: vector arguments in registers), and
+// the only byte-granular reads left are the message's (when it is not word-aligned) and the tag's.  Requires the prefix and the
+// message to be whole words long (the lengths the signature schemes produce: 32-byte messages, 48- / 96-byte keys); anything else
+// takes the byte-streaming form.  Output: NOUT / 4 big-endian words.
+#if defined(__HIPCC__)
+typedef uint32_t u32x8_t __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
+__device__ __noinline__ u32x8_t sha256_compress_v(u32x8_t hv, u32x16_t wv) {
+  uint32_t h[8], w[16];
+#pragma unroll
+  for (int i = 0; i < 8; i++) h[i] = hv[i];
+#pragma unroll
+  for (int i = 0; i < 16; i++) w[i] = wv[i];
+  sha256_rounds(h, w);
+  u32x8_t o;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o[i] = h[i];
+  return o;
+}
+#endif
+struct sha_words {
+  uint32_t h[8];
+  uint32_t w[16];     // the block being filled: a shift register, never indexed with a run-time value
+  uint32_t nw;        // words in it
+};
+BLS_FN void sha_words_block(sha_words& s) {
+#if defined(__HIPCC__)
+  u32x8_t hv;
+  u32x16_t wv;
+#pragma unroll
+  for (int i = 0; i < 8; i++) hv[i] = s.h[i];
+#pragma unroll
+  for (int i = 0; i < 16; i++) wv[i] = s.w[i];
+  hv = sha256_compress_v(hv, wv);
+#pragma unroll
+  for (int i = 0; i < 8; i++) s.h[i] = hv[i];
+#else
+  sha256_rounds(s.h, s.w);
+#endif
+}
+BLS_FN void sha_words_init(sha_words& s) {
+  s.h[0] = 0x6a09e667; s.h[1] = 0xbb67ae85; s.h[2] = 0x3c6ef372; s.h[3] = 0xa54ff53a;
+  s.h[4] = 0x510e527f; s.h[5] = 0x9b05688c; s.h[6] = 0x1f83d9ab; s.h[7] = 0x5be0cd19;
+#pragma unroll
+  for (int i = 0; i < 16; i++) s.w[i] = 0;
+  s.nw = 0;
+}
+BLS_FN void sha_words_feed(sha_words& s, uint32_t word) {
+#pragma unroll
+  for (int i = 0; i < 15; i++) s.w[i] = s.w[i + 1];
+  s.w[15] = word;
+  if (++s.nw == 16) {
+    sha_words_block(s);
+    s.nw = 0;
+  }
+}
+// bytes [j, j + 4) of  head[0 .. nhead) || tag || len(tag) || 0x80 || 0 0 0 ...  as one big-endian word
+BLS_FN uint32_t xmd_tail_word(uint32_t j, uint32_t nhead, uint32_t head, const uint8_t* dst, uint32_t dst_len) {
+  uint32_t word = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t q = j + k;
+    uint32_t b;
+    if (q < nhead) b = (head >> (8 * (nhead - 1 - q))) & 0xffu;
+    else if (q - nhead < dst_len) b = dst[q - nhead];
+    else if (q - nhead == dst_len) b = dst_len;
+    else if (q - nhead == dst_len + 1) b = 0x80u;
+    else b = 0;
+    word = (word << 8) | b;
+  }
+  return word;
+}
+// ... and the rest of a message of `before` bytes (already fed, a whole number of words): head, tag, its length, the padding, the bit length
+BLS_FN void xmd_finish(sha_words& s, uint32_t before, uint32_t nhead, uint32_t head, const uint8_t* dst, uint32_t dst_len) {
+  const uint32_t need = nhead + dst_len + 2, total = before + nhead + dst_len + 1;
+  for (uint32_t j = 0; j < need || s.nw != 14; j += 4) sha_words_feed(s, xmd_tail_word(j, nhead, head, dst, dst_len));
+  sha_words_feed(s, total >> 29);
+  sha_words_feed(s, total << 3);
+}
+BLS_FN uint32_t be32_at(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+template <int NOUT>
+BLS_FN void expand_message_xmd_words(uint32_t* out, const uint8_t* pre, uint32_t pre_len, const uint8_t* m, uint32_t m_len,
+                                     const uint8_t* dst, uint32_t dst_len) {
+  if ((pre_len | m_len) & 3u) {                      // not whole words: the byte-streaming form, its output repacked
+    uint8_t ub[NOUT];
+    expand_message_xmd<NOUT>(ub, pre, pre_len, m, m_len, dst, dst_len);
+    for (int i = 0; i < NOUT / 4; i++) out[i] = be32_at(ub + 4 * i);
+    return;
+  }
+  sha_words s;
+  sha_words_init(s);
+  for (int i = 0; i < 16; i++) sha_words_feed(s, 0);            // Z_pad: one block of zeros
+  for (uint32_t i = 0; i < pre_len; i += 4) sha_words_feed(s, be32_at(pre + i));
+  if (((size_t)m & 3u) == 0) {
+    for (uint32_t i = 0; i < m_len; i += 4) {
+      const uint32_t v = *(const uint32_t*)(m + i);              // little-endian load of big-endian bytes
+      sha_words_feed(s, (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24));
+    }
+  } else {
+    for (uint32_t i = 0; i < m_len; i += 4) sha_words_feed(s, be32_at(m + i));
+  }
+  xmd_finish(s, 64 + pre_len + m_len, 3, (uint32_t)NOUT << 8, dst, dst_len);   // l_i_b_str (two bytes), I2OSP(0, 1)
+  uint32_t b0[8], bi[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    b0[i] = s.h[i];
+    bi[i] = 0;
+  }
+  for (int blk = 1; blk <= NOUT / 32; blk++) {
+    sha_words_init(s);
+#pragma unroll
+    for (int i = 0; i < 8; i++) sha_words_feed(s, b0[i] ^ bi[i]);
+    xmd_finish(s, 32, 1, (uint32_t)blk, dst, dst_len);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      bi[i] = s.h[i];
+      out[8 * (blk - 1) + i] = bi[i];
+    }
+  }
+}
+// sixteen big-endian words (64 uniform bytes) -> Fp (Montgomery), as fp_from_be64
+BLS_FN void fp_from_be64_words(fp& r, const uint32_t* wbe) {
+  fp lo, hi, t, k;
+  uint32_t w[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) w[i] = i < 4 ? wbe[3 - i] : 0;
+  fp_set_words(hi, w);
+#pragma unroll
+  for (int i = 0; i < 12; i++) w[i] = wbe[15 - i];
+  fp_set_words(lo, w);
+  fp_load(k, FP_R2);
+  fp_mul(t, k, lo);
+  fp_load(k, FP_R2_384);
+  fp_mul(hi, k, hi);
+  fp_add(t, t, hi);
+  fp_reduce(r, t);
 }
 
 // 64 big-endian bytes -> Fp (Montgomery): (lo48 + hi16 * 2^384) mod p = REDC(lo48 R^2) + REDC(hi16 2^384 R^2)
@@ -300,14 +443,14 @@ __device__ __noinline__ void jac_mul_u64_pair(g1_jac& r, const g1_jac& p, uint64
 // with -[c] g2 instead of -g2 and needs no clearing: csrc/g2neg_lines.cuh)
 BLS_NOINLINE void hash_to_g1(g1_jac& r, const uint8_t* pre, uint32_t pre_len, const uint8_t* m, uint32_t m_len,
                        const uint8_t* dst, uint32_t dst_len, int lane2 = -1, bool no_clear = false) {
-  uint8_t ub[128];
-  expand_message_xmd<128>(ub, pre, pre_len, m, m_len, dst, dst_len);
+  uint32_t ub[32];                 // 128 uniform bytes as big-endian words
+  expand_message_xmd_words<128>(ub, pre, pre_len, m, m_len, dst, dst_len);
   fp u0, u1, xn, xd, y;
   g1_jac q0, q1;
 #if defined(__HIPCC__)
   if (lane2 >= 0) {
     g1_jac mine, other;
-    fp_from_be64(u0, ub + 64 * lane2);
+    fp_from_be64_words(u0, ub + 16 * lane2);
     sswu_g1(xn, xd, y, u0);
     iso_map_g1(mine, xn, xd, y);
     fp_lane_swap(other.x, mine.x);
@@ -319,8 +462,8 @@ BLS_NOINLINE void hash_to_g1(g1_jac& r, const uint8_t* pre, uint32_t pre_len, co
 #endif
   {
     (void)lane2;
-    fp_from_be64(u0, ub);
-    fp_from_be64(u1, ub + 64);
+    fp_from_be64_words(u0, ub);
+    fp_from_be64_words(u1, ub + 16);
     sswu_g1(xn, xd, y, u0);
     iso_map_g1(q0, xn, xd, y);
     sswu_g1(xn, xd, y, u1);
@@ -487,15 +630,15 @@ BLS_FN void iso_map_g2_hom(F2& X, F2& Y, F2& Z, const F2& x, const F2& y) {
 // no_clear: stop before the cofactor clearing (the caller clears it elsewhere: k_g2_clear_wide)
 BLS_NOINLINE void hash_to_g2(g2_jac& r, const uint8_t* pre, uint32_t pre_len, const uint8_t* m, uint32_t m_len,
                        const uint8_t* dst, uint32_t dst_len, int lane2 = -1, bool no_clear = false) {
-  uint8_t ub[256];
-  expand_message_xmd<256>(ub, pre, pre_len, m, m_len, dst, dst_len);
+  uint32_t ub[64];                 // 256 uniform bytes as big-endian words
+  expand_message_xmd_words<256>(ub, pre, pre_len, m, m_len, dst, dst_len);
   fp2 u0, u1, x, y;
   g2_jac q0, q1;
 #if defined(__HIPCC__)
   if (lane2 >= 0) {          // see hash_to_g1; in addition the point addition and the cofactor clearing -- Fp2 arithmetic -- run
     g2_jac mine, other;      // on the lane-split tower (tower_split.cuh): this lane keeps its component of every coordinate
-    fp_from_be64(u0.c0, ub + 128 * lane2);
-    fp_from_be64(u0.c1, ub + 128 * lane2 + 64);
+    fp_from_be64_words(u0.c0, ub + 32 * lane2);
+    fp_from_be64_words(u0.c1, ub + 32 * lane2 + 16);
     sswu_g2(x, y, u0);
     iso_map_g2(mine, x, y);
     fp_lane_swap(other.x.c0, mine.x.c0);
@@ -530,10 +673,10 @@ BLS_NOINLINE void hash_to_g2(g2_jac& r, const uint8_t* pre, uint32_t pre_len, co
   }
 #endif
   (void)lane2;
-  fp_from_be64(u0.c0, ub);
-  fp_from_be64(u0.c1, ub + 64);
-  fp_from_be64(u1.c0, ub + 128);
-  fp_from_be64(u1.c1, ub + 192);
+  fp_from_be64_words(u0.c0, ub);
+  fp_from_be64_words(u0.c1, ub + 16);
+  fp_from_be64_words(u1.c0, ub + 32);
+  fp_from_be64_words(u1.c1, ub + 48);
   sswu_g2(x, y, u0);
   iso_map_g2(q0, x, y);
   sswu_g2(x, y, u1);

@@ -3618,40 +3618,8 @@ __device__ __noinline__ void jac_mul_u64_rows(jac<wf>& r, const jac<wf>& p, uint
 // the current 64-byte block straight from where it lives (zero pad, message, length / DST suffix, padding), the block meets in
 // LDS, and every lane runs the compression on registers (fully unrolled, the sixteen message words passed by value): ~5 us per
 // block, ~11 blocks.  All 64 lanes of the wave must call it; every lane returns the same words.
-typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-__device__ __noinline__ u32x8 sha256_compress_v(u32x8 hv, u32x16 wv) {
-  uint32_t w[16], h[8];
-#pragma unroll
-  for (int i = 0; i < 16; i++) w[i] = wv[i];
-#pragma unroll
-  for (int i = 0; i < 8; i++) h[i] = hv[i];
-  uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
-#pragma unroll
-  for (int i = 0; i < 64; i++) {
-    uint32_t wi;
-    if (i < 16) {
-      wi = w[i];
-    } else {
-      const uint32_t w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
-      const uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
-      const uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
-      wi = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
-      w[i & 15] = wi;
-    }
-    const uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
-    const uint32_t ch = (e & f) ^ (~e & g);
-    const uint32_t t1 = hh + S1 + ch + SHA256_K[i] + wi;
-    const uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
-    const uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
-    const uint32_t t2 = S0 + mj;
-    hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
-  }
-  u32x8 r;
-  r[0] = h[0] + a; r[1] = h[1] + b; r[2] = h[2] + c; r[3] = h[3] + d;
-  r[4] = h[4] + e; r[5] = h[5] + f; r[6] = h[6] + g; r[7] = h[7] + hh;
-  return r;
-}
+typedef u32x8_t u32x8;      // (h2c.cuh: the compression with its operands by value, sha256_compress_v)
+typedef u32x16_t u32x16;
 __device__ __forceinline__ u32x8 sha256_iv() {
   u32x8 h;
   h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a;
