@@ -236,11 +236,30 @@ BLS_FN void expand_message_xmd_words(uint32_t* out, const uint8_t* pre, uint32_t
     b0[i] = s.h[i];
     bi[i] = 0;
   }
+  // the tail of every b_i -- I2OSP(i, 1) || tag || its length || the padding -- differs from one i to the next in its first byte
+  // only: its words are put together ONCE (tags of up to 93 bytes; all their byte reads issued together), not once per block
+  const int TW = 24;
+  const uint32_t need1 = dst_len + 3;
+  const bool cached = need1 <= 4 * TW;
+  uint32_t T[TW];
+  if (cached) {
+#pragma unroll
+    for (int k = 0; k < TW; k++) T[k] = xmd_tail_word(4 * k, 1, 0, dst, dst_len);
+  }
   for (int blk = 1; blk <= NOUT / 32; blk++) {
     sha_words_init(s);
 #pragma unroll
     for (int i = 0; i < 8; i++) sha_words_feed(s, b0[i] ^ bi[i]);
-    xmd_finish(s, 32, 1, (uint32_t)blk, dst, dst_len);
+    if (cached) {
+#pragma unroll
+      for (int k = 0; k < TW; k++)
+        if (4u * k < need1 || s.nw != 14) sha_words_feed(s, k == 0 ? T[0] | ((uint32_t)blk << 24) : T[k]);
+      while (s.nw != 14) sha_words_feed(s, 0);
+      sha_words_feed(s, 0);                             // 34 + dst_len bytes: the bit length fits the low word
+      sha_words_feed(s, (34 + dst_len) << 3);
+    } else {
+      xmd_finish(s, 32, 1, (uint32_t)blk, dst, dst_len);
+    }
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       bi[i] = s.h[i];

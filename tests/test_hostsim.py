@@ -127,6 +127,27 @@ def test_hash_to_curve(hs):
                     assert out.raw == c.g2_compress(c.hash_to_g2(m, dst))
 
 
+def test_hash_to_curve_word_form_boundaries(hs):
+    """expand_message_xmd in words (csrc/h2c.cuh expand_message_xmd_words, what the lane kernels run): whole-word messages at an
+    aligned and at an unaligned address, tags on both sides of the sizes where the tail of a block changes shape (one or two
+    blocks per b_i: 21 / 22 bytes; the cached tail words: 93 / 94 bytes), and the byte-streaming fallback for other lengths."""
+    for mlen in (0, 4, 32, 36, 60, 64, 33):
+        backing = bytearray(b'\x00' + bytes((7 * i + mlen) & 0xff for i in range(mlen)) + b'\x00' * 8)
+        for off in (0, 1):                               # the same message at two alignments
+            buf = (ctypes.c_char * (mlen + 8)).from_buffer(backing, off)
+            m = bytes(backing[off:off + mlen])
+            for dlen in (0, 1, 20, 21, 22, 23, 43, 54, 55, 56, 86, 87, 92, 93, 94, 95, 128, 255):
+                dst = bytes((11 * i + 3) & 0xff for i in range(dlen))
+                out = ctypes.create_string_buffer(48)
+                hs.hs_hash_to_g1(buf, mlen, dst, dlen, out)
+                assert out.raw == c.g1_compress(c.hash_to_g1(m, dst)), (mlen, off, dlen)
+        out = ctypes.create_string_buffer(96)
+        for dlen in (22, 43, 94):
+            dst = bytes((5 * i + 1) & 0xff for i in range(dlen))
+            hs.hs_hash_to_g2(bytes(backing[1:1 + mlen]), mlen, dst, dlen, out)
+            assert out.raw == c.g2_compress(c.hash_to_g2(bytes(backing[1:1 + mlen]), dst)), (mlen, dlen)
+
+
 def test_group_ops(hs):
     rng = random.Random(3)
     for _ in range(4):
