@@ -755,10 +755,11 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
 }
 
 // Pairing products, second form (round 3): the product over the items entry by entry, then one Horner chain (kernels.cuh
-// k_line_quad).  Chunks of one machine round of lane pairs walk their G2 points (k_linesp pass 1: the plain line values of every
-// item and entry), k_line_quad multiplies four items' values per entry into an Fp12 value, k_f12_fold4 folds each entry's values
-// four to one -- chunk by chunk while a level still fills the machine, then over all chunks' values together -- the engine takes
-// the last sixteen per entry (k_f12_tree_seg) and runs the Horner chain over the 68 products (k_f12_horner_wide).  What is
+// k_line_quad).  Chunks of one machine round of lane pairs walk their G2 points (k_linesp pass 1, or k_linesp4 on four lanes per
+// item: the plain line values of every item and entry), k_line_quad multiplies four items' values per entry into an Fp12 value,
+// k_f12_fold4 folds each entry's values four to one -- chunk by chunk while a level still fills the machine, then over all chunks'
+// values together down to 128 per entry -- the engine takes those in two launches (k_f12_tree_seg) and runs the Horner chain over
+// the 68 products (k_f12_horner_wide).  What is
 // left beyond whole rounds (< 1,024 items) is a small chunk of its own on the tail stream, beside the others.  Leaves the
 // Miller product as item 0 of d_f (*outputs = 1).  *done = false: not applicable (too few items,
 // no engine, no memory, BLSGPU_PRODUCT_TREE=0) -- the caller falls back to the accumulator kernels.
