@@ -89,6 +89,18 @@ void hs_fp_lazy(const int32_t* limbs, double lb, double vb, int32_t* out) {
   out[42] = fp_is_zero(a) ? 1 : 0;
   fp_get_words((uint32_t*)out + 43, t);
 }
+// fp_reduce_lin2 on lazy limbs: out = the reduced limbs of ka a + kb b
+void hs_fp_reduce_lin2(const int32_t* la, double lba, double vba, int ka, const int32_t* lb_, double lbb, double vbb, int kb, int32_t* out) {
+  fp a, b, t;
+  for (int i = 0; i < FP_NL; i++) {
+    a.l[i] = la[i];
+    b.l[i] = lb_[i];
+  }
+  FP_TRK(a.lb = lba; a.vb = vba; b.lb = lbb; b.vb = vbb;)
+  (void)lba; (void)vba; (void)lbb; (void)vbb;
+  fp_reduce_lin2(t, a, ka, b, kb);
+  for (int i = 0; i < FP_NL; i++) out[i] = t.l[i];
+}
 void hs_fp12_check(const uint32_t* a, const uint32_t* b, uint32_t* out) {
   // a, b: fp12 as 6 fp2 in w-power order, Montgomery.  out: mul, sqr(a), inv(a), frob1(a), frob2(a) plain w-order
   fp12 x, y, z;

@@ -97,6 +97,50 @@ def test_fp_lazy_limbs(hs):
         assert sum(w << (32 * i) for i, w in enumerate(words)) == v % P
 
 
+def test_fp_reduce_lin2(hs):
+    """fp_reduce_lin2 (csrc/fp.cuh: the value reduction of ka a + kb b in one pass on 64 bits, the 3 t +- 2 z of the compressed
+    squarings): against integers on redundant signed-limb operands -- limb magnitudes up to what three products' sums and a xi-twist
+    leave (6 x 2^28), coefficient pairs the kernels use and larger ones, values at the rounding boundary of the quotient estimate."""
+    rng = random.Random(15)
+    M = (1 << 28) - 1
+
+    def val(l):
+        return sum(int(x) << (28 * i) for i, x in enumerate(l))
+
+    def lazy(v, spread):      # redundant limbs of v: multiples of 2^28 moved between neighbours
+        base = [(v % (1 << 392) >> (28 * i)) & M for i in range(14)]
+        if v < 0:
+            base[13] -= 1 << 28
+        for i in range(13):
+            d = rng.randint(-spread, spread)
+            base[i] += d << 28
+            base[i + 1] -= d
+        assert val(base) == v
+        return base
+
+    out = (ctypes.c_int32 * 14)()
+    cases = []
+    for ka, kb in ((3, 2), (3, -2), (1, 1), (12, 0), (1, -12), (-3, 5)):
+        for _ in range(60):
+            va = rng.randrange(-4 * P, 4 * P)
+            vb = rng.randrange(-4 * P, 4 * P)
+            cases.append((ka, kb, lazy(va, rng.choice((0, 1, 5))), lazy(vb, rng.choice((0, 1, 5)))))
+        for k in (-7, 0, 3):                                # ka a + kb b at k p + p/2 +- a little (kb b = 0 there)
+            for d in (-1, 0, 1):
+                v = k * P + P // 2 + d
+                if v % ka == 0:
+                    cases.append((ka, kb, lazy(v // ka, 2), lazy(0, 2)))
+    for ka, kb, la, lb in cases:
+        va, vb = val(la), val(lb)
+        lba = float(max(abs(x) for x in la) + 1)
+        lbb = float(max(abs(x) for x in lb) + 1)
+        hs.hs_fp_reduce_lin2((ctypes.c_int32 * 14)(*la), ctypes.c_double(lba), ctypes.c_double(abs(va) / P + 1e-9), ka,
+                             (ctypes.c_int32 * 14)(*lb), ctypes.c_double(lbb), ctypes.c_double(abs(vb) / P + 1e-9), kb, out)
+        r = list(out)
+        want = ka * va + kb * vb
+        assert (val(r) - want) % P == 0 and all(0 <= x <= M for x in r[:13]) and abs(val(r)) * 100 <= 52 * P, (ka, kb)
+
+
 def test_fp12_ops(hs):
     rng = random.Random(2)
     for _ in range(5):
