@@ -194,7 +194,7 @@ def verify_batch(sig_group, scheme, pks, sigs, msgs, fmt=FMT_RAW_PROJ):
 def verify_batch_grouped(sig_group, scheme, pks, sigs, msgs, seed=None, fmt=FMT_RAW_PROJ):
     """the OPT-IN grouped form of verify_batch (groups of eight items share one final exponentiation through a random linear
     combination; failing groups are re-verified item by item): same status list unless a group that holds an invalid item passes
-    its combined check.  The 64-bit scalars are derived inside the library from the group's own inputs (include/blsgpu.h);
+    its combined check.  The 128-bit scalars are derived inside the library from the group's own inputs (include/blsgpu.h);
     `seed` is extra entropy mixed into that hash: a fresh random value by default, no secrecy needed."""
     if seed is None:
         import secrets

@@ -27,10 +27,16 @@ thread_local bool t_nested = false;  // inside a sharded call: the per-device su
 
 enum {
   KID_PREPARE, KID_MILLER2, KID_FINALEXP, KID_PREPARE_AGG, KID_PAIRS_AFF, KID_MILLER1, KID_F12_FOLD, KID_FINALEXP_ONE,
-  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_F12_IO, KID_MSM_SORT, KID_MSM_BUCKET, KID_MSM_CHUNK, KID_DECOMPRESS, KID_PAIRING_COOP, KID_KEY_SORT, KID_COEFF, KID_DUP, KID_FIRST_BAD, KID_MSM_PREP, KID_MSM_NORM, KID_MSM_MERGE, KID_WIDE, KID_LINES, KID_CYCRUN, KID_COUNT
+  KID_HASH, KID_ACCUM, KID_POINT_FOLD, KID_COMPRESS, KID_SIGN, KID_F12_IO, KID_MSM_SORT, KID_MSM_BUCKET, KID_MSM_CHUNK, KID_DECOMPRESS, KID_PAIRING_COOP, KID_KEY_SORT, KID_COEFF, KID_DUP, KID_FIRST_BAD, KID_MSM_PREP, KID_MSM_NORM, KID_MSM_MERGE, KID_WIDE, KID_LINES, KID_CYCRUN,
+  // round 4: one id per kernel on the paths bench.py reports (lumped ids made "the dominant kernel" meaningless)
+  KID_MILLER2_V1, KID_FINALEXP_V1, KID_LINESP, KID_LINESP4, KID_LINE_QUAD, KID_F12_FOLD4, KID_F12_TREE, KID_HORNER, KID_MILLERFP, KID_PAIRING_POST, KID_PAIRING_PRE,
+  KID_TAIL,        // everything launched on a context's tail stream: runs BESIDE the main stream's kernels, so its time is not additive
+  KID_COUNT
 };
-const char* KID_NAMES[KID_COUNT] = {"k_prepare", "k_miller2", "k_finalexp", "k_prepare_agg", "k_pairs_to_affine", "k_miller1", "k_f12_fold",
-                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign", "k_f12_io", "k_msm_sort", "k_msm_bucket", "k_msm_chunk", "k_decompress", "k_pairing_coop", "k_key_sort", "k_sha256_coeff", "k_duplicate_rule", "k_first_identity", "k_msm_prep", "k_normalize", "k_msm_merge", "k_wide", "k_lines2", "k_cyc_run4"};
+const char* KID_NAMES[KID_COUNT] = {"k_prepare", "k_millerf2s", "k_finalexp2s", "k_prepare_agg", "k_pairs_to_affine", "k_miller1s", "k_f12_fold",
+                                    "k_finalexp_one", "k_hash_to_point", "k_accumulate", "k_point_fold", "k_compress", "k_sign", "k_f12_io", "k_msm_sort", "k_msm_bucket", "k_msm_chunk", "k_decompress", "k_pairing_coop", "k_key_sort", "k_sha256_coeff", "k_duplicate_rule", "k_first_identity", "k_msm_prep", "k_normalize", "k_msm_merge", "k_wide", "k_lines2s", "k_cyc_run4",
+                                    "k_miller2s", "k_finalexps", "k_linesp", "k_linesp4", "k_line_quad", "k_f12_fold4", "k_f12_tree_seg", "k_f12_horner_wide", "k_millerfp", "k_pairing_post", "k_pairing_pre",
+                                    "tail_stream_overlapped"};
 
 struct Ctx {
   int dev = -1;
@@ -132,6 +138,80 @@ int fail(int code, const std::string& msg) {
   t_err = msg;
   return code;
 }
+// ---- run-time knobs: every BLSGPU_* environment variable the library reads, parsed ONCE into one struct (VERDICT r3 weak #9,
+// next #7).  Two classes:
+//   tuning  documented in README.md, clamped to what the kernels assume, change plans and sizes, never results;
+//   A/B     select kernel forms kept for measurements and for the suite's agreement tests; honoured only together with
+//           BLSGPU_AB_KNOBS=1, so that a single stray variable in somebody else's process cannot switch the product's kernels.
+// BLSGPU_STRICT_ENV=1: blsgpu_init refuses to start when the environment holds a BLSGPU_ variable this table does not know, or an
+// A/B variable without the gate (a typo or a leftover must not go unnoticed in production).
+extern "C" char** environ;
+struct Knobs {
+  long coop_max = 4096, wide_max = 512, shard_min = 8192, contexts = 2, fake_devices = 0, acc_lanes = 57344;
+  long msm_c = 0, msm_ch = 0, msm2_c = 0, msm2_ch = 0, msm2_q = 0;          // 0: the library's own choice
+  long host_trace = 0, strict_env = 0, ab_knobs = 0;
+  // A/B
+  long miller_chunk = 65536, miller_v1 = 0, row_pad = 192, wide_mode = 2, finalexp_seg = 0, finalexp_v1 = 0, prepare_lanes = 0, product_tree = 1,
+       tree_local = 0, lines4_max = -1, tree_engine_from = 0, agg_lanes = 0, msm_v1 = 0, msm_naive = 0, wide_test_block = 64, prepare_v1 = 0, post_v1 = 0;
+  std::string problem;        // what BLSGPU_STRICT_ENV objects to (empty: nothing)
+};
+struct KnobSpec { const char* name; long Knobs::*field; long lo, hi; bool ab; };
+const KnobSpec KNOB_TABLE[] = {
+    {"BLSGPU_COOP_MAX", &Knobs::coop_max, 0, 1 << 20, false},          {"BLSGPU_WIDE_MAX", &Knobs::wide_max, 0, 4096, false},
+    {"BLSGPU_SHARD_MIN", &Knobs::shard_min, 1, 1L << 40, false},        {"BLSGPU_CONTEXTS", &Knobs::contexts, 1, 16, false},
+    {"BLSGPU_FAKE_DEVICES", &Knobs::fake_devices, 0, 64, false},        {"BLSGPU_ACC_LANES", &Knobs::acc_lanes, 64, 1 << 20, false},
+    {"BLSGPU_MSM_C", &Knobs::msm_c, 4, 16, false},                      {"BLSGPU_MSM_CH", &Knobs::msm_ch, 1, 1 << 16, false},
+    {"BLSGPU_MSM2_C", &Knobs::msm2_c, 4, 16, false},                    {"BLSGPU_MSM2_CH", &Knobs::msm2_ch, 1, 1 << 16, false},
+    {"BLSGPU_MSM2_Q", &Knobs::msm2_q, 1, 8, false},                     {"BLSGPU_HOST_TRACE", &Knobs::host_trace, 0, 1, false},
+    {"BLSGPU_STRICT_ENV", &Knobs::strict_env, 0, 1, false},             {"BLSGPU_AB_KNOBS", &Knobs::ab_knobs, 0, 1, false},
+    {"BLSGPU_MILLER_CHUNK", &Knobs::miller_chunk, 0, 65536, true},      {"BLSGPU_MILLER_V1", &Knobs::miller_v1, 0, 1, true},
+    {"BLSGPU_ROW_PAD", &Knobs::row_pad, 0, 4096, true},                 {"BLSGPU_WIDE_MODE", &Knobs::wide_mode, 1, 2, true},
+    {"BLSGPU_FINALEXP_SEG", &Knobs::finalexp_seg, 0, 1, true},          {"BLSGPU_FINALEXP_V1", &Knobs::finalexp_v1, 0, 1, true},
+    {"BLSGPU_PREPARE_LANES", &Knobs::prepare_lanes, 0, 2, true},        {"BLSGPU_PRODUCT_TREE", &Knobs::product_tree, 0, 1, true},
+    {"BLSGPU_TREE_LOCAL", &Knobs::tree_local, 0, 65536, true},          {"BLSGPU_LINES4_MAX", &Knobs::lines4_max, 0, 65536, true},
+    {"BLSGPU_TREE_ENGINE_FROM", &Knobs::tree_engine_from, 0, 256, true}, {"BLSGPU_AGG_LANES", &Knobs::agg_lanes, 0, 2, true},
+    {"BLSGPU_MSM_V1", &Knobs::msm_v1, 0, 1, true},                      {"BLSGPU_MSM_NAIVE", &Knobs::msm_naive, 0, 1, true},
+    {"BLSGPU_WIDE_TEST_BLOCK", &Knobs::wide_test_block, 64, 256, true}, {"BLSGPU_PREPARE_V1", &Knobs::prepare_v1, 0, 1, true},
+    {"BLSGPU_POST_V1", &Knobs::post_v1, 0, 1, true},
+};
+// read by the Python wrapper / debug builds only, never by this file's product paths: known names for the strict check
+const char* const KNOB_OTHER_NAMES[] = {"BLSGPU_LIB", "BLSGPU_HASH_STOP"};
+Knobs parse_knobs() {
+  Knobs k;
+  const char* gate = getenv("BLSGPU_AB_KNOBS");
+  const bool ab_ok = gate && atol(gate) == 1;
+  for (const KnobSpec& sp : KNOB_TABLE) {
+    const char* e = getenv(sp.name);
+    if (!e || !*e) continue;
+    if (sp.ab && !ab_ok) {
+      if (k.problem.empty()) k.problem = std::string(sp.name) + " is an A/B switch and needs BLSGPU_AB_KNOBS=1";
+      fprintf(stderr, "libblsgpu: ignoring %s (an A/B switch: set BLSGPU_AB_KNOBS=1 to honour it)\n", sp.name);
+      continue;
+    }
+    char* end = nullptr;
+    long v = strtol(e, &end, 10);
+    if (end == e || *end) {
+      if (k.problem.empty()) k.problem = std::string(sp.name) + " is not an integer";
+      continue;
+    }
+    k.*sp.field = v < sp.lo ? sp.lo : v > sp.hi ? sp.hi : v;     // clamped: a wild value cannot force a fallback by exhausting memory
+  }
+  for (char** e = environ; e && *e; e++) {
+    if (strncmp(*e, "BLSGPU_", 7) != 0) continue;
+    const char* eq = strchr(*e, '=');
+    const std::string name(*e, eq ? (size_t)(eq - *e) : strlen(*e));
+    bool known = false;
+    for (const KnobSpec& sp : KNOB_TABLE) known = known || name == sp.name;
+    for (const char* o : KNOB_OTHER_NAMES) known = known || name == o;
+    if (!known && k.problem.empty()) k.problem = "unknown variable " + name;
+  }
+  return k;
+}
+const Knobs& knobs() {
+  static const Knobs k = parse_knobs();     // once per process (C++11 static initialisation is thread-safe)
+  return k;
+}
+
 #define HIPCK(x)                                                                                   \
   do {                                                                                             \
     hipError_t e_ = (x);                                                                           \
@@ -266,10 +346,21 @@ const char* DST_TABLE[2][3] = {
     {"BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_", "BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_AUG_",
      "BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_"},  // reference src/impls/g2.rs:108,112,116
 };
+// RFC 9380 section 5.3.3: a domain separation tag longer than 255 bytes enters expand_message_xmd as
+// SHA-256("H2C-OVERSIZE-DST-" || DST) -- the interface this replaces takes any DST (reference src/traits/hash_to_point.rs:11,
+// src/impls/g1.rs:17-19, g2.rs:15-17: ExpandMsgXmd<Sha256> in the dependency applies the same rule)
 dst_arg make_dst(const uint8_t* d, size_t n) {
   dst_arg a;
   memset(&a, 0, sizeof a);
-  memcpy(a.b, d, n);
+  if (n > 255) {
+    host_sha256 h;
+    h.update((const uint8_t*)"H2C-OVERSIZE-DST-", 17);
+    h.update(d, n);
+    h.final(a.b);
+    a.len = 32;
+    return a;
+  }
+  if (n) memcpy(a.b, d, n);
   a.len = (uint32_t)n;
   return a;
 }
@@ -297,15 +388,15 @@ hipEvent_t prof_event(Ctx* c) {
   (void)hipEventCreate(&e);
   return e;
 }
-void prof_pre(Ctx* c, int kid) {
+void prof_pre(Ctx* c, int kid, hipStream_t s = nullptr) {
   if (!c->prof_on) return;
   Ctx::Pending p{kid, prof_event(c), prof_event(c)};
-  (void)hipEventRecord(p.e0, c->stream);
+  (void)hipEventRecord(p.e0, s ? s : c->stream);
   c->prof_pending.push_back(p);
 }
-void prof_post(Ctx* c) {
+void prof_post(Ctx* c, hipStream_t s = nullptr) {
   if (!c->prof_on) return;
-  (void)hipEventRecord(c->prof_pending.back().e1, c->stream);
+  (void)hipEventRecord(c->prof_pending.back().e1, s ? s : c->stream);
 }
 // call after the stream has been synchronised
 void prof_flush(Ctx* c) {
@@ -328,6 +419,14 @@ void prof_flush(Ctx* c) {
     hipLaunchKernelGGL(kern, grid, block, 0, c->stream, __VA_ARGS__);           \
     prof_post(c);                                                               \
   } while (0)
+// a launch on another stream of the context (tail / side): recorded with events on THAT stream; the stream is joined to the main
+// one before the call's final synchronisation, so prof_flush finds the events complete
+#define KLS(kid, strm, kern, grid, block, ...)                                  \
+  do {                                                                          \
+    prof_pre(c, kid, strm);                                                     \
+    hipLaunchKernelGGL(kern, grid, block, 0, strm, __VA_ARGS__);                \
+    prof_post(c, strm);                                                         \
+  } while (0)
 // one Miller loop per MILLER1_GROUP items: leaves ceil(cnt / MILLER1_GROUP) partial products at the start of the Fp12 workspace
 #define MILLER1_OUTPUTS(cnt) (((cnt) + MILLER1_GROUP - 1) / MILLER1_GROUP)
 #define MILLER1_LAUNCH(cnt, ...) KL(KID_MILLER1, k_miller1s, dim3(blocks_for(2 * MILLER1_OUTPUTS(cnt))), dim3(BLS_BLOCK), cnt, __VA_ARGS__)
@@ -339,14 +438,9 @@ void prof_flush(Ctx* c) {
 
 // batches up to this size use the wave-cooperative pairing (one wave per item); BLSGPU_COOP_MAX overrides (0 = never)
 size_t coop_max_items() {
-  static long v = -1;
-  if (v < 0) {
-    const char* e = getenv("BLSGPU_COOP_MAX");
-    v = e ? atol(e) : 4096;   // measured crossover with the lane-split kernels (tools/dbg/mid3.py, round 3: whole calls from host lists): 11.4 vs 12.0 ms at
-                              // 3,072 items, 12.1 vs 12.1 at 4,096, 17.4 vs 12.5 at 6,144 (rounds 1-2, the one-kernel Miller loop: 6,144)
-    if (v < 0) v = 0;
-  }
-  return (size_t)v;
+  // default 4096: measured crossover with the lane-split kernels (tools/dbg/mid3.py, round 3: whole calls from host lists): 11.4 vs 12.0 ms at
+  // 3,072 items, 12.1 vs 12.1 at 4,096, 17.4 vs 12.5 at 6,144 (rounds 1-2, the one-kernel Miller loop: 6,144)
+  return (size_t)knobs().coop_max;
 }
 
 // batches up to this size finish on the row-wide engine (one 256-thread workgroup per item; csrc/wide_engine.cuh):
@@ -363,14 +457,8 @@ int hash_phase_stop() {
 #endif
 }
 size_t wide_max_items() {
-  static long v = -1;
-  if (v < 0) {
-    const char* e = getenv("BLSGPU_WIDE_MAX");
-    v = e ? atol(e) : 512;    // measured (tools/dbg/small.py): 1.9 ms up to 256 items (one workgroup per CU), 3.4 ms at 512, 5.3 ms at 768; the wave-cooperative path: 4.6-4.8 ms flat
-    if (v < 0) v = 0;
-    if (v > 4096) v = 4096;
-  }
-  return (size_t)v;
+  // default 512: measured (tools/dbg/small.py): 1.9 ms up to 256 items (one workgroup per CU), 3.4 ms at 512, 5.3 ms at 768; the wave-cooperative path: 4.6-4.8 ms flat
+  return (size_t)knobs().wide_max;
 }
 
 unsigned blocks_for(size_t n) { return (unsigned)((n + BLS_BLOCK - 1) / BLS_BLOCK); }
@@ -414,15 +502,7 @@ int run_scan_max_u32(Ctx* c, int kid, size_t m, uint32_t* d_v, uint32_t* d_tiles
 
 // ---- one process, several GPUs (blsgpu_init_devices): the items of a call are cut into contiguous ranges, one per bound
 // device, each handled by a host thread whose leases come from that device's context pool
-size_t shard_min_items() {
-  static long v = -1;
-  if (v < 0) {
-    const char* e = getenv("BLSGPU_SHARD_MIN");   // below this many items a call stays on device 0
-    v = e ? atol(e) : 8192;
-    if (v < 1) v = 1;
-  }
-  return (size_t)v;
-}
+size_t shard_min_items() { return (size_t)knobs().shard_min; }   // BLSGPU_SHARD_MIN: below this many items a call stays on device 0
 // how many devices a call over n items uses; device-resident inputs can only be sharded when the devices see each other
 size_t shard_devices(size_t n, std::initializer_list<const void*> inputs) {
   if (t_nested || g_devices.size() < 2 || n < shard_min_items()) return 1;
@@ -491,30 +571,12 @@ struct NestedScope {     // the calling thread's own follow-up calls (fold, fina
 // ---- shared device pipelines (stream-ordered; caller holds the context mutex) ------------------------
 
 // items per pass of the two-kernel Miller loop (0: the one-kernel loop); one full machine round of lane pairs by default
-size_t miller_chunk_items() {
-  static long v = -1;
-  if (v < 0) {
-    const char* e = getenv("BLSGPU_MILLER_CHUNK");
-    v = e ? atol(e) : 65536;
-    const char* o = getenv("BLSGPU_MILLER_V1");
-    if (o && atoi(o)) v = 0;
-    if (v < 0) v = 0;
-  }
-  return (size_t)v;
-}
+size_t miller_chunk_items() { return knobs().miller_v1 ? 0 : (size_t)knobs().miller_chunk; }
 size_t lanes_for(size_t items) { return (2 * items + BLS_BLOCK - 1) / BLS_BLOCK * BLS_BLOCK; }
 // Row stride (in words) of the line workspace and the value store for that many lanes: NOT a power of two -- consecutive rows of
 // a lane are a stride apart, and with 2^k-byte strides the 70 rows a wave touches per step camp on the same HBM channels
 // (measured on the 262,144-lane chunks of config 4: BLSGPU_ROW_PAD=0 restores the bare stride for A/B runs)
-size_t row_stride(size_t lanes) {
-  static long pad = -1;
-  if (pad < 0) {
-    const char* e = getenv("BLSGPU_ROW_PAD");
-    pad = e ? atol(e) : 192;
-    if (pad < 0) pad = 0;
-  }
-  return lanes + (size_t)pad;
-}
+size_t row_stride(size_t lanes) { return lanes + (size_t)knobs().row_pad; }
 // the context's line workspace; 0 on success, non-zero (and no error recorded) when the device has no room for it
 int lines_reserve(Ctx* c, size_t bytes) {
   if (bytes <= c->lines_cap) return 0;
@@ -541,12 +603,7 @@ int run_pairing2(Ctx* c, size_t n, uint32_t* d_pairs, uint32_t* d_f, int32_t* d_
     // single verifications and the one-verdict tails on the row-wide engine (csrc/wide_engine.cuh): one 256-thread workgroup
     // per item runs line coefficients, Miller loop, final exponentiation and verdict as one table program.
     // BLSGPU_WIDE_MODE=1: only the hard part of the final exponentiation on the engine, Miller loop + easy part per wave.
-    static int mode = -1;
-    if (mode < 0) {
-      const char* e = getenv("BLSGPU_WIDE_MODE");
-      mode = e ? atoi(e) : 2;
-    }
-    if (mode == 1) {
+    if (knobs().wide_mode == 1) {
       uint32_t* d_easy = (uint32_t*)arena_take(c, (size_t)WIDE_EASY_WORDS * 4 * n);   // arena_reserve keeps 1 MiB of headroom: 768 B per item
       if (!d_easy) return fail(BLSGPU_E_HIP, "internal: arena too small");
       KL(KID_PAIRING_COOP, k_pairing_coop_easy, dim3((unsigned)n), dim3(BLS_BLOCK), n, (const uint32_t*)d_pairs, (const int32_t*)d_status, fixed_g2, d_easy);
@@ -563,8 +620,8 @@ int run_pairing2(Ctx* c, size_t n, uint32_t* d_pairs, uint32_t* d_f, int32_t* d_
     // BLSGPU_FINALEXP_SEG=1: the final exponentiation in six segments with the 63 compressed squarings of every a^x on FOUR lanes per
     // item at four waves per SIMD between them (k_cyc_run4).  Measured and not adopted (profiles/r03_pmc_finalexp_segments_cycrun4.json):
     // the squarings take 5.27 ms instead of ~5.6 ms inside k_finalexp2s, the six segments 4.28 ms: 9.55 ms against 9.49 ms for the one kernel.
-    static const bool finalexp_seg = getenv("BLSGPU_FINALEXP_SEG") && atoi(getenv("BLSGPU_FINALEXP_SEG"));
-    static const bool finalexp_v1 = getenv("BLSGPU_FINALEXP_V1") && atoi(getenv("BLSGPU_FINALEXP_V1"));   // A/B: the one-kernel final exponentiation of rounds 1 and 2
+    const bool finalexp_seg = knobs().finalexp_seg != 0;
+    const bool finalexp_v1 = knobs().finalexp_v1 != 0;   // A/B: the one-kernel final exponentiation of rounds 1 and 2
     const size_t chunk = n < miller_chunk_items() ? n : miller_chunk_items();
     const size_t words_per_lane = (size_t)MILLER_ENTRIES * (LINE5_WORDS + (fixed_g2 ? 0 : LINE3_WORDS_H));   // two general pairs: pair 0's plain lines too
     if (chunk && lines_reserve(c, words_per_lane * 4 * row_stride(lanes_for(chunk))) == 0) {
@@ -592,10 +649,10 @@ int run_pairing2(Ctx* c, size_t n, uint32_t* d_pairs, uint32_t* d_f, int32_t* d_
           KL(KID_FINALEXP, k_finalexp2s, grid, dim3(BLS_BLOCK), n, first, cnt, (const uint32_t*)d_f, c->lines_ws, lanes, d_status);
         }
       }
-      if (finalexp_v1) KL(KID_FINALEXP, k_finalexps, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_f, d_status);
+      if (finalexp_v1) KL(KID_FINALEXP_V1, k_finalexps, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_f, d_status);
     } else {
-      KL(KID_MILLER2, k_miller2s, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_pairs, d_status, d_f, fixed_g2);
-      KL(KID_FINALEXP, k_finalexps, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_f, d_status);
+      KL(KID_MILLER2_V1, k_miller2s, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_pairs, d_status, d_f, fixed_g2);
+      KL(KID_FINALEXP_V1, k_finalexps, dim3(blocks_for(2 * n)), dim3(BLS_BLOCK), n, d_f, d_status);
     }
   }
   HIPCK(hipGetLastError());
@@ -685,7 +742,7 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
       (void)hipStreamSynchronize(c->side);
       return fail(BLSGPU_E_HIP, "side-stream launch failed");
     }
-    KL(KID_WIDE, k_pairing_post, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), n, (const uint32_t*)d_rec, d_status);
+    KL(KID_PAIRING_POST, k_pairing_post, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), n, (const uint32_t*)d_rec, d_status);
     HIPCK(hipGetLastError());
     return 0;
   }
@@ -716,13 +773,13 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
     hipLaunchKernelGGL(k_pairing_pre, dim3((unsigned)n, 1), dim3(WIDE_ENGINE_BLOCK), 0, c->side, n, d_rec, (const int32_t*)d_status, 2, 2);
     hipError_t e3 = hipGetLastError(), e4 = hipEventRecord(c->ev_join, c->side);
     hipError_t e5 = hipStreamWaitEvent(c->stream, c->ev_join2, 0);
-    KL(KID_WIDE, k_pairing_pre, dim3((unsigned)n, 1), dim3(WIDE_ENGINE_BLOCK), n, d_rec, (const int32_t*)d_status, 0, 0);
+    KL(KID_PAIRING_PRE, k_pairing_pre, dim3((unsigned)n, 1), dim3(WIDE_ENGINE_BLOCK), n, d_rec, (const int32_t*)d_status, 0, 0);
     hipError_t e6 = hipStreamWaitEvent(c->stream, c->ev_join, 0);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess || e6 != hipSuccess) {
       (void)hipStreamSynchronize(c->side);
       return fail(BLSGPU_E_HIP, "side-stream launch failed");
     }
-    KL(KID_WIDE, k_pairing_post, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), n, (const uint32_t*)d_rec, d_status);
+    KL(KID_PAIRING_POST, k_pairing_post, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), n, (const uint32_t*)d_rec, d_status);
     HIPCK(hipGetLastError());
     return 0;
   }
@@ -739,7 +796,7 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
   // two lanes per item (the two SSWU maps side by side, G2 point arithmetic on the lane-split tower): always for
   // Bls12381G2Impl, whose hash-to-G2 halves its per-lane work that way; for Bls12381G1Impl only in latency mode (the
   // Fp-only remainder would run redundantly and a full batch is faster with one lane per item -- both measured)
-  static const int force_lanes = getenv("BLSGPU_PREPARE_LANES") ? atoi(getenv("BLSGPU_PREPARE_LANES")) : 0;   // A/B aid: 1 or 2 lanes per item in k_prepare<1>
+  const int force_lanes = (int)knobs().prepare_lanes;   // A/B aid: 1 or 2 lanes per item in k_prepare<1>
   // two lanes per item also for full Bls12381G1Impl batches since round 3: 1.69 against 1.80 ms at 65,536 items (k_prepare is a one-wave-per-SIMD kernel
   // otherwise, and a lone wave issues a multiply-add every 8.8 cycles where two waves share the pipe at 4.4)
   const int two_lanes = force_lanes == 1 && sg == 1 ? 0 : 1;
@@ -770,9 +827,9 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
 // 2,049th runs alone after the others): in modes 1 - 3 the signature's pair is a one-item chunk of its own on the tail stream.
 int run_miller_product_tree(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs, int32_t* d_bad, uint32_t* d_f, size_t* outputs, bool* done, int last_mode) {
   *done = false;
-  static const int enabled = getenv("BLSGPU_PRODUCT_TREE") ? atoi(getenv("BLSGPU_PRODUCT_TREE")) : 1;
-  static const long local_env = getenv("BLSGPU_TREE_LOCAL") ? atol(getenv("BLSGPU_TREE_LOCAL")) : 0;
-  static const long lines4_env = getenv("BLSGPU_LINES4_MAX") ? atol(getenv("BLSGPU_LINES4_MAX")) : -1;   // A/B: 0 = the two-lane line kernel everywhere
+  const int enabled = (int)knobs().product_tree;
+  const long local_env = knobs().tree_local;
+  const long lines4_env = knobs().lines4_max;   // A/B: 0 = the two-lane line kernel everywhere
   if (!enabled || mm < 64 || !miller_chunk_items() || !(wide_max_items() > 0 && coop_max_items() > 0)) return 0;
   const size_t round = 65536, E = MILLER_ENTRIES;
   const size_t LOCAL = local_env > 16 ? (size_t)local_env : 1024;    // 68 x 1,024 lane pairs: one machine round
@@ -823,9 +880,9 @@ int run_miller_product_tree(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs,
     const uint32_t* pw = d_pairs + lo;
     const int32_t* bw = d_bad + lo;
     if (cnt <= lines4_max)
-      KL(KID_LINES, k_linesp4, dim3(blocks_for(4 * cnt)), dim3(BLS_BLOCK), cnt, stride, pw, bw, lines3, lanes);
+      KL(KID_LINESP4, k_linesp4, dim3(blocks_for(4 * cnt)), dim3(BLS_BLOCK), cnt, stride, pw, bw, lines3, lanes);
     else
-      KL(KID_LINES, k_linesp, dim3((unsigned)(nlanes / BLS_BLOCK)), dim3(BLS_BLOCK), cnt, cnt, stride, pw, bw, lines3, lines3, lanes, (size_t)0, cnt, 1);
+      KL(KID_LINESP, k_linesp, dim3((unsigned)(nlanes / BLS_BLOCK)), dim3(BLS_BLOCK), cnt, cnt, stride, pw, bw, lines3, lines3, lanes, (size_t)0, cnt, 1);
     if (k == 0 && (left || extra)) {
       // the leftover items and the signature's pair: chunks of their own on the tail stream, their values straight into the
       // combined level.  They start when the first chunk's line kernel is through -- beside that kernel, whose waves fill the
@@ -841,15 +898,15 @@ int run_miller_product_tree(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs,
       if (extra) {
         const uint32_t* px = d_pairs + (mm - 1);
         const int32_t* bx = d_bad + (mm - 1);
-        if (last_mode == 3) hipLaunchKernelGGL(k_linesp4, dim3(1), dim3(BLS_BLOCK), 0, c->tail, (size_t)1, stride, px, bx, lines3_x, lanes_x);
-        else hipLaunchKernelGGL(k_lines_fixed, dim3(1), dim3(BLS_BLOCK), 0, c->tail, stride, px, bx, lines3_x, lanes_x, last_mode);
-        hipLaunchKernelGGL(k_line_quad, dim3(1, (unsigned)E), dim3(BLS_BLOCK), 0, c->tail, (size_t)1, (size_t)1, bx, (const uint32_t*)lines3_x, lanes_x, comb, comb_stride, Qc,
+        if (last_mode == 3) KLS(KID_TAIL, c->tail, k_linesp4, dim3(1), dim3(BLS_BLOCK), (size_t)1, stride, px, bx, lines3_x, lanes_x);
+        else KLS(KID_TAIL, c->tail, k_lines_fixed, dim3(1), dim3(BLS_BLOCK), stride, px, bx, lines3_x, lanes_x, last_mode);
+        KLS(KID_TAIL, c->tail, k_line_quad, dim3(1, (unsigned)E), dim3(BLS_BLOCK), (size_t)1, (size_t)1, bx, (const uint32_t*)lines3_x, lanes_x, comb, comb_stride, Qc,
                            Qmain + ql);
       }
       if (left) {
-        hipLaunchKernelGGL(k_linesp4, dim3(blocks_for(4 * left)), dim3(BLS_BLOCK), 0, c->tail, left, stride, (const uint32_t*)(d_pairs + body),
+        KLS(KID_TAIL, c->tail, k_linesp4, dim3(blocks_for(4 * left)), dim3(BLS_BLOCK), left, stride, (const uint32_t*)(d_pairs + body),
                            (const int32_t*)(d_bad + body), lines3_left, lanes_left);
-        hipLaunchKernelGGL(k_line_quad, dim3(blocks_for(2 * ql), (unsigned)E), dim3(BLS_BLOCK), 0, c->tail, left, ql, (const int32_t*)(d_bad + body),
+        KLS(KID_TAIL, c->tail, k_line_quad, dim3(blocks_for(2 * ql), (unsigned)E), dim3(BLS_BLOCK), left, ql, (const int32_t*)(d_bad + body),
                            (const uint32_t*)lines3_left, lanes_left, comb, comb_stride, Qc, Qmain);
       }
       const hipError_t e1 = hipGetLastError(), e2 = hipEventRecord(c->ev_tail_join, c->tail);
@@ -860,16 +917,16 @@ int run_miller_product_tree(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs,
     }
     size_t q = quarter(cnt);
     if (q <= LOCAL) {
-      KL(KID_MILLER1, k_line_quad, dim3(blocks_for(2 * q), (unsigned)E), dim3(BLS_BLOCK), cnt, q, bw, (const uint32_t*)lines3, lanes, comb, comb_stride, Qc, comb_off);
+      KL(KID_LINE_QUAD, k_line_quad, dim3(blocks_for(2 * q), (unsigned)E), dim3(BLS_BLOCK), cnt, q, bw, (const uint32_t*)lines3, lanes, comb, comb_stride, Qc, comb_off);
     } else {
-      KL(KID_MILLER1, k_line_quad, dim3(blocks_for(2 * q), (unsigned)E), dim3(BLS_BLOCK), cnt, q, bw, (const uint32_t*)lines3, lanes, bufA, E * q, q, (size_t)0);
+      KL(KID_LINE_QUAD, k_line_quad, dim3(blocks_for(2 * q), (unsigned)E), dim3(BLS_BLOCK), cnt, q, bw, (const uint32_t*)lines3, lanes, bufA, E * q, q, (size_t)0);
       uint32_t *src = bufA, *dst = bufB;
       while (q > LOCAL) {
         const size_t qo = quarter(q);
         if (qo <= LOCAL)
-          KL(KID_F12_FOLD, k_f12_fold4, dim3(blocks_for(2 * qo), (unsigned)E), dim3(BLS_BLOCK), q, qo, 4, (const uint32_t*)src, E * q, q, comb, comb_stride, Qc, comb_off);
+          KL(KID_F12_FOLD4, k_f12_fold4, dim3(blocks_for(2 * qo), (unsigned)E), dim3(BLS_BLOCK), q, qo, 4, (const uint32_t*)src, E * q, q, comb, comb_stride, Qc, comb_off);
         else
-          KL(KID_F12_FOLD, k_f12_fold4, dim3(blocks_for(2 * qo), (unsigned)E), dim3(BLS_BLOCK), q, qo, 4, (const uint32_t*)src, E * q, q, dst, E * qo, qo, (size_t)0);
+          KL(KID_F12_FOLD4, k_f12_fold4, dim3(blocks_for(2 * qo), (unsigned)E), dim3(BLS_BLOCK), q, qo, 4, (const uint32_t*)src, E * q, q, dst, E * qo, qo, (size_t)0);
         uint32_t* t = src;
         src = dst;
         dst = t;
@@ -888,7 +945,7 @@ int run_miller_product_tree(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs,
     // per entry; the rest on the engine, sixteen values per workgroup (two launches for up to 256 values): a product there takes
     // 3.7 us against 43 on a lane pair, and a lane-pair level of a few hundred tasks is nothing but its chain of fan - 1 products
     // (~0.13 ms).  1,025 values per entry -- a round of pairs and the signature's -- go 205, 52 on lane pairs, then 4, 1 on the engine.
-    static const long engine_from_env = getenv("BLSGPU_TREE_ENGINE_FROM") ? atol(getenv("BLSGPU_TREE_ENGINE_FROM")) : 0;
+    const long engine_from_env = knobs().tree_engine_from;
     const size_t ENGINE_FROM = engine_from_env >= 16 && engine_from_env <= 256 ? (size_t)engine_from_env : 128;
     int levels = 0;
     for (size_t cap = ENGINE_FROM; cap < q; cap *= 5) levels++;
@@ -898,7 +955,7 @@ int run_miller_product_tree(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs,
       while (fan < 5 && (q + fan - 1) / fan > reach) fan++;    // (five always suffices: `levels` was counted for fan-in five)
       levels--;
       const size_t qo = (q + fan - 1) / fan;
-      KL(KID_F12_FOLD, k_f12_fold4, dim3(blocks_for(2 * qo), (unsigned)E), dim3(BLS_BLOCK), q, qo, (int)fan, src, E * q, q, dst, E * qo, qo, (size_t)0);
+      KL(KID_F12_FOLD4, k_f12_fold4, dim3(blocks_for(2 * qo), (unsigned)E), dim3(BLS_BLOCK), q, qo, (int)fan, src, E * q, q, dst, E * qo, qo, (size_t)0);
       src = dst;
       uint32_t* t = dst;
       dst = other;
@@ -907,12 +964,12 @@ int run_miller_product_tree(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs,
     }
     if (q > 16) {
       const size_t qo = (q + 15) / 16;
-      KL(KID_F12_FOLD, k_f12_tree_seg, dim3((unsigned)qo, (unsigned)E), dim3(WIDE_ENGINE_BLOCK), q, src, E * q, q, dst, E * qo, qo);
+      KL(KID_F12_TREE, k_f12_tree_seg, dim3((unsigned)qo, (unsigned)E), dim3(WIDE_ENGINE_BLOCK), q, src, E * q, q, dst, E * qo, qo);
       src = dst;
       q = qo;
     }
-    KL(KID_F12_FOLD, k_f12_tree_seg, dim3(1, (unsigned)E), dim3(WIDE_ENGINE_BLOCK), q, src, E * q, q, t68, T_STRIDE, (size_t)1);
-    KL(KID_F12_FOLD, k_f12_horner_wide, dim3(1), dim3(WIDE_ENGINE_BLOCK), (const uint32_t*)t68, T_STRIDE, d_f, stride);
+    KL(KID_F12_TREE, k_f12_tree_seg, dim3(1, (unsigned)E), dim3(WIDE_ENGINE_BLOCK), q, src, E * q, q, t68, T_STRIDE, (size_t)1);
+    KL(KID_HORNER, k_f12_horner_wide, dim3(1), dim3(WIDE_ENGINE_BLOCK), (const uint32_t*)t68, T_STRIDE, d_f, stride);
   }
   HIPCK(hipGetLastError());
   *outputs = 1;
@@ -953,7 +1010,7 @@ int run_miller_product(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs, int3
         }
         HIPCK(hipEventRecord(c->ev_tail_fork, c->stream));
         HIPCK(hipStreamWaitEvent(c->tail, c->ev_tail_fork, 0));
-        hipLaunchKernelGGL(k_miller1s, dim3(blocks_for(2 * MILLER1_OUTPUTS(left))), dim3(BLS_BLOCK), 0, c->tail, left, stride, (const uint32_t*)(d_pairs + cnt),
+        KLS(KID_TAIL, c->tail, k_miller1s, dim3(blocks_for(2 * MILLER1_OUTPUTS(left))), dim3(BLS_BLOCK), left, stride, (const uint32_t*)(d_pairs + cnt),
                            (const int32_t*)(d_bad + cnt), d_f + cnt);
         const hipError_t e1 = hipGetLastError(), e2 = hipEventRecord(c->ev_tail_join, c->tail);
         if (e1 != hipSuccess || e2 != hipSuccess) {
@@ -963,8 +1020,8 @@ int run_miller_product(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs, int3
       }
       const dim3 grid((unsigned)(nlanes / BLS_BLOCK));
       // k_linesp pass 1 on a "chunk" whose partners do not exist (half = cnt): every lane pair walks its own item and stores its lines
-      KL(KID_LINES, k_linesp, grid, dim3(BLS_BLOCK), cnt, cnt, stride, (const uint32_t*)d_pairs, (const int32_t*)d_bad, c->lines_ws, c->lines_ws, lanes, (size_t)0, cnt, 1);
-      KL(KID_MILLER1, k_millerfp3, grid, dim3(BLS_BLOCK), cnt, cnt, 1, (const int32_t*)d_bad, (const uint32_t*)c->lines_ws, lanes, d_f, stride, (size_t)0);
+      KL(KID_LINESP, k_linesp, grid, dim3(BLS_BLOCK), cnt, cnt, stride, (const uint32_t*)d_pairs, (const int32_t*)d_bad, c->lines_ws, c->lines_ws, lanes, (size_t)0, cnt, 1);
+      KL(KID_MILLERFP, k_millerfp3, grid, dim3(BLS_BLOCK), cnt, cnt, 1, (const int32_t*)d_bad, (const uint32_t*)c->lines_ws, lanes, d_f, stride, (size_t)0);
       if (left) HIPCK(hipStreamWaitEvent(c->stream, c->ev_tail_join, 0));
       HIPCK(hipGetLastError());
       *outputs = cnt + (left ? MILLER1_OUTPUTS(left) : 0);
@@ -1003,7 +1060,7 @@ int run_miller_product(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs, int3
     }
     HIPCK(hipEventRecord(c->ev_tail_fork, c->stream));
     HIPCK(hipStreamWaitEvent(c->tail, c->ev_tail_fork, 0));
-    hipLaunchKernelGGL(k_miller1s, dim3(blocks_for(2 * MILLER1_OUTPUTS(left))), dim3(BLS_BLOCK), 0, c->tail, left, stride, (const uint32_t*)(d_pairs + lo),
+    KLS(KID_TAIL, c->tail, k_miller1s, dim3(blocks_for(2 * MILLER1_OUTPUTS(left))), dim3(BLS_BLOCK), left, stride, (const uint32_t*)(d_pairs + lo),
                        (const int32_t*)(d_bad + lo), d_f + left_out0);
     const hipError_t e1 = hipGetLastError(), e2 = hipEventRecord(c->ev_tail_join, c->tail);
     if (e1 != hipSuccess || e2 != hipSuccess) {
@@ -1023,9 +1080,9 @@ int run_miller_product(Ctx* c, size_t mm, size_t stride, uint32_t* d_pairs, int3
     // the chunk's items as a workspace of its own: item v pairs with item v + cnt
     const uint32_t* pw = d_pairs + ch.lo;
     const int32_t* bw = d_bad + ch.lo;
-    KL(KID_LINES, k_linesp, grid, dim3(BLS_BLOCK), 2 * ch.cnt, ch.cnt, stride, pw, bw, c->lines_ws, lines3, lanes, (size_t)0, ch.cnt, 1);
-    KL(KID_LINES, k_linesp, grid, dim3(BLS_BLOCK), 2 * ch.cnt, ch.cnt, stride, pw, bw, c->lines_ws, lines3, lanes, (size_t)0, ch.cnt, 2);
-    KL(KID_MILLER1, k_millerfp, dim3(blocks_for(2 * q)), dim3(BLS_BLOCK), ch.cnt, q, group, (const uint32_t*)c->lines_ws, lanes, d_f, stride, out0);
+    KL(KID_LINESP, k_linesp, grid, dim3(BLS_BLOCK), 2 * ch.cnt, ch.cnt, stride, pw, bw, c->lines_ws, lines3, lanes, (size_t)0, ch.cnt, 1);
+    KL(KID_LINESP, k_linesp, grid, dim3(BLS_BLOCK), 2 * ch.cnt, ch.cnt, stride, pw, bw, c->lines_ws, lines3, lanes, (size_t)0, ch.cnt, 2);
+    KL(KID_MILLERFP, k_millerfp, dim3(blocks_for(2 * q)), dim3(BLS_BLOCK), ch.cnt, q, group, (const uint32_t*)c->lines_ws, lanes, d_f, stride, out0);
     out0 += q;
   }
   if (left) {
@@ -1087,12 +1144,7 @@ int run_f12_product_verdict(Ctx* c, uint32_t* d_f, size_t m, size_t stride, int3
 // use 355 registers), and workgroups go round-robin to the 8 XCDs, so two of them in one XCD cost it 16 slots.  Measured
 // (tools/dbg/acc.py, 2^20 keys): 1.15 / 1.17 ms at 58,368 / 57,344 lane pairs, 1.28 at 59,392, 1.48 at 61,440.
 size_t accumulate_lanes(size_t n) {
-  static long cap = -1;
-  if (cap < 0) {
-    const char* e = getenv("BLSGPU_ACC_LANES");          // tuning override
-    cap = e ? atol(e) : 57344;                            // 224 of 256 compute units at 256 lane pairs each
-    if (cap < 64) cap = 64;
-  }
+  const long cap = knobs().acc_lanes;                     // default 57,344: 224 of 256 compute units at 256 lane pairs each
   size_t t = n / 4;
   if (t < 64) t = 64;
   if (t > (size_t)cap) t = (size_t)cap;
@@ -1183,8 +1235,8 @@ msm_plan msm_make_plan(size_t n, int G) {
   // chunks (sort 0.4 + buckets 3.3 + chunks 2.9 ms against 0.6 + 2.7 + 3.9 with 12 / 8), G1 with 12 / 8 (0.6 + 1.4 + 2.5)
   p.c = n >= 16384 ? (G == 2 ? 11 : 12) : 8;
   p.CH = (n >= 16384 && G == 2) ? 4 : 8;   // short chunks: the 2^(c w) doublings of the chunk lanes dominate their critical path
-  if (const char* e = getenv("BLSGPU_MSM_C")) p.c = atoi(e);        // tuning overrides (window bits, buckets per chunk lane),
-  if (const char* e = getenv("BLSGPU_MSM_CH")) p.CH = atoi(e);      // clamped to what the kernels assume
+  if (knobs().msm_c) p.c = (int)knobs().msm_c;         // tuning overrides (window bits, buckets per chunk lane),
+  if (knobs().msm_ch) p.CH = (int)knobs().msm_ch;      // clamped to what the kernels assume
   if (p.c < 4) p.c = 4;
   if (p.c > 16) p.c = 16;
   if (p.CH < 1) p.CH = 1;
@@ -1217,8 +1269,8 @@ msm2_plan msm2_make_plan(size_t n, int G) {
   if (p.c < 6) p.c = 6;
   if (p.c > 14) p.c = 14;
   p.CH = 4;                               // short chunks: the chunk lanes are a latency chain (4 / 8 / 16 measured: 1.1 / 1.4 / 2.1 ms)
-  if (const char* e = getenv("BLSGPU_MSM2_C")) p.c = atoi(e);      // tuning overrides, clamped to what the kernels assume
-  if (const char* e = getenv("BLSGPU_MSM2_CH")) p.CH = atoi(e);
+  if (knobs().msm2_c) p.c = (int)knobs().msm2_c;      // tuning overrides, clamped to what the kernels assume
+  if (knobs().msm2_ch) p.CH = (int)knobs().msm2_ch;
   if (p.c < 4) p.c = 4;
   if (p.c > 16) p.c = 16;
   // bits + 1 positions (one spare for the recoding carry) in W windows whose widths differ by at most one (msm2.cuh)
@@ -1234,7 +1286,7 @@ msm2_plan msm2_make_plan(size_t n, int G) {
   // 1 / 2 / 4 parts at 40,960 bucket lanes: 2.2 / 1.3 / 0.8 ms for G1); a fully parallel pass merges the parts afterwards
   const size_t lanes = p.nb * (G == 1 ? 1 : 2);
   p.Q = (int)((131072 + lanes - 1) / lanes);
-  if (const char* e = getenv("BLSGPU_MSM2_Q")) p.Q = atoi(e);
+  if (knobs().msm2_q) p.Q = (int)knobs().msm2_q;
   if (p.Q < 1) p.Q = 1;
   if (p.Q > 8) p.Q = 8;
   return p;
@@ -1302,23 +1354,9 @@ int run_msm2_rest(Ctx* c, const uint8_t* d_scalars, size_t n, msm2_ws& w, uint8_
   HIPCK(hipMemcpyAsync(d_out, w.part, G == 1 ? 144 : 288, hipMemcpyDeviceToDevice, c->stream));
   return 0;
 }
-bool msm_use_v1() {
-  static int v1 = -1;
-  if (v1 < 0) {
-    const char* e = getenv("BLSGPU_MSM_V1");     // A/B switch: the first-generation bucket method (unsigned digits, full additions)
-    v1 = (e && e[0] == '1') ? 1 : 0;
-  }
-  return v1 != 0;
-}
+bool msm_use_v1() { return knobs().msm_v1 != 0; }   // A/B switch: the first-generation bucket method (unsigned digits, full additions)
 
-bool msm_use_pippenger(size_t n) {
-  static int force_naive = -1;
-  if (force_naive < 0) {
-    const char* e = getenv("BLSGPU_MSM_NAIVE");
-    force_naive = (e && e[0] == '1') ? 1 : 0;
-  }
-  return !force_naive && n >= 1024;
-}
+bool msm_use_pippenger(size_t n) { return !knobs().msm_naive && n >= 1024; }
 template <int G>
 int run_msm_pippenger(Ctx* c, const uint8_t* d_pts, int fmt, const uint8_t* d_scalars, const uint32_t* d_perm, size_t n, uint8_t* d_out) {
   msm_plan p = msm_make_plan(n, G);
@@ -1496,10 +1534,7 @@ static int bind_device(int device, int ndev) {
   HIPCK(hipGetDeviceProperties(&prop, device));
   if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
     return fail(BLSGPU_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 (MI355X) only");
-  int nctx = 2;                     // contexts per device (BLSGPU_CONTEXTS): concurrent callers beyond this queue up
-  if (const char* e = getenv("BLSGPU_CONTEXTS")) nctx = atoi(e);
-  if (nctx < 1) nctx = 1;
-  if (nctx > 16) nctx = 16;
+  const int nctx = (int)knobs().contexts;   // contexts per device (BLSGPU_CONTEXTS, default 2, 1..16): concurrent callers beyond this queue up
   Device* d = new Device();
   d->dev = device;
   for (int k = 0; k < nctx; k++) {
@@ -1558,8 +1593,15 @@ static void release_devices() {
   g_devices.clear();
 }
 
+// BLSGPU_STRICT_ENV=1: refuse to start over an environment the knob table does not fully understand (before any device is touched)
+static int strict_env_check() {
+  const Knobs& k = knobs();
+  if (k.strict_env && !k.problem.empty()) return fail(BLSGPU_E_ARG, "BLSGPU_STRICT_ENV: " + k.problem);
+  return 0;
+}
 int blsgpu_init(int device) try {
   std::lock_guard<std::mutex> lk(g_init_mu);
+  if (int rc = strict_env_check()) return rc;
   if (initialised()) {
     if (device >= 0 && device != g_devices[0]->dev)
       return fail(BLSGPU_E_ARG, "blsgpu_init: the library is already bound to device " + std::to_string(g_devices[0]->dev) +
@@ -1586,6 +1628,7 @@ API_CATCH
  * BLSGPU_FAKE_DEVICES=k (testing on a one-GPU box) binds k logical devices that all map to the one physical GPU. */
 int blsgpu_init_devices(int ndev_req) try {
   std::lock_guard<std::mutex> lk(g_init_mu);
+  if (int rc = strict_env_check()) return rc;
   if (initialised()) {
     if (ndev_req > 0 && (size_t)ndev_req != g_devices.size())
       return fail(BLSGPU_E_ARG, "blsgpu_init_devices: the library is already bound to " + std::to_string(g_devices.size()) +
@@ -1598,8 +1641,7 @@ int blsgpu_init_devices(int ndev_req) try {
     (void)hipGetLastError();
     return fail(BLSGPU_E_NO_DEVICE, "no HIP device available: libblsgpu has no CPU fallback");
   }
-  int fake = 0;
-  if (const char* f = getenv("BLSGPU_FAKE_DEVICES")) fake = atoi(f);
+  const int fake = (int)knobs().fake_devices;
   int want = ndev_req > 0 ? ndev_req : (fake > 0 ? fake : ndev);
   if (fake <= 0 && want > ndev) return fail(BLSGPU_E_ARG, "blsgpu_init_devices: more devices requested than visible");
   if (want > 64) return fail(BLSGPU_E_ARG, "blsgpu_init_devices: at most 64 devices");
@@ -1810,7 +1852,7 @@ int blsgpu_verify_batch_grouped(int sig_group, int scheme, const void* pks, cons
   KL(KID_ACCUM, k_group_sigsum, dim3(blocks_for(ng)), dim3(BLS_BLOCK), ng, n, (const uint8_t*)d_scaled, d_pairs, d_skip);
   MILLER1_LAUNCH(m, m, d_pairs, d_skip, d_f);
   KL(KID_F12_FOLD, k_f12_mul3, dim3(blocks_for(ng)), dim3(BLS_BLOCK), ng, (const uint32_t*)d_f, m, d_fg);
-  KL(KID_FINALEXP, k_finalexps, dim3(blocks_for(2 * ng)), dim3(BLS_BLOCK), ng, (const uint32_t*)d_fg, d_gst);
+  KL(KID_FINALEXP_V1, k_finalexps, dim3(blocks_for(2 * ng)), dim3(BLS_BLOCK), ng, (const uint32_t*)d_fg, d_gst);
   HIPCK(hipGetLastError());
   std::vector<int32_t> gst(ng);
   HIPCK(hipMemcpyAsync(gst.data(), d_gst, 4 * ng, hipMemcpyDeviceToHost, c->stream));
@@ -1958,12 +2000,12 @@ static int cut_tail_finish(Ctx* c, int rc, const uint8_t* d_pk_proj, CutTail& t,
   if (t.sg == 1) {
     KL(KID_PREPARE, k_prepare_keys<1>, dim3(1), dim3(BLS_BLOCK), (size_t)1, d_pk_proj, (const uint8_t*)nullptr, (const uint8_t*)nullptr, BLSGPU_FMT_RAW_PROJ, 2,
        t.rec, t.d_status);
-    KL(KID_WIDE, k_pairing_pre, dim3(1, 1), dim3(WIDE_ENGINE_BLOCK), (size_t)1, t.rec, (const int32_t*)t.d_status, 0, 0);
+    KL(KID_PAIRING_PRE, k_pairing_pre, dim3(1, 1), dim3(WIDE_ENGINE_BLOCK), (size_t)1, t.rec, (const int32_t*)t.d_status, 0, 0);
   } else {
     KL(KID_PREPARE, k_prepare_keys<2>, dim3(1), dim3(BLS_BLOCK), (size_t)1, d_pk_proj, (const uint8_t*)nullptr, (const uint8_t*)nullptr, BLSGPU_FMT_RAW_PROJ, 2,
        t.rec, t.d_status);
   }
-  KL(KID_WIDE, k_pairing_post, dim3(1), dim3(WIDE_ENGINE_BLOCK), (size_t)1, (const uint32_t*)t.rec, t.d_status);
+  KL(KID_PAIRING_POST, k_pairing_post, dim3(1), dim3(WIDE_ENGINE_BLOCK), (size_t)1, (const uint32_t*)t.rec, t.d_status);
   HIPCK(hipGetLastError());
   if ((rc = copy_out_and_sync(c, status, t.d_status, 4))) return rc;
   return 0;
@@ -2063,7 +2105,7 @@ static int aggregate_enqueue(Ctx* c, int sig_group, int scheme, const uint8_t* d
   // ... on two lanes per item (the two SSWU maps of the hash side by side) while that fits one machine round of lanes: the kernel is a
   // latency chain there (1.75 -> 1.1 ms at 32,768 pairs, 1.63 -> 0.96 at 4,096); beyond a round the redundant rest of the two-lane form costs more
   // than the shorter chains save (5.9 against 5.3 ms at 262,144).  BLSGPU_AGG_LANES=1 / 2 forces a form (A/B)
-  static const int agg_lanes_env = getenv("BLSGPU_AGG_LANES") ? atoi(getenv("BLSGPU_AGG_LANES")) : 0;
+  const int agg_lanes_env = (int)knobs().agg_lanes;
   const int agg_one_lane = agg_lanes_env == 1 || (agg_lanes_env != 2 && mm > 65536 + 1024);
   const int agg_flags = sig_group == 1 ? (agg_one_lane ? 2 : 3) : 1;
   if (mm > 0) {
@@ -2236,7 +2278,7 @@ int blsgpu_aggregate_verify(int sig_group, int scheme, const void* pks, const ui
   }
   CTX_ACQUIRE(c);
   uint64_t aux_h[2] = {0, 0};
-  const bool trace = getenv("BLSGPU_HOST_TRACE") != nullptr;
+  const bool trace = knobs().host_trace != 0;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_start = now();
   const bool basic = scheme == BLSGPU_SCHEME_BASIC;
@@ -2403,7 +2445,7 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
     return 0;
   }
   CTX_ACQUIRE(c);
-  const bool trace = getenv("BLSGPU_HOST_TRACE") != nullptr;
+  const bool trace = knobs().host_trace != 0;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const size_t psz = pk_size(sig_group, fmt), width = sig_group == 1 ? 96 : 48, T = accumulate_lanes(n);
   size_t need = pad256(psz * n) + pad256(width * n) + pad256(32 * n) + pad256(288 * T) + pad256(msg_len) + 16384 + msm_ws_bytes(n) +
@@ -2702,7 +2744,6 @@ API_CATCH
 
 static int hash_to_group(int group, const uint8_t* msgs, const uint64_t* msg_offsets, size_t n, const uint8_t* dst, size_t dst_len, void* out) {
   if (!initialised()) return NOT_INIT();
-  if (dst_len > 255) return fail(BLSGPU_E_ARG, "dst longer than 255 bytes is not supported");
   if (n == 0) return 0;
   if (!msg_offsets || !out || !dst) return fail(BLSGPU_E_ARG, "null argument");
   CTX_ACQUIRE(c);
@@ -3053,7 +3094,7 @@ int blsgpu_debug_wide_mul(const uint8_t* a, const uint8_t* b, size_t n, int reps
   uint8_t* d_out = is_device_ptr(out) ? out : (uint8_t*)arena_take(c, 48 * n);
   if (!d_out) return fail(BLSGPU_E_HIP, "internal: arena too small");
   // BLSGPU_WIDE_TEST_BLOCK=256: sixteen items per 256-thread workgroup (the engine's shape) instead of four per wave
-  const unsigned tb = (getenv("BLSGPU_WIDE_TEST_BLOCK") && atoi(getenv("BLSGPU_WIDE_TEST_BLOCK")) == 256) ? 256 : 64, per = tb / 16;
+  const unsigned tb = knobs().wide_test_block == 256 ? 256 : 64, per = tb / 16;
   KL(KID_WIDE, k_wide_mul_test, dim3((unsigned)((n + per - 1) / per)), dim3(tb), n, (const uint8_t*)d_a, (const uint8_t*)d_b, d_out, reps);
   HIPCK(hipGetLastError());
   if (d_out != out && (rc = copy_out(c, out, d_out, 48 * n))) return rc;
@@ -3194,7 +3235,7 @@ int blsgpu_core_verify(int sig_group, const uint8_t* dst, size_t dst_len, const 
                        const uint64_t* msg_offsets, size_t n, int fmt, int32_t* status) try {
   int rc = check_common(sig_group, 0, fmt);
   if (rc) return rc;
-  if (dst_len > 255 || (!dst && dst_len)) return fail(BLSGPU_E_ARG, "dst must be at most 255 bytes");
+  if (!dst && dst_len) return fail(BLSGPU_E_ARG, "null dst with a non-zero length");
   return core_verify_entry(sig_group, make_dst(dst, dst_len), 0, pks, sigs, msgs, msg_offsets, n, fmt, status);
 }
 API_CATCH

@@ -224,6 +224,18 @@ BLS_NOINLINE void jac_mul_u64(jac<F>& r, const jac<F>& p, uint64_t k) {
   r = acc;
 }
 
+// [hi 2^64 + lo] P (the 128-bit scalars of the opt-in grouped verification: per-lane values, the branch diverges)
+template <class F>
+BLS_NOINLINE void jac_mul_u128(jac<F>& r, const jac<F>& p, uint64_t hi, uint64_t lo) {
+  jac<F> acc;
+  jac_set_inf(acc);
+  for (int i = 127; i >= 0; i--) {
+    jac_dbl_body(acc, acc);
+    if (((i >= 64 ? hi : lo) >> (i & 63)) & 1) jac_add_body(acc, acc, p);
+  }
+  r = acc;
+}
+
 // [k] P for a 256-bit scalar given as 8 little-endian 32-bit words (per-lane scalars: the branch diverges)
 template <class F>
 BLS_NOINLINE void jac_mul_scalar(jac<F>& r, const jac<F>& p, const uint32_t* k) {

@@ -423,9 +423,10 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare(size_t n, const uint8_
 // statuses are those of blsgpu_verify_batch.  The scalars are DERIVED FROM THE GROUP'S OWN INPUTS (Fiat-Shamir; round 3, after
 // the advisor's finding on seed-only scalars: with r_a, r_b known in advance sig_a + [r_b] D and sig_b - [r_a] D cancel in the
 // combined check): d_i = SHA-256(tag || seed || n || i || pk_i || sig_i || |m_i| || m_i) over the caller's bytes, D = SHA-256(d of the
-// group's eight slots, zero for slots past n), r_i = the first 64 bits of SHA-256(D || i) (1 if they are all zero).  Whoever
+// group's eight slots, zero for slots past n), r_i = the first 128 bits of SHA-256(D || i) (1 if they are all zero; 128 bits since round 4:
+// the advisor's offline grinding against 64-bit scalars with a known seed took 2^64 hash evaluations).  Whoever
 // chooses the inputs of a group learns its scalars only after all of them are fixed, so making an invalid item pass takes about
-// 2^64 hash evaluations per group; the caller's seed is mixed in as optional extra entropy and needs no secrecy.
+// 2^128 hash evaluations per group; the caller's seed is mixed in as optional extra entropy and needs no secrecy.
 // This kernel: the per-item checks and hash of k_prepare, then A_i = r_i H(m_i) (affine, with the key: one pair of the
 // group's Miller loops) and B_i = r_i sig_i (Jacobian, for k_group_sigsum).  Pair slots: item i sits at (i / 8) + (i % 8) ng
 // of a workspace of 9 ng one-pair items, so that k_miller1s (items g, g + q, g + 2q per loop, q = 3 ng) leaves the three
@@ -434,13 +435,14 @@ __device__ __forceinline__ void sha256_u64(sha256_ctx& c, uint64_t x) {
   for (int k = 7; k >= 0; k--) sha256_byte(c, (uint8_t)(x >> (8 * k)));
 }
 // the scalar of item i; every lane of the wave calls this (lanes past n contribute zero digests), groups are aligned octets of lanes
-__device__ __noinline__ uint64_t grouped_scalar(uint64_t seed, size_t n, size_t i, const uint8_t* pk, uint32_t pk_len, const uint8_t* sig, uint32_t sig_len,
+struct u128_pair { uint64_t hi, lo; };
+__device__ __noinline__ u128_pair grouped_scalar(uint64_t seed, size_t n, size_t i, const uint8_t* pk, uint32_t pk_len, const uint8_t* sig, uint32_t sig_len,
                                               const uint8_t* m, uint32_t mlen) {
   static_assert(GROUPED_ITEMS == 8 && BLS_BLOCK % GROUPED_ITEMS == 0, "a group is an aligned octet of lanes");
   uint8_t d[32];
   sha256_ctx c;
   if (i < n) {
-    const char tag[] = "blsgpu-grouped-v2";
+    const char tag[] = "blsgpu-grouped-v3";
     sha256_init(c);
     sha256_update(c, (const uint8_t*)tag, sizeof tag - 1);
     sha256_u64(c, seed);
@@ -470,9 +472,11 @@ __device__ __noinline__ uint64_t grouped_scalar(uint64_t seed, size_t n, size_t 
   sha256_update(c, d, 32);
   sha256_u64(c, (uint64_t)i);
   sha256_final(c, d);
-  uint64_t r = 0;
-  for (int k = 0; k < 8; k++) r = (r << 8) | d[k];
-  return r ? r : 1;
+  u128_pair r{0, 0};
+  for (int k = 0; k < 8; k++) r.hi = (r.hi << 8) | d[k];
+  for (int k = 8; k < 16; k++) r.lo = (r.lo << 8) | d[k];
+  if (!(r.hi | r.lo)) r.lo = 1;
+  return r;
 }
 template <int SG>
 __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare_grouped(size_t n, const uint8_t* pks, const uint8_t* sigs, int fmt, int aug, const uint8_t* msgs,
@@ -485,7 +489,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare_grouped(size_t n, cons
   const uint8_t* m = msgs + offs[ii];
   const uint32_t mlen = (uint32_t)(offs[ii + 1] - offs[ii]);
   const uint32_t pk_len = fmt == 0 ? 288 : 192, sig_len = fmt == 0 ? 144 : 96;
-  const uint64_t r = grouped_scalar(seed, n, i, pks + ii * pk_len, pk_len, sigs + ii * sig_len, sig_len, m, mlen);   // all lanes: the group's digests travel by shuffles
+  const u128_pair r = grouped_scalar(seed, n, i, pks + ii * pk_len, pk_len, sigs + ii * sig_len, sig_len, m, mlen);   // all lanes: the group's digests travel by shuffles
   if (!live) return;
   const size_t slot = i / GROUPED_ITEMS + (i % GROUPED_ITEMS) * ng, stride = (GROUPED_ITEMS + 1) * ng;
   g1_aff P[2];
@@ -502,9 +506,9 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare_grouped(size_t n, cons
     return;
   }
   jac_from_aff(a, P[0]);
-  jac_mul_u64(a, a, r);
+  jac_mul_u128(a, a, r.hi, r.lo);
   jac_from_aff(b, P[1]);
-  jac_mul_u64(b, b, r);
+  jac_mul_u128(b, b, r.hi, r.lo);
   g1_aff A;
   jac_to_aff(A, a);
   ws_st_pair(pairs, stride, slot, 0, A, Q[0]);

@@ -190,14 +190,14 @@ int blsgpu_aggregate_secure(int sig_group, const void* pks, const void* sigs, si
 
 /* OPT-IN grouped verification of independent items (sig_group 1 only): same arguments and status vector as
  * blsgpu_verify_batch (raw formats), but groups of eight items share one final exponentiation through a random linear
- * combination with 64-bit scalars; every group whose combined check fails is re-verified item by item, so
+ * combination with 128-bit scalars; every group whose combined check fails is re-verified item by item, so
  *   - a valid item is never reported invalid, identity errors are reported as in blsgpu_verify_batch,
  *   - an invalid item is reported valid only if its group's combined check passes.
  * The scalars are derived INSIDE the library from the group's own inputs (SHA-256 over the keys, signatures and messages of
  * the group's eight items, their indices, n and `seed`; csrc/kernels.cuh grouped_scalar): whoever chooses the inputs learns
- * the scalars only once all of them are fixed, so forging takes about 2^64 hash evaluations per group.  `seed` is optional
- * extra entropy (a fresh random value makes the scalars unpredictable even to someone who knows the other inputs); it needs
- * no secrecy and 0 is acceptable.  Not the reference's semantics to the last bit (the reference has no batched
+ * the scalars only once all of them are fixed, so forging takes about 2^128 hash evaluations per group (64-bit scalars, as
+ * in round 3, could be ground offline in 2^64 by whoever knows `seed`).  `seed` SHOULD be a fresh random value per call: it makes
+ * the scalars unpredictable even to someone who knows every other input.  It needs no secrecy afterwards.  Not the reference's semantics to the last bit (the reference has no batched
  * verification); callers opt in.  Pays on all-valid input; failing groups cost their items' ordinary verification on top. */
 int blsgpu_verify_batch_grouped(int sig_group, int scheme, const void* pks, const void* sigs, const uint8_t* msgs, const uint64_t* msg_offsets,
                                 size_t n, int fmt, uint64_t seed, int32_t* status);

@@ -359,7 +359,12 @@ static void sha_final(sha256* s, uint8_t* out) {
 
 /* ------------------------------------------------------------------ RFC 9380 hash_to_curve */
 static void expand_xmd(uint8_t* out, int nout, const uint8_t* pre, size_t prel, const uint8_t* m, size_t ml, const uint8_t* dst, size_t dl) {
-  sha256 s; uint8_t b0[32], bi[32] = {0}, z[64] = {0}, t[3] = {(uint8_t)(nout >> 8), (uint8_t)nout, 0}, dlb = (uint8_t)dl;
+  sha256 s; uint8_t b0[32], bi[32] = {0}, z[64] = {0}, t[3] = {(uint8_t)(nout >> 8), (uint8_t)nout, 0}, big[32];
+  if (dl > 255) {   /* RFC 9380 5.3.3: DST' = H("H2C-OVERSIZE-DST-" || DST) */
+    sha_init(&s); sha_update(&s, (const uint8_t*)"H2C-OVERSIZE-DST-", 17); sha_update(&s, dst, dl); sha_final(&s, big);
+    dst = big; dl = 32;
+  }
+  uint8_t dlb = (uint8_t)dl;
   sha_init(&s); sha_update(&s, z, 64); sha_update(&s, pre, prel); sha_update(&s, m, ml); sha_update(&s, t, 3);
   sha_update(&s, dst, dl); sha_update(&s, &dlb, 1); sha_final(&s, b0);
   for (int blk = 1; blk <= nout / 32; blk++) {

@@ -568,7 +568,7 @@ def test_segmented_final_exponentiation_and_one_kernel_miller_loop_agree():
         "print(repr(out))\n") % (util.ROOT, os.path.join(util.ROOT, 'tests'))
     res = {}
     for name, env in (('default', {}), ('seg', {'BLSGPU_FINALEXP_SEG': '1'}), ('fe_v1', {'BLSGPU_FINALEXP_V1': '1'}), ('miller_v1', {'BLSGPU_MILLER_V1': '1'})):
-        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, BLSGPU_AB_KNOBS='1', **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (name, r.stderr[-2000:])
         res[name] = eval(r.stdout.strip().splitlines()[-1])
     want = res['default']
@@ -615,7 +615,7 @@ def test_pairing_product_tree_and_accumulator_forms_agree(api):
                 ('lines2', {'BLSGPU_LINES4_MAX': '0'}), ('levels', {'BLSGPU_TREE_LOCAL': '64', 'BLSGPU_TREE_ENGINE_FROM': '16'}),
                 ('agg1', {'BLSGPU_AGG_LANES': '1'}))
     for name, env in variants:
-        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, BLSGPU_AB_KNOBS='1', **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, (name, r.stderr[-2000:])
         res[name] = eval(r.stdout.strip().splitlines()[-1])
     assert len(res['tree']) == 2 * 10 * 5

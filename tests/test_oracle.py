@@ -30,6 +30,20 @@ def test_rfc9380_vectors():
                     0x05cb8437535e20ecffaef7752baddf98034139c38452458baeefab379ba13dff5bf5dd71b72418717047f5b0f37da03d)
 
 
+def test_rfc9380_oversize_dst_vector():
+    """RFC 9380 section 5.3.3 / appendix K.2: a DST longer than 255 bytes enters expand_message_xmd as
+    SHA-256("H2C-OVERSIZE-DST-" || DST).  The K.2 vector (256-byte DST, msg = "", 32 bytes out) pins the rule the boundary
+    inherits from the reference's dependency (reference src/traits/hash_to_point.rs:11 takes any DST)."""
+    dst = b'QUUX-V01-CS02-with-expander-SHA256-128-long-DST-' + b'1' * 208
+    assert len(dst) == 256
+    assert hashlib.sha256(b'H2C-OVERSIZE-DST-' + dst).hexdigest() == '412717974da474d0f8c420f320ff81e8432adb7c927d9bd082b4fb4d16c0a236'
+    assert c.expand_message_xmd(b'', dst, 0x20).hex() == 'e8dc0c8b686b7ef2074086fbdd2f30e3f8bfbd3bdf177f73f04b97ce618a3ed3'
+    # at 255 bytes the DST is used as it is
+    d255 = dst[:255]
+    b0 = hashlib.sha256(bytes(64) + b'm' + (32).to_bytes(2, 'big') + b'\x00' + d255 + b'\xff').digest()
+    assert c.expand_message_xmd(b'm', d255, 32) == hashlib.sha256(b0 + b'\x01' + d255 + b'\xff').digest()
+
+
 def test_sswu_curves_and_isogenies():
     """The derived isogeny tables: E' has the order of E, the maps land on E and are group homomorphisms."""
     rng = random.Random(5)

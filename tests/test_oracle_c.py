@@ -50,6 +50,10 @@ def test_c_oracle_vs_python_oracle(bo):
             out = ctypes.create_string_buffer(48 * group)
             bo.bo_hash_to_point(group, m, len(m), dst, len(dst), out)
             assert out.raw == comp(h(m, dst))
+        for dl in (255, 256, 300):          # RFC 9380 5.3.3: from 256 bytes on the DST is hashed first (pinned by K.2 in test_oracle.py)
+            dst = (b'oversize-dst-%d-' % group) * 30
+            bo.bo_hash_to_point(group, b'abc', 3, dst[:dl], dl, out)
+            assert out.raw == comp(h(b'abc', dst[:dl])), dl
     for C, sg in ((ref.G1Impl, 1), (ref.G2Impl, 2)):
         pkraw, sigraw = (util.g2_raw, util.g1_raw) if sg == 1 else (util.g1_raw, util.g2_raw)
         for scheme in (ref.BASIC, ref.AUG, ref.POP):

@@ -2,9 +2,9 @@
 # Round profiles on the GPU box (run through gpurun from the repo root): rocprofv3 kernel statistics of the bench command and
 # of all configs, PMC passes (HBM traffic, wait shares, instruction counts) of the bench command, the dominant kernels' HBM-side
 # traffic as bench.py reads it (pmc_traffic.json), and the CPU legs of configs 1/3/4/5 (SKIP_CPU_LEGS=1 skips them).
-# Outputs under gpurun_out/prof_$ROUND/ (ROUND defaults to r03); copy the summaries into profiles/ with the round's prefix.
+# Outputs under gpurun_out/prof_$ROUND/ (ROUND defaults to r04); copy the summaries into profiles/ with the round's prefix.
 set -e -o pipefail
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 OUT=gpurun_out/prof_$ROUND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
@@ -25,7 +25,7 @@ python3 - $OUT $ROUND <<'PY'
 import json, sys
 out, rnd = sys.argv[1], sys.argv[2]
 d = json.load(open(out + '/pmc_default.json'))
-names = {'k_finalexp2s': 'k_finalexp', 'k_millerf2s': 'k_miller2', 'k_lines2s': 'k_lines2', 'k_prepare<1>': 'k_prepare', 'k_finalexps': 'k_finalexp', 'k_miller2s': 'k_miller2'}
+names = {'k_finalexp2s': 'k_finalexp2s', 'k_millerf2s': 'k_millerf2s', 'k_lines2s': 'k_lines2s', 'k_prepare<1>': 'k_prepare', 'k_finalexps': 'k_finalexps', 'k_miller2s': 'k_miller2s'}   # rocprof kernel name -> the library's profile id (blsgpu_profile_get)
 res = {}
 for k, v in d.items():
     if k in names and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v and names[k] not in res:
