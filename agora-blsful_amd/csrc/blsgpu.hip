@@ -78,6 +78,7 @@ bool g_peer_ok = true;              // every bound device can read every other o
 std::mutex g_init_mu;
 bool initialised() { return !g_devices.empty(); }
 
+void trim_workspaces(Ctx* c);
 struct Lease {
   Ctx* c = nullptr;
   std::unique_lock<std::mutex> lk;
@@ -103,6 +104,7 @@ struct Lease {
       (void)hipGetLastError();
       (void)hipStreamSynchronize(c->tail);
     }
+    trim_workspaces(c);
   }
 };
 Lease acquire_ctx(size_t devidx) {
@@ -150,6 +152,7 @@ struct Knobs {
   long coop_max = 4096, wide_max = 512, shard_min = 8192, contexts = 2, fake_devices = 0, acc_lanes = 57344;
   long msm_c = 0, msm_ch = 0, msm2_c = 0, msm2_ch = 0, msm2_q = 0;          // 0: the library's own choice
   long host_trace = 0, strict_env = 0, ab_knobs = 0;
+  long ws_keep_mb = 4096;     // a context's line workspace above this many MiB is released when the call that grew it returns
   // A/B
   long miller_chunk = 65536, miller_v1 = 0, row_pad = 192, wide_mode = 2, finalexp_seg = 0, finalexp_v1 = 0, prepare_lanes = 0, product_tree = 1,
        tree_local = 0, lines4_max = -1, tree_engine_from = 0, agg_lanes = 0, msm_v1 = 0, msm_naive = 0, wide_test_block = 64, prepare_v1 = 0, post_v1 = 0;
@@ -163,6 +166,7 @@ const KnobSpec KNOB_TABLE[] = {
     {"BLSGPU_MSM_C", &Knobs::msm_c, 4, 16, false},                      {"BLSGPU_MSM_CH", &Knobs::msm_ch, 1, 1 << 16, false},
     {"BLSGPU_MSM2_C", &Knobs::msm2_c, 4, 16, false},                    {"BLSGPU_MSM2_CH", &Knobs::msm2_ch, 1, 1 << 16, false},
     {"BLSGPU_MSM2_Q", &Knobs::msm2_q, 1, 8, false},                     {"BLSGPU_HOST_TRACE", &Knobs::host_trace, 0, 1, false},
+    {"BLSGPU_WS_KEEP_MB", &Knobs::ws_keep_mb, 0, 1L << 20, false},
     {"BLSGPU_STRICT_ENV", &Knobs::strict_env, 0, 1, false},             {"BLSGPU_AB_KNOBS", &Knobs::ab_knobs, 0, 1, false},
     {"BLSGPU_MILLER_CHUNK", &Knobs::miller_chunk, 0, 65536, true},      {"BLSGPU_MILLER_V1", &Knobs::miller_v1, 0, 1, true},
     {"BLSGPU_ROW_PAD", &Knobs::row_pad, 0, 4096, true},                 {"BLSGPU_WIDE_MODE", &Knobs::wide_mode, 1, 2, true},
@@ -207,10 +211,10 @@ Knobs parse_knobs() {
   }
   return k;
 }
-const Knobs& knobs() {
-  static const Knobs k = parse_knobs();     // once per process (C++11 static initialisation is thread-safe)
-  return k;
-}
+// Parsed when the library binds its devices (blsgpu_init / blsgpu_init_devices on an unbound library, under g_init_mu) and constant
+// until blsgpu_shutdown: no compute call can run while the library is unbound, so nobody reads the struct while it is rewritten.
+Knobs g_knobs;
+const Knobs& knobs() { return g_knobs; }
 
 #define HIPCK(x)                                                                                   \
   do {                                                                                             \
@@ -580,8 +584,13 @@ size_t row_stride(size_t lanes) { return lanes + (size_t)knobs().row_pad; }
 // the context's line workspace; 0 on success, non-zero (and no error recorded) when the device has no room for it
 int lines_reserve(Ctx* c, size_t bytes) {
   if (bytes <= c->lines_cap) return 0;
+  auto note = [&](const char* why) {      // the caller falls back to a slower plan: say so once per process instead of changing plans silently (advisor r3)
+    static std::atomic<bool> said{false};
+    if (!said.exchange(true)) fprintf(stderr, "libblsgpu: no room for a %zu MiB line workspace (%s): falling back to the one-kernel Miller loops\n", bytes >> 20, why);
+  };
   if (hipStreamSynchronize(c->stream) != hipSuccess) {
     (void)hipGetLastError();
+    note("stream error");
     return 1;
   }
   if (c->lines_ws) (void)hipFree(c->lines_ws);
@@ -590,10 +599,20 @@ int lines_reserve(Ctx* c, size_t bytes) {
   if (hipMalloc((void**)&c->lines_ws, bytes) != hipSuccess) {
     (void)hipGetLastError();
     c->lines_ws = nullptr;
+    note("hipMalloc failed");
     return 1;
   }
   c->lines_cap = bytes;
   return 0;
+}
+// end of a call (Lease::~Lease, streams idle): a line workspace above BLSGPU_WS_KEEP_MB (default 4 GiB; the 65,536-item chunk of a
+// batch needs 2.5 GB, the 262,144-pair plan of an aggregate 2.6 GB) does not stay with the pooled context for the life of the process
+void trim_workspaces(Ctx* c) {
+  if (c->lines_ws && (c->lines_cap >> 20) > (size_t)knobs().ws_keep_mb) {
+    (void)hipFree(c->lines_ws);
+    c->lines_ws = nullptr;
+    c->lines_cap = 0;
+  }
 }
 
 // the two-pair pairing check of every item whose status is still BLS_OK: status <- OK / INVALID_SIGNATURE.
@@ -793,9 +812,8 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
     KL(KID_PREPARE, k_prepare_hashed<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_pks, d_sigs, (const uint8_t*)d_hashes, d_pairs, d_status, fmt);
     return run_pairing2(c, n, d_pairs, d_f, d_status, 2);
   }
-  // two lanes per item (the two SSWU maps side by side, G2 point arithmetic on the lane-split tower): always for
-  // Bls12381G2Impl, whose hash-to-G2 halves its per-lane work that way; for Bls12381G1Impl only in latency mode (the
-  // Fp-only remainder would run redundantly and a full batch is faster with one lane per item -- both measured)
+  // two lanes per item (the two SSWU maps side by side, G2 point arithmetic on the lane-split tower) for both implementations
+  // and every batch size (rounds 1-2 used one lane per item for full Bls12381G1Impl batches; see below)
   const int force_lanes = (int)knobs().prepare_lanes;   // A/B aid: 1 or 2 lanes per item in k_prepare<1>
   // two lanes per item also for full Bls12381G1Impl batches since round 3: 1.69 against 1.80 ms at 65,536 items (k_prepare is a one-wave-per-SIMD kernel
   // otherwise, and a lone wave issues a multiply-add every 8.8 cycles where two waves share the pipe at 4.4)
@@ -1595,6 +1613,7 @@ static void release_devices() {
 
 // BLSGPU_STRICT_ENV=1: refuse to start over an environment the knob table does not fully understand (before any device is touched)
 static int strict_env_check() {
+  if (!initialised()) g_knobs = parse_knobs();
   const Knobs& k = knobs();
   if (k.strict_env && !k.problem.empty()) return fail(BLSGPU_E_ARG, "BLSGPU_STRICT_ENV: " + k.problem);
   return 0;
@@ -2760,7 +2779,7 @@ static int hash_to_group(int group, const uint8_t* msgs, const uint64_t* msg_off
   uint8_t* d_out = is_device_ptr(out) ? (uint8_t*)out : (uint8_t*)arena_take(c, osz * n);
   if (!d_out) return fail(BLSGPU_E_HIP, "internal: arena too small");
   dst_arg d = make_dst(dst, dst_len);
-  // two lanes per message as in run_verify_items: always for G2, for G1 only in latency mode (small batches)
+  // two lanes per message: always for G2; for G1 up to the cooperative threshold (a full hash-only batch is faster with one lane per message)
   const int two = (group == 2 || n <= coop_max_items()) ? 1 : 0;
   if (group == 1 && n <= wide_max_items())   // a few messages: one wave each in the row-wide field type (0.98 ms against 1.6 ms of latency)
   {

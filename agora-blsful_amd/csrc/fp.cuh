@@ -135,8 +135,7 @@ BLS_FN void fp_norm(fp& r, const fp& a) {
 // Value reduction: subtract the multiple of p nearest to the value (quotient estimated from the top limb, whose unit
 // 2^364 is p / 106,514, so the lazy lower limbs cannot disturb it) in one exact carry pass.
 // Result: limbs 0..12 in [0, 2^28), signed top limb, value in (-0.52 p, 0.52 p).  Any input with limbs below 2^31 - 2^8.
-BLS_FN void fp_reduce(fp& r, const fp& a) {
-  FP_TRK(if (a.lb >= 2147483392.0) fp_trk_fail("fp_reduce limb < 2^31 - 2^8", a.lb, 0); if (a.vb > 120.0) fp_trk_fail("fp_reduce |value| < 120 p", a.vb, 0);)
+BLS_FN void fp_reduce_body(fp& r, const fp& a) {
   const int32_t k = (int32_t)rintf((float)a.l[FP_NL - 1] * FP_PTOP_INV);
   int32_t c = 0;
 #pragma unroll
@@ -150,6 +149,16 @@ BLS_FN void fp_reduce(fp& r, const fp& a) {
     }
   }
   FP_TRK(r.lb = FP_LB_N; r.vb = 0.52;)
+}
+BLS_FN void fp_reduce(fp& r, const fp& a) {
+  FP_TRK(if (a.lb >= 2147483392.0) fp_trk_fail("fp_reduce limb < 2^31 - 2^8", a.lb, 0); if (a.vb > 120.0) fp_trk_fail("fp_reduce |value| < 120 p", a.vb, 0);)
+  fp_reduce_body(r, a);
+}
+// the same pass on the exact limbs of a non-negative integer below 2^392 (fp_from_raw): limbs in [0, 2^28), so the quotient (at most
+// 2^392 / p = 2,522) times a limb of p stays far inside 64 bits and the carries inside 32
+BLS_FN void fp_reduce_shifted_raw(fp& r, const fp& a) {
+  FP_TRK(if (a.lb > FP_LB_N) fp_trk_fail("fp_reduce_shifted_raw exact limbs", a.lb, 0); if (a.vb > 2522.0) fp_trk_fail("fp_reduce_shifted_raw value < 2^392", a.vb, 0);)
+  fp_reduce_body(r, a);
 }
 
 // The value reduction of ka a + kb b (small integer coefficients, e.g. 3 t - 2 z of a compressed squaring) in ONE pass: the
@@ -430,14 +439,72 @@ BLS_FN void fp_from_mont(fp& r, const fp& a) {
   fp_mul(t, a, one);
   fp_canon(r, t);
 }
-// caller format: blst's Montgomery words (R = 2^384)
+// caller format: blst's Montgomery words (R = 2^384).  The internal form is the same residue times 2^8 (R = 2^392): the limbs of the
+// raw integer SHIFTED LEFT BY EIGHT BITS -- it stays below 2^392, fourteen limbs exactly -- and one value reduction.  No
+// multiplication (round 4; rounds 1-3 multiplied by 2^400 mod p: ~530 instructions per element against ~75 -- 6 of the 49
+// multiplication-equivalents per key of a 2^20-key sum).  The reduction's quotient estimate reads the top limb (below 2^28 here: the
+// float conversion is off by at most 2^4 units of p / 106,514) and its carry pass is exact for any quotient below 2^31 / 2^28, so
+// the 256 p (2,522 p for a caller's non-canonical words) of the shifted integer are as good as fp_reduce's usual few dozen.
 BLS_FN void fp_from_raw(fp& r, const uint32_t* w) {
+  fp t;
+  t.l[0] = (int32_t)((w[0] << 8) & FP_MASK);
+#pragma unroll
+  for (int i = 1; i < FP_NL; i++) {
+    const int bit = FP_LB * i - 8, j = bit >> 5, sh = bit & 31;
+    uint64_t x = w[j];
+    if (j + 1 < 12) x |= (uint64_t)w[j + 1] << 32;
+    t.l[i] = (int32_t)((uint32_t)(x >> sh) & FP_MASK);
+  }
+  FP_TRK(t.lb = FP_LB_N; t.vb = 2522.0;)   // 2^392 / p
+  fp_reduce_shifted_raw(r, t);
+}
+// (the multiplication form, kept for the host-side cross-check of the shifted one: tests/hostsim hs_from_raw_forms_agree)
+BLS_FN void fp_from_raw_mul(fp& r, const uint32_t* w) {
   fp t, k;
   fp_set_words(t, w);
   fp_load(k, FP_C400);
   fp_mul(r, t, k);
 }
+// ... and back: the caller's residue is the internal one divided by 2^8 modulo p.  Exactly, without a multiplication (round 4): T = the
+// canonical integer in [0, p); the multiple m p with m = -T p^-1 mod 2^8 clears T's low eight bits (one digit of a Montgomery
+// reduction in radix 2^8); (T + m p) / 2^8 is below p + p / 256, so one conditional subtraction of p gives the canonical words --
+// the very words the multiplication by 2^384 mod p of rounds 1-3 produced (fp_to_raw_mul, cross-checked in tests/hostsim).
 BLS_FN void fp_to_raw(uint32_t* w, const fp& a) {
+  fp t, v, d;
+  fp_canon(t, a);
+  const int32_t m = (int32_t)(((uint32_t)t.l[0] * (FP_N0INV & 0xffu)) & 0xffu);
+  int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) {             // U = T + m p on exact limbs (the top limb takes what is left)
+    const int64_t x = (int64_t)t.l[i] + (int64_t)m * (int32_t)FP_P[i] + c;
+    if (i < FP_NL - 1) {
+      t.l[i] = (int32_t)((uint32_t)x & FP_MASK);
+      c = x >> FP_LB;
+    } else {
+      t.l[i] = (int32_t)x;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++)               // V = U / 2^8: limb i takes its own upper 20 bits and the low 8 of limb i + 1
+    v.l[i] = (int32_t)(((uint32_t)t.l[i] >> 8) | (i + 1 < FP_NL ? ((uint32_t)t.l[i + 1] & 0xffu) << 20 : 0u));
+  int32_t b = 0;
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) {             // D = V - p with borrows
+    const int32_t x = v.l[i] - (int32_t)FP_P[i] + b;
+    if (i < FP_NL - 1) {
+      d.l[i] = x & (int32_t)FP_MASK;
+      b = x >> FP_LB;
+    } else {
+      d.l[i] = x;
+    }
+  }
+  const bool ge = d.l[FP_NL - 1] >= 0;          // V >= p
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) v.l[i] = ge ? d.l[i] : v.l[i];
+  FP_TRK(v.lb = FP_LB_N; v.vb = 1.0;)
+  fp_get_words(w, v);
+}
+BLS_FN void fp_to_raw_mul(uint32_t* w, const fp& a) {
   fp t, k;
   fp_load(k, FP_C384);
   fp_mul(t, a, k);

@@ -557,6 +557,7 @@ def main(argv=None):
     ap.add_argument('--cpu-sample', type=int, default=4096)
     ap.add_argument('--config', type=int, default=2, choices=[2, 3, 4, 5])
     ap.add_argument('--variant', default='g1m', choices=sorted(VARIANTS))
+    ap.add_argument('--impl', default='g1', choices=['g1', 'g2'], help='config 2: Bls12381G1Impl (the headline, BASELINE configs[1]) or Bls12381G2Impl (profiling aid: implies --no-extras, no CPU leg)')
     ap.add_argument('--size', type=int, default=None, help='total size of config 3 / 4 / 5 (default: BASELINE.json\'s)')
     ap.add_argument('--keys-as-deserialised', action='store_true', help='config 3: feed keys with Z = 1 (what a verifier holds after decoding the wire bytes)')
     ap.add_argument('--grouped', type=int, default=None, metavar='K', help='config 2 through the opt-in grouped entry with every K-th item tampered (0: all valid); not the headline, not in the default run (frozen: DESIGN 9.5)')
@@ -576,6 +577,10 @@ def main(argv=None):
     if args.config == 2 and args.grouped is not None:
         out = run_config2_grouped(h, args.steps, args.warmup, args.n, args.grouped)
         out.update(common)
+    elif args.config == 2 and args.impl == 'g2':
+        out = run_config2(h, args, sg=2, headline=False)
+        if out is not None:
+            out['config']['note'] = 'NOT the headline: Bls12381G2Impl orientation of configs[1] (--impl g2)'
     elif args.config == 2:
         out = run_config2(h, args)
         if not args.no_extras:

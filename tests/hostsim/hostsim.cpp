@@ -60,6 +60,35 @@ int hs_device_path_only = 0;   // tools/count_fpmul.py: run exactly what the ker
 void hs_fp_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) {
   fp x, y, z; fp_from_raw(x, a); fp_from_raw(y, b); fp_mul(z, x, y); fp_to_raw(out, z);
 }
+// the two conversions from the caller's words: the shifted integer with one value reduction (round 4) and the multiplication by
+// 2^400 mod p (rounds 1-3).  out: the canonical limbs of each (14 + 14 words); returns 1 when they are equal
+int hs_from_raw_forms(const uint32_t* a, int32_t* out) {
+  fp x, y;
+  fp_from_raw(x, a);
+  fp_from_raw_mul(y, a);
+  fp_canon(x, x);
+  fp_canon(y, y);
+  int same = 1;
+  for (int i = 0; i < FP_NL; i++) {
+    out[i] = x.l[i];
+    out[FP_NL + i] = y.l[i];
+    same &= x.l[i] == y.l[i];
+  }
+  return same;
+}
+// lazy limbs (any redundant form within the stated bounds) -> the caller's words, both forms; returns 1 when they are equal
+int hs_to_raw_forms(const int32_t* limbs, double lb, double vb, uint32_t* out) {
+  fp a;
+  for (int i = 0; i < FP_NL; i++) a.l[i] = limbs[i];
+  FP_TRK(a.lb = lb; a.vb = vb;)
+  (void)lb; (void)vb;
+  uint32_t w2[12];
+  fp_to_raw(out, a);
+  fp_to_raw_mul(w2, a);
+  int same = 1;
+  for (int i = 0; i < 12; i++) same &= out[i] == w2[i];
+  return same;
+}
 void hs_fp_inv_var(const uint32_t* a, uint32_t* out) {   // the variable-time inversion of the lone-lane paths
   fp x, z; fp_from_raw(x, a); fp_inv_var(z, x); fp_to_raw(out, z);
 }

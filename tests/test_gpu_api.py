@@ -409,7 +409,7 @@ def test_verify_batch_large_property(api):
 def test_verify_batch_vs_c_oracle(api, sg, path):
     """Device-signed items with tampered messages, swapped signatures and swapped keys, both orientations, all three schemes'
     DSTs: the status vector must equal the C oracle's, item by item.  704 items take the wave-cooperative pairing and the
-    two-lane prepare, 6,656 (beyond the threshold of 6,144) the lane-split Miller / final-exponentiation kernels."""
+    two-lane prepare, 6,656 (beyond the threshold, BLSGPU_COOP_MAX = 4,096 since round 3) the lane-split Miller / final-exponentiation kernels."""
     import os
     n = 704 if path == 'cooperative' else int(os.environ.get('BLS_DIFF_N', '6656'))     # soak runs: BLS_DIFF_N=60000
     bo = util.load_c_oracle()
@@ -446,7 +446,7 @@ def test_verify_batch_vs_c_oracle(api, sg, path):
 @pytest.mark.parametrize('sg', [1, 2])
 def test_verify_batch_ragged_sizes(api, sg):
     """Batch sizes around the wave (32 items) and workgroup boundaries and on both sides of the cooperative / lane-split
-    threshold (6,144 items), empty batch included: one tampered item per batch, exact verdict vectors, both orientations."""
+    threshold (4,096 items since round 3; 6,145 stays in the list as a plain lane-split size), empty batch included: one tampered item per batch, exact verdict vectors, both orientations."""
     sizes = (0, 1, 2, 31, 32, 33, 63, 65, 255, 257, 511, 512, 513, 1023, 1024, 1025, 1057, 4096, 4097, 4129, 6145) if sg == 1 else (0, 1, 33, 511, 513, 1025, 4097)
     nmax = max(sizes)
     sks = [0x5151 + 3 * i for i in range(nmax)]

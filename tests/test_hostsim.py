@@ -38,6 +38,53 @@ def test_fp_ops(hs):
         assert util.fp_from_raw(out.raw) == (pow(a, -1, P) if a else 0)
 
 
+def test_fp_from_raw_without_a_multiplication(hs):
+    """fp_from_raw since round 4: the raw integer shifted left by eight bits (R = 2^384 -> 2^392) and ONE value reduction, no
+    multiplication.  Against the integers and against the multiplication form of rounds 1-3, on canonical words, on the edges, and
+    on NON-canonical words up to 2^384 - 1 (2,522 p after the shift: the quotient estimate's largest input; the bound tracker checks
+    the stated limits on the way)."""
+    rng = random.Random(44)
+    R384 = 1 << 384
+    M = (1 << 28) - 1
+    vals = [0, 1, 2, P - 1, P, P + 1, 2 * P - 1, R384 - 1, R384 - P, (R384 // P) * P, (R384 // P) * P - 1, 1 << 383, (1 << 376) - 1, 0xff << 376]
+    # integers whose shifted form sits at the rounding boundary of the quotient estimate: (k + 1/2) p / 256 for many k
+    vals += [((2 * k + 1) * P // 512 + d) % R384 for k in (0, 1, 7, 100, 1260, 2520, 2521) for d in (-1, 0, 1)]
+    vals += [rng.randrange(R384) for _ in range(2000)] + [rng.randrange(P) for _ in range(1000)]
+    out = (ctypes.c_int32 * 28)()
+    for v in vals:
+        words = v.to_bytes(48, 'little')
+        assert hs.hs_from_raw_forms(words, out) == 1, hex(v)
+        got = sum((out[i] & 0xffffffff if i < 13 else out[i]) << (28 * i) for i in range(14))
+        assert got == (v << 8) % P and all(0 <= out[i] <= M for i in range(13)), hex(v)     # the element a * 2^392 for raw = a * 2^384
+
+
+def test_fp_to_raw_without_a_multiplication(hs):
+    """fp_to_raw since round 4: canonical integer, one radix-2^8 Montgomery digit, one conditional subtraction.  Against the integers
+    (internal value v = e 2^392 -> words of e 2^384 mod p = v / 2^8 mod p) and against the multiplication form, on values whose
+    quotient lands on both sides of the conditional subtraction and on redundant signed limbs."""
+    rng = random.Random(45)
+    inv256 = pow(256, -1, P)
+    M = (1 << 28) - 1
+    vals = [0, 1, 255, 256, 257, P - 1, P - 256, P - 255, (P - 1) // 2]
+    vals += [(256 * t - m * P) % P for t in (P - 1, P - 2, 0, 1, P // 2) for m in (0, 1, 128, 255)]     # T + m p = 256 t: t at the top and bottom of the range
+    vals += [rng.randrange(P) for _ in range(3000)]
+    out = (ctypes.c_uint32 * 12)()
+    for v in vals:
+        limbs = [(v >> (28 * i)) & M for i in range(14)]
+        if rng.random() < 0.5:                    # a redundant form of the same integer: borrow between neighbours, add a few p
+            k = rng.randint(-3, 3)
+            vv = v + k * P
+            limbs = [((vv >> (28 * i)) & M) for i in range(13)] + [vv >> (28 * 13)]
+            for i in range(13):
+                d = rng.randint(-5, 5)
+                limbs[i] += d << 28
+                limbs[i + 1] -= d
+        arr = (ctypes.c_int32 * 14)(*limbs)
+        assert hs.hs_to_raw_forms(arr, ctypes.c_double(max(abs(x) for x in limbs) + 1), ctypes.c_double(5.0), out) == 1, hex(v)
+        got = sum(int(out[i]) << (32 * i) for i in range(12))
+        assert got == v * inv256 % P, hex(v)
+
+
 def test_fp_lazy_limbs(hs):
     """fp_norm / fp_reduce / fp_canon / fp_is_zero on redundant signed-limb vectors: exact multiples of p in lazy form,
     values at the rounding boundary of the quotient estimate, negative values, maximal limb magnitudes."""

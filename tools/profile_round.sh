@@ -20,6 +20,17 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_C
   echo "pmc pass $i ($c) done"
 done
 python3 tools/pmc_summary.py $OUT/pmc_* > $OUT/pmc_default.json
+# the same wait / issue counters for the Bls12381G2Impl batch (k_prepare<2>, two-pass k_lines2s): two passes
+if [ -z "$SKIP_G2IMPL" ]; then
+  j=0
+  for c in "SQ_WAVES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
+    j=$((j+1))
+    d=$OUT/pmcg2_$j
+    rocprofv3 --pmc $c --output-format csv -d $d -- python3 bench.py --impl g2 --steps 2 --warmup 1 > /dev/null 2> $d.err
+    echo "pmc g2impl pass $j ($c) done"
+  done
+  python3 tools/pmc_summary.py $OUT/pmcg2_* > $OUT/pmc_g2impl.json
+fi
 # what bench.py reads for roofline.traffic: FETCH_SIZE / WRITE_SIZE (KB) per launch, keyed by the library's profile names
 python3 - $OUT $ROUND <<'PY'
 import json, sys
