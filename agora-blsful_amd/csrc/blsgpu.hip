@@ -155,7 +155,7 @@ struct Knobs {
   long ws_keep_mb = 4096;     // a context's line workspace above this many MiB is released when the call that grew it returns
   // A/B
   long miller_chunk = 65536, miller_v1 = 0, row_pad = 192, wide_mode = 2, finalexp_seg = 0, finalexp_v1 = 0, prepare_lanes = 0, product_tree = 1,
-       tree_local = 0, lines4_max = -1, tree_engine_from = 0, agg_lanes = 0, msm_v1 = 0, msm_naive = 0, wide_test_block = 64, prepare_v1 = 0, post_v1 = 0;
+       tree_local = 0, lines4_max = -1, tree_engine_from = 0, agg_lanes = 0, msm_v1 = 0, msm_naive = 0, wide_test_block = 64;
   std::string problem;        // what BLSGPU_STRICT_ENV objects to (empty: nothing)
 };
 struct KnobSpec { const char* name; long Knobs::*field; long lo, hi; bool ab; };
@@ -175,8 +175,7 @@ const KnobSpec KNOB_TABLE[] = {
     {"BLSGPU_TREE_LOCAL", &Knobs::tree_local, 0, 65536, true},          {"BLSGPU_LINES4_MAX", &Knobs::lines4_max, 0, 65536, true},
     {"BLSGPU_TREE_ENGINE_FROM", &Knobs::tree_engine_from, 0, 256, true}, {"BLSGPU_AGG_LANES", &Knobs::agg_lanes, 0, 2, true},
     {"BLSGPU_MSM_V1", &Knobs::msm_v1, 0, 1, true},                      {"BLSGPU_MSM_NAIVE", &Knobs::msm_naive, 0, 1, true},
-    {"BLSGPU_WIDE_TEST_BLOCK", &Knobs::wide_test_block, 64, 256, true}, {"BLSGPU_PREPARE_V1", &Knobs::prepare_v1, 0, 1, true},
-    {"BLSGPU_POST_V1", &Knobs::post_v1, 0, 1, true},
+    {"BLSGPU_WIDE_TEST_BLOCK", &Knobs::wide_test_block, 64, 256, true},
 };
 // read by the Python wrapper / debug builds only, never by this file's product paths: known names for the strict check
 const char* const KNOB_OTHER_NAMES[] = {"BLSGPU_LIB", "BLSGPU_HASH_STOP"};
