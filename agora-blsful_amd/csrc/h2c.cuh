@@ -359,30 +359,43 @@ BLS_NOINLINE void sswu_g1(F& xn, F& xd, F& y, const F& u) {
   xd = tv4;
 }
 
-// homogenised Horner: sum_i k_i xn^i xd^(D-i), zp[j] = xd^j
-BLS_FN void iso1_poly(fp& r, const uint32_t (*k)[FP_NL], int deg, const fp& xn, const fp* zp) {
-  fp acc, c, t;
-  fp_load(acc, k[deg]);
-  for (int i = deg - 1; i >= 0; i--) {
-    fp_mul(acc, acc, xn);
-    fp_load(c, k[i]);
-    fp_mul(t, c, zp[deg - i]);
-    fp_add(acc, acc, t);
-  }
-  r = acc;
-}
-
-// 11-isogeny E'1 -> E1 applied to (xn/xd, y); Jacobian output
+// The four polynomials of the 11-isogeny E'1 -> E1 in homogenised Horner form, sum_i k_i xn^i xd^(D-i), evaluated IN LOCKSTEP over one
+// running power xd^j (round 4): acc_q <- acc_q xn + k_q[D_q - j] xd^j for every polynomial of degree D_q >= j.  The same 15 + 2 x 51
+// multiplications as with a table of the sixteen powers, but the table was 896 bytes of scratch per lane read through a run-time index (14 loads in
+// front of every second multiplication) -- the largest frame of the k_prepare<1> / k_prepare_agg<1> / k_hash_to_g1 family, whose waves wait
+// twice as long as the other kernels' (profiles/r04_pmc_default.json).
 BLS_NOINLINE void iso_map_g1(g1_jac& r, const fp& xn, const fp& xd, const fp& y) {
-  fp zp[16];
-  fp_one(zp[0]);
-  zp[1] = xd;
-  for (int i = 2; i < 16; i++) fp_mul(zp[i], zp[i - 1], xd);
-  fp XN, XD, YN, YD, zx, t, yd2;
-  iso1_poly(XN, ISO1_XNUM, 11, xn, zp);
-  iso1_poly(XD, ISO1_XDEN, 10, xn, zp);
-  iso1_poly(YN, ISO1_YNUM, 15, xn, zp);
-  iso1_poly(YD, ISO1_YDEN, 15, xn, zp);
+  fp XN, XD, YN, YD, pw, c, t;
+  fp_load(XN, ISO1_XNUM[11]);
+  fp_load(XD, ISO1_XDEN[10]);
+  fp_load(YN, ISO1_YNUM[15]);
+  fp_load(YD, ISO1_YDEN[15]);
+  pw = xd;
+#pragma unroll          // static coefficient addresses: their loads are issued ahead of the multiplications instead of one exposed latency per term
+  for (int j = 1; j <= 15; j++) {
+    if (j > 1) fp_mul(pw, pw, xd);
+    if (j <= 11) {
+      fp_mul(XN, XN, xn);
+      fp_load(c, ISO1_XNUM[11 - j]);
+      fp_mul(t, c, pw);
+      fp_add(XN, XN, t);
+    }
+    if (j <= 10) {
+      fp_mul(XD, XD, xn);
+      fp_load(c, ISO1_XDEN[10 - j]);
+      fp_mul(t, c, pw);
+      fp_add(XD, XD, t);
+    }
+    fp_mul(YN, YN, xn);
+    fp_load(c, ISO1_YNUM[15 - j]);
+    fp_mul(t, c, pw);
+    fp_add(YN, YN, t);
+    fp_mul(YD, YD, xn);
+    fp_load(c, ISO1_YDEN[15 - j]);
+    fp_mul(t, c, pw);
+    fp_add(YD, YD, t);
+  }
+  fp zx, yd2;
   fp_mul(zx, XD, xd);     // x_out = XN / zx,  y_out = y YN / YD
   fp_mul(r.z, zx, YD);    // Z = zx YD
   fp_sqr(yd2, YD);

@@ -228,8 +228,8 @@ OVERLAPPED = ('tail_stream_overlapped',)   # launched on a side stream beside th
 
 
 def r6(x):
-    """six significant digits: the driver keeps the last 8 KB of stdout, the line must fit"""
-    return float('%.6g' % x)
+    """six significant digits (whole numbers stay exact): the driver keeps the last 8 KB of stdout, the line must fit"""
+    return int(round(x)) if abs(x - round(x)) < 1e-9 * max(1.0, abs(x)) else float('%.6g' % x)
 
 
 def kernel_ms(prof, steps):
