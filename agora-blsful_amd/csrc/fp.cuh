@@ -64,7 +64,8 @@ static void fp_trk_fail(const char* what, double x, double y) {
 
 struct fp {
   int32_t l[FP_NL];
-  FP_TRK(double lb; double vb;)   // worst-case |limb| and |value| / p
+  FP_TRK(double lb; double vb;      // worst-case |limb| and |value| / p
+         bool nn = false;)         // limbs 0..12 known to lie in [0, 2^28) and the top limb within +-2^20 (a REDC / fp_reduce output): fp_lin4 bounds such operands by sign
 };
 
 // ---- basic ops -----------------------------------------------------------------------------------
@@ -72,7 +73,7 @@ struct fp {
 BLS_FN void fp_load(fp& r, const uint32_t* c) {
 #pragma unroll
   for (int i = 0; i < FP_NL; i++) r.l[i] = (int32_t)c[i];
-  FP_TRK(r.lb = FP_LB_N; r.vb = 1.125;)
+  FP_TRK(r.lb = FP_LB_N; r.vb = 1.125; r.nn = false;)
 }
 
 BLS_FN void fp_store(uint32_t* c, const fp& a) {
@@ -84,7 +85,7 @@ BLS_FN void fp_store(uint32_t* c, const fp& a) {
 BLS_FN void fp_zero(fp& r) {
 #pragma unroll
   for (int i = 0; i < FP_NL; i++) r.l[i] = 0;
-  FP_TRK(r.lb = 0; r.vb = 0;)
+  FP_TRK(r.lb = 0; r.vb = 0; r.nn = true;)
 }
 
 BLS_FN void fp_one(fp& r) { fp_load(r, FP_ONE); }
@@ -92,28 +93,28 @@ BLS_FN void fp_one(fp& r) { fp_load(r, FP_ONE); }
 BLS_FN void fp_cmov(fp& r, const fp& a, bool c) {  // r = c ? a : r
 #pragma unroll
   for (int i = 0; i < FP_NL; i++) r.l[i] = c ? a.l[i] : r.l[i];
-  FP_TRK(r.lb = fmax(r.lb, a.lb); r.vb = fmax(r.vb, a.vb);)
+  FP_TRK(r.lb = fmax(r.lb, a.lb); r.vb = fmax(r.vb, a.vb); r.nn = r.nn && a.nn;)
 }
 
 BLS_FN void fp_add(fp& r, const fp& a, const fp& b) {
   FP_TRK(const double lb = a.lb + b.lb, vb = a.vb + b.vb; if (lb >= 2147483648.0) fp_trk_fail("fp_add limb < 2^31", a.lb, b.lb);)
 #pragma unroll
   for (int i = 0; i < FP_NL; i++) r.l[i] = a.l[i] + b.l[i];
-  FP_TRK(r.lb = lb; r.vb = vb;)
+  FP_TRK(r.lb = lb; r.vb = vb; r.nn = false;)
 }
 
 BLS_FN void fp_sub(fp& r, const fp& a, const fp& b) {
   FP_TRK(const double lb = a.lb + b.lb, vb = a.vb + b.vb; if (lb >= 2147483648.0) fp_trk_fail("fp_sub limb < 2^31", a.lb, b.lb);)
 #pragma unroll
   for (int i = 0; i < FP_NL; i++) r.l[i] = a.l[i] - b.l[i];
-  FP_TRK(r.lb = lb; r.vb = vb;)
+  FP_TRK(r.lb = lb; r.vb = vb; r.nn = false;)
 }
 
 BLS_FN void fp_neg(fp& r, const fp& a) {
   FP_TRK(const double lb = a.lb, vb = a.vb;)
 #pragma unroll
   for (int i = 0; i < FP_NL; i++) r.l[i] = -a.l[i];
-  FP_TRK(r.lb = lb; r.vb = vb;)
+  FP_TRK(r.lb = lb; r.vb = vb; r.nn = false;)
 }
 
 BLS_FN void fp_dbl(fp& r, const fp& a) { fp_add(r, a, a); }
@@ -129,7 +130,7 @@ BLS_FN void fp_norm(fp& r, const fp& a) {
   for (int i = FP_NL - 2; i >= 1; i--) r.l[i] = (a.l[i] & FP_MASK) + c[i - 1];
   r.l[0] = a.l[0] & FP_MASK;
   r.l[FP_NL - 1] = top;
-  FP_TRK(r.lb = lb; r.vb = vb;)
+  FP_TRK(r.lb = lb; r.vb = vb; r.nn = false;)
 }
 
 // Value reduction: subtract the multiple of p nearest to the value (quotient estimated from the top limb, whose unit
@@ -148,7 +149,7 @@ BLS_FN void fp_reduce_body(fp& r, const fp& a) {
       r.l[i] = (int32_t)x;
     }
   }
-  FP_TRK(r.lb = FP_LB_N; r.vb = 0.52;)
+  FP_TRK(r.lb = FP_LB_N; r.vb = 0.52; r.nn = true;)
 }
 BLS_FN void fp_reduce(fp& r, const fp& a) {
   FP_TRK(if (a.lb >= 2147483392.0) fp_trk_fail("fp_reduce limb < 2^31 - 2^8", a.lb, 0); if (a.vb > 120.0) fp_trk_fail("fp_reduce |value| < 120 p", a.vb, 0);)
@@ -187,7 +188,7 @@ BLS_FN void fp_reduce_lin2(fp& r, const fp& a, int ka, const fp& b, int kb) {
       r.l[i] = (int32_t)x;
     }
   }
-  FP_TRK(r.lb = FP_LB_N; r.vb = 0.52;)
+  FP_TRK(r.lb = FP_LB_N; r.vb = 0.52; r.nn = true;)
 }
 
 // The representative in [0, p) with exact limbs.
@@ -206,7 +207,7 @@ BLS_FN void fp_canon(fp& r, const fp& a) {
       r.l[i] = x;
     }
   }
-  FP_TRK(r.lb = FP_LB_N; r.vb = 1.0;)
+  FP_TRK(r.lb = FP_LB_N; r.vb = 1.0; r.nn = true;)
 }
 
 BLS_FN bool fp_is_zero(const fp& a) {
@@ -287,7 +288,132 @@ BLS_FN void fp_redc_products(fp& r, const fp& a, const fp& b, const fp& c, const
   t[FP_NL - 1] = (int32_t)acc;
 #pragma unroll
   for (int i = 0; i < FP_NL; i++) r.l[i] = t[i];
-  FP_TRK(r.lb = FP_LB_N; r.vb = 1.125;)
+  FP_TRK(r.lb = FP_LB_N; r.vb = 1.125; r.nn = true;)
+}
+
+// A WHOLE Fp2 product on one lane by Karatsuba (round 4, second session; tools/ubench/ubench4.hip form 3, measured there: 22.8 G Fp2
+// products/s against 19.9 for the lane-split pair of fused passes):  (a0 + a1 u)(b0 + b1 u) = r0 + r1 u with
+//     r0 = REDC(a0 b0 - a1 b1)            r1 = REDC((a0 + a1)(b0 + b1) - a0 b0 - a1 b1)
+// Per column k: U_k = sum a0_i b0_(k-i) and V'_k = sum (-a1)_i b1_(k-i) in fresh 64-bit accumulators, W_k = sum (a0+a1)_i (b0+b1)_(k-i)
+// straight onto r1's running accumulator; r0's chain takes U_k + V'_k, r1's W_k + V'_k - U_k; two interleaved reduction chains.
+// 3 x 196 + 2 x 196 = 980 multiply-adds (the lane-split pair: 2 x 588) and no partner exchange.
+// Column bound: r1's accumulator holds 14 (|a0|+|a1|)(|b0|+|b1|) + 14 (|a0||b0| + |a1||b1|) + the reduction's 14 * 2^56 + a carry:
+// below 2^63 for operands with limbs up to 2^28 + 2^8 (7 * 2^59.81 = 2^62.62), i.e. NORMALISED operands.
+// fp_lin4: r = ka a + kb b + kc c + kd d limb-wise, small integer coefficients known at compile time (exact on the integers).  When every
+// operand is a REDC / fp_reduce output (limbs 0..12 in [0, 2^28): the tracker's `nn`) the result's limbs lie between -N 2^28 and P 2^28
+// for the sums N, P of the negative and positive coefficients -- the tracker then bounds them by the larger of the two instead of the
+// sum of magnitudes (a0 - b0 + b1 stays below 2^29, not 3 * 2^28): what lets the Karatsuba pass below take sums of differences
+// without a carry pass.
+BLS_FN void fp_lin4(fp& r, const fp& a, int ka, const fp& b, int kb, const fp& c, int kc, const fp& d, int kd) {
+#if defined(BLS_TRACK_BOUNDS) && !defined(__HIPCC__)
+  const int ks[4] = {ka, kb, kc, kd};
+  const fp* xs[4] = {&a, &b, &c, &d};
+  double mag = 0, pos = 0, neg = 0, vb = 0;
+  bool all_nn = true;
+  for (int j = 0; j < 4; j++) {
+    if (!ks[j]) continue;
+    const double k = ks[j] < 0 ? -ks[j] : ks[j];
+    mag += k * xs[j]->lb;
+    vb += k * xs[j]->vb;
+    if (ks[j] > 0) pos += k * xs[j]->lb; else neg += k * xs[j]->lb;
+    all_nn = all_nn && xs[j]->nn;
+  }
+  const double lb = all_nn ? fmax(pos, neg) : mag;
+  if (lb >= 2147483648.0) fp_trk_fail("fp_lin4 limb < 2^31", lb, mag);
+#endif
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) r.l[i] = ka * a.l[i] + kb * b.l[i] + kc * c.l[i] + kd * d.l[i];
+  FP_TRK(r.lb = lb; r.vb = vb; r.nn = false;)
+}
+// the pass proper: operands prepared by the caller -- a0, na1 = -a1, b0, b1, s = a0 + a1, t = b0 + b1 (each with its own tracked bound)
+BLS_FN void fp2_kara_core(fp& r0, fp& r1, const fp& a0, const fp& na1, const fp& b0, const fp& b1, const fp& s_, const fp& t_) {
+#if defined(BLS_TRACK_BOUNDS) && !defined(__HIPCC__)
+  {
+    const double uv = a0.lb * b0.lb + na1.lb * b1.lb, w = s_.lb * t_.lb;
+    if (14.0 * (uv + w) + 14.0 * 72057594037927936.0 + 68719476736.0 >= 9223372036854775808.0) fp_trk_fail("kara column sum < 2^63", uv, w);
+    if (a0.vb * b0.vb + na1.vb * b1.vb > 256.0 || a0.vb * b1.vb + na1.vb * b0.vb > 256.0) fp_trk_fail("kara REDC input <= 256 p^2", a0.vb * b0.vb + na1.vb * b1.vb, a0.vb * b1.vb + na1.vb * b0.vb);
+  }
+#endif
+  int32_t s[FP_NL], t[FP_NL], n1[FP_NL];
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) {
+    s[i] = s_.l[i];
+    t[i] = t_.l[i];
+    n1[i] = na1.l[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(s[i]));
+    asm volatile("" : "+v"(t[i]));
+    asm volatile("" : "+v"(n1[i]));
+#endif
+  }
+  int64_t acc0 = 0, acc1 = 0;
+  int32_t m0[FP_NL], m1[FP_NL], t0[FP_NL], t1[FP_NL];
+#pragma unroll
+  for (int k = 0; k < 2 * FP_NL - 1; k++) {
+    const int lo = k > FP_NL - 1 ? k - (FP_NL - 1) : 0, hi = k < FP_NL - 1 ? k : FP_NL - 1;
+    int64_t U = 0, Vn = 0;
+#pragma unroll
+    for (int i = lo; i <= hi; i++) {
+      FP_MADI(U, a0.l[i], b0.l[k - i]);
+      FP_MADI(Vn, n1[i], b1.l[k - i]);
+    }
+#pragma unroll
+    for (int i = lo; i <= hi; i++) FP_MADI(acc1, s[i], t[k - i]);
+    acc0 += U;
+    acc0 += Vn;
+    acc1 += Vn;
+    acc1 -= U;
+#pragma unroll
+    for (int i = lo; i <= hi; i++) {
+      if (k < FP_NL && i == k) continue;
+      FP_MADU(acc0, m0[i], FP_P[k - i]);
+      FP_MADU(acc1, m1[i], FP_P[k - i]);
+    }
+    if (k < FP_NL) {
+      m0[k] = (int32_t)(((uint32_t)acc0 * FP_N0INV) & FP_MASK);
+      m1[k] = (int32_t)(((uint32_t)acc1 * FP_N0INV) & FP_MASK);
+      FP_MADU(acc0, m0[k], FP_P[0]);
+      FP_MADU(acc1, m1[k], FP_P[0]);
+      acc0 >>= FP_LB;
+      acc1 >>= FP_LB;
+    } else {
+      t0[k - FP_NL] = (int32_t)((uint32_t)acc0 & FP_MASK);
+      t1[k - FP_NL] = (int32_t)((uint32_t)acc1 & FP_MASK);
+      acc0 >>= FP_LB;
+      acc1 >>= FP_LB;
+    }
+  }
+  t0[FP_NL - 1] = (int32_t)acc0;
+  t1[FP_NL - 1] = (int32_t)acc1;
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) {
+    r0.l[i] = t0[i];
+    r1.l[i] = t1[i];
+  }
+  FP_TRK(r0.lb = FP_LB_N; r0.vb = 1.125; r0.nn = true; r1.lb = FP_LB_N; r1.vb = 1.125; r1.nn = true;)
+}
+// (a0 + a1 u)(b0 + b1 u) for operands as they are
+BLS_FN void fp2_kara_products(fp& r0, fp& r1, const fp& a0, const fp& a1, const fp& b0, const fp& b1) {
+  fp n1, s, t;
+  fp_neg(n1, a1);
+  fp_add(s, a0, a1);
+  fp_add(t, b0, b1);
+  fp2_kara_core(r0, r1, a0, n1, b0, b1, s, t);
+}
+// (a - b)(a - xi b) for REDUCED a, b (xi = 1 + u):  a - xi b = (a0 - b0 + b1) + (a1 - b0 - b1) u.  The operands' limbs lie in [0, 2^28),
+// so every limb of these differences stays inside (-2^29, 2^29) -- a0 - b0 and a1 - b1 inside +-2^28 -- without a carry pass, and so do
+// the two sums the Karatsuba pass takes, (a0 + a1) - (b0 + b1) and (a0 + a1) - 2 b0: 14 (2^58 + 2^58) + 14 * 2^56 + 2^36 = 126 * 2^56 + 2^36
+// < 2^63 per column (fp_lin4's sign-aware bound is what proves it on the host; with the sum form (a + b)(a + xi b) the operands reach
+// 3 * 2^28 and the pass needs four carry passes first).  Half of an Fp4 squaring: a^2 + xi b^2 = (a - b)(a - xi b) + (1 + xi) a b.
+BLS_FN void fp2_kara_diffs(fp& r0, fp& r1, const fp& a0, const fp& a1, const fp& b0, const fp& b1) {
+  fp x0, nx1, y0, y1, s, t;
+  fp_lin4(x0, a0, 1, b0, -1, b0, 0, b0, 0);
+  fp_lin4(nx1, b1, 1, a1, -1, a1, 0, a1, 0);        // -(a1 - b1)
+  fp_lin4(y0, a0, 1, b1, 1, b0, -1, b0, 0);
+  fp_lin4(y1, a1, 1, b0, -1, b1, -1, b1, 0);
+  fp_lin4(s, a0, 1, a1, 1, b0, -1, b1, -1);
+  fp_lin4(t, a0, 1, a1, 1, b0, -2, b0, 0);
+  fp2_kara_core(r0, r1, x0, nx1, y0, y1, s, t);
 }
 
 #if defined(BLS_COUNT_FPMUL)
@@ -393,6 +519,15 @@ BLS_FN void fp_mul(fp& r, const fp& a, const fp& b) {
   FP_COUNT(2);
   fp_redc_products<1>(r, a, b, a, b);
 }
+// host twin of the one-lane Karatsuba Fp2 product (tower_split.cuh's host emulation of the compressed squarings)
+BLS_FN void fp2_mul_kara(fp& r0, fp& r1, const fp& a0, const fp& a1, const fp& b0, const fp& b1) {
+  FP_COUNT(5);  // three product streams + two reductions = 2.5 multiplications
+  fp2_kara_products(r0, r1, a0, a1, b0, b1);
+}
+BLS_FN void fp2_mul_kara_diffs(fp& r0, fp& r1, const fp& a0, const fp& a1, const fp& b0, const fp& b1) {
+  FP_COUNT(5);
+  fp2_kara_diffs(r0, r1, a0, a1, b0, b1);
+}
 BLS_FN void fp_sqr(fp& r, const fp& a) {
   FP_COUNT(2);
   fp_redc_products<0>(r, a, a, a, a);
@@ -414,7 +549,7 @@ BLS_FN void fp_set_words(fp& r, const uint32_t* w) {
     if (j + 1 < 12) x |= (uint64_t)w[j + 1] << 32;
     r.l[i] = (int32_t)((uint32_t)(x >> s) & FP_MASK);
   }
-  FP_TRK(r.lb = FP_LB_N; r.vb = 9.85;)   // 2^384 / p
+  FP_TRK(r.lb = FP_LB_N; r.vb = 9.85; r.nn = true;)   // 2^384 / p
 }
 // canonical limbs (fp_canon output) -> 12 little-endian 32-bit words
 BLS_FN void fp_get_words(uint32_t* w, const fp& a) {
@@ -455,7 +590,7 @@ BLS_FN void fp_from_raw(fp& r, const uint32_t* w) {
     if (j + 1 < 12) x |= (uint64_t)w[j + 1] << 32;
     t.l[i] = (int32_t)((uint32_t)(x >> sh) & FP_MASK);
   }
-  FP_TRK(t.lb = FP_LB_N; t.vb = 2522.0;)   // 2^392 / p
+  FP_TRK(t.lb = FP_LB_N; t.vb = 2522.0; t.nn = true;)   // 2^392 / p
   fp_reduce_shifted_raw(r, t);
 }
 // (the multiplication form, kept for the host-side cross-check of the shifted one: tests/hostsim hs_from_raw_forms_agree)
@@ -501,7 +636,7 @@ BLS_FN void fp_to_raw(uint32_t* w, const fp& a) {
   const bool ge = d.l[FP_NL - 1] >= 0;          // V >= p
 #pragma unroll
   for (int i = 0; i < FP_NL; i++) v.l[i] = ge ? d.l[i] : v.l[i];
-  FP_TRK(v.lb = FP_LB_N; v.vb = 1.0;)
+  FP_TRK(v.lb = FP_LB_N; v.vb = 1.0; v.nn = true;)
   fp_get_words(w, v);
 }
 BLS_FN void fp_to_raw_mul(uint32_t* w, const fp& a) {
@@ -767,7 +902,7 @@ BLS_NOINLINE void fp_inv_var(fp& r, const fp& a) {   // 0 -> 0
   fp y, k;
 #pragma unroll
   for (int i = 0; i < FP_NL; i++) y.l[i] = (d[i] ^ neg) - neg;
-  FP_TRK(y.lb = FP_LB_N; y.vb = 2.0;)
+  FP_TRK(y.lb = FP_LB_N; y.vb = 2.0; y.nn = false;)
   fp_load(k, FP_R3);
   fp_mul(r, y, k);
 }
@@ -799,7 +934,7 @@ BLS_NOINLINE void fp_inv(fp& r, const fp& a) {   // 0 -> 0
   fp y, k;
 #pragma unroll
   for (int i = 0; i < FP_NL; i++) y.l[i] = (d[i] ^ neg) - neg;
-  FP_TRK(y.lb = FP_LB_N; y.vb = 2.0;)
+  FP_TRK(y.lb = FP_LB_N; y.vb = 2.0; y.nn = false;)
   fp_load(k, FP_R3);
   fp_mul(r, y, k);
 }

@@ -2132,6 +2132,40 @@ __device__ __forceinline__ void cpow_slot(int k, int j, int& slot, int& idx) {  
   slot = 3 + q / 6;
   idx = q % 6;
 }
+#ifndef BLS_CYC_KARA
+#define BLS_CYC_KARA 1       // 1: one lane per Fp4 squaring, one-lane Karatsuba products (tower_split.cuh f12_sh_cyc_c_sqr_kara_body); 0: round 3's lane-split squarings
+#endif
+#if BLS_CYC_KARA
+static __device__ __noinline__ void fx_pow_run(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t) {
+  const vs_ref v = {vp, lanes, t};
+  {                                        // the four coordinates out of A's packed slots into the loop's layout (A is dead from here:
+    fp z2, z3, z4, z5;                     // fx_pow_finish rebuilds it from the saved powers, the fallback from V[2])
+    sh_ld_fp(z2, sh, 39);
+    sh_ld_fp(z3, sh, 26);
+    sh_ld_fp(z4, sh, 13);
+    sh_ld_fp(z5, sh, 65);
+    cyck_from_split(sh, z2, z3, z4, z5);
+  }
+  const bool hi = lane_hi();
+  const lds_u32* pa = sh + (hi ? CYCK_Q : CYCK_P) * BLS_SH_STRIDE;     // the squared element a + b s: (P, Q) on the even lane, (Q, P) on the odd one
+  const lds_u32* pb = sh + (hi ? CYCK_P : CYCK_Q) * BLS_SH_STRIDE;
+  int k = 0;
+  for (int i = 1; i <= 63; i++) {
+    f12_sh_cyc_c_sqr_kara_body(sh, pa, pb);
+    if ((BLS_X_ABS >> i) & 1) {
+      fp x[4];
+      cyck_to_split(x[0], x[1], x[2], x[3], sh);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {        // z2, z3, z4, z5
+        int slot, idx;
+        cpow_slot(k, j, slot, idx);
+        vs_st(v, slot, idx, x[j]);
+      }
+      k++;
+    }
+  }
+}
+#else
 static __device__ __noinline__ void fx_pow_run(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t) {
   const vs_ref v = {vp, lanes, t};
   {                                        // the four coordinates out of A's packed slots into the unpacked layout of the loop (A is dead from here:
@@ -2161,6 +2195,7 @@ static __device__ __noinline__ void fx_pow_run(lds_u32* sh, uint32_t* vp, size_t
     }
   }
 }
+#endif
 // ... and the rest: the six powers decompressed with one shared inversion (Montgomery's trick over the denominators 4 z2) and
 // multiplied into A.  Returns false on the lanes of an item one of whose z2 vanishes (never seen for honest inputs): the caller
 // then runs the plain chain for that item.

@@ -395,6 +395,102 @@ __device__ __forceinline__ void f12_sh_cyc_c_sqr_unpacked_body(lds_u32* sh) {
   fp2_reduce_lin2(o, t2, 3, z3, -2);
   shu_st_fp(sh, CYCU_Z3, o.v);
 }
+// ---- The compressed squarings with ONE LANE PER Fp4 SQUARING (round 4, second session) -----------------------------------------
+// A compressed squaring is two independent Fp4 squarings, (z2 + z3 s)^2 and (z4 + z5 s)^2.  Split by COMPONENT (above) each of them
+// is three lane-split Fp2 squarings: 6 x 392 = 2,352 multiply-adds per lane and a partner exchange inside every one.  Split by
+// SQUARING -- the even lane owns z2 and z3 whole, the odd lane z4 and z5 -- each lane runs
+//     B = a b,   A = (a - b)(a - xi b)      ->      a^2 + xi b^2 = A + (1 + xi) B = A + (2 + u) B,     2 a b = 2 B
+// as two one-lane Karatsuba Fp2 products (fp.cuh fp2_kara_products: 3 product streams + 2 reductions each): 2 x 980 = 1,960
+// multiply-adds per lane, no exchange inside the products, and ONE exchange per squaring (each lane's results update the OTHER lane's
+// coordinates: z4' = 3 c0 - 2 z4, z5' = 3 c1 + 2 z5 from (z2, z3); z2' = 3 xi c1 + 2 z2, z3' = 3 c0 - 2 z3 from (z4, z5)).
+// Lane state, unpacked in the lane's LDS column: P = the coordinate that takes "+ 2" (z2 on the even lane, z5 on the odd lane) at
+// words 0..27 (real part, imaginary part), Q = the one that takes "- 2" (z3 / z4) at words 28..55.  The squared element is
+// a + b s with (a, b) = (P, Q) on the even lane and (Q, P) on the odd lane: the two product functions take per-lane LDS pointers.
+// The products are non-inlined leaves that load their operands from LDS themselves (a call passes at most 32 VGPRs: 56 operand
+// limbs would travel through scratch) and return the 28 result limbs in registers.
+#define CYCK_P 0
+#define CYCK_Q (2 * FP_NL)
+typedef int32_t i32x28 __attribute__((ext_vector_type(28)));
+template <int SUMS>
+__device__ __noinline__ i32x28 cyck_product_leaf(const lds_u32* pa, const lds_u32* pb) {
+  fp a0, a1, b0, b1, r0, r1;
+  shu_ld_fp(a0, pa, 0);
+  shu_ld_fp(a1, pa, FP_NL);
+  shu_ld_fp(b0, pb, 0);
+  shu_ld_fp(b1, pb, FP_NL);
+  if (SUMS) fp2_kara_diffs(r0, r1, a0, a1, b0, b1);      // (a - b)(a - xi b)
+  else fp2_kara_products(r0, r1, a0, a1, b0, b1);       // a b
+  i32x28 o;
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) {
+    o[i] = r0.l[i];
+    o[FP_NL + i] = r1.l[i];
+  }
+  return o;
+}
+// the lane's state from / to the lane-split components x2..x5 (this lane's component of z2..z5)
+__device__ __forceinline__ void cyck_from_split(lds_u32* sh, const fp& x2, const fp& x3, const fp& x4, const fp& x5) {
+  const bool hi = lane_hi();
+  fp sa, sb, ra, rb, t;
+  fp_sel(sa, hi, x2, x5);
+  fp_sel(sb, hi, x3, x4);
+  fp_partner(ra, sa);          // even: im z2, odd: re z5
+  fp_partner(rb, sb);          // even: im z3, odd: re z4
+  fp_sel(t, hi, ra, x2);
+  shu_st_fp(sh, CYCK_P, t);
+  fp_sel(t, hi, x5, ra);
+  shu_st_fp(sh, CYCK_P + FP_NL, t);
+  fp_sel(t, hi, rb, x3);
+  shu_st_fp(sh, CYCK_Q, t);
+  fp_sel(t, hi, x4, rb);
+  shu_st_fp(sh, CYCK_Q + FP_NL, t);
+}
+__device__ __forceinline__ void cyck_to_split(fp& x2, fp& x3, fp& x4, fp& x5, const lds_u32* sh) {
+  const bool hi = lane_hi();
+  fp pr, pi, qr, qi, s, r1, r2;
+  shu_ld_fp(pr, sh, CYCK_P);
+  shu_ld_fp(pi, sh, CYCK_P + FP_NL);
+  shu_ld_fp(qr, sh, CYCK_Q);
+  shu_ld_fp(qi, sh, CYCK_Q + FP_NL);
+  fp_sel(s, hi, pr, pi);
+  fp_partner(r1, s);           // even: re z5, odd: im z2
+  fp_sel(s, hi, qr, qi);
+  fp_partner(r2, s);           // even: re z4, odd: im z3
+  fp_sel(x2, hi, r1, pr);
+  fp_sel(x3, hi, r2, qr);
+  fp_sel(x4, hi, qi, r2);
+  fp_sel(x5, hi, pi, r1);
+}
+__device__ __forceinline__ void f12_sh_cyc_c_sqr_kara_body(lds_u32* sh, const lds_u32* pa, const lds_u32* pb) {
+  const int32_t m = lane_hi() ? -1 : 0;
+  const i32x28 B = cyck_product_leaf<0>(pa, pb);
+  const i32x28 A = cyck_product_leaf<1>(pa, pb);
+  fp c0r, c0i, c1r, c1i, r0r, r0i, r1r, r1i, s, o;
+#pragma unroll
+  for (int i = 0; i < FP_NL; i++) {
+    const int32_t b0 = B[i], b1 = B[FP_NL + i];
+    c0r.l[i] = A[i] + 2 * b0 - b1;                 // c0 = A + (2 + u) B
+    c0i.l[i] = A[FP_NL + i] + b0 + 2 * b1;
+    c1r.l[i] = 2 * (b0 - (b1 & m));                // c1 = 2 B, times xi on the odd lane (its results feed z2' = 3 xi c1 + 2 z2)
+    c1i.l[i] = 2 * (b1 + (b0 & m));
+  }
+  fp_partner(r0r, c0r);
+  fp_partner(r0i, c0i);
+  fp_partner(r1r, c1r);
+  fp_partner(r1i, c1i);
+  shu_ld_fp(s, sh, CYCK_P);
+  fp_reduce_lin2(o, r1r, 3, s, 2);
+  shu_st_fp(sh, CYCK_P, o);
+  shu_ld_fp(s, sh, CYCK_P + FP_NL);
+  fp_reduce_lin2(o, r1i, 3, s, 2);
+  shu_st_fp(sh, CYCK_P + FP_NL, o);
+  shu_ld_fp(s, sh, CYCK_Q);
+  fp_reduce_lin2(o, r0r, 3, s, -2);
+  shu_st_fp(sh, CYCK_Q, o);
+  shu_ld_fp(s, sh, CYCK_Q + FP_NL);
+  fp_reduce_lin2(o, r0i, 3, s, -2);
+  shu_st_fp(sh, CYCK_Q + FP_NL, o);
+}
 __device__ __noinline__ void f12_sh_cyc_c_sqr(lds_u32* sh) { f12_sh_cyc_c_sqr_body(sh); }
 // the plain chain (Granger-Scott squarings, five multiplications) with the running power in LDS: fallback of fp12_pow_x
 __device__ __noinline__ void fp12_pow_x_plain_sh(fp12_t<hfp2>& r, const fp12_t<hfp2>& a, lds_u32* sh) {
@@ -535,6 +631,45 @@ static inline void fp2_inv(hfp2& r, const hfp2& a) {
   fp_mul(r.c[0], a.c[0], n);
   fp_mul(t, a.c[1], n);
   fp_neg(r.c[1], t);
+}
+// The compressed squaring with one lane per Fp4 squaring (device: f12_sh_cyc_c_sqr_kara_body above): lane 0 squares z2 + z3 s, lane 1
+// z4 + z5 s, each by two one-lane Karatsuba products; the results cross once and update the OTHER lane's coordinates.  A non-template
+// overload: fp12_pow_x_compressed<hfp2> (pairing.cuh) picks it over the generic cyc_c_sqr, so every lane-split verdict of tests/hostsim
+// runs this form under the bound tracker; g_cyc_kara = 0 gives the lane-split squarings of round 3 (k_finalexps and the A/B builds).
+static int g_cyc_kara = 1;
+static inline void cyc_c_sqr(cyc_c<hfp2>& r, const cyc_c<hfp2>& in) {
+  if (!g_cyc_kara) {
+    cyc_c_sqr<hfp2>(r, in);
+    return;
+  }
+  const hfp2* as[2] = {&in.z2, &in.z4};
+  const hfp2* bs[2] = {&in.z3, &in.z5};
+  fp c0r[2], c0i[2], c1r[2], c1i[2];
+  for (int lane = 0; lane < 2; lane++) {
+    const fp &a0 = as[lane]->c[0], &a1 = as[lane]->c[1], &b0 = bs[lane]->c[0], &b1 = bs[lane]->c[1];
+    fp Br, Bi, Ar, Ai;
+    fp2_mul_kara(Br, Bi, a0, a1, b0, b1);
+    fp2_mul_kara_diffs(Ar, Ai, a0, a1, b0, b1);
+    fp_lin4(c0r[lane], Ar, 1, Br, 2, Bi, -1, Bi, 0);          // c0 = A + (2 + u) B
+    fp_lin4(c0i[lane], Ai, 1, Br, 1, Bi, 2, Bi, 0);
+    if (lane == 0) {                                          // c1 = 2 B ...
+      fp_lin4(c1r[lane], Br, 2, Bi, 0, Bi, 0, Bi, 0);
+      fp_lin4(c1i[lane], Bi, 2, Br, 0, Br, 0, Br, 0);
+    } else {                                                  // ... times xi on the odd lane
+      fp_lin4(c1r[lane], Br, 2, Bi, -2, Bi, 0, Bi, 0);
+      fp_lin4(c1i[lane], Bi, 2, Br, 2, Br, 0, Br, 0);
+    }
+  }
+  cyc_c<hfp2> o;
+  fp_reduce_lin2(o.z2.c[0], c1r[1], 3, in.z2.c[0], 2);       // lane 0 takes lane 1's results: z2' = 3 xi c1 + 2 z2, z3' = 3 c0 - 2 z3
+  fp_reduce_lin2(o.z2.c[1], c1i[1], 3, in.z2.c[1], 2);
+  fp_reduce_lin2(o.z3.c[0], c0r[1], 3, in.z3.c[0], -2);
+  fp_reduce_lin2(o.z3.c[1], c0i[1], 3, in.z3.c[1], -2);
+  fp_reduce_lin2(o.z5.c[0], c1r[0], 3, in.z5.c[0], 2);       // lane 1 takes lane 0's: z5' = 3 c1 + 2 z5, z4' = 3 c0 - 2 z4
+  fp_reduce_lin2(o.z5.c[1], c1i[0], 3, in.z5.c[1], 2);
+  fp_reduce_lin2(o.z4.c[0], c0r[0], 3, in.z4.c[0], -2);
+  fp_reduce_lin2(o.z4.c[1], c0i[0], 3, in.z4.c[1], -2);
+  r = o;
 }
 #endif
 

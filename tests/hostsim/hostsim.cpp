@@ -55,6 +55,9 @@ static void msm2_eval(jac<F>& res, int n, const F* qx, const F* qy, const uint8_
 }
 
 extern "C" {
+// 1 (what k_finalexp2s runs since round 4): the compressed squarings with one lane per Fp4 squaring and one-lane Karatsuba products
+// (tower_split.cuh cyc_c_sqr overload); 0: round 3's lane-split squarings (k_finalexps, k_finalexp_seg / k_cyc_run4)
+void hs_set_cyc_kara(int on) { g_cyc_kara = on; }
 uint64_t hs_phase_marks[3] = {0, 0, 0};   // BLS_COUNT_FPMUL builds: the census after prepare / Miller loop / final exponentiation
 int hs_device_path_only = 0;   // tools/count_fpmul.py: run exactly what the kernels run (prepare, then the lane-split pairing)
 void hs_fp_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) {
@@ -382,6 +385,49 @@ int hs_pow_x_compressed_check(const uint32_t* g1s, const uint32_t* g2s) {
   // and against the one-lane result
   fp2 chk; chk.c0 = as.c0.a0.c[0]; chk.c1 = as.c0.a0.c[1];
   return fp2_eq(chk, a.c0.a0) ? 1 : -4;
+}
+// the compressed squaring with one lane per Fp4 squaring against the lane-split form and the one-lane tower, `steps` squarings in a row
+// on the cyclotomic element of a pairing: the canonical coordinates must agree after every step.  1 = all equal
+int hs_cyc_kara_check(const uint32_t* g1s, const uint32_t* g2s, int steps) {
+  g1_aff P[1]; g2_aff Q[1];
+  fp_from_raw(P[0].x, g1s); fp_from_raw(P[0].y, g1s + 12); P[0].inf = false;
+  raw_fp2(Q[0].x, g2s); raw_fp2(Q[0].y, g2s + 24); Q[0].inf = false;
+  fp12 f, e, er;
+  miller_loop<1>(f, P, Q);
+  final_exponentiation(e, f);
+  fp12_reduce(er, e);
+  cyc_c<fp2> c1;
+  cyc_compress(c1, er);
+  cyc_c<hfp2> ck, cs;
+  const fp2* src[4] = {&c1.z2, &c1.z3, &c1.z4, &c1.z5};
+  hfp2* dk[4] = {&ck.z2, &ck.z3, &ck.z4, &ck.z5};
+  hfp2* ds[4] = {&cs.z2, &cs.z3, &cs.z4, &cs.z5};
+  for (int k = 0; k < 4; k++) { dk[k]->c[0] = src[k]->c0; dk[k]->c[1] = src[k]->c1; *ds[k] = *dk[k]; }
+  const int keep = g_cyc_kara;
+  int ok = 1;
+  for (int i = 0; i < steps && ok == 1; i++) {
+    cyc_c_sqr(c1, c1);
+    g_cyc_kara = 1; cyc_c_sqr(ck, ck);
+    g_cyc_kara = 0; cyc_c_sqr(cs, cs);
+    const fp2* w[4] = {&c1.z2, &c1.z3, &c1.z4, &c1.z5};
+    for (int k = 0; k < 4; k++) {
+      if (!fp2_eq(*dk[k], *ds[k])) ok = -1 - i;
+      fp2 chk; chk.c0 = dk[k]->c[0]; chk.c1 = dk[k]->c[1];
+      if (!fp2_eq(chk, *w[k])) ok = -1000 - i;
+    }
+  }
+  g_cyc_kara = keep;
+  return ok;
+}
+// one Fp2 product by the one-lane Karatsuba pass and (a - b)(a - xi b) by its difference form, on caller-chosen reduced operands
+// (Montgomery words): out = the two results as Montgomery words (24 + 24)
+void hs_fp2_kara(const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  fp a0, a1, b0, b1, r0, r1;
+  fp_from_raw(a0, a); fp_from_raw(a1, a + 12); fp_from_raw(b0, b); fp_from_raw(b1, b + 12);
+  fp2_mul_kara(r0, r1, a0, a1, b0, b1);
+  fp_to_raw(out, r0); fp_to_raw(out + 12, r1);
+  fp2_mul_kara_diffs(r0, r1, a0, a1, b0, b1);
+  fp_to_raw(out + 24, r0); fp_to_raw(out + 36, r1);
 }
 // checked decompression: returns the status code; on success writes the re-compressed (modern) bytes
 int hs_decompress(int group, const uint8_t* in, int legacy, uint8_t* out) {

@@ -188,6 +188,24 @@ def test_fp_reduce_lin2(hs):
         assert (val(r) - want) % P == 0 and all(0 <= x <= M for x in r[:13]) and abs(val(r)) * 100 <= 52 * P, (ka, kb)
 
 
+def test_fp2_one_lane_karatsuba(hs):
+    """fp2_kara_products / fp2_kara_diffs (csrc/fp.cuh: a whole Fp2 product on one lane, three product streams and two interleaved
+    reductions; the difference form (a - b)(a - xi b) that the compressed squarings take without a carry pass) against the integers,
+    edge values included, bound tracker on."""
+    rng = random.Random(44)
+    edge = [0, 1, P - 1, (P - 1) // 2, (P + 1) // 2, 2**380, P - 2**200]
+    vals = [(x, y) for x in edge for y in edge[:4]] + [(rng.randrange(P), rng.randrange(P)) for _ in range(200)]
+    out = ctypes.create_string_buffer(4 * 48)
+    xi = (1, 1)
+    for i in range(len(vals) - 1):
+        a, b = vals[i], vals[(i * 5 + 2) % len(vals)]
+        hs.hs_fp2_kara(util.fp_raw(a[0]) + util.fp_raw(a[1]), util.fp_raw(b[0]) + util.fp_raw(b[1]), out)
+        r = out.raw
+        assert (util.fp_from_raw(r[0:48]), util.fp_from_raw(r[48:96])) == c.f2_mul(a, b)
+        want = c.f2_mul(c.f2_sub(a, b), c.f2_sub(a, c.f2_mul(xi, b)))
+        assert (util.fp_from_raw(r[96:144]), util.fp_from_raw(r[144:192])) == want
+
+
 def test_fp12_ops(hs):
     rng = random.Random(2)
     for _ in range(5):
@@ -300,6 +318,12 @@ def test_pairing_values(hs):
     assert util.f12_from_plain_words(out.raw) == c.final_exponentiation(c.miller_loop([(P1, Q1), (P2, Q2)]))
     assert hs.hs_cyclotomic_check(1, util.g1_aff_raw(P1), util.g2_aff_raw(Q1)) == 1
     assert hs.hs_pow_x_compressed_check(util.g1_aff_raw(P1), util.g2_aff_raw(Q1)) == 1   # Karabina chain == plain chain
+    # round 4: the compressed squarings with one lane per Fp4 squaring (one-lane Karatsuba products, k_finalexp2s fx_pow_run) against
+    # the lane-split squarings and the one-lane tower, coordinate by coordinate over a whole run of 63; and the whole chain in both forms
+    assert hs.hs_cyc_kara_check(util.g1_aff_raw(P1), util.g2_aff_raw(Q1), 63) == 1
+    for on in (0, 1):
+        hs.hs_set_cyc_kara(on)
+        assert hs.hs_pow_x_compressed_check(util.g1_aff_raw(P2), util.g2_aff_raw(Q2)) == 1
     # the precomputed -g2 line table (tools/gen_g2_lines.py) reproduces the generic loop's Miller value bit for bit
     assert hs.hs_miller_fixed_g2_matches(util.g1_aff_raw(P1), util.g2_aff_raw(Q1), util.g1_aff_raw(P2)) == 1
     # round 3: the two line values of a step merged before they touch f (k_lines2s / k_millerf2s), fixed lines normalised so that
@@ -485,5 +509,5 @@ def test_device_headers_under_ubsan(tmp_path):
                            os.path.join(util.ROOT, 'tests', 'hostsim', 'hostsim.cpp')])
     env = dict(os.environ, BLS_HOSTSIM_SO=so)
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(util.ROOT, 'tests', 'test_hostsim.py'), '-q', '-x', '-p', 'no:cacheprovider',
-                        '-k', 'fp_ops or fp12_ops or pairing_values or verify_items or g2_split or msm2'], env=env, capture_output=True, text=True, timeout=900)
+                        '-k', 'fp_ops or fp12_ops or pairing_values or verify_items or g2_split or msm2 or karatsuba'], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
