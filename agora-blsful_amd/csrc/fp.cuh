@@ -294,11 +294,9 @@ BLS_FN void fp_redc_products(fp& r, const fp& a, const fp& b, const fp& c, const
 // A WHOLE Fp2 product on one lane by Karatsuba (round 4, second session; tools/ubench/ubench4.hip form 3, measured there: 22.8 G Fp2
 // products/s against 19.9 for the lane-split pair of fused passes):  (a0 + a1 u)(b0 + b1 u) = r0 + r1 u with
 //     r0 = REDC(a0 b0 - a1 b1)            r1 = REDC((a0 + a1)(b0 + b1) - a0 b0 - a1 b1)
-// Per column k: U_k = sum a0_i b0_(k-i) and V'_k = sum (-a1)_i b1_(k-i) in fresh 64-bit accumulators, W_k = sum (a0+a1)_i (b0+b1)_(k-i)
-// straight onto r1's running accumulator; r0's chain takes U_k + V'_k, r1's W_k + V'_k - U_k; two interleaved reduction chains.
-// 3 x 196 + 2 x 196 = 980 multiply-adds (the lane-split pair: 2 x 588) and no partner exchange.
-// Column bound: r1's accumulator holds 14 (|a0|+|a1|)(|b0|+|b1|) + 14 (|a0||b0| + |a1||b1|) + the reduction's 14 * 2^56 + a carry:
-// below 2^63 for operands with limbs up to 2^28 + 2^8 (7 * 2^59.81 = 2^62.62), i.e. NORMALISED operands.
+// Three product streams and two interleaved reduction chains: 3 x 196 + 2 x 196 = 980 multiply-adds (the lane-split pair: 2 x 588) and no
+// partner exchange.  Column bound: the second accumulator holds 14 (|a0|+|a1|)(|b0|+|b1|) + 2 * 14 |a1||b1| + the reduction's 14 * 2^56 + a
+// carry: below 2^63 for operands with limbs up to 2^28 + 2^8 (7 * 2^59.81 = 2^62.62), i.e. NORMALISED operands.
 // fp_lin4: r = ka a + kb b + kc c + kd d limb-wise, small integer coefficients known at compile time (exact on the integers).  When every
 // operand is a REDC / fp_reduce output (limbs 0..12 in [0, 2^28): the tracker's `nn`) the result's limbs lie between -N 2^28 and P 2^28
 // for the sums N, P of the negative and positive coefficients -- the tracker then bounds them by the larger of the two instead of the
@@ -325,13 +323,17 @@ BLS_FN void fp_lin4(fp& r, const fp& a, int ka, const fp& b, int kb, const fp& c
   for (int i = 0; i < FP_NL; i++) r.l[i] = ka * a.l[i] + kb * b.l[i] + kc * c.l[i] + kd * d.l[i];
   FP_TRK(r.lb = lb; r.vb = vb; r.nn = false;)
 }
-// the pass proper: operands prepared by the caller -- a0, na1 = -a1, b0, b1, s = a0 + a1, t = b0 + b1 (each with its own tracked bound)
-BLS_FN void fp2_kara_core(fp& r0, fp& r1, const fp& a0, const fp& na1, const fp& b0, const fp& b1, const fp& s_, const fp& t_) {
+// the pass proper: operands prepared by the caller -- a0, na1 = -a1, b0, b1, s = a0 + a1, t = b0 + b1 (each with its own tracked bound).
+// Returns r0 = REDC(a0 b0 - a1 b1) = c0 and rs = REDC((a0 + a1)(b0 + b1) - 2 a1 b1) = c1 + c0: with V' = sum (-a1) b1 in a fresh accumulator per
+// column, a0 b0 chained onto r0's accumulator and (a0 + a1)(b0 + b1) onto rs's, the two chains take V' and 2 V' -- two 64-bit additions per
+// column, where forming c1 = W - U - V itself takes U and V' apart and five; the caller subtracts r0 from rs on the reduced limbs (or
+// folds that into the linear combination it forms anyway).
+BLS_FN void fp2_kara_core(fp& r0, fp& rs, const fp& a0, const fp& na1, const fp& b0, const fp& b1, const fp& s_, const fp& t_) {
 #if defined(BLS_TRACK_BOUNDS) && !defined(__HIPCC__)
   {
-    const double uv = a0.lb * b0.lb + na1.lb * b1.lb, w = s_.lb * t_.lb;
-    if (14.0 * (uv + w) + 14.0 * 72057594037927936.0 + 68719476736.0 >= 9223372036854775808.0) fp_trk_fail("kara column sum < 2^63", uv, w);
-    if (a0.vb * b0.vb + na1.vb * b1.vb > 256.0 || a0.vb * b1.vb + na1.vb * b0.vb > 256.0) fp_trk_fail("kara REDC input <= 256 p^2", a0.vb * b0.vb + na1.vb * b1.vb, a0.vb * b1.vb + na1.vb * b0.vb);
+    const double uv = a0.lb * b0.lb + na1.lb * b1.lb, w = s_.lb * t_.lb + 2.0 * na1.lb * b1.lb;
+    if (14.0 * fmax(uv, w) + 14.0 * 72057594037927936.0 + 68719476736.0 >= 9223372036854775808.0) fp_trk_fail("kara column sum < 2^63", uv, w);
+    if (a0.vb * b0.vb + na1.vb * b1.vb > 256.0 || s_.vb * t_.vb + 2.0 * na1.vb * b1.vb > 256.0) fp_trk_fail("kara REDC input <= 256 p^2", a0.vb * b0.vb + na1.vb * b1.vb, s_.vb * t_.vb + 2.0 * na1.vb * b1.vb);
   }
 #endif
   int32_t s[FP_NL], t[FP_NL], n1[FP_NL];
@@ -351,18 +353,16 @@ BLS_FN void fp2_kara_core(fp& r0, fp& r1, const fp& a0, const fp& na1, const fp&
 #pragma unroll
   for (int k = 0; k < 2 * FP_NL - 1; k++) {
     const int lo = k > FP_NL - 1 ? k - (FP_NL - 1) : 0, hi = k < FP_NL - 1 ? k : FP_NL - 1;
-    int64_t U = 0, Vn = 0;
+    int64_t Vn = 0;
 #pragma unroll
     for (int i = lo; i <= hi; i++) {
-      FP_MADI(U, a0.l[i], b0.l[k - i]);
+      FP_MADI(acc0, a0.l[i], b0.l[k - i]);
       FP_MADI(Vn, n1[i], b1.l[k - i]);
     }
 #pragma unroll
     for (int i = lo; i <= hi; i++) FP_MADI(acc1, s[i], t[k - i]);
-    acc0 += U;
     acc0 += Vn;
-    acc1 += Vn;
-    acc1 -= U;
+    acc1 += 2 * Vn;
 #pragma unroll
     for (int i = lo; i <= hi; i++) {
       if (k < FP_NL && i == k) continue;
@@ -388,24 +388,24 @@ BLS_FN void fp2_kara_core(fp& r0, fp& r1, const fp& a0, const fp& na1, const fp&
 #pragma unroll
   for (int i = 0; i < FP_NL; i++) {
     r0.l[i] = t0[i];
-    r1.l[i] = t1[i];
+    rs.l[i] = t1[i];
   }
-  FP_TRK(r0.lb = FP_LB_N; r0.vb = 1.125; r0.nn = true; r1.lb = FP_LB_N; r1.vb = 1.125; r1.nn = true;)
+  FP_TRK(r0.lb = FP_LB_N; r0.vb = 1.125; r0.nn = true; rs.lb = FP_LB_N; rs.vb = 1.125; rs.nn = true;)
 }
-// (a0 + a1 u)(b0 + b1 u) for operands as they are
-BLS_FN void fp2_kara_products(fp& r0, fp& r1, const fp& a0, const fp& a1, const fp& b0, const fp& b1) {
+// (a0 + a1 u)(b0 + b1 u) for operands as they are: r0 = c0, rs = c1 + c0
+BLS_FN void fp2_kara_products(fp& r0, fp& rs, const fp& a0, const fp& a1, const fp& b0, const fp& b1) {
   fp n1, s, t;
   fp_neg(n1, a1);
   fp_add(s, a0, a1);
   fp_add(t, b0, b1);
-  fp2_kara_core(r0, r1, a0, n1, b0, b1, s, t);
+  fp2_kara_core(r0, rs, a0, n1, b0, b1, s, t);
 }
 // (a - b)(a - xi b) for REDUCED a, b (xi = 1 + u):  a - xi b = (a0 - b0 + b1) + (a1 - b0 - b1) u.  The operands' limbs lie in [0, 2^28),
 // so every limb of these differences stays inside (-2^29, 2^29) -- a0 - b0 and a1 - b1 inside +-2^28 -- without a carry pass, and so do
 // the two sums the Karatsuba pass takes, (a0 + a1) - (b0 + b1) and (a0 + a1) - 2 b0: 14 (2^58 + 2^58) + 14 * 2^56 + 2^36 = 126 * 2^56 + 2^36
 // < 2^63 per column (fp_lin4's sign-aware bound is what proves it on the host; with the sum form (a + b)(a + xi b) the operands reach
 // 3 * 2^28 and the pass needs four carry passes first).  Half of an Fp4 squaring: a^2 + xi b^2 = (a - b)(a - xi b) + (1 + xi) a b.
-BLS_FN void fp2_kara_diffs(fp& r0, fp& r1, const fp& a0, const fp& a1, const fp& b0, const fp& b1) {
+BLS_FN void fp2_kara_diffs(fp& r0, fp& rs, const fp& a0, const fp& a1, const fp& b0, const fp& b1) {      // r0 = c0, rs = c1 + c0
   fp x0, nx1, y0, y1, s, t;
   fp_lin4(x0, a0, 1, b0, -1, b0, 0, b0, 0);
   fp_lin4(nx1, b1, 1, a1, -1, a1, 0, a1, 0);        // -(a1 - b1)
@@ -413,7 +413,7 @@ BLS_FN void fp2_kara_diffs(fp& r0, fp& r1, const fp& a0, const fp& a1, const fp&
   fp_lin4(y1, a1, 1, b0, -1, b1, -1, b1, 0);
   fp_lin4(s, a0, 1, a1, 1, b0, -1, b1, -1);
   fp_lin4(t, a0, 1, a1, 1, b0, -2, b0, 0);
-  fp2_kara_core(r0, r1, x0, nx1, y0, y1, s, t);
+  fp2_kara_core(r0, rs, x0, nx1, y0, y1, s, t);
 }
 
 #if defined(BLS_COUNT_FPMUL)
@@ -522,11 +522,15 @@ BLS_FN void fp_mul(fp& r, const fp& a, const fp& b) {
 // host twin of the one-lane Karatsuba Fp2 product (tower_split.cuh's host emulation of the compressed squarings)
 BLS_FN void fp2_mul_kara(fp& r0, fp& r1, const fp& a0, const fp& a1, const fp& b0, const fp& b1) {
   FP_COUNT(5);  // three product streams + two reductions = 2.5 multiplications
-  fp2_kara_products(r0, r1, a0, a1, b0, b1);
+  fp rs;
+  fp2_kara_products(r0, rs, a0, a1, b0, b1);
+  fp_lin4(r1, rs, 1, r0, -1, r0, 0, r0, 0);
 }
 BLS_FN void fp2_mul_kara_diffs(fp& r0, fp& r1, const fp& a0, const fp& a1, const fp& b0, const fp& b1) {
   FP_COUNT(5);
-  fp2_kara_diffs(r0, r1, a0, a1, b0, b1);
+  fp rs;
+  fp2_kara_diffs(r0, rs, a0, a1, b0, b1);
+  fp_lin4(r1, rs, 1, r0, -1, r0, 0, r0, 0);
 }
 BLS_FN void fp_sqr(fp& r, const fp& a) {
   FP_COUNT(2);

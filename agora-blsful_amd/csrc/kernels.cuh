@@ -2150,9 +2150,9 @@ static __device__ __noinline__ void fx_pow_run(lds_u32* sh, uint32_t* vp, size_t
   const lds_u32* pa = sh + (hi ? CYCK_Q : CYCK_P) * BLS_SH_STRIDE;     // the squared element a + b s: (P, Q) on the even lane, (Q, P) on the odd one
   const lds_u32* pb = sh + (hi ? CYCK_P : CYCK_Q) * BLS_SH_STRIDE;
   int k = 0;
-  for (int i = 1; i <= 63; i++) {
+  for (int i = 1; i <= BLS_XK_LAST; i++) {          // 61 squarings, four powers saved: the four-power chain of pairing.cuh fp12_pow_x_compressed4
     f12_sh_cyc_c_sqr_kara_body(sh, pa, pb);
-    if ((BLS_X_ABS >> i) & 1) {
+    if ((BLS_XK_SAVE >> i) & 1) {
       fp x[4];
       cyck_to_split(x[0], x[1], x[2], x[3], sh);
 #pragma unroll
@@ -2199,11 +2199,18 @@ static __device__ __noinline__ void fx_pow_run(lds_u32* sh, uint32_t* vp, size_t
 // ... and the rest: the six powers decompressed with one shared inversion (Montgomery's trick over the denominators 4 z2) and
 // multiplied into A.  Returns false on the lanes of an item one of whose z2 vanishes (never seen for honest inputs): the caller
 // then runs the plain chain for that item.
-static __device__ __noinline__ bool fx_pow_finish(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t) {
+// NP = 6: the powers of |x|'s six set bits, multiplied together.  NP = 4 (the run above): the powers 2^16, 2^48, 2^57, 2^61 and the plain
+// tail of fp12_pow_x_compressed4 -- A = a^(2^61) conj(a^(2^57)) = c, parked in slot 6 (the four powers fill slots 3..5 only), three
+// Granger-Scott squarings, A <- A conj(c) = c^7, then the two low powers.
+static __device__ __noinline__ void fx_mul(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t, int slot, int mode);
+static __device__ __noinline__ void fx_store(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t, int slot);
+static __device__ __noinline__ void fx_cyc_sqr(lds_u32* sh);
+template <int NP>
+static __device__ __noinline__ bool fx_pow_finish_n(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t) {
   const vs_ref v = {vp, lanes, t};
   hfp2 pre, d, inv, tt;
   bool ok = true;
-  for (int i = 0; i < 6; i++) {            // prefix products of the denominators -> slot 7
+  for (int i = 0; i < NP; i++) {           // prefix products of the denominators -> slot 7
     int slot, idx;
     hfp2 z2;
     cpow_slot(i, 0, slot, idx);
@@ -2218,7 +2225,8 @@ static __device__ __noinline__ bool fx_pow_finish(lds_u32* sh, uint32_t* vp, siz
   }
   if (!ok) return false;
   fp2_inv(inv, pre);
-  for (int i = 5; i >= 0; i--) {
+#pragma nounroll
+  for (int i = NP - 1; i >= 0; i--) {
     hfp2 di;
     cyc_c<hfp2> s;
     int slot, idx;
@@ -2243,15 +2251,22 @@ static __device__ __noinline__ bool fx_pow_finish(lds_u32* sh, uint32_t* vp, siz
     vs_ld(s.z5.v, v, slot, idx);
     fp12_t<hfp2> e;
     cyc_decompress(e, s, di);
-    if (i == 5) {
+    if (i == NP - 1) {
       fp12_reduce(e, e);
       sh_st_f12(sh, e);
     } else {
+      if (NP == 4 && i == 2) fp12_conj(e, e);
       f12_sh_mul_body(sh, e);
+      if (NP == 4 && i == 2) {             // A = c = a^(2^61) conj(a^(2^57))
+        fx_store(sh, vp, lanes, t, 6);
+        for (int j = 0; j < 3; j++) fx_cyc_sqr(sh);
+        fx_mul(sh, vp, lanes, t, 6, FX_CONJ);   // c^8 conj(c)
+      }
     }
   }
   return true;
 }
+static __device__ __noinline__ bool fx_pow_finish(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t) { return fx_pow_finish_n<6>(sh, vp, lanes, t); }
 // the plain chain on A (Granger-Scott squarings, five multiplications by a = V[2]): the fallback of fx_pow_finish
 static __device__ __noinline__ void fx_pow_plain(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t) {
   fx_load(sh, vp, lanes, t, 2, FX_PLAIN);
@@ -2275,7 +2290,11 @@ static __device__ __noinline__ void fx_conj(lds_u32* sh) {
 __device__ __forceinline__ void fx_pow_x(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t) {
   fx_store(sh, vp, lanes, t, 2);           // a: the fallback's operand
   fx_pow_run(sh, vp, lanes, t);
+#if BLS_CYC_KARA
+  if (!fx_pow_finish_n<4>(sh, vp, lanes, t)) fx_pow_plain(sh, vp, lanes, t);
+#else
   if (!fx_pow_finish(sh, vp, lanes, t)) fx_pow_plain(sh, vp, lanes, t);
+#endif
   fx_conj(sh);
 }
 static __device__ __noinline__ int fx_is_one(lds_u32* sh) {

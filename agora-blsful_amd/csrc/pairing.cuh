@@ -504,6 +504,65 @@ BLS_NOINLINE bool fp12_pow_x_compressed(fp12_t<F2>& r, const fp12_t<F2>& a) {
   return true;
 }
 
+// The same with a short plain tail (round 4; what k_finalexp2s runs):  |x| = 2^16 + 2^48 + 2^57 (1 + 2^3 + 2^5 + 2^6) and 1 + 8 + 32 + 64 = 105
+// = 15 * 7, so with b = a^(2^57)
+//     c = b^15 = a^(2^61) conj(b),        b^105 = c^7 = c^8 conj(c)        (the conjugate is the inverse in the cyclotomic subgroup):
+// 61 compressed squarings, FOUR powers to decompress (2^16, 2^48, 2^57, 2^61) and four products, plus three Granger-Scott squarings --
+// against 63, six and five: two decompressions, six of the fifteen products of the shared inversion and one Fp12 product less per a^x.
+#define BLS_XK_LAST 61
+#define BLS_XK_SAVE ((1ull << 16) | (1ull << 48) | (1ull << 57) | (1ull << 61))
+template <class F2>
+BLS_NOINLINE bool fp12_pow_x_compressed4(fp12_t<F2>& r, const fp12_t<F2>& a) {
+  cyc_c<F2> c, s[4];
+  {
+    fp12_t<F2> ar;
+    fp12_reduce(ar, a);                      // a may carry negated limbs (a conjugate)
+    cyc_compress(c, ar);
+  }
+  int k = 0;
+  for (int i = 1; i <= BLS_XK_LAST; i++) {
+    cyc_c_sqr(c, c);
+    if ((BLS_XK_SAVE >> i) & 1) s[k++] = c;
+  }
+  F2 d[4], pre[4], inv, t;
+  bool ok = true;
+  for (int i = 0; i < 4; i++) {
+    if (fp2_is_zero(s[i].z2)) ok = false;
+    fp2_dbl(t, s[i].z2);
+    fp2_dbl(t, t);
+    fp2_norm(d[i], t);                       // 4 z2
+  }
+  if (!ok) return false;
+  pre[0] = d[0];
+  for (int i = 1; i < 4; i++) fp2_mul(pre[i], pre[i - 1], d[i]);
+  fp2_inv(inv, pre[3]);
+  fp12_t<F2> acc, e, cc;
+  for (int i = 3; i >= 0; i--) {
+    F2 di;
+    if (i) {
+      fp2_mul(di, inv, pre[i - 1]);          // 1 / d_i
+      fp2_mul(inv, inv, d[i]);
+    } else {
+      di = inv;
+    }
+    cyc_decompress(e, s[i], di);
+    if (i == 3) {
+      fp12_reduce(acc, e);                   // a^(2^61)
+    } else if (i == 2) {
+      fp12_conj(e, e);
+      fp12_mul(acc, acc, e);                 // c = b^15
+      cc = acc;
+      for (int j = 0; j < 3; j++) fp12_cyclotomic_sqr(acc, acc);
+      fp12_conj(e, cc);
+      fp12_mul(acc, acc, e);                 // c^7 = b^105
+    } else {
+      fp12_mul(acc, acc, e);
+    }
+  }
+  fp12_conj(r, acc);
+  return true;
+}
+
 template <class F2>
 BLS_FN void fp12_pow_x(fp12_t<F2>& r, const fp12_t<F2>& a) {
   if (!fp12_pow_x_compressed(r, a)) fp12_pow_x_plain(r, a);

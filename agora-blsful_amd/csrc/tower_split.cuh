@@ -418,8 +418,8 @@ __device__ __noinline__ i32x28 cyck_product_leaf(const lds_u32* pa, const lds_u3
   shu_ld_fp(a1, pa, FP_NL);
   shu_ld_fp(b0, pb, 0);
   shu_ld_fp(b1, pb, FP_NL);
-  if (SUMS) fp2_kara_diffs(r0, r1, a0, a1, b0, b1);      // (a - b)(a - xi b)
-  else fp2_kara_products(r0, r1, a0, a1, b0, b1);       // a b
+  if (SUMS) fp2_kara_diffs(r0, r1, a0, a1, b0, b1);      // (a - b)(a - xi b): real part, real + imaginary part
+  else fp2_kara_products(r0, r1, a0, a1, b0, b1);       // a b: likewise
   i32x28 o;
 #pragma unroll
   for (int i = 0; i < FP_NL; i++) {
@@ -468,9 +468,9 @@ __device__ __forceinline__ void f12_sh_cyc_c_sqr_kara_body(lds_u32* sh, const ld
   fp c0r, c0i, c1r, c1i, r0r, r0i, r1r, r1i, s, o;
 #pragma unroll
   for (int i = 0; i < FP_NL; i++) {
-    const int32_t b0 = B[i], b1 = B[FP_NL + i];
-    c0r.l[i] = A[i] + 2 * b0 - b1;                 // c0 = A + (2 + u) B
-    c0i.l[i] = A[FP_NL + i] + b0 + 2 * b1;
+    const int32_t b0 = B[i], b1 = B[FP_NL + i] - b0, a0 = A[i], a1 = A[FP_NL + i] - a0;    // (the products return real and real + imaginary parts)
+    c0r.l[i] = a0 + 2 * b0 - b1;                   // c0 = A + (2 + u) B
+    c0i.l[i] = a1 + b0 + 2 * b1;
     c1r.l[i] = 2 * (b0 - (b1 & m));                // c1 = 2 B, times xi on the odd lane (its results feed z2' = 3 xi c1 + 2 z2)
     c1i.l[i] = 2 * (b1 + (b0 & m));
   }
@@ -637,6 +637,9 @@ static inline void fp2_inv(hfp2& r, const hfp2& a) {
 // overload: fp12_pow_x_compressed<hfp2> (pairing.cuh) picks it over the generic cyc_c_sqr, so every lane-split verdict of tests/hostsim
 // runs this form under the bound tracker; g_cyc_kara = 0 gives the lane-split squarings of round 3 (k_finalexps and the A/B builds).
 static int g_cyc_kara = 1;
+static inline bool fp12_pow_x_compressed(fp12_t<hfp2>& r, const fp12_t<hfp2>& a) {   // k_finalexp2s: the four-power chain; the others: six
+  return g_cyc_kara ? fp12_pow_x_compressed4<hfp2>(r, a) : fp12_pow_x_compressed<hfp2>(r, a);
+}
 static inline void cyc_c_sqr(cyc_c<hfp2>& r, const cyc_c<hfp2>& in) {
   if (!g_cyc_kara) {
     cyc_c_sqr<hfp2>(r, in);

@@ -371,6 +371,9 @@ int hs_pow_x_compressed_check(const uint32_t* g1s, const uint32_t* g2s) {
   uint32_t wa[144], wb[144];
   store_fp12_plain(wa, a); store_fp12_plain(wb, b);
   if (memcmp(wa, wb, sizeof wa)) return 0;
+  if (!fp12_pow_x_compressed4(b, e)) return -6;       // the four-power chain with the plain tail (k_finalexp2s), one-lane tower
+  store_fp12_plain(wb, b);
+  if (memcmp(wa, wb, sizeof wa)) return -7;
   // the lane-split instantiation
   fp12_t<hfp2> es, as, bs;
   const fp2* src[6] = {&e.c0.a0, &e.c0.a1, &e.c0.a2, &e.c1.a0, &e.c1.a1, &e.c1.a2};
