@@ -2302,6 +2302,20 @@ static __device__ __noinline__ int fx_is_one(lds_u32* sh) {
   sh_ld_f12(a, sh);
   return fp12_is_one(a) ? BLS_OK : BLS_ERR_INVALID_SIGNATURE;
 }
+// A == conj(V[slot]) ?
+static __device__ __noinline__ int fx_eq_conj(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t, int slot) {
+  const vs_ref v = {vp, lanes, t};
+  bool eq = true;
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    hfp2 a, b;
+    sh_ld_fp(a.v, sh, 13 * j);
+    vs_ld(b.v, v, slot, j);
+    if (j >= 3) fp2_neg(b, b);
+    eq = fp2_eq(a, b) && eq;
+  }
+  return eq ? BLS_OK : BLS_ERR_INVALID_SIGNATURE;
+}
 // items [first, first + count) of the Fp12 workspace fws (stride n, as k_millerf2s / k_miller2s leave it)
 __global__ void __launch_bounds__(BLS_BLOCK, BLS_SPLIT_WAVES) __attribute__((disable_tail_calls))
 k_finalexp2s(size_t n, size_t first, size_t count, const uint32_t* fws, uint32_t* vp, size_t lanes, int32_t* status) {
@@ -2345,9 +2359,8 @@ k_finalexp2s(size_t n, size_t first, size_t count, const uint32_t* fws, uint32_t
   fx_store(sh, vp, lanes, t, 0);
   fx_load(sh, vp, lanes, t, 1, FX_PLAIN);
   fx_cyc_sqr(sh);
-  fx_mul(sh, vp, lanes, t, 1, FX_PLAIN);         // f^3
-  fx_mul(sh, vp, lanes, t, 0, FX_PLAIN);
-  const int st = fx_is_one(sh);
+  fx_mul(sh, vp, lanes, t, 0, FX_PLAIN);         // t f^2
+  const int st = fx_eq_conj(sh, vp, lanes, t, 1);   // == conj(f) = 1 / f  <=>  t f^3 == 1 (pairing.cuh final_exp_is_one)
   if (!lane_hi()) status[i] = st;
 }
 // The same final exponentiation in SEGMENTS between which k_cyc_run4 (four lanes per item, four waves per SIMD) runs the 63

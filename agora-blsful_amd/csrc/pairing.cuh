@@ -568,10 +568,11 @@ BLS_FN void fp12_pow_x(fp12_t<F2>& r, const fp12_t<F2>& a) {
   if (!fp12_pow_x_compressed(r, a)) fp12_pow_x_plain(r, a);
 }
 
-// f^(3 (p^12 - 1)/r), using 3 (p^4 - p^2 + 1)/r = (x-1)^2 (x+p) (x^2+p^2-1) + 3
+// f^(3 (p^12 - 1)/r), using 3 (p^4 - p^2 + 1)/r = (x-1)^2 (x+p) (x^2+p^2-1) + 3.
+// final_exp_parts: f <- fin after the easy part, t <- f^((x-1)^2 (x+p) (x^2+p^2-1)); the value is t f^3.
 template <class F2>
-BLS_FN void final_exponentiation(fp12_t<F2>& r, const fp12_t<F2>& fin) {
-  fp12_t<F2> f, t, u, v;
+BLS_FN void final_exp_parts(fp12_t<F2>& t, fp12_t<F2>& f, const fp12_t<F2>& fin) {
+  fp12_t<F2> u, v;
   // easy part: f^((p^6 - 1)(p^2 + 1))
   fp12_inv(t, fin);
   fp12_conj(f, fin);
@@ -594,7 +595,24 @@ BLS_FN void final_exponentiation(fp12_t<F2>& r, const fp12_t<F2>& fin) {
   fp12_mul(u, u, v);
   fp12_conj(v, t);
   fp12_mul(t, u, v);  // ^(x^2+p^2-1)
+}
+template <class F2>
+BLS_FN void final_exponentiation(fp12_t<F2>& r, const fp12_t<F2>& fin) {
+  fp12_t<F2> f, t, u;
+  final_exp_parts(t, f, fin);
   fp12_cyclotomic_sqr(u, f);
   fp12_mul(u, u, f);  // f^3
   fp12_mul(r, t, u);
+}
+// the verdict only: t f^3 == 1  <=>  t f^2 == conj(f)  (f lies in the cyclotomic subgroup after the easy part: its conjugate is its
+// inverse) -- one Fp12 product less than forming the value (round 4)
+template <class F2>
+BLS_FN bool final_exp_is_one(const fp12_t<F2>& fin) {
+  fp12_t<F2> f, t, u, c;
+  final_exp_parts(t, f, fin);
+  fp12_cyclotomic_sqr(u, f);
+  fp12_mul(u, t, u);
+  fp12_conj(c, f);
+  return fp2_eq(u.c0.a0, c.c0.a0) && fp2_eq(u.c0.a1, c.c0.a1) && fp2_eq(u.c0.a2, c.c0.a2) && fp2_eq(u.c1.a0, c.c1.a0) && fp2_eq(u.c1.a1, c.c1.a1) &&
+         fp2_eq(u.c1.a2, c.c1.a2);
 }

@@ -175,7 +175,5 @@ BLS_FN int prepare_g2impl(g1_aff* P, g2_aff* Q, const g1_jac& pk, const g2_jac& 
 
 template <class F2>
 BLS_FN int pairing_verdict(const fp12_t<F2>& f) {
-  fp12_t<F2> e;
-  final_exponentiation(e, f);
-  return fp12_is_one(e) ? BLS_OK : BLS_ERR_INVALID_SIGNATURE;
+  return final_exp_is_one(f) ? BLS_OK : BLS_ERR_INVALID_SIGNATURE;
 }

@@ -432,6 +432,28 @@ void hs_fp2_kara(const uint32_t* a, const uint32_t* b, uint32_t* out) {
   fp2_mul_kara_diffs(r0, r1, a0, a1, b0, b1);
   fp_to_raw(out + 24, r0); fp_to_raw(out + 36, r1);
 }
+// a^x for a = 1: every compressed coordinate vanishes, the compressed chains must decline (z2 = 0: the other decompression formula)
+// and fp12_pow_x must come back with 1 through the plain chain -- the fallback of k_finalexp2s / fx_pow_plain.  Both towers, both
+// chain forms.  1 = as expected
+int hs_pow_x_identity_check(void) {
+  fp12 one, r;
+  fp12_one(one);
+  if (fp12_pow_x_compressed(r, one) || fp12_pow_x_compressed4(r, one)) return -1;
+  fp12_pow_x(r, one);
+  if (!fp12_is_one(r)) return -2;
+  fp12_t<hfp2> os, rs;
+  fp12_one(os);
+  const int keep = g_cyc_kara;
+  int ok = 1;
+  for (int on = 0; on < 2 && ok == 1; on++) {
+    g_cyc_kara = on;
+    if (fp12_pow_x_compressed(rs, os)) ok = -3 - on;
+    fp12_pow_x(rs, os);
+    if (!fp12_is_one(rs)) ok = -5 - on;
+  }
+  g_cyc_kara = keep;
+  return ok;
+}
 // checked decompression: returns the status code; on success writes the re-compressed (modern) bytes
 int hs_decompress(int group, const uint8_t* in, int legacy, uint8_t* out) {
   if (group == 1) {

@@ -324,6 +324,8 @@ def test_pairing_values(hs):
     for on in (0, 1):
         hs.hs_set_cyc_kara(on)
         assert hs.hs_pow_x_compressed_check(util.g1_aff_raw(P2), util.g2_aff_raw(Q2)) == 1
+    hs.hs_set_cyc_kara(1)
+    assert hs.hs_pow_x_identity_check() == 1     # a = 1: the compressed chains decline (z2 = 0) and the plain chain answers
     # the precomputed -g2 line table (tools/gen_g2_lines.py) reproduces the generic loop's Miller value bit for bit
     assert hs.hs_miller_fixed_g2_matches(util.g1_aff_raw(P1), util.g2_aff_raw(Q1), util.g1_aff_raw(P2)) == 1
     # round 3: the two line values of a step merged before they touch f (k_lines2s / k_millerf2s), fixed lines normalised so that
