@@ -361,9 +361,12 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_prepare(size_t n, const uint8_
   // side (h2c.cuh) and everything else redundantly with identical operands; lane 0 of the pair stores.
   // bit 1 (SG == 1): the message point stays uncleared and pair 1 becomes (sig, -[c] g2) (verify.cuh prepare_g1impl): the
   // pairing that follows must take the line table of THAT point (fixed_g2 = 2)
+  // (Bls12381G2Impl is only ever launched with two lanes per item: a compile-time fact there, so that the one-lane form of hash_to_g2 --
+  // 5 KB of frame that no lane ever touched -- is not part of k_prepare<2>)
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t i = (two_lanes & 1) ? gid >> 1 : gid;
-  const int lane2 = (two_lanes & 1) ? (int)(gid & 1) : -1;
+  const bool tl = SG == 2 || (two_lanes & 1) != 0;
+  const size_t i = tl ? gid >> 1 : gid;
+  const int lane2 = tl ? (int)(gid & 1) : -1;
   if (i >= n) return;
   if (pre_status && status[i] != BLS_OK) return;   // the item already failed to decode
   size_t mi = single_msg ? 0 : i;
