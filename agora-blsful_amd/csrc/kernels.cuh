@@ -1209,6 +1209,10 @@ __device__ __forceinline__ gc_u32* uni_global(const uint32_t* p) { return (gc_u3
 // word `w` (a lane offset whose BYTE offset fits 32 bits: the hosts keep rows below 2^30 words) of a uniform row
 __device__ __forceinline__ uint32_t g_ld(gc_u32* row, uint32_t w) { return *(gc_u32*)((__attribute__((address_space(1))) const char*)row + (w << 2)); }
 __device__ __forceinline__ void g_st(g_u32* row, uint32_t w, uint32_t x) { *(g_u32*)((__attribute__((address_space(1))) char*)row + (w << 2)) = x; }
+// ... for data that streams through once (a chunk's line values: 2.5 GB written by the line kernel, read once by the accumulator's): non-temporal,
+// so that it does not push the spill slots of the functions in between out of the XCD's L2
+__device__ __forceinline__ uint32_t g_ld_nt(gc_u32* row, uint32_t w) { return __builtin_nontemporal_load((gc_u32*)((__attribute__((address_space(1))) const char*)row + (w << 2))); }
+__device__ __forceinline__ void g_st_nt(g_u32* row, uint32_t w, uint32_t x) { __builtin_nontemporal_store(x, (g_u32*)((__attribute__((address_space(1))) char*)row + (w << 2))); }
 __device__ __forceinline__ void ws_ld_hfp12(fp12_t<hfp2>& f, const uint32_t* ws, size_t stride, size_t i) {
   ws_ld_hfp2(f.c0.a0, ws, stride, i, 0);
   ws_ld_hfp2(f.c0.a1, ws, stride, i, W2);
@@ -1306,7 +1310,7 @@ __device__ __forceinline__ void line5_st(uint32_t* lines, size_t lanes, uint32_t
   for (int j = 0; j < 5; j++)
 #pragma unroll
     for (int k = 0; k < FP_NL; k++) {
-      g_st(row, t, (uint32_t)c[j]->l[k]);
+      g_st_nt(row, t, (uint32_t)c[j]->l[k]);
       row += lanes;
     }
 }
@@ -1318,7 +1322,7 @@ __device__ __forceinline__ void line5_ld(line5_t<hfp2>& L, const uint32_t* lines
   for (int j = 0; j < 5; j++)
 #pragma unroll
     for (int k = 0; k < FP_NL; k++) {
-      c[j]->l[k] = (int32_t)g_ld(row, t);
+      c[j]->l[k] = (int32_t)g_ld_nt(row, t);
       row += lanes;
     }
 }
@@ -1381,7 +1385,7 @@ __device__ __forceinline__ void line3_st(uint32_t* lines3, size_t lanes, uint32_
   for (int j = 0; j < 3; j++)
 #pragma unroll
     for (int k = 0; k < FP_NL; k++) {
-      g_st(row, t, (uint32_t)c[j]->l[k]);
+      g_st_nt(row, t, (uint32_t)c[j]->l[k]);
       row += lanes;
     }
 }
@@ -1393,7 +1397,7 @@ __device__ __forceinline__ void line3_ld(hfp2& l0, hfp2& l2, hfp2& l3, const uin
   for (int j = 0; j < 3; j++)
 #pragma unroll
     for (int k = 0; k < FP_NL; k++) {
-      c[j]->l[k] = (int32_t)g_ld(row, t);
+      c[j]->l[k] = (int32_t)g_ld_nt(row, t);
       row += lanes;
     }
 }
@@ -1591,13 +1595,13 @@ __device__ __forceinline__ void line3_st4(uint32_t* lines3, size_t lanes, uint32
   const uint32_t w = t2 + (pr ? (uint32_t)(2 * FP_NL) * (uint32_t)lanes : 0u);
 #pragma unroll
   for (int k = 0; k < FP_NL; k++) {
-    g_st(row, w, (uint32_t)first.v.l[k]);
+    g_st_nt(row, w, (uint32_t)first.v.l[k]);
     row += lanes;
   }
   if (!pr) {
 #pragma unroll
     for (int k = 0; k < FP_NL; k++) {
-      g_st(row, t2, (uint32_t)l2.v.l[k]);
+      g_st_nt(row, t2, (uint32_t)l2.v.l[k]);
       row += lanes;
     }
   }
@@ -1740,6 +1744,8 @@ static __device__ __noinline__ void f12_sh_sqr_fn(lds_u32* sh) {
   fp12_sqr_body(r, a);
   sh_st_f12(sh, r);
 }
+// (measured and not adopted, round 4: the five coefficients fetched where they are needed -- three for the first Fp6 product, two for the
+// sparse one, all five again for the Karatsuba sum -- instead of held: the same 46 spilled registers, 70 more loads, +2 %)
 static __device__ __noinline__ void f12_sh_mul_line5_fn(lds_u32* sh, const uint32_t* lines, size_t lanes, uint32_t t, int e) {
   line5_t<hfp2> L;
   line5_ld(L, lines, lanes, t, e);
@@ -1836,7 +1842,7 @@ static __device__ __noinline__ void f12_sh_mul_line3_fn(lds_u32* sh, const uint3
   for (int j = 0; j < 3; j++)
 #pragma unroll
     for (int k = 0; k < FP_NL; k++) {
-      c[j]->l[k] = (int32_t)g_ld(row, t);
+      c[j]->l[k] = (int32_t)g_ld_nt(row, t);
       row += lanes;
     }
   f12_sh_mul_line3(sh, l0, l2, l3);
@@ -1884,7 +1890,7 @@ __device__ __forceinline__ void quad_line_ld(hfp2& l0, hfp2& l2, hfp2& l3, size_
     for (int j = 0; j < 3; j++)
 #pragma unroll
       for (int k = 0; k < FP_NL; k++) {
-        c[j]->l[k] = (int32_t)g_ld(row, t);
+        c[j]->l[k] = (int32_t)g_ld_nt(row, t);
         row += lanes;
       }
   } else {
@@ -1938,7 +1944,7 @@ __device__ __forceinline__ void wsu_ld_hfp6(fp6_t<hfp2>& r, const uint32_t* ws, 
   for (int j = 0; j < 3; j++) {
 #pragma unroll
     for (int k = 0; k < FP_NL; k++) {
-      c[j]->l[k] = (int32_t)g_ld(row, off);
+      c[j]->l[k] = (int32_t)g_ld_nt(row, off);
       row += stride;
     }
     row += (size_t)(W2 - FP_NL) * stride;
@@ -1952,7 +1958,7 @@ __device__ __forceinline__ void wsu_st_hfp6(uint32_t* ws, size_t stride, uint32_
   for (int j = 0; j < 3; j++) {
 #pragma unroll
     for (int k = 0; k < FP_NL; k++) {
-      g_st(row, off, (uint32_t)c[j]->l[k]);
+      g_st_nt(row, off, (uint32_t)c[j]->l[k]);
       row += stride;
     }
     row += (size_t)(W2 - FP_NL) * stride;
