@@ -2208,34 +2208,41 @@ static __device__ __noinline__ void fx_pow_run(lds_u32* sh, uint32_t* vp, size_t
 // ... and the rest: the six powers decompressed with one shared inversion (Montgomery's trick over the denominators 4 z2) and
 // multiplied into A.  Returns false on the lanes of an item one of whose z2 vanishes (never seen for honest inputs): the caller
 // then runs the plain chain for that item.
-// NP = 6: the powers of |x|'s six set bits, multiplied together.  NP = 4 (the run above): the powers 2^16, 2^48, 2^57, 2^61 and the plain
-// tail of fp12_pow_x_compressed4 -- A = a^(2^61) conj(a^(2^57)) = c, parked in slot 6 (the four powers fill slots 3..5 only), three
-// Granger-Scott squarings, A <- A conj(c) = c^7, then the two low powers.
+// NP = 6: the powers of |x|'s six set bits, multiplied together (i from NP - 1 down to 0 in one call).
+// NP = 4 (the run above: the powers 2^16, 2^48, 2^57, 2^61 and the plain tail of pairing.cuh fp12_pow_x_compressed4) in TWO calls around the
+// tail, so that no call sits inside the loop that carries the inversion's state (with fx_store / fx_cyc_sqr / fx_mul inside it the frame
+// grew from 720 to 1,104 bytes): PART 0 takes i = 3, 2 -- A = a^(2^61) conj(a^(2^57)) = c -- and leaves the running inverse in the
+// store (slot 7, position 5); the caller parks c in slot 6, squares three times and multiplies by conj(c); PART 1 takes i = 1, 0.
 static __device__ __noinline__ void fx_mul(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t, int slot, int mode);
 static __device__ __noinline__ void fx_store(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t, int slot);
 static __device__ __noinline__ void fx_cyc_sqr(lds_u32* sh);
-template <int NP>
+template <int NP, int PART>
 static __device__ __noinline__ bool fx_pow_finish_n(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t) {
   const vs_ref v = {vp, lanes, t};
   hfp2 pre, d, inv, tt;
-  bool ok = true;
-  for (int i = 0; i < NP; i++) {           // prefix products of the denominators -> slot 7
-    int slot, idx;
-    hfp2 z2;
-    cpow_slot(i, 0, slot, idx);
-    vs_ld(z2.v, v, slot, idx);
-    if (fp2_is_zero(z2)) ok = false;
-    fp2_dbl(tt, z2);
-    fp2_dbl(tt, tt);
-    fp2_norm(d, tt);                       // 4 z2
-    if (i == 0) pre = d;
-    else fp2_mul(pre, pre, d);
-    vs_st(v, 7, i, pre.v);
+  if (PART == 0) {
+    bool ok = true;
+    for (int i = 0; i < NP; i++) {           // prefix products of the denominators -> slot 7
+      int slot, idx;
+      hfp2 z2;
+      cpow_slot(i, 0, slot, idx);
+      vs_ld(z2.v, v, slot, idx);
+      if (fp2_is_zero(z2)) ok = false;
+      fp2_dbl(tt, z2);
+      fp2_dbl(tt, tt);
+      fp2_norm(d, tt);                       // 4 z2
+      if (i == 0) pre = d;
+      else fp2_mul(pre, pre, d);
+      vs_st(v, 7, i, pre.v);
+    }
+    if (!ok) return false;
+    fp2_inv(inv, pre);
+  } else {
+    vs_ld(inv.v, v, 7, 5);
   }
-  if (!ok) return false;
-  fp2_inv(inv, pre);
+  const int hi = PART == 0 ? NP - 1 : 1, lo = (NP == 4 && PART == 0) ? 2 : 0;
 #pragma nounroll
-  for (int i = NP - 1; i >= 0; i--) {
+  for (int i = hi; i >= lo; i--) {
     hfp2 di;
     cyc_c<hfp2> s;
     int slot, idx;
@@ -2260,22 +2267,28 @@ static __device__ __noinline__ bool fx_pow_finish_n(lds_u32* sh, uint32_t* vp, s
     vs_ld(s.z5.v, v, slot, idx);
     fp12_t<hfp2> e;
     cyc_decompress(e, s, di);
+    if (NP == 4) {                         // the second power enters as its conjugate (a sign, not a branch: the loop body stays one)
+      const int32_t m = i == 2 ? -1 : 0;
+      fp* hi3[3] = {&e.c1.a0.v, &e.c1.a1.v, &e.c1.a2.v};
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int k = 0; k < FP_NL; k++) hi3[j]->l[k] = (hi3[j]->l[k] ^ m) - m;
+    }
     if (i == NP - 1) {
       fp12_reduce(e, e);
       sh_st_f12(sh, e);
     } else {
-      if (NP == 4 && i == 2) fp12_conj(e, e);
       f12_sh_mul_body(sh, e);
-      if (NP == 4 && i == 2) {             // A = c = a^(2^61) conj(a^(2^57))
-        fx_store(sh, vp, lanes, t, 6);
-        for (int j = 0; j < 3; j++) fx_cyc_sqr(sh);
-        fx_mul(sh, vp, lanes, t, 6, FX_CONJ);   // c^8 conj(c)
-      }
     }
+  }
+  if (NP == 4 && PART == 0) {
+    fp2_reduce(inv, inv);
+    vs_st(v, 7, 5, inv.v);
   }
   return true;
 }
-static __device__ __noinline__ bool fx_pow_finish(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t) { return fx_pow_finish_n<6>(sh, vp, lanes, t); }
+static __device__ __noinline__ bool fx_pow_finish(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t) { return fx_pow_finish_n<6, 0>(sh, vp, lanes, t); }
 // the plain chain on A (Granger-Scott squarings, five multiplications by a = V[2]): the fallback of fx_pow_finish
 static __device__ __noinline__ void fx_pow_plain(lds_u32* sh, uint32_t* vp, size_t lanes, uint32_t t) {
   fx_load(sh, vp, lanes, t, 2, FX_PLAIN);
@@ -2300,7 +2313,14 @@ __device__ __forceinline__ void fx_pow_x(lds_u32* sh, uint32_t* vp, size_t lanes
   fx_store(sh, vp, lanes, t, 2);           // a: the fallback's operand
   fx_pow_run(sh, vp, lanes, t);
 #if BLS_CYC_KARA
-  if (!fx_pow_finish_n<4>(sh, vp, lanes, t)) fx_pow_plain(sh, vp, lanes, t);
+  if (fx_pow_finish_n<4, 0>(sh, vp, lanes, t)) {     // A = c = a^(2^61) conj(a^(2^57))
+    fx_store(sh, vp, lanes, t, 6);
+    for (int j = 0; j < 3; j++) fx_cyc_sqr(sh);
+    fx_mul(sh, vp, lanes, t, 6, FX_CONJ);             // c^8 conj(c) = c^7
+    fx_pow_finish_n<4, 1>(sh, vp, lanes, t);          // ... a^(2^48) a^(2^16)
+  } else {
+    fx_pow_plain(sh, vp, lanes, t);
+  }
 #else
   if (!fx_pow_finish(sh, vp, lanes, t)) fx_pow_plain(sh, vp, lanes, t);
 #endif
