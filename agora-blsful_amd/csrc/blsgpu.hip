@@ -151,6 +151,7 @@ extern "C" char** environ;
 struct Knobs {
   long coop_max = 4096, wide_max = 512, shard_min = 8192, contexts = 2, fake_devices = 0, acc_lanes = 57344;
   long msm_c = 0, msm_ch = 0, msm2_c = 0, msm2_ch = 0, msm2_q = 0;          // 0: the library's own choice
+  long msm2_tables = 1;       // verify_secure: weighted window tables of every key, built while the host hashes (0: off)
   long host_trace = 0, strict_env = 0, ab_knobs = 0;
   long ws_keep_mb = 4096;     // a context's line workspace above this many MiB is released when the call that grew it returns
   // A/B
@@ -166,7 +167,7 @@ const KnobSpec KNOB_TABLE[] = {
     {"BLSGPU_MSM_C", &Knobs::msm_c, 4, 16, false},                      {"BLSGPU_MSM_CH", &Knobs::msm_ch, 1, 1 << 16, false},
     {"BLSGPU_MSM2_C", &Knobs::msm2_c, 4, 16, false},                    {"BLSGPU_MSM2_CH", &Knobs::msm2_ch, 1, 1 << 16, false},
     {"BLSGPU_MSM2_Q", &Knobs::msm2_q, 1, 8, false},                     {"BLSGPU_HOST_TRACE", &Knobs::host_trace, 0, 1, false},
-    {"BLSGPU_WS_KEEP_MB", &Knobs::ws_keep_mb, 0, 1L << 20, false},
+    {"BLSGPU_WS_KEEP_MB", &Knobs::ws_keep_mb, 0, 1L << 20, false},        {"BLSGPU_MSM2_TABLES", &Knobs::msm2_tables, 0, 1, false},
     {"BLSGPU_STRICT_ENV", &Knobs::strict_env, 0, 1, false},             {"BLSGPU_AB_KNOBS", &Knobs::ab_knobs, 0, 1, false},
     {"BLSGPU_MILLER_CHUNK", &Knobs::miller_chunk, 0, 65536, true},      {"BLSGPU_MILLER_V1", &Knobs::miller_v1, 0, 1, true},
     {"BLSGPU_ROW_PAD", &Knobs::row_pad, 0, 4096, true},                 {"BLSGPU_WIDE_MODE", &Knobs::wide_mode, 1, 2, true},
@@ -1179,8 +1180,10 @@ struct msm2_ws {
   uint32_t *aff, *cnt, *off, *cur, *idx, *tiles;
   uint64_t* subs;
   uint8_t *inf, *sums, *part;
+  uint32_t *tab = nullptr, *jt = nullptr;     // weighted tables (k_msm2_tables) and their Jacobian staging: verify_secure only
 };
-int msm2_ws_take(Ctx* c, size_t n, int G, msm2_ws& w);
+int msm2_ws_take(Ctx* c, size_t n, int G, msm2_ws& w, bool tables = false);
+size_t msm2_tables_bytes(size_t n, int G);
 template <int G>
 int run_msm2_prep(Ctx* c, const uint8_t* d_pts, int fmt, const uint32_t* d_perm, size_t n, msm2_ws& w);
 template <int G>
@@ -1319,10 +1322,21 @@ size_t msm2_ws_bytes(size_t n) {          // callers reserve for either group
   }
   return need;
 }
-int msm2_ws_take(Ctx* c, size_t n, int G, msm2_ws& w) {
+// the weighted tables of k_msm2_tables: W affine entries per image, and 4 coordinates per window of Jacobian staging
+size_t msm2_tables_bytes(size_t n, int G) {
+  const msm2_plan p = msm2_make_plan(n, G);
+  const size_t affw = (G == 1 ? 2 : 4) * FP_NL;
+  return pad256(4 * affw * p.E * p.W * n) + pad256(4 * (affw / 2) * 4 * (p.W > 1 ? p.W - 1 : 1) * n) + 512;
+}
+int msm2_ws_take(Ctx* c, size_t n, int G, msm2_ws& w, bool tables) {
   w.p = msm2_make_plan(n, G);
   const msm2_plan& p = w.p;
   const size_t affw = (G == 1 ? 2 : 4) * FP_NL;
+  if (tables) {
+    w.tab = (uint32_t*)arena_take(c, 4 * affw * p.E * p.W * n);
+    w.jt = (uint32_t*)arena_take(c, 4 * (affw / 2) * 4 * (p.W > 1 ? p.W - 1 : 1) * n);
+    if (!w.tab || !w.jt) return fail(BLSGPU_E_HIP, "internal: arena too small");
+  }
   w.aff = (uint32_t*)arena_take(c, 4 * affw * p.E * n);
   w.inf = (uint8_t*)arena_take(c, n);
   w.subs = (uint64_t*)arena_take(c, 32 * n);
@@ -1341,6 +1355,8 @@ int msm2_ws_take(Ctx* c, size_t n, int G, msm2_ws& w) {
 template <int G>
 int run_msm2_prep(Ctx* c, const uint8_t* d_pts, int fmt, const uint32_t* d_perm, size_t n, msm2_ws& w) {
   KL(KID_MSM_PREP, k_msm2_prep<G>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, d_pts, fmt, d_perm, w.aff, w.inf);
+  if (w.tab)     // every window's multiple of every image, while the caller's host still hashes (verify_secure)
+    KL(KID_MSM_PREP, k_msm2_tables<G>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint32_t*)w.aff, (const uint8_t*)w.inf, w.p.W, w.tab, w.jt);
   HIPCK(hipGetLastError());
   return 0;
 }
@@ -1355,14 +1371,16 @@ int run_msm2_rest(Ctx* c, const uint8_t* d_scalars, size_t n, msm2_ws& w, uint8_
   if (rc) return rc;
   KL(KID_MSM_SORT, k_msm2_fill<G>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint64_t*)w.subs, (const uint8_t*)w.inf, p.W, (const uint32_t*)w.off, w.cur, w.idx);
   const size_t nbq = p.nb * p.Q;
-  if (G == 2) KL(KID_MSM_BUCKET, k_msm2_bucket_g2s, dim3(blocks_for(2 * nbq)), dim3(BLS_BLOCK), p.nb, p.Q, (const uint32_t*)w.aff, (const uint32_t*)w.cnt, (const uint32_t*)w.off, (const uint32_t*)w.idx, w.sums);
-  else KL(KID_MSM_BUCKET, k_msm2_bucket_g1, dim3(blocks_for(nbq)), dim3(BLS_BLOCK), p.nb, p.Q, (const uint32_t*)w.aff, (const uint32_t*)w.cnt, (const uint32_t*)w.off, (const uint32_t*)w.idx, w.sums);
+  const uint32_t* pts_ws = w.tab ? w.tab : w.aff;
+  const int tabW = w.tab ? p.W : 0, weighted = w.tab ? 1 : 0;
+  if (G == 2) KL(KID_MSM_BUCKET, k_msm2_bucket_g2s, dim3(blocks_for(2 * nbq)), dim3(BLS_BLOCK), p.nb, p.Q, pts_ws, (const uint32_t*)w.cnt, (const uint32_t*)w.off, (const uint32_t*)w.idx, w.sums, tabW);
+  else KL(KID_MSM_BUCKET, k_msm2_bucket_g1, dim3(blocks_for(nbq)), dim3(BLS_BLOCK), p.nb, p.Q, pts_ws, (const uint32_t*)w.cnt, (const uint32_t*)w.off, (const uint32_t*)w.idx, w.sums, tabW);
   if (p.Q > 1) {
     if (G == 2) KL(KID_MSM_MERGE, k_msm2_merge_g2s, dim3(blocks_for(2 * p.nb)), dim3(BLS_BLOCK), p.nb, p.Q, w.sums);
     else KL(KID_MSM_MERGE, k_msm2_merge_g1, dim3(blocks_for(p.nb)), dim3(BLS_BLOCK), p.nb, p.Q, w.sums);
   }
-  if (G == 2) KL(KID_MSM_CHUNK, k_msm2_chunk_g2q, dim3(blocks_for(4 * p.nchunks)), dim3(BLS_BLOCK), p.W, p.CH, p.Q, (const uint8_t*)w.sums, w.part);
-  else KL(KID_MSM_CHUNK, k_msm2_chunk_g1p, dim3(blocks_for(2 * p.nchunks)), dim3(BLS_BLOCK), p.W, p.CH, p.Q, (const uint8_t*)w.sums, w.part);
+  if (G == 2) KL(KID_MSM_CHUNK, k_msm2_chunk_g2q, dim3(blocks_for(4 * p.nchunks)), dim3(BLS_BLOCK), p.W, p.CH, p.Q, (const uint8_t*)w.sums, w.part, weighted);
+  else KL(KID_MSM_CHUNK, k_msm2_chunk_g1p, dim3(blocks_for(2 * p.nchunks)), dim3(BLS_BLOCK), p.W, p.CH, p.Q, (const uint8_t*)w.sums, w.part, weighted);
   if (int rc = run_point_fold<G>(c, w.part, p.nchunks)) return rc;
   // Z = 1 makes the output bytes independent of the (atomic) bucket fill order; a caller that only feeds the point to the
   // pairing stages skips it
@@ -2466,8 +2484,10 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
   const bool trace = knobs().host_trace != 0;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const size_t psz = pk_size(sig_group, fmt), width = sig_group == 1 ? 96 : 48, T = accumulate_lanes(n);
+  // weighted MSM tables (csrc/kernels.cuh k_msm2_tables): built while the host hashes the key stream; BLSGPU_MSM2_TABLES=0 switches them off
+  const bool msm_tables = knobs().msm2_tables != 0 && msm_use_pippenger(n) && !msm_use_v1();
   size_t need = pad256(psz * n) + pad256(width * n) + pad256(32 * n) + pad256(288 * T) + pad256(msg_len) + 16384 + msm_ws_bytes(n) +
-                keysort_ws_bytes(n, width);
+                keysort_ws_bytes(n, width) + (msm_tables ? msm2_tables_bytes(n, sig_group == 1 ? 2 : 1) : 0);
   if ((rc = arena_reserve(c, need))) return rc;
   c->arena_off = 0;
   int32_t st = BLSGPU_OK;
@@ -2528,7 +2548,7 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
   const bool msm2 = msm_use_pippenger(n) && !msm_use_v1();
   msm2_ws mw;
   if (msm2) {
-    if ((rc = msm2_ws_take(c, n, sig_group == 1 ? 2 : 1, mw))) return rc;
+    if ((rc = msm2_ws_take(c, n, sig_group == 1 ? 2 : 1, mw, msm_tables))) return rc;
     if (sig_group == 1) rc = run_msm2_prep<2>(c, (const uint8_t*)d_pks, fmt, nullptr, n, mw);
     else rc = run_msm2_prep<1>(c, (const uint8_t*)d_pks, fmt, nullptr, n, mw);
     if (rc) return rc;

@@ -286,15 +286,17 @@ __global__ void k_normalize(uint8_t* pt);
 template <int G>
 __global__ void k_msm2_prep(size_t n, const uint8_t* pts, int fmt, const uint32_t* perm, uint32_t* affws, uint8_t* inf);
 template <int G>
+__global__ void k_msm2_tables(size_t n, const uint32_t* affws, const uint8_t* inf, int W, uint32_t* tab, uint32_t* jt);
+template <int G>
 __global__ void k_msm2_count(size_t n, const uint8_t* scalars, const uint8_t* inf, int W, uint32_t* cnt, uint64_t* subs);
 template <int G>
 __global__ void k_msm2_fill(size_t n, const uint64_t* subs, const uint8_t* inf, int W, const uint32_t* off, uint32_t* cursor, uint32_t* idx);
 __global__ void k_msm2_merge_g1(size_t nb, int Q, uint8_t* sums);
 __global__ void k_msm2_merge_g2s(size_t nb, int Q, uint8_t* sums);
-__global__ void k_msm2_bucket_g1(size_t nb, int Q, const uint32_t* affws, const uint32_t* cnt, const uint32_t* off, const uint32_t* idx, uint8_t* sums);
-__global__ void k_msm2_bucket_g2s(size_t nb, int Q, const uint32_t* affws, const uint32_t* cnt, const uint32_t* off, const uint32_t* idx, uint8_t* sums);
-__global__ void k_msm2_chunk_g1p(int W, int CH, int stride, const uint8_t* sums, uint8_t* partials);
-__global__ void k_msm2_chunk_g2q(int W, int CH, int stride, const uint8_t* sums, uint8_t* partials);
+__global__ void k_msm2_bucket_g1(size_t nb, int Q, const uint32_t* affws, const uint32_t* cnt, const uint32_t* off, const uint32_t* idx, uint8_t* sums, int tabW);
+__global__ void k_msm2_bucket_g2s(size_t nb, int Q, const uint32_t* affws, const uint32_t* cnt, const uint32_t* off, const uint32_t* idx, uint8_t* sums, int tabW);
+__global__ void k_msm2_chunk_g1p(int W, int CH, int stride, const uint8_t* sums, uint8_t* partials, int weighted);
+__global__ void k_msm2_chunk_g2q(int W, int CH, int stride, const uint8_t* sums, uint8_t* partials, int weighted);
 // wire bytes (48/96 B, modern or legacy header) -> RAW_PROJ with the checks of from_compressed; status[i] = 0 / 7 / 8.
 // keep != 0: leave a non-zero status[i] that is already there (first error wins when keys and signatures are decoded)
 template <int G>
@@ -2734,6 +2736,101 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_msm2_prep(size_t n, const uint8_t
     }
   }
 }
+// WEIGHTED TABLES (round 4; verify_secure only, where this runs while a host core still hashes the sorted key stream): for every key
+// the multiples 2^start(w) P of its windows w = 1 .. W - 1, affine, each with its endomorphism images -- entry ((i E + j) W + w) of
+// `tab` (entry w = 0: the images k_msm2_prep left).  A digit of window w then adds the ALREADY WEIGHTED point into its bucket, so the
+// chunk lanes -- the latency chain of the whole sum -- lose their start(w) doublings (up to 52 on G2, 116 on G1) and the windows' sums
+// are simply added.  Doubling commutes with the endomorphisms, so one chain of doublings per key serves all its images; the W - 1
+// Jacobian multiples wait in `jt` (X, Y, Z and the running product of the Z's, 4 coordinates per window) for ONE shared inversion.
+// Neither curve has a point of order two (both group orders are odd), so no multiple of a key is the identity and no Z vanishes.
+__device__ __forceinline__ void co_st(uint32_t* e, const fp& a) { aff_st_fp(e, 0, a); }
+__device__ __forceinline__ void co_st(uint32_t* e, const fp2& a) {
+  aff_st_fp(e, 0, a.c0);
+  aff_st_fp(e, FP_NL, a.c1);
+}
+__device__ __forceinline__ void co_ld(fp& r, const uint32_t* e) { aff_ld_fp(r, e, 0); }
+__device__ __forceinline__ void co_ld(fp2& r, const uint32_t* e) {
+  aff_ld_fp(r.c0, e, 0);
+  aff_ld_fp(r.c1, e, FP_NL);
+}
+template <int G>
+__global__ void __launch_bounds__(BLS_BLOCK) k_msm2_tables(size_t n, const uint32_t* affws, const uint8_t* inf, int W, uint32_t* tab, uint32_t* jt) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || inf[i]) return;
+  typedef typename msm_pt<G>::jac_t J;
+  typedef decltype(J().x) F;
+  constexpr int E = MSM2_E(G), AFFW = MSM2_AFF_WORDS(G), C = AFFW / 2;     // C: words per coordinate
+  const msm2_layout L = msm2_make_layout(G == 1 ? 128 : 64, W);
+  const uint32_t* e0 = affws + i * E * AFFW;
+  uint32_t* ti = tab + i * E * (size_t)W * AFFW;
+  for (int j = 0; j < E; j++)                                             // window 0: the images as they are
+    for (int k = 0; k < AFFW; k++) ti[(size_t)j * W * AFFW + k] = e0[j * AFFW + k];
+  if (W < 2) return;
+  uint32_t* ji = jt + i * (size_t)(W - 1) * 4 * C;
+  J T;
+  co_ld(T.x, e0);
+  co_ld(T.y, e0 + C);
+  fe_one(T.z);
+  F acc;
+  for (int w = 1; w < W; w++) {
+    const int k = msm2_start(L, w) - msm2_start(L, w - 1);
+    for (int d = 0; d < k; d++) jac_dbl(T, T);
+    uint32_t* r = ji + (size_t)(w - 1) * 4 * C;
+    co_st(r, T.x);
+    co_st(r + C, T.y);
+    co_st(r + 2 * C, T.z);
+    if (w == 1) acc = T.z;
+    else fe_mul(acc, acc, T.z);
+    co_st(r + 3 * C, acc);                                                // Z_1 ... Z_w
+  }
+  F inv;
+  fe_inv(inv, acc);
+  for (int w = W - 1; w >= 1; w--) {
+    const uint32_t* r = ji + (size_t)(w - 1) * 4 * C;
+    F zi, t, x, y;
+    if (w > 1) {
+      co_ld(t, r - 4 * C + 3 * C);                                        // Z_1 ... Z_(w-1)
+      fe_mul(zi, inv, t);
+      co_ld(t, r + 2 * C);
+      fe_mul(inv, inv, t);
+    } else {
+      zi = inv;
+    }
+    fe_sqr(t, zi);
+    co_ld(x, r);
+    fe_mul(x, x, t);
+    fe_mul(t, t, zi);
+    co_ld(y, r + C);
+    fe_mul(y, y, t);
+    if (G == 1) {
+      g1_aff a;
+      a.x = *(fp*)&x;
+      a.y = *(fp*)&y;
+      a.inf = false;
+      fp qx[2], qy[2];
+      msm2_images_g1(qx, qy, a);
+      for (int j = 0; j < 2; j++) {
+        uint32_t* q = ti + ((size_t)j * W + w) * AFFW;
+        aff_st_fp(q, 0, qx[j]);
+        aff_st_fp(q, FP_NL, qy[j]);
+      }
+    } else {
+      g2_aff a;
+      a.x = *(fp2*)&x;
+      a.y = *(fp2*)&y;
+      a.inf = false;
+      fp2 qx[4], qy[4];
+      msm2_images_g2(qx, qy, a);
+      for (int j = 0; j < 4; j++) {
+        uint32_t* q = ti + ((size_t)j * W + w) * AFFW;
+        aff_st_fp(q, 0, qx[j].c0);
+        aff_st_fp(q, FP_NL, qx[j].c1);
+        aff_st_fp(q, 2 * FP_NL, qy[j].c0);
+        aff_st_fp(q, 3 * FP_NL, qy[j].c1);
+      }
+    }
+  }
+}
 // scalar -> E sub-scalars (stored for k_msm2_fill) -> signed digits -> bucket sizes.  Bucket of digit magnitude m in
 // window w: msm2_bucket_base(w) + m - 1 (window layout in msm2.cuh).
 template <int G>
@@ -2965,8 +3062,9 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_msm_chunk_g1p(int c, int W, int c
 
 // one lane per (bucket, part): part q of Q takes entries q, q + Q, ... of the bucket's list (Q > 1 fills the machine when
 // there are fewer buckets than lanes); mixed additions of affine images
+// tabW != 0: affws is the weighted table of k_msm2_tables (tabW windows per image): the entry of this bucket's window
 __global__ void __launch_bounds__(BLS_BLOCK) k_msm2_bucket_g1(size_t nb, int Q, const uint32_t* affws, const uint32_t* cnt, const uint32_t* off,
-                                                           const uint32_t* idx, uint8_t* sums) {
+                                                           const uint32_t* idx, uint8_t* sums, int tabW) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nb * (size_t)Q) return;
   const size_t b = t / Q;
@@ -2974,9 +3072,10 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_msm2_bucket_g1(size_t nb, int Q, 
   g1_jac acc;
   jac_set_inf(acc);
   const uint32_t m = cnt[b], o = off[b];
+  const size_t per = tabW ? (size_t)tabW : 1, wsel = tabW ? (size_t)msm2_window_of(msm2_make_layout(128, tabW), b) : 0;
   for (uint32_t j = q; j < m; j += Q) {
     const uint32_t code = idx[o + j];
-    const uint32_t* e = affws + (size_t)(code >> 1) * 2 * FP_NL;
+    const uint32_t* e = affws + ((size_t)(code >> 1) * per + wsel) * 2 * FP_NL;
     fp x, y;
     aff_ld_fp(x, e, 0);
     aff_ld_fp(y, e, FP_NL);
@@ -3000,7 +3099,8 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_msm2_merge_g1(size_t nb, int Q, u
 }
 // chunk lanes as k_msm_chunk_g1p (two lanes per chunk sharing the doubling chains), for the signed-digit layout: bucket index
 // t of a window stands for digit t + 1 and window w weighs 2^start(w); bucket sums sit `stride` records apart
-__global__ void __launch_bounds__(BLS_BLOCK) k_msm2_chunk_g1p(int W, int CH, int stride, const uint8_t* sums, uint8_t* partials) {
+// weighted != 0: the bucket sums already carry their window's weight (k_msm2_tables): no doublings at the end
+__global__ void __launch_bounds__(BLS_BLOCK) k_msm2_chunk_g1p(int W, int CH, int stride, const uint8_t* sums, uint8_t* partials, int weighted) {
   const msm2_layout L = msm2_make_layout(128, W);
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, t = gid >> 1;
   const bool hi = (gid & 1) != 0;
@@ -3024,11 +3124,12 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_msm2_chunk_g1p(int W, int CH, int
     }
     jac_add(acc, acc, s);
   }
-  const int shift = msm2_start(L, w);
+  const int shift = weighted ? 0 : msm2_start(L, w);
   for (int k = 0; k < shift; k++) jac_dbl_pair(acc, hi);   // the window's weight
   if (!hi) store_g1_pt(partials, t, acc);
 }
 template __global__ void k_msm2_prep<1>(size_t, const uint8_t*, int, const uint32_t*, uint32_t*, uint8_t*);
+template __global__ void k_msm2_tables<1>(size_t, const uint32_t*, const uint8_t*, int, uint32_t*, uint32_t*);
 template __global__ void k_msm2_count<1>(size_t, const uint8_t*, const uint8_t*, int, uint32_t*, uint64_t*);
 template __global__ void k_msm2_fill<1>(size_t, const uint64_t*, const uint8_t*, int, const uint32_t*, uint32_t*, uint32_t*);
 template __global__ void k_decompress<1>(size_t, const uint8_t*, int, uint8_t*, int32_t*, int);
@@ -3039,7 +3140,7 @@ template __global__ void k_normalize<1>(uint8_t*);
 
 // G2 buckets on two lanes per (bucket, part) (jac<hfp2>): each lane loads its own component of the affine entry
 __global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm2_bucket_g2s(size_t nb, int Q, const uint32_t* affws, const uint32_t* cnt, const uint32_t* off,
-                                                               const uint32_t* idx, uint8_t* sums) {
+                                                               const uint32_t* idx, uint8_t* sums, int tabW) {
   const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
   if (t >= nb * (size_t)Q) return;
   const size_t b = t / Q;
@@ -3048,9 +3149,10 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm2_bucket_g2s(size_t nb, int
   jac_set_inf(acc);
   const uint32_t m = cnt[b], o = off[b];
   const int half = lane_hi() ? FP_NL : 0;
+  const size_t per = tabW ? (size_t)tabW : 1, wsel = tabW ? (size_t)msm2_window_of(msm2_make_layout(64, tabW), b) : 0;
   for (uint32_t j = q; j < m; j += Q) {
     const uint32_t code = idx[o + j];
-    const uint32_t* e = affws + (size_t)(code >> 1) * 4 * FP_NL;
+    const uint32_t* e = affws + ((size_t)(code >> 1) * per + wsel) * 4 * FP_NL;
     hfp2 x, y;
     aff_ld_fp(x.v, e, half);
     aff_ld_fp(y.v, e, 2 * FP_NL + half);
@@ -3071,7 +3173,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm2_merge_g2s(size_t nb, int 
   st_g2s(sums, b * Q, acc);
 }
 // chunk lanes as k_msm_chunk_g2q (four lanes per chunk: two lane pairs sharing the doubling chains), signed-digit layout
-__global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm2_chunk_g2q(int W, int CH, int stride, const uint8_t* sums, uint8_t* partials) {
+__global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm2_chunk_g2q(int W, int CH, int stride, const uint8_t* sums, uint8_t* partials, int weighted) {
   const msm2_layout L = msm2_make_layout(64, W);
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, t = gid >> 2;
   const bool hi2 = ((gid >> 1) & 1) != 0;
@@ -3095,11 +3197,12 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm2_chunk_g2q(int W, int CH, 
     }
     jac_add(acc, acc, s);
   }
-  const int shift = msm2_start(L, w);
+  const int shift = weighted ? 0 : msm2_start(L, w);
   for (int k = 0; k < shift; k++) jac_dbl_quad(acc, hi2);
   if (!hi2) st_g2s(partials, t, acc);
 }
 template __global__ void k_msm2_prep<2>(size_t, const uint8_t*, int, const uint32_t*, uint32_t*, uint8_t*);
+template __global__ void k_msm2_tables<2>(size_t, const uint32_t*, const uint8_t*, int, uint32_t*, uint32_t*);
 template __global__ void k_msm2_count<2>(size_t, const uint8_t*, const uint8_t*, int, uint32_t*, uint64_t*);
 template __global__ void k_msm2_fill<2>(size_t, const uint64_t*, const uint8_t*, int, const uint32_t*, uint32_t*, uint32_t*);
 template __global__ void k_decompress<2>(size_t, const uint8_t*, int, uint8_t*, int32_t*, int);

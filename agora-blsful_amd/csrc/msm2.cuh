@@ -159,6 +159,12 @@ BLS_FN size_t msm2_bucket_base(const msm2_layout& L, int w) {
   return ((size_t)wide << L.base) + ((size_t)(w - wide) << (L.base - 1));
 }
 BLS_FN size_t msm2_buckets(const msm2_layout& L) { return msm2_bucket_base(L, L.W); }
+// the window of bucket b (inverse of msm2_bucket_base: the first `rem` windows have 2^base buckets each, the others 2^(base-1))
+BLS_FN int msm2_window_of(const msm2_layout& L, size_t b) {
+  const size_t wide = (size_t)L.rem << L.base;
+  if (b < wide) return (int)(b >> L.base);
+  return L.rem + (int)((b - wide) >> (L.base - 1));
+}
 // signed digit of window w of a sub-scalar given as `words` 64-bit words: digits in (-2^(c-1), 2^(c-1)], recoded from the
 // low end (digit w needs the carry of digit w - 1, so the caller walks w upwards and threads `carry` through)
 BLS_FN int32_t msm2_digit(const uint64_t* a, int words, const msm2_layout& L, int w, uint32_t& carry) {
