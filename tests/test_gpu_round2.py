@@ -581,6 +581,36 @@ def test_segmented_final_exponentiation_and_one_kernel_miller_loop_agree():
 
 
 @pytest.mark.gpu
+def test_verify_secure_with_and_without_weighted_tables():
+    """verify_secure's key sum with every key's weighted window multiples built under the host hash (k_msm2_tables, the default) and
+    without them (BLSGPU_MSM2_TABLES=0: the chunk lanes double their sums into place): the same verdicts for a valid aggregate, a key
+    short and a wrong message, both orientations, at a size whose windows differ in width (child processes: the knob is read once)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge\n"
+        "api = ge.import_pkg().api; api.init()\n"
+        "out = []\n"
+        "for sg, kg in ((1, 2), (2, 1)):\n"
+        "    n = 1500\n"
+        "    sks = [0x4242 + 7 * i for i in range(n)]; msg = b'tables or not'\n"
+        "    pks, sigs = api.sign_batch(sg, api.BASIC, sks, [msg] * n)\n"
+        "    st, perm, ts = api.secure_coefficients(api.serialize(kg, pks))\n"
+        "    agg = api.point_sum(sg, [sigs[i] for i in perm], ts)\n"
+        "    out.append([st, api.verify_secure(sg, api.BASIC, pks, agg, msg), api.verify_secure(sg, api.BASIC, pks[:-1], agg, msg),\n"
+        "                api.verify_secure(sg, api.BASIC, pks, agg, msg + b'!')])\n"
+        "print(repr(out))\n") % (util.ROOT, os.path.join(util.ROOT, 'tests'))
+    res = {}
+    for name, env in (('tables', {}), ('plain', {'BLSGPU_MSM2_TABLES': '0'})):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        res[name] = eval(r.stdout.strip().splitlines()[-1])
+    assert res['tables'] == [[0, 0, 1, 1], [0, 0, 1, 1]]
+    assert res['plain'] == res['tables']
+
+
+@pytest.mark.gpu
 def test_pairing_product_tree_and_accumulator_forms_agree(api):
     """AggregateSignature::verify's pairing product in its two forms -- the per-entry products over the items with one Horner chain
     (k_line_quad / k_f12_fold4 / k_f12_horner_wide, the default from 64 pairs) and one accumulator per item or pair of items
