@@ -2485,7 +2485,9 @@ int blsgpu_verify_secure(int sig_group, int scheme, const void* pks, size_t n, c
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const size_t psz = pk_size(sig_group, fmt), width = sig_group == 1 ? 96 : 48, T = accumulate_lanes(n);
   // weighted MSM tables (csrc/kernels.cuh k_msm2_tables): built while the host hashes the key stream; BLSGPU_MSM2_TABLES=0 switches them off
-  const bool msm_tables = knobs().msm2_tables != 0 && msm_use_pippenger(n) && !msm_use_v1();
+  // (up to 262,144 keys: the tables are 4.5 KB per G2 key -- 1.2 GB there -- and stay in the context's arena; beyond that size the sum
+  // is throughput-bound and its chunk lanes' latency no longer shows)
+  const bool msm_tables = knobs().msm2_tables != 0 && msm_use_pippenger(n) && !msm_use_v1() && n <= ((size_t)1 << 18);
   size_t need = pad256(psz * n) + pad256(width * n) + pad256(32 * n) + pad256(288 * T) + pad256(msg_len) + 16384 + msm_ws_bytes(n) +
                 keysort_ws_bytes(n, width) + (msm_tables ? msm2_tables_bytes(n, sig_group == 1 ? 2 : 1) : 0);
   if ((rc = arena_reserve(c, need))) return rc;
