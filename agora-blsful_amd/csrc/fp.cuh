@@ -792,7 +792,9 @@ BLS_FN void fp_divstep_update_fg(int32_t* f, int32_t* g, const fp_divstep_mat& t
   g[FP_NL - 1] = (int32_t)cg;
 }
 // (d, e) <- t (d, e) / 2^28 mod p, keeping d, e in (-2p, p)
-BLS_FN void fp_divstep_update_de(int32_t* d, int32_t* e, const fp_divstep_mat& tt) {
+// (mask = 0 switches the multiples of p off: the same pass then IS the exact update of (f, g) -- tower_split.cuh fp_inv_pair runs it on a
+// lane pair, (f, g) on one lane and (d, e) on the other)
+BLS_FN void fp_divstep_update_de(int32_t* d, int32_t* e, const fp_divstep_mat& tt, int32_t mask = -1) {
   fp_divstep_mat t = tt;
   FP_OPAQUE32(t.u);
   FP_OPAQUE32(t.v);
@@ -815,6 +817,8 @@ BLS_FN void fp_divstep_update_de(int32_t* d, int32_t* e, const fp_divstep_mat& t
   int64_t ce = (int64_t)t.q * d[0] + (int64_t)t.r * e[0];
   md -= (int32_t)((FP_PINV28 * (uint32_t)cd + (uint32_t)md) & FP_MASK);
   me -= (int32_t)((FP_PINV28 * (uint32_t)ce + (uint32_t)me) & FP_MASK);
+  md &= mask;
+  me &= mask;
   FP_OPAQUE32(md);
   FP_OPAQUE32(me);
   cd += (int64_t)pl[0] * md;
