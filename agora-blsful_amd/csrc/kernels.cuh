@@ -2774,7 +2774,7 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_msm2_tables(size_t n, const uint3
   F acc;
   for (int w = 1; w < W; w++) {
     const int k = msm2_start(L, w) - msm2_start(L, w - 1);
-    for (int d = 0; d < k; d++) jac_dbl(T, T);
+    for (int d = 0; d < k; d++) jac_dbl_body(T, T);     // inlined: through the non-inlined jac_dbl the point travelled by reference, through scratch
     uint32_t* r = ji + (size_t)(w - 1) * 4 * C;
     co_st(r, T.x);
     co_st(r + C, T.y);
