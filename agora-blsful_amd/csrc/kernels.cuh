@@ -956,8 +956,8 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_accumulate_g2s(size_t n, const
   for (size_t i = t; i < n; i += T) {
     ld_g2s_fmt(p, pts, i, fmt);
     fe_sub(d, p.z, one);
-    if (fe_is_zero(d)) jac_madd(acc, acc, p.x, p.y);
-    else jac_add(acc, acc, p);
+    if (fe_is_zero(d)) jac_madd_body(acc, acc, p.x, p.y);     // (bodies, not the non-inlined functions: through those the accumulator
+    else jac_add_body(acc, acc, p);                           //  travelled by reference, through scratch, once per key)
   }
   st_g2s(partials, t, acc);
 }
@@ -970,7 +970,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_point_fold_g2s(size_t m, size_
   jac<hfp2> a, b;
   ld_g2s(a, partials, i);
   ld_g2s(b, partials, i + half);
-  jac_add(a, a, b);
+  jac_add_body(a, a, b);
   st_g2s(partials, i, a);
 }
 // Stage 2: partial[i] += partial[i + half]
@@ -982,13 +982,13 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_point_fold(size_t m, size_t half,
     g1_jac a, b;
     load_g1_pt(a, partials, i, 0);
     load_g1_pt(b, partials, i + half, 0);
-    jac_add(a, a, b);
+    jac_add_body(a, a, b);
     store_g1_pt(partials, i, a);
   } else {
     g2_jac a, b;
     load_g2_pt(a, partials, i, 0);
     load_g2_pt(b, partials, i + half, 0);
-    jac_add(a, a, b);
+    jac_add_body(a, a, b);
     store_g2_pt(partials, i, a);
   }
 }
@@ -3080,7 +3080,7 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_msm2_bucket_g1(size_t nb, int Q, 
     aff_ld_fp(x, e, 0);
     aff_ld_fp(y, e, FP_NL);
     if (code & 1u) fp_neg(y, y);
-    jac_madd(acc, acc, x, y);
+    jac_madd_body(acc, acc, x, y);
   }
   store_g1_pt(sums, t, acc);
 }
@@ -3093,7 +3093,7 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_msm2_merge_g1(size_t nb, int Q, u
   load_g1_pt(acc, sums, b * Q, 0);
   for (int q = 1; q < Q; q++) {
     load_g1_pt(s, sums, b * Q + q, 0);
-    jac_add(acc, acc, s);
+    jac_add_body(acc, acc, s);
   }
   store_g1_pt(sums, b * Q, acc);
 }
@@ -3112,8 +3112,8 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_msm2_chunk_g1p(int W, int CH, int
   jac_set_inf(acc);
   for (int d = CH - 1; d >= 0; d--) {
     load_g1_pt(s, sums, (msm2_bucket_base(L, w) + lo + d) * stride, 0);
-    jac_add(run, run, s);
-    jac_add(acc, acc, run);   // acc = sum_d (d + 1) S_{lo + d}
+    jac_add_body(run, run, s);
+    jac_add_body(acc, acc, run);   // acc = sum_d (d + 1) S_{lo + d}
   }
   if (lo != 0) {              // sum_d (lo + d + 1) S = acc + lo * run
     jac_set_inf(s);
@@ -3122,7 +3122,7 @@ __global__ void __launch_bounds__(BLS_BLOCK) k_msm2_chunk_g1p(int W, int CH, int
       jac_dbl_pair(s, hi);
       if ((mlt >> bit) & 1u) jac_add(s, s, run);
     }
-    jac_add(acc, acc, s);
+    jac_add_body(acc, acc, s);
   }
   const int shift = weighted ? 0 : msm2_start(L, w);
   for (int k = 0; k < shift; k++) jac_dbl_pair(acc, hi);   // the window's weight
@@ -3157,7 +3157,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm2_bucket_g2s(size_t nb, int
     aff_ld_fp(x.v, e, half);
     aff_ld_fp(y.v, e, 2 * FP_NL + half);
     if (code & 1u) fp_neg(y.v, y.v);
-    jac_madd(acc, acc, x, y);
+    jac_madd_body(acc, acc, x, y);
   }
   st_g2s(sums, t, acc);
 }
@@ -3168,7 +3168,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm2_merge_g2s(size_t nb, int 
   ld_g2s(acc, sums, b * Q);
   for (int q = 1; q < Q; q++) {
     ld_g2s(s, sums, b * Q + q);
-    jac_add(acc, acc, s);
+    jac_add_body(acc, acc, s);
   }
   st_g2s(sums, b * Q, acc);
 }
@@ -3185,8 +3185,8 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm2_chunk_g2q(int W, int CH, 
   jac_set_inf(acc);
   for (int d = CH - 1; d >= 0; d--) {
     ld_g2s(s, sums, (msm2_bucket_base(L, w) + lo + d) * stride);
-    jac_add(run, run, s);
-    jac_add(acc, acc, run);
+    jac_add_body(run, run, s);
+    jac_add_body(acc, acc, run);
   }
   if (lo != 0) {
     jac_set_inf(s);
@@ -3195,7 +3195,7 @@ __global__ void __launch_bounds__(BLS_BLOCK, 2) k_msm2_chunk_g2q(int W, int CH, 
       jac_dbl_quad(s, hi2);
       if ((mlt >> bit) & 1u) jac_add(s, s, run);
     }
-    jac_add(acc, acc, s);
+    jac_add_body(acc, acc, s);
   }
   const int shift = weighted ? 0 : msm2_start(L, w);
   for (int k = 0; k < shift; k++) jac_dbl_quad(acc, hi2);
