@@ -58,6 +58,8 @@ struct Ctx {
   uint32_t* fold_ws = nullptr;    // two small ping-pong buffers of the engine levels of an Fp12 fold tree (run_f12_fold)
   uint32_t* lines_ws = nullptr;   // merged line values on their way from k_lines2s to k_millerf2s (kernels.cuh): 19 KB per lane
   size_t lines_cap = 0;           // bytes; grown on demand, kept between calls
+  uint32_t* stream_flags = nullptr;   // hand-over flags of the streamed cut (kernels.cuh k_pairing_stream): written by that kernel only
+  uint32_t stream_epoch = 0;          // the value its last launch on this context published with
   // optional per-kernel timing with HIP events on `stream` (blsgpu_profile_*)
   bool prof_on = false;
   struct Pending { int kid; hipEvent_t e0, e1; };
@@ -152,6 +154,7 @@ struct Knobs {
   long coop_max = 4096, wide_max = 512, shard_min = 8192, contexts = 2, fake_devices = 0, acc_lanes = 57344;
   long msm_c = 0, msm_ch = 0, msm2_c = 0, msm2_ch = 0, msm2_q = 0;          // 0: the library's own choice
   long msm2_tables = 1;       // verify_secure: weighted window tables of every key, built while the host hashes (0: off)
+  long stream_lines = 1;      // a check whose lines cannot be had early runs them BESIDE its Miller loop (k_pairing_stream; 0: two launches)
   long host_trace = 0, strict_env = 0, ab_knobs = 0;
   long ws_keep_mb = 4096;     // a context's line workspace above this many MiB is released when the call that grew it returns
   // A/B
@@ -168,6 +171,7 @@ const KnobSpec KNOB_TABLE[] = {
     {"BLSGPU_MSM2_C", &Knobs::msm2_c, 4, 16, false},                    {"BLSGPU_MSM2_CH", &Knobs::msm2_ch, 1, 1 << 16, false},
     {"BLSGPU_MSM2_Q", &Knobs::msm2_q, 1, 8, false},                     {"BLSGPU_HOST_TRACE", &Knobs::host_trace, 0, 1, false},
     {"BLSGPU_WS_KEEP_MB", &Knobs::ws_keep_mb, 0, 1L << 20, false},        {"BLSGPU_MSM2_TABLES", &Knobs::msm2_tables, 0, 1, false},
+    {"BLSGPU_STREAM_LINES", &Knobs::stream_lines, 0, 1, false},
     {"BLSGPU_STRICT_ENV", &Knobs::strict_env, 0, 1, false},             {"BLSGPU_AB_KNOBS", &Knobs::ab_knobs, 0, 1, false},
     {"BLSGPU_MILLER_CHUNK", &Knobs::miller_chunk, 0, 65536, true},      {"BLSGPU_MILLER_V1", &Knobs::miller_v1, 0, 1, true},
     {"BLSGPU_ROW_PAD", &Knobs::row_pad, 0, 4096, true},                 {"BLSGPU_WIDE_MODE", &Knobs::wide_mode, 1, 2, true},
@@ -728,6 +732,30 @@ bool launch_hash_g2_small(hipStream_t stream, size_t n, const uint8_t* d_msgs, c
   return false;
 }
 
+// Pair 0's lines and the late part of the cut check: ONE launch in which the lines travel from one workgroup to the other while
+// the Miller loop already runs (kernels.cuh k_pairing_stream) -- for up to WSTREAM_MAX_ITEMS checks whose lines have nothing to
+// hide behind; otherwise the two launches k_pairing_pre (part 0), k_pairing_post.  The flag buffer belongs to the context and
+// is written by that kernel alone, with a value per launch that no earlier launch used.
+int launch_lines_and_post(Ctx* c, size_t n, uint32_t* d_rec, int32_t* d_status) {
+  if (knobs().stream_lines != 0 && n <= WSTREAM_MAX_ITEMS) {
+    const size_t fb = (size_t)WSTREAM_MAX_ITEMS * WSTREAM_FLAGS * 4;
+    if (!c->stream_flags) {
+      HIPCK(hipMalloc((void**)&c->stream_flags, fb));
+      c->stream_epoch = 0;
+    }
+    if (c->stream_epoch == 0 || c->stream_epoch == 0xffffffffu) {      // first use, or the counter is about to repeat itself
+      HIPCK(hipMemsetAsync(c->stream_flags, 0, fb, c->stream));
+      c->stream_epoch = 0;
+    }
+    c->stream_epoch++;
+    KL(KID_PAIRING_POST, k_pairing_stream, dim3((unsigned)n, 2), dim3(WIDE_ENGINE_BLOCK), n, d_rec, d_status, c->stream_flags, c->stream_epoch);
+    return 0;
+  }
+  KL(KID_PAIRING_PRE, k_pairing_pre, dim3((unsigned)n, 1), dim3(WIDE_ENGINE_BLOCK), n, d_rec, (const int32_t*)d_status, 0, 0);
+  KL(KID_PAIRING_POST, k_pairing_post, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), n, (const uint32_t*)d_rec, d_status);
+  return 0;
+}
+
 // one core_verify per item: statuses end up in d_status (device)
 int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_t* d_sigs, int fmt, const uint8_t* d_msgs,
                      const uint64_t* d_offs, int single_msg, const dst_arg& dst, size_t n, uint32_t* d_pairs, uint32_t* d_f,
@@ -792,13 +820,17 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
     hipLaunchKernelGGL(k_pairing_pre, dim3((unsigned)n, 1), dim3(WIDE_ENGINE_BLOCK), 0, c->side, n, d_rec, (const int32_t*)d_status, 2, 2);
     hipError_t e3 = hipGetLastError(), e4 = hipEventRecord(c->ev_join, c->side);
     hipError_t e5 = hipStreamWaitEvent(c->stream, c->ev_join2, 0);
-    KL(KID_PAIRING_PRE, k_pairing_pre, dim3((unsigned)n, 1), dim3(WIDE_ENGINE_BLOCK), n, d_rec, (const int32_t*)d_status, 0, 0);
     hipError_t e6 = hipStreamWaitEvent(c->stream, c->ev_join, 0);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess || e6 != hipSuccess) {
       (void)hipStreamSynchronize(c->side);
       return fail(BLSGPU_E_HIP, "side-stream launch failed");
     }
-    KL(KID_PAIRING_POST, k_pairing_post, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), n, (const uint32_t*)d_rec, d_status);
+    // H(m)'s lines have nothing left to hide behind (the signature's half on the side stream ended under the hash): they run
+    // beside the Miller loop that consumes them
+    if ((rc = launch_lines_and_post(c, n, d_rec, d_status))) {
+      (void)hipStreamSynchronize(c->side);
+      return rc;
+    }
     HIPCK(hipGetLastError());
     return 0;
   }
@@ -1606,6 +1638,7 @@ static void release_devices() {
       if (c->arena) (void)hipFree(c->arena);
       if (c->lines_ws) (void)hipFree(c->lines_ws);
       if (c->fold_ws) (void)hipFree(c->fold_ws);
+      if (c->stream_flags) (void)hipFree(c->stream_flags);
       if (c->ev_tail_fork) (void)hipEventDestroy(c->ev_tail_fork);
       if (c->ev_tail_join) (void)hipEventDestroy(c->ev_tail_join);
       if (c->tail) (void)hipStreamDestroy(c->tail);
@@ -2036,12 +2069,17 @@ static int cut_tail_finish(Ctx* c, int rc, const uint8_t* d_pk_proj, CutTail& t,
   if (t.sg == 1) {
     KL(KID_PREPARE, k_prepare_keys<1>, dim3(1), dim3(BLS_BLOCK), (size_t)1, d_pk_proj, (const uint8_t*)nullptr, (const uint8_t*)nullptr, BLSGPU_FMT_RAW_PROJ, 2,
        t.rec, t.d_status);
-    KL(KID_PAIRING_PRE, k_pairing_pre, dim3(1, 1), dim3(WIDE_ENGINE_BLOCK), (size_t)1, t.rec, (const int32_t*)t.d_status, 0, 0);
+    // the summed key's lines beside the Miller loop that consumes them
+    if ((rc = launch_lines_and_post(c, 1, t.rec, t.d_status))) {
+      (void)hipStreamSynchronize(c->side);
+      (void)hipStreamSynchronize(c->side2);
+      return rc;
+    }
   } else {
     KL(KID_PREPARE, k_prepare_keys<2>, dim3(1), dim3(BLS_BLOCK), (size_t)1, d_pk_proj, (const uint8_t*)nullptr, (const uint8_t*)nullptr, BLSGPU_FMT_RAW_PROJ, 2,
        t.rec, t.d_status);
+    KL(KID_PAIRING_POST, k_pairing_post, dim3(1), dim3(WIDE_ENGINE_BLOCK), (size_t)1, (const uint32_t*)t.rec, t.d_status);
   }
-  KL(KID_PAIRING_POST, k_pairing_post, dim3(1), dim3(WIDE_ENGINE_BLOCK), (size_t)1, (const uint32_t*)t.rec, t.d_status);
   HIPCK(hipGetLastError());
   if ((rc = copy_out_and_sync(c, status, t.d_status, 4))) return rc;
   return 0;

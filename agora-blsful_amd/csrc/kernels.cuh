@@ -337,6 +337,16 @@ template <int SG>
 __global__ void k_prepare_keys(size_t n, const uint8_t* pks, const uint8_t* sigs, const uint8_t* hashes, int fmt, int parts, uint32_t* rec, int32_t* status);
 __global__ void k_pairing_pre(size_t n, uint32_t* rec, const int32_t* status, int first_part, int second_part);   // grid (n, 1 or 2): part 0 = pair 0's lines, 1 = F1 (G1Impl), 2 = F1 (G2Impl)
 __global__ void k_pairing_post(size_t n, const uint32_t* rec, int32_t* status);
+// part 0 and k_pairing_post side by side, for the checks whose lines cannot be had early (the summed key of MultiSignature::verify /
+// verify_secure, Bls12381G2Impl's H(m)): grid (n, 2), workgroup (i, 0) derives item i's lines (program PRE_LINES_S) and hands them
+// over through the record eight steps at a time, workgroup (i, 1) runs POST_S on them as they arrive.  flags: WSTREAM_FLAGS words
+// per item in a buffer that ONLY this kernel writes; epoch: a value no earlier launch on that buffer used (never 0).  n <= WSTREAM_MAX_ITEMS:
+// both workgroups of an item must be resident together.
+#define WSTREAM_FLAGS 16
+#define WSTREAM_MAX_ITEMS 64
+#define WSTREAM_SPIN_LIMIT (1u << 21)      // polls (~1 us each) before the consumer gives up: status BLS_ERR_STREAM_TIMEOUT
+#define BLS_ERR_STREAM_TIMEOUT (-2)        // = BLSGPU_E_HIP: a device-side failure, not a verdict
+__global__ void k_pairing_stream(size_t n, uint32_t* rec, int32_t* status, uint32_t* flags, uint32_t epoch);
 // the last levels of a point sum on the engine: workgroup b <- the sum of points [16 b, 16 b + 16) (RAW_PROJ in and out)
 template <int G>
 __global__ void k_point_tree_wide(size_t m, const uint8_t* in, uint8_t* out);
@@ -3620,6 +3630,94 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_post(size_t n, co
   if (threadIdx.x == 0) S.flag = 1;
   __syncthreads();
   wide_exec(S, WIDE_PROG_POST_LEN, K);
+  if (threadIdx.x < 12) {
+    fp x, one;
+    w_load_local(x, S.V[WV_T + threadIdx.x]);
+    bool ok;
+    if (threadIdx.x == 0) {
+      fp_one(one);
+      ok = fp_eq(x, one);
+    } else {
+      ok = fp_is_zero(x);
+    }
+    if (!ok) S.flag = 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) status[item] = S.flag ? BLS_OK : BLS_ERR_INVALID_SIGNATURE;
+}
+
+// The streamed cut (declaration above).  Hand-over of chunk k (line steps [8 k, 8 k + 8)): the producer stores the chunk into the
+// item's record, every thread fences, and after the workgroup's barrier thread 0 RELEASES flags[k] = epoch at device scope; the
+// consumer's thread 0 polls flags[k] with device-scope ACQUIRE loads, and after the barrier every thread fences and reads the
+// chunk.  The two workgroups sit on different CUs -- as a rule on different XCDs with their own L2 -- so it is the device-scope
+// release / acquire pair (L2 write-back on one side, invalidation on the other) that makes the lines visible, not the barrier.
+// The poll is bounded: a consumer whose producer never arrives ends with BLS_ERR_STREAM_TIMEOUT instead of holding its CU.
+struct wide_stream_hook {
+  wide_lds_t<wide_tb_f12>* S;
+  uint32_t* r;
+  uint32_t* flags;
+  uint32_t epoch;
+  __device__ __forceinline__ bool operator()(uint32_t kind, uint32_t k) const {
+    const int s0 = WIDE_STREAM_CHUNK * (int)k, ns = WIDE_STEPS - s0 < WIDE_STREAM_CHUNK ? WIDE_STEPS - s0 : WIDE_STREAM_CHUNK;
+    if (kind == WOP_PUB - WOP_FPINV) {
+      for (int t = threadIdx.x; t < ns * 96; t += WIDE_ENGINE_BLOCK) {
+        const int st = s0 + t / 96, w = t % 96;
+        r[16 * WREC_L + 96 * st + w] = S->V[WV_L + 12 * st + (w >> 4)][w & 15];
+      }
+      __threadfence();
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(flags + k, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      return true;
+    }
+    if (threadIdx.x == 0) {
+      int ok = 0;
+      for (uint32_t spin = 0; spin < WSTREAM_SPIN_LIMIT; spin++) {
+        if (__hip_atomic_load(flags + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == epoch) {
+          ok = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      S->hook_ok = ok;
+    }
+    __syncthreads();
+    if (!S->hook_ok) return false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (int t = threadIdx.x; t < ns * 96; t += WIDE_ENGINE_BLOCK) {
+      const int st = s0 + t / 96, w = t % 96;
+      S->V[WV_L + 12 * st + (w >> 4)][w & 15] = r[16 * WREC_L + 96 * st + w];
+    }
+    return true;
+  }
+};
+__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_stream(size_t n, uint32_t* rec, int32_t* status, uint32_t* flags, uint32_t epoch) {
+  __shared__ wide_lds_t<wide_tb_f12> S;
+  const size_t item = blockIdx.x;
+  if (item >= n) return;
+  if (status[item] != BLS_OK) return;                   // uniform over the workgroup, and the same in both workgroups of the item:
+  wide_consts K;                                        // the consumer writes the status only after the producer's last chunk
+  wide_init(K);
+  uint32_t* r = rec + item * WREC_WORDS;
+  const wide_stream_hook hook = {&S, r, flags + item * WSTREAM_FLAGS, epoch};
+  const int l = (int)(threadIdx.x & 15u), v = (int)(threadIdx.x >> 4);
+  if (blockIdx.y == 0) {
+    wide_stage(S, WIDE_PROG_PRE_LINES_S, WIDE_PROG_PRE_LINES_S_LEN);
+    if (v < 6) S.V[WV_PT0 + 6 + v][l] = r[16 * (WREC_Q0 + v) + l];      // Q, Jacobian (QPREP makes it homogeneous and sets T = Q)
+    __syncthreads();
+    wide_exec(S, WIDE_PROG_PRE_LINES_S_LEN, K, hook);
+    return;
+  }
+  wide_stage(S, WIDE_PROG_POST_S, WIDE_PROG_POST_S_LEN);
+  if (v < 3) S.V[WV_P + v][l] = r[16 * (WREC_P0 + v) + l];
+  if (v == 3) S.V[WV_P + 3][l] = 0u;
+  if (v >= 4) S.V[WV_F + v - 4][l] = (v == 4 && l < FP_NL) ? FP_ONE[l] : 0u;   // f = 1
+  if (v < 12) S.V[WV_W + v][l] = r[16 * (WREC_F1 + v) + l];
+  if (threadIdx.x == 0) S.flag = 1;
+  __syncthreads();
+  if (!wide_exec(S, WIDE_PROG_POST_S_LEN, K, hook)) {
+    if (threadIdx.x == 0) status[item] = BLS_ERR_STREAM_TIMEOUT;
+    return;
+  }
   if (threadIdx.x < 12) {
     fp x, one;
     w_load_local(x, S.V[WV_T + threadIdx.x]);

@@ -611,6 +611,48 @@ def test_verify_secure_with_and_without_weighted_tables():
 
 
 @pytest.mark.gpu
+def test_streamed_and_two_launch_cut_checks_agree():
+    """The checks whose lines cannot be had early -- the summed key of MultiSignature::verify / verify_secure (Bls12381G1Impl), H(m) of
+    a Bls12381G2Impl verification -- with the lines handed from one workgroup to the other while the Miller loop runs
+    (k_pairing_stream, the default up to 64 items) and as two launches (BLSGPU_STREAM_LINES=0): the same verdicts for valid and
+    tampered inputs, at one item, at the form's upper bound and just beyond it, repeated on one context (the hand-over flags are
+    reused with a fresh value per launch).  Child processes: the knob is read once."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge\n"
+        "api = ge.import_pkg().api; api.init()\n"
+        "out = []\n"
+        "n = 300; sks = [0x5151 + 5 * i for i in range(n)]; msg = b'lines beside the loop'\n"
+        "pks, sigs = api.sign_batch(1, api.POP, sks, [msg] * n)\n"
+        "agg = api.point_sum(1, sigs)\n"
+        "for rep in range(3):\n"
+        "    out.append([api.multi_verify(1, api.POP, pks, agg, msg), api.multi_verify(1, api.POP, pks[:-1], agg, msg),\n"
+        "                api.multi_verify(1, api.POP, pks, agg, msg + b'?')])\n"
+        "pkb, sgb = api.sign_batch(1, api.BASIC, sks, [msg] * n)\n"
+        "st, perm, ts = api.secure_coefficients(api.serialize(2, pkb))\n"
+        "sagg = api.point_sum(1, [sgb[i] for i in perm], ts)\n"
+        "out.append([st, api.verify_secure(1, api.BASIC, pkb, sagg, msg), api.verify_secure(1, api.BASIC, pkb[1:], sagg, msg)])\n"
+        "for m in (1, 3, 64, 65):\n"
+        "    ms = [hashlib.sha256(b'g2 item %%d' %% i).digest() for i in range(m)]\n"
+        "    pk2, sg2 = api.sign_batch(2, api.POP, sks[:m], ms)\n"
+        "    ms[m // 2] = ms[m // 2] + b'!'\n"
+        "    out.append(list(api.verify_batch(2, api.POP, pk2, sg2, ms)))\n"
+        "print(repr(out))\n") % (util.ROOT, os.path.join(util.ROOT, 'tests'))
+    res = {}
+    for name, env in (('streamed', {}), ('two_launches', {'BLSGPU_STREAM_LINES': '0'})):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        res[name] = eval(r.stdout.strip().splitlines()[-1])
+    want = [[0, 1, 1]] * 3 + [[0, 0, 1]]
+    for m in (1, 3, 64, 65):
+        want.append([1 if i == m // 2 else 0 for i in range(m)])
+    assert res['streamed'] == want
+    assert res['two_launches'] == want
+
+
+@pytest.mark.gpu
 def test_pairing_product_tree_and_accumulator_forms_agree(api):
     """AggregateSignature::verify's pairing product in its two forms -- the per-entry products over the items with one Horner chain
     (k_line_quad / k_f12_fold4 / k_f12_horner_wide, the default from 64 pairs) and one accumulator per item or pair of items

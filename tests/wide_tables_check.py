@@ -100,8 +100,9 @@ def psi_consts():
     return k
 
 
-def sim_program(ops, lay, steps, V):
-    """the device's semantics on a flat integer value store: every step reads its operand arrays at their base index"""
+def sim_program(ops, lay, steps, V, hook=None):
+    """the device's semantics on a flat integer value store: every step reads its operand arrays at their base index;
+    hook(name, k, V): the built-ins of the streamed cut (ACQ / PUB with their chunk index)"""
     by = {o.name: o for o in ops}
     cb = lay.base.get('CONST')
     if cb is not None:
@@ -110,6 +111,9 @@ def sim_program(ops, lay, steps, V):
     for name, d, x, y in steps:
         if name == 'FPINV':
             V[lay.ref(d)] = c.fp_inv(V[lay.ref(x)]) if V[lay.ref(x)] else 0
+            continue
+        if name in ('ACQ', 'PUB'):
+            hook(name, d, V)
             continue
         op = by[name]
         base = {DST: lay.ref(d), SA: lay.ref(x), SB: lay.ref(y), TMP: lay.base['TMP'], CONST: cb}
@@ -165,6 +169,7 @@ def check_programs():
         # the cut: three stores that share nothing but what the device hands over (pair 0's lines, the function of pair 1)
         V1 = [0] * lay.count
         set_pt(V1, 0, pk)
+        V1s_pt = V1[B['PT0']:B['PT0'] + 32]
         sim_program(OPS, lay, dict(PROGRAMS)['PRE_LINES'], V1)
         V2 = [0] * lay.count
         V2[B['F']:B['F'] + 12] = flat(c.F12_ONE)
@@ -177,13 +182,40 @@ def check_programs():
         assert V2g[B['F']:B['F'] + 12] == V2[B['F']:B['F'] + 12], 'PRE_F1G'
         V3 = [0] * lay.count
         V3[B['F']:B['F'] + 12] = flat(c.F12_ONE)
-        V3[B['P']:B['P'] + 4] = jac(Hm)
+        V3[B['P']:B['P'] + 4] = V3p = jac(Hm)
         for stp in range(NSTEPS):
             o = B['L'] + 12 * stp
             V3[o:o + 6] = V1[o:o + 6]
         V3[B['W']:B['W'] + 12] = V2[B['F']:B['F'] + 12]
         sim_program(OPS, lay, dict(PROGRAMS)['POST'], V3)
         assert unflat(V3[B['T']:B['T'] + 12]) == want, 'cut pairing programs'
+        # the streamed cut: PRE_LINES_S publishes chunks of eight line steps, POST_S acquires each one before its first use -- two
+        # stores that share only the published chunks (the device: two workgroups of k_pairing_stream); a line read before its
+        # chunk arrived would be a zero here and the result wrong
+        CH = g.STREAM_CHUNK
+        wire, order = {}, []
+        V4 = [0] * lay.count
+
+        def pub(name, k, V):
+            assert name == 'PUB' and k == len(wire), 'chunks are published in order, once'
+            wire[k] = [V[B['L'] + 12 * stp:B['L'] + 12 * stp + 6] for stp in range(CH * k, min(CH * k + CH, NSTEPS))]
+        V4[B['PT0']:B['PT0'] + 32] = V1s_pt
+        sim_program(OPS, lay, dict(PROGRAMS)['PRE_LINES_S'], V4, pub)
+        assert len(wire) == (NSTEPS + CH - 1) // CH
+        for stp in range(NSTEPS):
+            assert V4[B['L'] + 12 * stp:B['L'] + 12 * stp + 6] == V1[B['L'] + 12 * stp:B['L'] + 12 * stp + 6], 'PRE_LINES_S = PRE_LINES'
+        V5 = [0] * lay.count
+        V5[B['F']:B['F'] + 12] = flat(c.F12_ONE)
+        V5[B['P']:B['P'] + 4] = V3p
+        V5[B['W']:B['W'] + 12] = V2[B['F']:B['F'] + 12]
+
+        def acq(name, k, V):
+            assert name == 'ACQ' and k == len(order), 'chunks are acquired in order, once'
+            order.append(k)
+            for j, line in enumerate(wire[k]):
+                V[B['L'] + 12 * (CH * k + j):B['L'] + 12 * (CH * k + j) + 6] = line
+        sim_program(OPS, lay, dict(PROGRAMS)['POST_S'], V5, acq)
+        assert order == list(range(len(wire))) and unflat(V5[B['T']:B['T'] + 12]) == want, 'streamed cut programs'
     # the fold tree's sixteen-way product
     vals = [tuple((rng.randrange(P), rng.randrange(P)) for _ in range(6)) for _ in range(16)]
     Vt = [0] * lay.count

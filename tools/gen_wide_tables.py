@@ -869,7 +869,9 @@ class Layout:
         self.count = off
 
     def ref(self, r):
-        """'F' or ('L', 12) -> value index"""
+        """'F' or ('L', 12) -> value index; a plain integer (the argument of a built-in step) stays what it is"""
+        if isinstance(r, int):
+            return r
         if isinstance(r, tuple):
             return self.base[r[0]] + r[1]
         return self.base[r]
@@ -901,16 +903,27 @@ def prog_final_hard():
     return st
 
 
-def prog_key_lines(pair):
-    """the UNSCALED line coefficients of the Miller steps of pair `pair` (its point workspace holds Q, Jacobian) -> L[step][pair]"""
+STREAM_CHUNK = 8                 # line steps per hand-over of the streamed cut (PUB / ACQ below); LSCALE<p>X8 scales as many at once
+
+
+def prog_key_lines(pair, publish=False):
+    """the UNSCALED line coefficients of the Miller steps of pair `pair` (its point workspace holds Q, Jacobian) -> L[step][pair].
+    publish: after every STREAM_CHUNK steps (and after the last) the built-in PUB k hands lines [8 k, 8 k + 8) to the workgroup that
+    runs prog_miller_stream beside this one (kernels.cuh k_pairing_stream)"""
     pt = 'PT%d' % pair
     st, step = [('QPREP' + x, pt, pt, pt) for x in 'ABC'], 0
+
+    def done():
+        if publish and (step % STREAM_CHUNK == 0 or step == NSTEPS):
+            st.append(('PUB', (step - 1) // STREAM_CHUNK, pt, pt))
     for i in range(62, -1, -1):
         st += [('PDBL1', pt, pt, pt), ('PDBL2', pt, pt, pt), ('COPY6', ('L', 12 * step + 6 * pair), pt, pt)]
         step += 1
+        done()
         if (X_ABS >> i) & 1:
             st += [('PADD%d' % k, pt, pt, pt) for k in (1, 2, 3, 4)] + [('COPY6', ('L', 12 * step + 6 * pair), pt, pt)]
             step += 1
+            done()
     assert step == NSTEPS
     return st
 
@@ -941,6 +954,27 @@ def prog_miller(pairs=(0, 1)):
                 st.append(('LSCALE' + sfx, ls, ls, 'P'))
             st += [('MUL_LINE', 'F', 'F', ('L', 12 * step + 6 * p)) for p in pairs]
             step += 1
+    return st
+
+
+def prog_miller_stream():
+    """prog_miller((0,)) for lines that ARRIVE while the loop runs: the built-in ACQ k waits for lines [8 k, 8 k + 8) of the workgroup that
+    runs prog_key_lines(0, publish=True) and copies them into L, LSCALE0X<n> evaluates them at P0, then the Miller steps that use them"""
+    st, step, have = [], 0, 0
+    for i in range(62, -1, -1):
+        nl = 2 if (X_ABS >> i) & 1 else 1
+        while have < step + nl:
+            k = min(STREAM_CHUNK, NSTEPS - have)
+            assert k in (8, 4) and have % STREAM_CHUNK == 0
+            ls = ('L', 12 * have)
+            st += [('ACQ', have // STREAM_CHUNK, 'F', 'F'), ('LSCALE0X%d' % k, ls, ls, 'P')]
+            have += k
+        if i != 62:
+            st.append(('SQR', 'F', 'F', 'F'))
+        for _ in range(nl):
+            st.append(('MUL_LINE', 'F', 'F', ('L', 12 * step)))
+            step += 1
+    assert step == NSTEPS and have == NSTEPS
     return st
 
 
@@ -994,6 +1028,10 @@ PROGRAMS = [('FINAL_HARD', prog_final_hard()),
             # Bls12381G2Impl: pair 1 is (-g1, signature): its lines come from the signature, then the same Miller function
             ('PRE_F1G', prog_key_lines(1) + prog_pprep((1,)) + prog_miller((1,))),
             ('POST', prog_pprep((0,)) + prog_miller((0,)) + [('MUL', 'F', 'F', 'W')] + CONJ_F + prog_easy() + prog_final_hard()),
+            # PRE_LINES and POST side by side on two workgroups of one launch, the lines handed over eight steps at a time (k_pairing_stream):
+            # for the checks whose key (or H(m)) only exists when everything else is done -- the tail of a key sum, Bls12381G2Impl's hash
+            ('PRE_LINES_S', prog_key_lines(0, publish=True)),
+            ('POST_S', prog_pprep((0,)) + prog_miller_stream() + [('MUL', 'F', 'F', 'W')] + CONJ_F + prog_easy() + prog_final_hard()),
             ('F12_TREE16', prog_f12_tree16()),
             ('HORNER', prog_horner())]
 
@@ -1070,6 +1108,12 @@ def emit_set(out, ops, lay, programs, prefix, vprefix, trait, has_inv):
     if has_inv:
         out.append('#define WOP_FPINV %d   // interpreter built-in: value dst <- (value a)^-1 in Fp on a lone lane (fp_inv_var)' % len(names))
         names.append('FPINV')
+        # built-ins of the streamed cut, handled by the kernel's hook (wide_engine.cuh wide_exec): the step's dst field is the chunk index
+        out.append('#define WOP_ACQ %d     // wait for chunk dst of the partner workgroup\'s lines and copy it into L' % len(names))
+        names.append('ACQ')
+        out.append('#define WOP_PUB %d     // hand chunk dst of L to the partner workgroup' % len(names))
+        names.append('PUB')
+        out.append('#define WIDE_STREAM_CHUNK %d' % STREAM_CHUNK)
     out.append('// value store (indices of 16-word values)')
     for k, v in lay.base.items():
         out.append('#define %s_%s %d' % (vprefix, k, v))
