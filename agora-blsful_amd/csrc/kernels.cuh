@@ -339,10 +339,10 @@ __global__ void k_pairing_pre(size_t n, uint32_t* rec, const int32_t* status, in
 __global__ void k_pairing_post(size_t n, const uint32_t* rec, int32_t* status);
 // part 0 and k_pairing_post side by side, for the checks whose lines cannot be had early (the summed key of MultiSignature::verify /
 // verify_secure, Bls12381G2Impl's H(m)): grid (n, 2), workgroup (i, 0) derives item i's lines (program PRE_LINES_S) and hands them
-// over through the record eight steps at a time, workgroup (i, 1) runs POST_S on them as they arrive.  flags: WSTREAM_FLAGS words
+// over through the record a few steps at a time (tools/gen_wide_tables.py STREAM_BOUNDS), workgroup (i, 1) runs POST_S on them as they arrive.  flags: WSTREAM_FLAGS words
 // per item in a buffer that ONLY this kernel writes; epoch: a value no earlier launch on that buffer used (never 0).  n <= WSTREAM_MAX_ITEMS:
 // both workgroups of an item must be resident together.
-#define WSTREAM_FLAGS 16
+#define WSTREAM_FLAGS 32              // one per four line steps: a chunk's flag is its first step / 4
 #define WSTREAM_MAX_ITEMS 64
 #define WSTREAM_SPIN_LIMIT (1u << 21)      // polls (~1 us each) before the consumer gives up: status BLS_ERR_STREAM_TIMEOUT
 #define BLS_ERR_STREAM_TIMEOUT (-2)        // = BLSGPU_E_HIP: a device-side failure, not a verdict
@@ -3646,19 +3646,21 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_post(size_t n, co
   if (threadIdx.x == 0) status[item] = S.flag ? BLS_OK : BLS_ERR_INVALID_SIGNATURE;
 }
 
-// The streamed cut (declaration above).  Hand-over of chunk k (line steps [8 k, 8 k + 8)): the producer stores the chunk into the
-// item's record, every thread fences, and after the workgroup's barrier thread 0 RELEASES flags[k] = epoch at device scope; the
-// consumer's thread 0 polls flags[k] with device-scope ACQUIRE loads, and after the barrier every thread fences and reads the
+// The streamed cut (declaration above).  Hand-over of a chunk (line steps [s0, s0 + ns), flag s0 / 4): the producer stores the chunk into the
+// item's record, every thread fences, and after the workgroup's barrier thread 0 RELEASES flag = epoch at device scope; the
+// consumer's thread 0 polls the flag with device-scope ACQUIRE loads, and after the barrier every thread fences and reads the
 // chunk.  The two workgroups sit on different CUs -- as a rule on different XCDs with their own L2 -- so it is the device-scope
 // release / acquire pair (L2 write-back on one side, invalidation on the other) that makes the lines visible, not the barrier.
 // The poll is bounded: a consumer whose producer never arrives ends with BLS_ERR_STREAM_TIMEOUT instead of holding its CU.
+static_assert((WIDE_STEPS + 3) / 4 <= WSTREAM_FLAGS, "a flag per four line steps");
 struct wide_stream_hook {
   wide_lds_t<wide_tb_f12>* S;
   uint32_t* r;
   uint32_t* flags;
   uint32_t epoch;
-  __device__ __forceinline__ bool operator()(uint32_t kind, uint32_t k) const {
-    const int s0 = WIDE_STREAM_CHUNK * (int)k, ns = WIDE_STEPS - s0 < WIDE_STREAM_CHUNK ? WIDE_STEPS - s0 : WIDE_STREAM_CHUNK;
+  __device__ __forceinline__ bool operator()(uint32_t kind, uint32_t first, uint32_t count) const {
+    const int s0 = (int)first, ns = (int)count;
+    const uint32_t k = first >> 2;
     if (kind == WOP_PUB - WOP_FPINV) {
       for (int t = threadIdx.x; t < ns * 96; t += WIDE_ENGINE_BLOCK) {
         const int st = s0 + t / 96, w = t % 96;

@@ -113,7 +113,7 @@ def sim_program(ops, lay, steps, V, hook=None):
             V[lay.ref(d)] = c.fp_inv(V[lay.ref(x)]) if V[lay.ref(x)] else 0
             continue
         if name in ('ACQ', 'PUB'):
-            hook(name, d, V)
+            hook(name, d, x, V)
             continue
         op = by[name]
         base = {DST: lay.ref(d), SA: lay.ref(x), SB: lay.ref(y), TMP: lay.base['TMP'], CONST: cb}
@@ -192,16 +192,15 @@ def check_programs():
         # the streamed cut: PRE_LINES_S publishes chunks of eight line steps, POST_S acquires each one before its first use -- two
         # stores that share only the published chunks (the device: two workgroups of k_pairing_stream); a line read before its
         # chunk arrived would be a zero here and the result wrong
-        CH = g.STREAM_CHUNK
         wire, order = {}, []
         V4 = [0] * lay.count
 
-        def pub(name, k, V):
-            assert name == 'PUB' and k == len(wire), 'chunks are published in order, once'
-            wire[k] = [V[B['L'] + 12 * stp:B['L'] + 12 * stp + 6] for stp in range(CH * k, min(CH * k + CH, NSTEPS))]
+        def pub(name, first, cnt, V):
+            assert name == 'PUB' and first == sum(len(x) for x in wire.values()) and cnt > 0, 'chunks are published in order, once, without gaps'
+            wire[first] = [V[B['L'] + 12 * stp:B['L'] + 12 * stp + 6] for stp in range(first, first + cnt)]
         V4[B['PT0']:B['PT0'] + 32] = V1s_pt
         sim_program(OPS, lay, dict(PROGRAMS)['PRE_LINES_S'], V4, pub)
-        assert len(wire) == (NSTEPS + CH - 1) // CH
+        assert sum(len(x) for x in wire.values()) == NSTEPS and all(f % 4 == 0 and f // 4 < 32 for f in wire)      # the device's flag index
         for stp in range(NSTEPS):
             assert V4[B['L'] + 12 * stp:B['L'] + 12 * stp + 6] == V1[B['L'] + 12 * stp:B['L'] + 12 * stp + 6], 'PRE_LINES_S = PRE_LINES'
         V5 = [0] * lay.count
@@ -209,13 +208,13 @@ def check_programs():
         V5[B['P']:B['P'] + 4] = V3p
         V5[B['W']:B['W'] + 12] = V2[B['F']:B['F'] + 12]
 
-        def acq(name, k, V):
-            assert name == 'ACQ' and k == len(order), 'chunks are acquired in order, once'
-            order.append(k)
-            for j, line in enumerate(wire[k]):
-                V[B['L'] + 12 * (CH * k + j):B['L'] + 12 * (CH * k + j) + 6] = line
+        def acq(name, first, cnt, V):
+            assert name == 'ACQ' and len(wire[first]) == cnt and first not in order, 'the consumer acquires exactly the published chunks, once'
+            order.append(first)
+            for j, line in enumerate(wire[first]):
+                V[B['L'] + 12 * (first + j):B['L'] + 12 * (first + j) + 6] = line
         sim_program(OPS, lay, dict(PROGRAMS)['POST_S'], V5, acq)
-        assert order == list(range(len(wire))) and unflat(V5[B['T']:B['T'] + 12]) == want, 'streamed cut programs'
+        assert order == sorted(wire) and unflat(V5[B['T']:B['T'] + 12]) == want, 'streamed cut programs'
     # the fold tree's sixteen-way product
     vals = [tuple((rng.randrange(P), rng.randrange(P)) for _ in range(6)) for _ in range(16)]
     Vt = [0] * lay.count

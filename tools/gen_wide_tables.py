@@ -903,19 +903,25 @@ def prog_final_hard():
     return st
 
 
-STREAM_CHUNK = 8                 # line steps per hand-over of the streamed cut (PUB / ACQ below); LSCALE<p>X8 scales as many at once
+# hand-overs of the streamed cut (PUB / ACQ below): line steps [b[j-1], b[j]) travel together.  The producer makes a line in ~3.2 us,
+# the consumer uses one in ~4.4 us, both start together: a short first chunk gets the consumer going, later ones may grow as the
+# producer pulls ahead (3.2 b[j] <= 3.2 b[0] + 4.4 b[j-1]).  Multiples of four: LSCALE<p>X4 / X8 evaluate four / eight steps at once
+STREAM_BOUNDS = [4, 8, 12, 20, 32, 48, 68]
+assert STREAM_BOUNDS[-1] == NSTEPS and all(b % 4 == 0 for b in STREAM_BOUNDS)
 
 
 def prog_key_lines(pair, publish=False):
     """the UNSCALED line coefficients of the Miller steps of pair `pair` (its point workspace holds Q, Jacobian) -> L[step][pair].
-    publish: after every STREAM_CHUNK steps (and after the last) the built-in PUB k hands lines [8 k, 8 k + 8) to the workgroup that
-    runs prog_miller_stream beside this one (kernels.cuh k_pairing_stream)"""
+    publish: when a chunk of STREAM_BOUNDS is complete the built-in PUB (first step, steps) hands it to the workgroup that runs
+    prog_miller_stream beside this one (kernels.cuh k_pairing_stream)"""
     pt = 'PT%d' % pair
     st, step = [('QPREP' + x, pt, pt, pt) for x in 'ABC'], 0
 
     def done():
-        if publish and (step % STREAM_CHUNK == 0 or step == NSTEPS):
-            st.append(('PUB', (step - 1) // STREAM_CHUNK, pt, pt))
+        if publish and step in STREAM_BOUNDS:
+            j = STREAM_BOUNDS.index(step)
+            first = STREAM_BOUNDS[j - 1] if j else 0
+            st.append(('PUB', first, step - first, 0))
     for i in range(62, -1, -1):
         st += [('PDBL1', pt, pt, pt), ('PDBL2', pt, pt, pt), ('COPY6', ('L', 12 * step + 6 * pair), pt, pt)]
         step += 1
@@ -958,17 +964,20 @@ def prog_miller(pairs=(0, 1)):
 
 
 def prog_miller_stream():
-    """prog_miller((0,)) for lines that ARRIVE while the loop runs: the built-in ACQ k waits for lines [8 k, 8 k + 8) of the workgroup that
-    runs prog_key_lines(0, publish=True) and copies them into L, LSCALE0X<n> evaluates them at P0, then the Miller steps that use them"""
+    """prog_miller((0,)) for lines that ARRIVE while the loop runs: before the first use of a chunk of STREAM_BOUNDS the built-in ACQ
+    (first step, steps) waits for it -- the workgroup that runs prog_key_lines(0, publish=True) -- and copies it into L, LSCALE0X<n>
+    evaluates its lines at P0, then the Miller steps that use them"""
     st, step, have = [], 0, 0
     for i in range(62, -1, -1):
         nl = 2 if (X_ABS >> i) & 1 else 1
         while have < step + nl:
-            k = min(STREAM_CHUNK, NSTEPS - have)
-            assert k in (8, 4) and have % STREAM_CHUNK == 0
-            ls = ('L', 12 * have)
-            st += [('ACQ', have // STREAM_CHUNK, 'F', 'F'), ('LSCALE0X%d' % k, ls, ls, 'P')]
-            have += k
+            b = min(x for x in STREAM_BOUNDS if x > have)
+            st.append(('ACQ', have, b - have, 0))
+            for s0 in range(have, b, 8):
+                k = min(8, b - s0)
+                assert k in (8, 4)
+                st.append(('LSCALE0X%d' % k, ('L', 12 * s0), ('L', 12 * s0), 'P'))
+            have = b
         if i != 62:
             st.append(('SQR', 'F', 'F', 'F'))
         for _ in range(nl):
@@ -1108,12 +1117,12 @@ def emit_set(out, ops, lay, programs, prefix, vprefix, trait, has_inv):
     if has_inv:
         out.append('#define WOP_FPINV %d   // interpreter built-in: value dst <- (value a)^-1 in Fp on a lone lane (fp_inv_var)' % len(names))
         names.append('FPINV')
-        # built-ins of the streamed cut, handled by the kernel's hook (wide_engine.cuh wide_exec): the step's dst field is the chunk index
-        out.append('#define WOP_ACQ %d     // wait for chunk dst of the partner workgroup\'s lines and copy it into L' % len(names))
+        # built-ins of the streamed cut, handled by the kernel's hook (wide_engine.cuh wide_exec): the step's dst field is the first line
+        # step of a chunk, its a field the number of steps
+        out.append('#define WOP_ACQ %d     // wait for line steps [dst, dst + a) of the partner workgroup and copy them into L' % len(names))
         names.append('ACQ')
-        out.append('#define WOP_PUB %d     // hand chunk dst of L to the partner workgroup' % len(names))
+        out.append('#define WOP_PUB %d     // hand line steps [dst, dst + a) of L to the partner workgroup' % len(names))
         names.append('PUB')
-        out.append('#define WIDE_STREAM_CHUNK %d' % STREAM_CHUNK)
     out.append('// value store (indices of 16-word values)')
     for k, v in lay.base.items():
         out.append('#define %s_%s %d' % (vprefix, k, v))
