@@ -155,6 +155,7 @@ struct Knobs {
   long msm_c = 0, msm_ch = 0, msm2_c = 0, msm2_ch = 0, msm2_q = 0;          // 0: the library's own choice
   long msm2_tables = 1;       // verify_secure: weighted window tables of every key, built while the host hashes (0: off)
   long stream_lines = 1;      // a check whose lines cannot be had early runs them BESIDE its Miller loop (k_pairing_stream; 0: two launches)
+  long post_split = 1;        // the late part of a cut check runs its Miller loop on two workgroups (k_pairing_post2; 0: one)
   long host_trace = 0, strict_env = 0, ab_knobs = 0;
   long ws_keep_mb = 4096;     // a context's line workspace above this many MiB is released when the call that grew it returns
   // A/B
@@ -171,7 +172,7 @@ const KnobSpec KNOB_TABLE[] = {
     {"BLSGPU_MSM2_C", &Knobs::msm2_c, 4, 16, false},                    {"BLSGPU_MSM2_CH", &Knobs::msm2_ch, 1, 1 << 16, false},
     {"BLSGPU_MSM2_Q", &Knobs::msm2_q, 1, 8, false},                     {"BLSGPU_HOST_TRACE", &Knobs::host_trace, 0, 1, false},
     {"BLSGPU_WS_KEEP_MB", &Knobs::ws_keep_mb, 0, 1L << 20, false},        {"BLSGPU_MSM2_TABLES", &Knobs::msm2_tables, 0, 1, false},
-    {"BLSGPU_STREAM_LINES", &Knobs::stream_lines, 0, 1, false},
+    {"BLSGPU_STREAM_LINES", &Knobs::stream_lines, 0, 1, false},        {"BLSGPU_POST_SPLIT", &Knobs::post_split, 0, 1, false},
     {"BLSGPU_STRICT_ENV", &Knobs::strict_env, 0, 1, false},             {"BLSGPU_AB_KNOBS", &Knobs::ab_knobs, 0, 1, false},
     {"BLSGPU_MILLER_CHUNK", &Knobs::miller_chunk, 0, 65536, true},      {"BLSGPU_MILLER_V1", &Knobs::miller_v1, 0, 1, true},
     {"BLSGPU_ROW_PAD", &Knobs::row_pad, 0, 4096, true},                 {"BLSGPU_WIDE_MODE", &Knobs::wide_mode, 1, 2, true},
@@ -736,24 +737,40 @@ bool launch_hash_g2_small(hipStream_t stream, size_t n, const uint8_t* d_msgs, c
 // the Miller loop already runs (kernels.cuh k_pairing_stream) -- for up to WSTREAM_MAX_ITEMS checks whose lines have nothing to
 // hide behind; otherwise the two launches k_pairing_pre (part 0), k_pairing_post.  The flag buffer belongs to the context and
 // is written by that kernel alone, with a value per launch that no earlier launch used.
+static int stream_epoch_next(Ctx* c) {
+  const size_t fb = (size_t)WSTREAM_MAX_ITEMS * WSTREAM_FLAGS * 4;
+  if (!c->stream_flags) {
+    HIPCK(hipMalloc((void**)&c->stream_flags, fb));
+    c->stream_epoch = 0;
+  }
+  if (c->stream_epoch == 0 || c->stream_epoch == 0xffffffffu) {      // first use, or the counter is about to repeat itself
+    HIPCK(hipMemsetAsync(c->stream_flags, 0, fb, c->stream));
+    c->stream_epoch = 0;
+  }
+  c->stream_epoch++;
+  return 0;
+}
+// the late part of the cut check alone (its lines are in the record): for up to WSTREAM_MAX_ITEMS items with the Miller loop on two
+// workgroups per item (kernels.cuh k_pairing_post2)
+int launch_post(Ctx* c, size_t n, uint32_t* d_rec, int32_t* d_status) {
+  if (knobs().post_split != 0 && n <= WSTREAM_MAX_ITEMS) {
+    int rc = stream_epoch_next(c);
+    if (rc) return rc;
+    KL(KID_PAIRING_POST, k_pairing_post2, dim3((unsigned)n, 2), dim3(WIDE_ENGINE_BLOCK), n, d_rec, d_status, c->stream_flags, c->stream_epoch);
+    return 0;
+  }
+  KL(KID_PAIRING_POST, k_pairing_post, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), n, (const uint32_t*)d_rec, d_status);
+  return 0;
+}
 int launch_lines_and_post(Ctx* c, size_t n, uint32_t* d_rec, int32_t* d_status) {
   if (knobs().stream_lines != 0 && n <= WSTREAM_MAX_ITEMS) {
-    const size_t fb = (size_t)WSTREAM_MAX_ITEMS * WSTREAM_FLAGS * 4;
-    if (!c->stream_flags) {
-      HIPCK(hipMalloc((void**)&c->stream_flags, fb));
-      c->stream_epoch = 0;
-    }
-    if (c->stream_epoch == 0 || c->stream_epoch == 0xffffffffu) {      // first use, or the counter is about to repeat itself
-      HIPCK(hipMemsetAsync(c->stream_flags, 0, fb, c->stream));
-      c->stream_epoch = 0;
-    }
-    c->stream_epoch++;
+    int rc = stream_epoch_next(c);
+    if (rc) return rc;
     KL(KID_PAIRING_POST, k_pairing_stream, dim3((unsigned)n, 2), dim3(WIDE_ENGINE_BLOCK), n, d_rec, d_status, c->stream_flags, c->stream_epoch);
     return 0;
   }
   KL(KID_PAIRING_PRE, k_pairing_pre, dim3((unsigned)n, 1), dim3(WIDE_ENGINE_BLOCK), n, d_rec, (const int32_t*)d_status, 0, 0);
-  KL(KID_PAIRING_POST, k_pairing_post, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), n, (const uint32_t*)d_rec, d_status);
-  return 0;
+  return launch_post(c, n, d_rec, d_status);
 }
 
 // one core_verify per item: statuses end up in d_status (device)
@@ -789,7 +806,10 @@ int run_verify_items(Ctx* c, int sg, int aug, const uint8_t* d_pks, const uint8_
       (void)hipStreamSynchronize(c->side);
       return fail(BLSGPU_E_HIP, "side-stream launch failed");
     }
-    KL(KID_PAIRING_POST, k_pairing_post, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), n, (const uint32_t*)d_rec, d_status);
+    if ((rc = launch_post(c, n, d_rec, d_status))) {
+      (void)hipStreamSynchronize(c->side);
+      return rc;
+    }
     HIPCK(hipGetLastError());
     return 0;
   }
@@ -2078,7 +2098,11 @@ static int cut_tail_finish(Ctx* c, int rc, const uint8_t* d_pk_proj, CutTail& t,
   } else {
     KL(KID_PREPARE, k_prepare_keys<2>, dim3(1), dim3(BLS_BLOCK), (size_t)1, d_pk_proj, (const uint8_t*)nullptr, (const uint8_t*)nullptr, BLSGPU_FMT_RAW_PROJ, 2,
        t.rec, t.d_status);
-    KL(KID_PAIRING_POST, k_pairing_post, dim3(1), dim3(WIDE_ENGINE_BLOCK), (size_t)1, (const uint32_t*)t.rec, t.d_status);
+    if ((rc = launch_post(c, 1, t.rec, t.d_status))) {
+      (void)hipStreamSynchronize(c->side);
+      (void)hipStreamSynchronize(c->side2);
+      return rc;
+    }
   }
   HIPCK(hipGetLastError());
   if ((rc = copy_out_and_sync(c, status, t.d_status, 4))) return rc;

@@ -331,7 +331,8 @@ __global__ void k_hash_to_g1_engine(size_t n, const uint8_t* msgs, const uint64_
 #define WREC_F1 12       // G1Impl: Miller function of (signature, -[c] g2), the pair that balances the uncleared P0 (k_pairing_pre, part 1)
 #define WREC_L 24        // pair 0's 68 unscaled lines, 6 values each (k_pairing_pre, part 0)
 #define WREC_Q1 (24 + 6 * 68)   // Bls12381G2Impl only: pair 1's G2 point (the signature), Jacobian: 6 values
-#define WREC_VALUES (WREC_Q1 + 6)
+#define WREC_F2 (WREC_Q1 + 6)    // the split Miller loop's hand-over (k_pairing_post2): the second workgroup's Fp12 accumulator
+#define WREC_VALUES (WREC_F2 + 12)
 #define WREC_WORDS (16 * WREC_VALUES)
 template <int SG>
 __global__ void k_prepare_keys(size_t n, const uint8_t* pks, const uint8_t* sigs, const uint8_t* hashes, int fmt, int parts, uint32_t* rec, int32_t* status);
@@ -347,6 +348,10 @@ __global__ void k_pairing_post(size_t n, const uint32_t* rec, int32_t* status);
 #define WSTREAM_SPIN_LIMIT (1u << 21)      // polls (~1 us each) before the consumer gives up: status BLS_ERR_STREAM_TIMEOUT
 #define BLS_ERR_STREAM_TIMEOUT (-2)        // = BLSGPU_E_HIP: a device-side failure, not a verdict
 __global__ void k_pairing_stream(size_t n, uint32_t* rec, int32_t* status, uint32_t* flags, uint32_t epoch);
+// k_pairing_post with its Miller loop on two workgroups (programs POST_LO / POST_HI: the last 41 iterations from 1 beside the first
+// 22 and 41 squarings): grid (n, 2), workgroup (i, 0) hands its accumulator to workgroup (i, 1) through the record; same flags,
+// epoch and bound on n as k_pairing_stream
+__global__ void k_pairing_post2(size_t n, uint32_t* rec, int32_t* status, uint32_t* flags, uint32_t epoch);
 // the last levels of a point sum on the engine: workgroup b <- the sum of points [16 b, 16 b + 16) (RAW_PROJ in and out)
 template <int G>
 __global__ void k_point_tree_wide(size_t m, const uint8_t* in, uint8_t* out);
@@ -3652,25 +3657,14 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_post(size_t n, co
 // chunk.  The two workgroups sit on different CUs -- as a rule on different XCDs with their own L2 -- so it is the device-scope
 // release / acquire pair (L2 write-back on one side, invalidation on the other) that makes the lines visible, not the barrier.
 // The poll is bounded: a consumer whose producer never arrives ends with BLS_ERR_STREAM_TIMEOUT instead of holding its CU.
-static_assert((WIDE_STEPS + 3) / 4 <= WSTREAM_FLAGS, "a flag per four line steps");
+static_assert((WIDE_STEPS + 3) / 4 < WSTREAM_FLAGS, "a flag per four line steps, the last one for the Fp12 hand-over");
 struct wide_stream_hook {
   wide_lds_t<wide_tb_f12>* S;
   uint32_t* r;
   uint32_t* flags;
   uint32_t epoch;
-  __device__ __forceinline__ bool operator()(uint32_t kind, uint32_t first, uint32_t count) const {
-    const int s0 = (int)first, ns = (int)count;
-    const uint32_t k = first >> 2;
-    if (kind == WOP_PUB - WOP_FPINV) {
-      for (int t = threadIdx.x; t < ns * 96; t += WIDE_ENGINE_BLOCK) {
-        const int st = s0 + t / 96, w = t % 96;
-        r[16 * WREC_L + 96 * st + w] = S->V[WV_L + 12 * st + (w >> 4)][w & 15];
-      }
-      __threadfence();
-      __syncthreads();
-      if (threadIdx.x == 0) __hip_atomic_store(flags + k, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      return true;
-    }
+  // thread 0 waits for flag k (bounded), everybody learns the outcome and fences
+  __device__ __forceinline__ bool wait_for(uint32_t k) const {
     if (threadIdx.x == 0) {
       int ok = 0;
       for (uint32_t spin = 0; spin < WSTREAM_SPIN_LIMIT; spin++) {
@@ -3685,6 +3679,37 @@ struct wide_stream_hook {
     __syncthreads();
     if (!S->hook_ok) return false;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+  }
+  // every thread's stores so far become visible device-wide, then flag k says so
+  __device__ __forceinline__ void announce(uint32_t k) const {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flags + k, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __device__ __forceinline__ bool operator()(uint32_t kind, uint32_t first, uint32_t count) const {
+    if (kind == WOP_PUBF - WOP_FPINV || kind == WOP_ACQF - WOP_FPINV) {       // an Fp12 value: array `first` of the value store <-> WREC_F2
+      const int l = (int)(threadIdx.x & 15u), v = (int)(threadIdx.x >> 4);
+      if (kind == WOP_PUBF - WOP_FPINV) {
+        if (v < 12) r[16 * (WREC_F2 + v) + l] = S->V[first + v][l];
+        announce(WSTREAM_FLAGS - 1);
+        return true;
+      }
+      if (!wait_for(WSTREAM_FLAGS - 1)) return false;
+      if (v < 12) S->V[first + v][l] = r[16 * (WREC_F2 + v) + l];
+      return true;
+    }
+    const int s0 = (int)first, ns = (int)count;
+    const uint32_t k = first >> 2;
+    if (kind == WOP_PUB - WOP_FPINV) {
+      for (int t = threadIdx.x; t < ns * 96; t += WIDE_ENGINE_BLOCK) {
+        const int st = s0 + t / 96, w = t % 96;
+        r[16 * WREC_L + 96 * st + w] = S->V[WV_L + 12 * st + (w >> 4)][w & 15];
+      }
+      announce(k);
+      return true;
+    }
+    if (!wait_for(k)) return false;
     for (int t = threadIdx.x; t < ns * 96; t += WIDE_ENGINE_BLOCK) {
       const int st = s0 + t / 96, w = t % 96;
       S->V[WV_L + 12 * st + (w >> 4)][w & 15] = r[16 * WREC_L + 96 * st + w];
@@ -3717,6 +3742,53 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_stream(size_t n, 
   if (threadIdx.x == 0) S.flag = 1;
   __syncthreads();
   if (!wide_exec(S, WIDE_PROG_POST_S_LEN, K, hook)) {
+    if (threadIdx.x == 0) status[item] = BLS_ERR_STREAM_TIMEOUT;
+    return;
+  }
+  if (threadIdx.x < 12) {
+    fp x, one;
+    w_load_local(x, S.V[WV_T + threadIdx.x]);
+    bool ok;
+    if (threadIdx.x == 0) {
+      fp_one(one);
+      ok = fp_eq(x, one);
+    } else {
+      ok = fp_is_zero(x);
+    }
+    if (!ok) S.flag = 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) status[item] = S.flag ? BLS_OK : BLS_ERR_INVALID_SIGNATURE;
+}
+
+__global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_post2(size_t n, uint32_t* rec, int32_t* status, uint32_t* flags, uint32_t epoch) {
+  __shared__ wide_lds_t<wide_tb_f12> S;
+  const size_t item = blockIdx.x;
+  if (item >= n) return;
+  if (status[item] != BLS_OK) return;                   // as in k_pairing_stream: the same in both workgroups of the item
+  wide_consts K;
+  wide_init(K);
+  uint32_t* r = rec + item * WREC_WORDS;
+  const wide_stream_hook hook = {&S, r, flags + item * WSTREAM_FLAGS, epoch};
+  const bool lo = blockIdx.y == 0;
+  if (lo) wide_stage(S, WIDE_PROG_POST_LO, WIDE_PROG_POST_LO_LEN);
+  else wide_stage(S, WIDE_PROG_POST_HI, WIDE_PROG_POST_HI_LEN);
+  const int l = (int)(threadIdx.x & 15u), v = (int)(threadIdx.x >> 4);
+  if (v < 3) S.V[WV_P + v][l] = r[16 * (WREC_P0 + v) + l];
+  if (v == 3) S.V[WV_P + 3][l] = 0u;
+  if (v >= 4) S.V[WV_F + v - 4][l] = (v == 4 && l < FP_NL) ? FP_ONE[l] : 0u;   // f = 1
+  if (!lo && v < 12) S.V[WV_W + v][l] = r[16 * (WREC_F1 + v) + l];
+  for (int t = threadIdx.x; t < WIDE_STEPS * 6 * 16; t += WIDE_ENGINE_BLOCK) {
+    const int st = t / 96, w = t % 96;
+    S.V[WV_L + 12 * st + (w >> 4)][w & 15] = r[16 * WREC_L + 96 * st + w];
+  }
+  if (threadIdx.x == 0) S.flag = 1;
+  __syncthreads();
+  if (lo) {
+    wide_exec(S, WIDE_PROG_POST_LO_LEN, K, hook);
+    return;
+  }
+  if (!wide_exec(S, WIDE_PROG_POST_HI_LEN, K, hook)) {
     if (threadIdx.x == 0) status[item] = BLS_ERR_STREAM_TIMEOUT;
     return;
   }

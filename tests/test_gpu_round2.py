@@ -611,12 +611,14 @@ def test_verify_secure_with_and_without_weighted_tables():
 
 
 @pytest.mark.gpu
-def test_streamed_and_two_launch_cut_checks_agree():
-    """The checks whose lines cannot be had early -- the summed key of MultiSignature::verify / verify_secure (Bls12381G1Impl), H(m) of
-    a Bls12381G2Impl verification -- with the lines handed from one workgroup to the other while the Miller loop runs
-    (k_pairing_stream, the default up to 64 items) and as two launches (BLSGPU_STREAM_LINES=0): the same verdicts for valid and
-    tampered inputs, at one item, at the form's upper bound and just beyond it, repeated on one context (the hand-over flags are
-    reused with a fresh value per launch).  Child processes: the knob is read once."""
+def test_streamed_split_and_plain_cut_checks_agree():
+    """The single-verdict checks in the forms that hand data between workgroups of one launch, against the plain ones: the checks whose
+    lines cannot be had early -- the summed key of MultiSignature::verify / verify_secure (Bls12381G1Impl), H(m) of a Bls12381G2Impl
+    verification -- with the lines travelling while the Miller loop runs (k_pairing_stream; BLSGPU_STREAM_LINES=0: two launches), and
+    the late part of every other cut check with its Miller loop on two workgroups (k_pairing_post2; BLSGPU_POST_SPLIT=0: one).  Both
+    are the default up to 64 items: the same verdicts for valid and tampered inputs at one item, at the forms' upper bound and just
+    beyond it, both orientations, repeated on one context (the hand-over flags are reused with a fresh value per launch).  Child
+    processes: the knobs are read once."""
     import subprocess
     import sys
     code = (
@@ -634,22 +636,29 @@ def test_streamed_and_two_launch_cut_checks_agree():
         "st, perm, ts = api.secure_coefficients(api.serialize(2, pkb))\n"
         "sagg = api.point_sum(1, [sgb[i] for i in perm], ts)\n"
         "out.append([st, api.verify_secure(1, api.BASIC, pkb, sagg, msg), api.verify_secure(1, api.BASIC, pkb[1:], sagg, msg)])\n"
-        "for m in (1, 3, 64, 65):\n"
-        "    ms = [hashlib.sha256(b'g2 item %%d' %% i).digest() for i in range(m)]\n"
-        "    pk2, sg2 = api.sign_batch(2, api.POP, sks[:m], ms)\n"
-        "    ms[m // 2] = ms[m // 2] + b'!'\n"
-        "    out.append(list(api.verify_batch(2, api.POP, pk2, sg2, ms)))\n"
+        "pk2m, sg2m = api.sign_batch(2, api.POP, sks, [msg] * n)\n"
+        "agg2 = api.point_sum(2, sg2m)\n"
+        "out.append([api.multi_verify(2, api.POP, pk2m, agg2, msg), api.multi_verify(2, api.POP, pk2m[:-1], agg2, msg)])\n"
+        "for sg in (2, 1):\n"
+        "    for m in (1, 3, 64, 65):\n"
+        "        ms = [hashlib.sha256(b'item %%d' %% i).digest() for i in range(m)]\n"
+        "        pkm, sgm = api.sign_batch(sg, api.POP, sks[:m], ms)\n"
+        "        ms[m // 2] = ms[m // 2] + b'!'\n"
+        "        out.append(list(api.verify_batch(sg, api.POP, pkm, sgm, ms)))\n"
         "print(repr(out))\n") % (util.ROOT, os.path.join(util.ROOT, 'tests'))
     res = {}
-    for name, env in (('streamed', {}), ('two_launches', {'BLSGPU_STREAM_LINES': '0'})):
+    variants = (('default', {}), ('two_launches', {'BLSGPU_STREAM_LINES': '0'}), ('one_workgroup', {'BLSGPU_POST_SPLIT': '0'}),
+                ('plain', {'BLSGPU_STREAM_LINES': '0', 'BLSGPU_POST_SPLIT': '0'}))
+    for name, env in variants:
         r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (name, r.stderr[-2000:])
         res[name] = eval(r.stdout.strip().splitlines()[-1])
-    want = [[0, 1, 1]] * 3 + [[0, 0, 1]]
-    for m in (1, 3, 64, 65):
-        want.append([1 if i == m // 2 else 0 for i in range(m)])
-    assert res['streamed'] == want
-    assert res['two_launches'] == want
+    want = [[0, 1, 1]] * 3 + [[0, 0, 1], [0, 1]]
+    for sg in (2, 1):
+        for m in (1, 3, 64, 65):
+            want.append([1 if i == m // 2 else 0 for i in range(m)])
+    for name, _ in variants:
+        assert res[name] == want, name
 
 
 @pytest.mark.gpu

@@ -115,6 +115,9 @@ def sim_program(ops, lay, steps, V, hook=None):
         if name in ('ACQ', 'PUB'):
             hook(name, d, x, V)
             continue
+        if name in ('ACQF', 'PUBF'):
+            hook(name, lay.ref(d), V)
+            continue
         op = by[name]
         base = {DST: lay.ref(d), SA: lay.ref(x), SB: lay.ref(y), TMP: lay.base['TMP'], CONST: cb}
         at = lambda i: V[base[i >> 12] + (i & 0xfff)]  # noqa: E731
@@ -215,6 +218,28 @@ def check_programs():
                 V[B['L'] + 12 * (first + j):B['L'] + 12 * (first + j) + 6] = line
         sim_program(OPS, lay, dict(PROGRAMS)['POST_S'], V5, acq)
         assert order == sorted(wire) and unflat(V5[B['T']:B['T'] + 12]) == want, 'streamed cut programs'
+        # one Miller loop on two workgroups: POST_LO accumulates the last SPLIT_AT iterations from 1 and publishes, POST_HI runs the
+        # first ones, squares SPLIT_AT times, takes the partner's value and finishes the check
+        box = {}
+        V6, V7 = [0] * lay.count, [0] * lay.count
+        for Vx in (V6, V7):
+            Vx[B['F']:B['F'] + 12] = flat(c.F12_ONE)
+            Vx[B['P']:B['P'] + 4] = V3p
+            for stp in range(NSTEPS):
+                o = B['L'] + 12 * stp
+                Vx[o:o + 6] = V1[o:o + 6]
+        V7[B['W']:B['W'] + 12] = V2[B['F']:B['F'] + 12]
+
+        def pubf(name, at, V):
+            assert name == 'PUBF' and not box
+            box['f'] = V[at:at + 12]
+
+        def acqf(name, at, V):
+            assert name == 'ACQF'
+            V[at:at + 12] = box['f']
+        sim_program(OPS, lay, dict(PROGRAMS)['POST_LO'], V6, pubf)
+        sim_program(OPS, lay, dict(PROGRAMS)['POST_HI'], V7, acqf)
+        assert unflat(V7[B['T']:B['T'] + 12]) == want, 'split Miller loop programs'
     # the fold tree's sixteen-way product
     vals = [tuple((rng.randrange(P), rng.randrange(P)) for _ in range(6)) for _ in range(16)]
     Vt = [0] * lay.count

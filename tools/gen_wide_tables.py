@@ -987,6 +987,55 @@ def prog_miller_stream():
     return st
 
 
+CONJ_F = [('CONJ', 'F', 'F', 'F')]                 # x < 0: the Miller function of |x| is conjugated once, after the product
+
+
+# One Miller loop on two workgroups (kernels.cuh k_pairing_post2): the accumulator after all iterations is (f_hi)^(2^SPLIT_AT) f_lo, f_hi the
+# accumulation over iterations 62..SPLIT_AT and f_lo the one over the last SPLIT_AT iterations started from 1 -- squaring is
+# multiplicative.  A squaring alone is half an iteration (1.9 of 3.8 us), so the first workgroup runs 22 iterations and 41 squarings
+# (~170 us) while the second runs 41 iterations (~160 us) instead of one workgroup running 63 (~250 us).
+SPLIT_AT = 41
+
+
+def miller_line_steps(i_from, i_to):
+    """(first line step, one past the last) of iterations i_from..i_to (downwards)"""
+    first = sum(2 if (X_ABS >> i) & 1 else 1 for i in range(62, i_from, -1))
+    return first, first + sum(2 if (X_ABS >> i) & 1 else 1 for i in range(i_from, i_to - 1, -1))
+
+
+def prog_miller_part(i_from, i_to):
+    """the iterations i_from..i_to of prog_miller((0,)) on the accumulator F (no squaring in the first one: F is 1 there); their
+    lines are evaluated at P0 first, in whole LSCALE0X4 / X8 pieces (a piece may reach into the neighbour's lines: harmless)"""
+    lo, hi = miller_line_steps(i_from, i_to)
+    st = []
+    s0 = lo - lo % 4
+    while s0 < hi:
+        k = 8 if hi - s0 > 4 else 4
+        assert s0 + k <= NSTEPS
+        st.append(('LSCALE0X%d' % k, ('L', 12 * s0), ('L', 12 * s0), 'P'))
+        s0 += k
+    step = lo
+    for i in range(i_from, i_to - 1, -1):
+        if i != i_from:
+            st.append(('SQR', 'F', 'F', 'F'))
+        for _ in range(2 if (X_ABS >> i) & 1 else 1):
+            st.append(('MUL_LINE', 'F', 'F', ('L', 12 * step)))
+            step += 1
+    assert step == hi
+    return st
+
+
+def prog_post_hi():
+    """first workgroup: f_hi, its SPLIT_AT squarings, then f_lo from the partner (built-in ACQF: into U) and the rest of POST"""
+    return (prog_pprep((0,)) + prog_miller_part(62, SPLIT_AT) + [('SQR', 'F', 'F', 'F')] * SPLIT_AT + [('ACQF', 'U', 0, 0), ('MUL', 'F', 'F', 'U'), ('MUL', 'F', 'F', 'W')]
+            + CONJ_F + prog_easy() + prog_final_hard())
+
+
+def prog_post_lo():
+    """second workgroup: f_lo, handed over with the built-in PUBF"""
+    return prog_pprep((0,)) + prog_miller_part(SPLIT_AT - 1, 0) + [('PUBF', 'F', 0, 0)]
+
+
 def prog_f12_inv():
     """T <- F^-1 with U = conj(F) given: F conj(F) lies in Fp6 (even coefficients); FPINV is the interpreter's one built-in, an
     inversion in Fp on a lone lane.  W is scratch."""
@@ -1024,7 +1073,6 @@ def prog_horner():
     return st + [('CONJ', 'F', 'F', 'F')]
 
 
-CONJ_F = [('CONJ', 'F', 'F', 'F')]                 # x < 0: the Miller function of |x| is conjugated once, after the product
 PROGRAMS = [('FINAL_HARD', prog_final_hard()),
             ('FINAL', prog_easy() + prog_final_hard()),              # the whole final exponentiation of a Miller product (aggregate verify)
             # core_verify of Bls12381G1Impl: pair 1's G2 argument is the constant -g2, its lines come from a table
@@ -1041,6 +1089,9 @@ PROGRAMS = [('FINAL_HARD', prog_final_hard()),
             # for the checks whose key (or H(m)) only exists when everything else is done -- the tail of a key sum, Bls12381G2Impl's hash
             ('PRE_LINES_S', prog_key_lines(0, publish=True)),
             ('POST_S', prog_pprep((0,)) + prog_miller_stream() + [('MUL', 'F', 'F', 'W')] + CONJ_F + prog_easy() + prog_final_hard()),
+            # POST with its Miller loop on two workgroups (k_pairing_post2)
+            ('POST_HI', prog_post_hi()),
+            ('POST_LO', prog_post_lo()),
             ('F12_TREE16', prog_f12_tree16()),
             ('HORNER', prog_horner())]
 
@@ -1123,6 +1174,10 @@ def emit_set(out, ops, lay, programs, prefix, vprefix, trait, has_inv):
         names.append('ACQ')
         out.append('#define WOP_PUB %d     // hand line steps [dst, dst + a) of L to the partner workgroup' % len(names))
         names.append('PUB')
+        out.append('#define WOP_ACQF %d    // wait for the partner workgroup\'s Fp12 value and copy it into array dst' % len(names))
+        names.append('ACQF')
+        out.append('#define WOP_PUBF %d    // hand the Fp12 value in array dst to the partner workgroup' % len(names))
+        names.append('PUBF')
     out.append('// value store (indices of 16-word values)')
     for k, v in lay.base.items():
         out.append('#define %s_%s %d' % (vprefix, k, v))
