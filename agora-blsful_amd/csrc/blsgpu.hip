@@ -733,10 +733,8 @@ bool launch_hash_g2_small(hipStream_t stream, size_t n, const uint8_t* d_msgs, c
   return false;
 }
 
-// Pair 0's lines and the late part of the cut check: ONE launch in which the lines travel from one workgroup to the other while
-// the Miller loop already runs (kernels.cuh k_pairing_stream) -- for up to WSTREAM_MAX_ITEMS checks whose lines have nothing to
-// hide behind; otherwise the two launches k_pairing_pre (part 0), k_pairing_post.  The flag buffer belongs to the context and
-// is written by that kernel alone, with a value per launch that no earlier launch used.
+// The hand-over flags of the kernels whose workgroups pass data to each other inside one launch (kernels.cuh k_pairing_stream,
+// k_pairing_post2): a buffer of the context that those kernels alone write, and a value per launch that no earlier launch used.
 static int stream_epoch_next(Ctx* c) {
   const size_t fb = (size_t)WSTREAM_MAX_ITEMS * WSTREAM_FLAGS * 4;
   if (!c->stream_flags) {
@@ -762,11 +760,14 @@ int launch_post(Ctx* c, size_t n, uint32_t* d_rec, int32_t* d_status) {
   KL(KID_PAIRING_POST, k_pairing_post, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), n, (const uint32_t*)d_rec, d_status);
   return 0;
 }
+// Pair 0's lines and the late part of the cut check: ONE launch in which the lines travel from one workgroup to two others while
+// the Miller loop already runs there (kernels.cuh k_pairing_stream) -- for up to WSTREAM_MAX_ITEMS checks whose lines have nothing
+// to hide behind; otherwise the launches k_pairing_pre (part 0), then the late part as above.
 int launch_lines_and_post(Ctx* c, size_t n, uint32_t* d_rec, int32_t* d_status) {
   if (knobs().stream_lines != 0 && n <= WSTREAM_MAX_ITEMS) {
     int rc = stream_epoch_next(c);
     if (rc) return rc;
-    KL(KID_PAIRING_POST, k_pairing_stream, dim3((unsigned)n, 2), dim3(WIDE_ENGINE_BLOCK), n, d_rec, d_status, c->stream_flags, c->stream_epoch);
+    KL(KID_PAIRING_POST, k_pairing_stream, dim3((unsigned)n, 3), dim3(WIDE_ENGINE_BLOCK), n, d_rec, d_status, c->stream_flags, c->stream_epoch);
     return 0;
   }
   KL(KID_PAIRING_PRE, k_pairing_pre, dim3((unsigned)n, 1), dim3(WIDE_ENGINE_BLOCK), n, d_rec, (const int32_t*)d_status, 0, 0);

@@ -339,10 +339,11 @@ __global__ void k_prepare_keys(size_t n, const uint8_t* pks, const uint8_t* sigs
 __global__ void k_pairing_pre(size_t n, uint32_t* rec, const int32_t* status, int first_part, int second_part);   // grid (n, 1 or 2): part 0 = pair 0's lines, 1 = F1 (G1Impl), 2 = F1 (G2Impl)
 __global__ void k_pairing_post(size_t n, const uint32_t* rec, int32_t* status);
 // part 0 and k_pairing_post side by side, for the checks whose lines cannot be had early (the summed key of MultiSignature::verify /
-// verify_secure, Bls12381G2Impl's H(m)): grid (n, 2), workgroup (i, 0) derives item i's lines (program PRE_LINES_S) and hands them
-// over through the record a few steps at a time (tools/gen_wide_tables.py STREAM_BOUNDS), workgroup (i, 1) runs POST_S on them as they arrive.  flags: WSTREAM_FLAGS words
-// per item in a buffer that ONLY this kernel writes; epoch: a value no earlier launch on that buffer used (never 0).  n <= WSTREAM_MAX_ITEMS:
-// both workgroups of an item must be resident together.
+// verify_secure, Bls12381G2Impl's H(m)): grid (n, 3), workgroup (i, 0) derives item i's lines (program PRE_LINES_S) and hands them
+// over through the record a few steps at a time (tools/gen_wide_tables.py STREAM_BOUNDS); workgroups (i, 1) and (i, 2) run the Miller
+// loop on them as they arrive, split as in k_pairing_post2 below (POST_LO_S: the last 27 iterations from 1; POST_HI_S: the rest of POST).  flags: WSTREAM_FLAGS words
+// per item in a buffer that ONLY these kernels write; epoch: a value no earlier launch on that buffer used (never 0).  n <= WSTREAM_MAX_ITEMS:
+// the workgroups of an item must be resident together.
 #define WSTREAM_FLAGS 32              // one per four line steps: a chunk's flag is its first step / 4
 #define WSTREAM_MAX_ITEMS 64
 #define WSTREAM_SPIN_LIMIT (1u << 21)      // polls (~1 us each) before the consumer gives up: status BLS_ERR_STREAM_TIMEOUT
@@ -3721,27 +3722,33 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_stream(size_t n, 
   __shared__ wide_lds_t<wide_tb_f12> S;
   const size_t item = blockIdx.x;
   if (item >= n) return;
-  if (status[item] != BLS_OK) return;                   // uniform over the workgroup, and the same in both workgroups of the item:
-  wide_consts K;                                        // the consumer writes the status only after the producer's last chunk
+  if (status[item] != BLS_OK) return;                   // uniform over the workgroup, and the same in all workgroups of the item:
+  wide_consts K;                                        // the last consumer writes the status only after everybody's hand-overs
   wide_init(K);
   uint32_t* r = rec + item * WREC_WORDS;
   const wide_stream_hook hook = {&S, r, flags + item * WSTREAM_FLAGS, epoch};
   const int l = (int)(threadIdx.x & 15u), v = (int)(threadIdx.x >> 4);
-  if (blockIdx.y == 0) {
+  if (blockIdx.y == 0) {                                // the producer: pair 0's lines
     wide_stage(S, WIDE_PROG_PRE_LINES_S, WIDE_PROG_PRE_LINES_S_LEN);
     if (v < 6) S.V[WV_PT0 + 6 + v][l] = r[16 * (WREC_Q0 + v) + l];      // Q, Jacobian (QPREP makes it homogeneous and sets T = Q)
     __syncthreads();
     wide_exec(S, WIDE_PROG_PRE_LINES_S_LEN, K, hook);
     return;
   }
-  wide_stage(S, WIDE_PROG_POST_S, WIDE_PROG_POST_S_LEN);
+  const bool lo = blockIdx.y == 1;                      // the Miller loop's last iterations from 1 (POST_LO_S); the other one: the rest (POST_HI_S)
+  if (lo) wide_stage(S, WIDE_PROG_POST_LO_S, WIDE_PROG_POST_LO_S_LEN);
+  else wide_stage(S, WIDE_PROG_POST_HI_S, WIDE_PROG_POST_HI_S_LEN);
   if (v < 3) S.V[WV_P + v][l] = r[16 * (WREC_P0 + v) + l];
   if (v == 3) S.V[WV_P + 3][l] = 0u;
   if (v >= 4) S.V[WV_F + v - 4][l] = (v == 4 && l < FP_NL) ? FP_ONE[l] : 0u;   // f = 1
-  if (v < 12) S.V[WV_W + v][l] = r[16 * (WREC_F1 + v) + l];
+  if (!lo && v < 12) S.V[WV_W + v][l] = r[16 * (WREC_F1 + v) + l];
   if (threadIdx.x == 0) S.flag = 1;
   __syncthreads();
-  if (!wide_exec(S, WIDE_PROG_POST_S_LEN, K, hook)) {
+  if (lo) {
+    wide_exec(S, WIDE_PROG_POST_LO_S_LEN, K, hook);     // a timeout here leaves the partner without its value: it times out in turn
+    return;
+  }
+  if (!wide_exec(S, WIDE_PROG_POST_HI_S_LEN, K, hook)) {
     if (threadIdx.x == 0) status[item] = BLS_ERR_STREAM_TIMEOUT;
     return;
   }
@@ -3760,7 +3767,6 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_stream(size_t n, 
   __syncthreads();
   if (threadIdx.x == 0) status[item] = S.flag ? BLS_OK : BLS_ERR_INVALID_SIGNATURE;
 }
-
 __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_post2(size_t n, uint32_t* rec, int32_t* status, uint32_t* flags, uint32_t epoch) {
   __shared__ wide_lds_t<wide_tb_f12> S;
   const size_t item = blockIdx.x;

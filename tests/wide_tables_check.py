@@ -206,18 +206,32 @@ def check_programs():
         assert sum(len(x) for x in wire.values()) == NSTEPS and all(f % 4 == 0 and f // 4 < 32 for f in wire)      # the device's flag index
         for stp in range(NSTEPS):
             assert V4[B['L'] + 12 * stp:B['L'] + 12 * stp + 6] == V1[B['L'] + 12 * stp:B['L'] + 12 * stp + 6], 'PRE_LINES_S = PRE_LINES'
-        V5 = [0] * lay.count
-        V5[B['F']:B['F'] + 12] = flat(c.F12_ONE)
-        V5[B['P']:B['P'] + 4] = V3p
-        V5[B['W']:B['W'] + 12] = V2[B['F']:B['F'] + 12]
+        # ... and the two consumers (the Miller loop split at SPLIT_S): each acquires exactly the chunks of its own line steps
+        V5h, V5l = [0] * lay.count, [0] * lay.count
+        for Vx in (V5h, V5l):
+            Vx[B['F']:B['F'] + 12] = flat(c.F12_ONE)
+            Vx[B['P']:B['P'] + 4] = V3p
+        V5h[B['W']:B['W'] + 12] = V2[B['F']:B['F'] + 12]
+        sbox = {}
 
-        def acq(name, first, cnt, V):
-            assert name == 'ACQ' and len(wire[first]) == cnt and first not in order, 'the consumer acquires exactly the published chunks, once'
-            order.append(first)
-            for j, line in enumerate(wire[first]):
-                V[B['L'] + 12 * (first + j):B['L'] + 12 * (first + j) + 6] = line
-        sim_program(OPS, lay, dict(PROGRAMS)['POST_S'], V5, acq)
-        assert order == sorted(wire) and unflat(V5[B['T']:B['T'] + 12]) == want, 'streamed cut programs'
+        def consumer(name, a, b, V=None):
+            if name == 'ACQ':
+                first, cnt = a, b
+                assert len(wire[first]) == cnt and first not in order, 'the consumers acquire exactly the published chunks, once'
+                order.append(first)
+                for j, line in enumerate(wire[first]):
+                    V[B['L'] + 12 * (first + j):B['L'] + 12 * (first + j) + 6] = line
+            elif name == 'PUBF':
+                assert not sbox
+                sbox['f'] = b[a:a + 12]
+            else:
+                assert name == 'ACQF'
+                b[a:a + 12] = sbox['f']
+        sim_program(OPS, lay, dict(PROGRAMS)['POST_LO_S'], V5l, consumer)
+        lo_chunks = list(order)
+        sim_program(OPS, lay, dict(PROGRAMS)['POST_HI_S'], V5h, consumer)
+        assert lo_chunks == sorted(lo_chunks) and min(lo_chunks) == g.miller_line_steps(g.SPLIT_S - 1, 0)[0]
+        assert sorted(order) == sorted(wire) and unflat(V5h[B['T']:B['T'] + 12]) == want, 'streamed cut programs'
         # one Miller loop on two workgroups: POST_LO accumulates the last SPLIT_AT iterations from 1 and publishes, POST_HI runs the
         # first ones, squares SPLIT_AT times, takes the partner's value and finishes the check
         box = {}

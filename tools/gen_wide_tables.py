@@ -905,8 +905,11 @@ def prog_final_hard():
 
 # hand-overs of the streamed cut (PUB / ACQ below): line steps [b[j-1], b[j]) travel together.  The producer makes a line in ~3.2 us,
 # the consumer uses one in ~4.4 us, both start together: a short first chunk gets the consumer going, later ones may grow as the
-# producer pulls ahead (3.2 b[j] <= 3.2 b[0] + 4.4 b[j-1]).  Multiples of four: LSCALE<p>X4 / X8 evaluate four / eight steps at once
-STREAM_BOUNDS = [4, 8, 12, 20, 32, 48, 68]
+# producer pulls ahead (3.2 b[j] <= 3.2 b[0] + 4.4 b[j-1]).  Multiples of four: LSCALE<p>X4 / X8 evaluate four / eight steps at once.
+# The Miller loop itself runs on TWO consumers (the split of prog_post_hi / prog_post_lo below, at SPLIT_S): the second one starts at
+# line step 40 and gets short chunks again from there
+STREAM_BOUNDS = [4, 8, 12, 20, 32, 40, 44, 52, 60, 68]
+SPLIT_S = 27                     # the streamed cut's own split (below): its second consumer starts when line step 40 exists
 assert STREAM_BOUNDS[-1] == NSTEPS and all(b % 4 == 0 for b in STREAM_BOUNDS)
 
 
@@ -963,12 +966,20 @@ def prog_miller(pairs=(0, 1)):
     return st
 
 
-def prog_miller_stream():
-    """prog_miller((0,)) for lines that ARRIVE while the loop runs: before the first use of a chunk of STREAM_BOUNDS the built-in ACQ
-    (first step, steps) waits for it -- the workgroup that runs prog_key_lines(0, publish=True) -- and copies it into L, LSCALE0X<n>
-    evaluates its lines at P0, then the Miller steps that use them"""
-    st, step, have = [], 0, 0
-    for i in range(62, -1, -1):
+def miller_line_steps(i_from, i_to):
+    """(first line step, one past the last) of iterations i_from..i_to (downwards)"""
+    first = sum(2 if (X_ABS >> i) & 1 else 1 for i in range(62, i_from, -1))
+    return first, first + sum(2 if (X_ABS >> i) & 1 else 1 for i in range(i_from, i_to - 1, -1))
+
+
+def prog_miller_stream(i_from=62, i_to=0):
+    """prog_miller_part(i_from, i_to) for lines that ARRIVE while the loop runs: before the first use of a chunk of STREAM_BOUNDS the
+    built-in ACQ (first step, steps) waits for it -- the workgroup that runs prog_key_lines(0, publish=True) -- and copies it into L,
+    LSCALE0X<n> evaluates its lines at P0, then the Miller steps that use them"""
+    lo, hi = miller_line_steps(i_from, i_to)
+    assert lo == 0 or lo in STREAM_BOUNDS
+    st, step, have = [], lo, lo
+    for i in range(i_from, i_to - 1, -1):
         nl = 2 if (X_ABS >> i) & 1 else 1
         while have < step + nl:
             b = min(x for x in STREAM_BOUNDS if x > have)
@@ -978,12 +989,12 @@ def prog_miller_stream():
                 assert k in (8, 4)
                 st.append(('LSCALE0X%d' % k, ('L', 12 * s0), ('L', 12 * s0), 'P'))
             have = b
-        if i != 62:
+        if i != i_from:
             st.append(('SQR', 'F', 'F', 'F'))
         for _ in range(nl):
             st.append(('MUL_LINE', 'F', 'F', ('L', 12 * step)))
             step += 1
-    assert step == NSTEPS and have == NSTEPS
+    assert step == hi and have == hi
     return st
 
 
@@ -995,12 +1006,6 @@ CONJ_F = [('CONJ', 'F', 'F', 'F')]                 # x < 0: the Miller function 
 # multiplicative.  A squaring alone is half an iteration (1.9 of 3.8 us), so the first workgroup runs 22 iterations and 41 squarings
 # (~170 us) while the second runs 41 iterations (~160 us) instead of one workgroup running 63 (~250 us).
 SPLIT_AT = 41
-
-
-def miller_line_steps(i_from, i_to):
-    """(first line step, one past the last) of iterations i_from..i_to (downwards)"""
-    first = sum(2 if (X_ABS >> i) & 1 else 1 for i in range(62, i_from, -1))
-    return first, first + sum(2 if (X_ABS >> i) & 1 else 1 for i in range(i_from, i_to - 1, -1))
 
 
 def prog_miller_part(i_from, i_to):
@@ -1085,10 +1090,13 @@ PROGRAMS = [('FINAL_HARD', prog_final_hard()),
             # Bls12381G2Impl: pair 1 is (-g1, signature): its lines come from the signature, then the same Miller function
             ('PRE_F1G', prog_key_lines(1) + prog_pprep((1,)) + prog_miller((1,))),
             ('POST', prog_pprep((0,)) + prog_miller((0,)) + [('MUL', 'F', 'F', 'W')] + CONJ_F + prog_easy() + prog_final_hard()),
-            # PRE_LINES and POST side by side on two workgroups of one launch, the lines handed over eight steps at a time (k_pairing_stream):
+            # PRE_LINES and POST side by side on workgroups of one launch, the lines handed over a few steps at a time and the Miller loop
+            # itself on two of them (k_pairing_stream):
             # for the checks whose key (or H(m)) only exists when everything else is done -- the tail of a key sum, Bls12381G2Impl's hash
             ('PRE_LINES_S', prog_key_lines(0, publish=True)),
-            ('POST_S', prog_pprep((0,)) + prog_miller_stream() + [('MUL', 'F', 'F', 'W')] + CONJ_F + prog_easy() + prog_final_hard()),
+            ('POST_HI_S', prog_pprep((0,)) + prog_miller_stream(62, SPLIT_S) + [('SQR', 'F', 'F', 'F')] * SPLIT_S
+             + [('ACQF', 'U', 0, 0), ('MUL', 'F', 'F', 'U'), ('MUL', 'F', 'F', 'W')] + CONJ_F + prog_easy() + prog_final_hard()),
+            ('POST_LO_S', prog_pprep((0,)) + prog_miller_stream(SPLIT_S - 1, 0) + [('PUBF', 'F', 0, 0)]),
             # POST with its Miller loop on two workgroups (k_pairing_post2)
             ('POST_HI', prog_post_hi()),
             ('POST_LO', prog_post_lo()),
