@@ -244,6 +244,63 @@ def test_context_pool_overlaps_callers(api):
     assert dt_short < t_long['dt']
 
 
+def test_hand_over_kernels_under_a_full_device(api):
+    """The single-verdict checks whose workgroups wait for each other inside one launch (k_pairing_post2, k_pairing_stream) while
+    another caller keeps every CU busy: a 65,536-item batch holds all wave slots and nearly all LDS, so the engine workgroups of the
+    short calls are placed one by one as room appears -- a consumer must never be resident without its producer having been
+    placed (they are the lower block indices), and no bounded wait may run out (status -2).  Three threads of short calls -- one
+    Bls12381G1Impl verification, one Bls12381G2Impl verification, a MultiSignature::verify tail -- alternate valid and tampered inputs
+    for a few seconds beside the batches; every verdict is the sequential one."""
+    import threading
+    import time
+    n = 65536
+    pks, sigs = api.sign_batch(1, api.POP, [77 + i for i in range(n)], [b'full device'] * n)
+    small = {}
+    for sg in (1, 2):
+        small[sg] = api.sign_batch(sg, api.POP, [991, 992], [b'short call', b'short call'])
+    mk, ms = api.sign_batch(1, api.POP, [3000 + i for i in range(200)], [b'tail'] * 200)
+    magg = api.point_sum(1, ms)
+    stop = time.perf_counter() + 6.0
+    bad, counts = [], {'batch': 0, 1: 0, 2: 0, 'multi': 0}
+
+    def batches():
+        while time.perf_counter() < stop:
+            st = api.verify_batch(1, api.POP, pks, sigs, [b'full device'] * n)
+            if any(st):
+                bad.append(('batch', [x for x in st if x][:3]))
+            counts['batch'] += 1
+
+    def singles(sg):
+        pk, sig = small[sg]
+        k = 0
+        while time.perf_counter() < stop:
+            want = k & 1
+            got = api.verify_batch(sg, api.POP, [pk[want]], [sig[0]], [b'short call'])[0]     # key 1 with signature 0: invalid
+            if got != want:
+                bad.append((sg, k, got))
+            k += 1
+        counts[sg] = k
+
+    def multi():
+        k = 0
+        while time.perf_counter() < stop:
+            want = k & 1
+            got = api.multi_verify(1, api.POP, mk[:200 - want], magg, b'tail')
+            if got != want:
+                bad.append(('multi', k, got))
+            k += 1
+        counts['multi'] = k
+
+    th = [threading.Thread(target=batches), threading.Thread(target=singles, args=(1,)), threading.Thread(target=singles, args=(2,)),
+          threading.Thread(target=multi)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not bad, bad[:5]
+    assert counts['batch'] >= 2 and counts[1] >= 20 and counts[2] >= 20 and counts['multi'] >= 20, counts
+
+
 # ------------------------------------------------------------------ N2: the serde_bare form of Signature<C>
 @pytest.mark.parametrize('C,sg', [(ref.G1Impl, 1), (ref.G2Impl, 2)], ids=['g1', 'g2'])
 def test_signature_serde_bare_tagged_bytes(api, C, sg):
