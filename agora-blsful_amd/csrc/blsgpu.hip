@@ -344,6 +344,19 @@ int copy_out_and_sync(Ctx* c, void* dst, const void* dsrc, size_t bytes) {
   return 0;
 }
 
+// the statuses of a call on their way to the caller.  A device-side hand-over that ran out of its bounded wait (kernels.cuh
+// BLS_ERR_STREAM_TIMEOUT, the one negative value a kernel ever writes into a status) is a failure of the CALL, not a verdict:
+// wherever the host gets to see the statuses it says so with the return code; a caller that keeps them on the device finds the
+// -2 in the item's entry (include/blsgpu.h).
+int status_out_and_sync(Ctx* c, int32_t* status, const int32_t* d_status, size_t n) {
+  int rc = copy_out_and_sync(c, status, d_status, 4 * n);
+  if (rc) return rc;
+  if (n <= WSTREAM_MAX_ITEMS && !is_device_ptr(status))
+    for (size_t i = 0; i < n; i++)
+      if (status[i] == BLS_ERR_STREAM_TIMEOUT) return fail(BLSGPU_E_HIP, "a workgroup hand-over on the device ran out of its bounded wait");
+  return 0;
+}
+
 size_t g1_size(int fmt) { return fmt == BLSGPU_FMT_RAW_PROJ ? 144 : fmt == BLSGPU_FMT_RAW_AFFINE ? 96 : 48; }
 size_t g2_size(int fmt) { return fmt == BLSGPU_FMT_RAW_PROJ ? 288 : fmt == BLSGPU_FMT_RAW_AFFINE ? 192 : 96; }
 size_t pk_size(int sg, int fmt) { return sg == 1 ? g2_size(fmt) : g1_size(fmt); }
@@ -1890,7 +1903,7 @@ int blsgpu_verify_batch(int sig_group, int scheme, const void* pks, const void* 
   rc = run_verify_items(c, sig_group, scheme == BLSGPU_SCHEME_AUG, (const uint8_t*)d_pks, (const uint8_t*)d_sigs, kfmt,
                         (const uint8_t*)d_msgs, (const uint64_t*)d_offs, 0, scheme_dst(sig_group, scheme), n, d_pairs, d_f, d_status, pre);
   if (rc) return rc;
-  if ((rc = copy_out_and_sync(c, status, d_status, 4 * n))) return rc;
+  if ((rc = status_out_and_sync(c, status, d_status, n))) return rc;
   return 0;
 }
 API_CATCH
@@ -1981,7 +1994,7 @@ int blsgpu_verify_batch_grouped(int sig_group, int scheme, const void* pks, cons
     KL(KID_COMPRESS, k_scatter_i32, dim3(blocks_for(cnt)), dim3(BLS_BLOCK), cnt, (const uint32_t*)d_idx, (const int32_t*)d_st2, d_status);
     HIPCK(hipGetLastError());
   }
-  if ((rc = copy_out_and_sync(c, status, d_status, 4 * n))) return rc;
+  if ((rc = status_out_and_sync(c, status, d_status, n))) return rc;
   return 0;
 }
 API_CATCH
@@ -2020,7 +2033,7 @@ static int verify_one_tail(Ctx* c, int sig_group, int scheme, int aug_prefix, co
                           scheme_dst(sig_group, scheme), 1, d_pairs, d_f, d_status);
   }
   if (rc) return rc;
-  if ((rc = copy_out_and_sync(c, status, d_status, 4))) return rc;
+  if ((rc = status_out_and_sync(c, status, d_status, 1))) return rc;
   return 0;
 }
 
@@ -2106,7 +2119,7 @@ static int cut_tail_finish(Ctx* c, int rc, const uint8_t* d_pk_proj, CutTail& t,
     }
   }
   HIPCK(hipGetLastError());
-  if ((rc = copy_out_and_sync(c, status, t.d_status, 4))) return rc;
+  if ((rc = status_out_and_sync(c, status, t.d_status, 1))) return rc;
   return 0;
 }
 static bool cut_tail_applies(int sig_group, int scheme) {
@@ -3016,7 +3029,7 @@ int blsgpu_pop_verify_batch(int sig_group, const void* pks, const void* proofs, 
   rc = run_verify_items(c, sig_group, 2, (const uint8_t*)d_pks, (const uint8_t*)d_sigs, fmt, (const uint8_t*)d_offs, d_offs, 1,
                         make_dst((const uint8_t*)pd, strlen(pd)), n, d_pairs, d_f, d_status);
   if (rc) return rc;
-  if ((rc = copy_out_and_sync(c, status, d_status, 4 * n))) return rc;
+  if ((rc = status_out_and_sync(c, status, d_status, n))) return rc;
   return 0;
 }
 API_CATCH
@@ -3331,7 +3344,7 @@ static int core_verify_entry(int sig_group, const dst_arg& dst, int aug, const v
   rc = run_verify_items(c, sig_group, aug, (const uint8_t*)d_pks, (const uint8_t*)d_sigs, fmt, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, 0,
                         dst, n, d_pairs, d_f, d_status);
   if (rc) return rc;
-  if ((rc = copy_out_and_sync(c, status, d_status, 4 * n))) return rc;
+  if ((rc = status_out_and_sync(c, status, d_status, n))) return rc;
   return 0;
 }
 int blsgpu_core_verify(int sig_group, const uint8_t* dst, size_t dst_len, const void* pks, const void* sigs, const uint8_t* msgs,
@@ -3368,7 +3381,7 @@ int blsgpu_core_verify_hashed(int sig_group, const void* pks, const void* sigs, 
   if (sig_group == 1) KL(KID_PREPARE, k_prepare_hashed<1>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sigs, (const uint8_t*)d_h, d_pairs, d_status, 0);
   else KL(KID_PREPARE, k_prepare_hashed<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_pks, (const uint8_t*)d_sigs, (const uint8_t*)d_h, d_pairs, d_status, 0);
   if ((rc = run_pairing2(c, n, d_pairs, d_f, d_status, sig_group == 1 ? 1 : 0))) return rc;
-  if ((rc = copy_out_and_sync(c, status, d_status, 4 * n))) return rc;
+  if ((rc = status_out_and_sync(c, status, d_status, n))) return rc;
   return 0;
 }
 API_CATCH
@@ -3425,7 +3438,7 @@ int blsgpu_sig_proof_verify_batch(int sig_group, int scheme, const void* commitm
     KL(KID_PREPARE, k_prepare_proof<2>, dim3(blocks_for(n)), dim3(BLS_BLOCK), n, (const uint8_t*)d_u, (const uint8_t*)d_v, (const uint8_t*)d_pks,
        (const uint8_t*)d_ys, fmt, (const uint8_t*)d_msgs, (const uint64_t*)d_offs, dst, d_pairs, d_status);
   if ((rc = run_pairing2(c, n, d_pairs, d_f, d_status, sig_group == 1 ? 1 : 0))) return rc;
-  if ((rc = copy_out_and_sync(c, status, d_status, 4 * n))) return rc;
+  if ((rc = status_out_and_sync(c, status, d_status, n))) return rc;
   return 0;
 }
 API_CATCH

@@ -65,7 +65,9 @@ extern "C" {
 #define BLSGPU_PROOF_IDENTITY 10     /* InvalidInputs("proof is the identity point")             sig_proof.rs:115-119 */
 #define BLSGPU_ZERO_CHALLENGE 11     /* InvalidInputs("y is the zero")                           sig_proof.rs:125-127 */
 
-/* runtime failures (< 0) */
+/* runtime failures (< 0): return codes.  One of them can also appear IN a status entry: BLSGPU_E_HIP when the device-side work of
+ * that item failed (single-verdict checks run on workgroups that wait for each other with a bound; a wait that ran out is not a
+ * verdict).  Calls whose statuses pass through host memory report it as their return code instead. */
 #define BLSGPU_E_NO_DEVICE (-1)
 #define BLSGPU_E_HIP (-2)
 #define BLSGPU_E_ARG (-3)
