@@ -1646,12 +1646,26 @@ static int bind_device(int device, int ndev) {
       e = hipHostMalloc((void**)&c->hsmall, HSMALL_BYTES, hipHostMallocDefault);
       if (e != hipSuccess) (void)hipStreamDestroy(c->stream);
     }
+    if (e == hipSuccess) {
+      // the hand-over flags of the single-verdict kernels (stream_epoch_next): here, not on first use -- an allocation inside a
+      // call costs that call a few hundred microseconds
+      const size_t fb = (size_t)WSTREAM_MAX_ITEMS * WSTREAM_FLAGS * 4;
+      e = hipMalloc((void**)&c->stream_flags, fb);
+      if (e == hipSuccess) e = hipMemset(c->stream_flags, 0, fb);
+      if (e == hipSuccess) c->stream_epoch = 1;         // cleared: the first launch publishes with 2
+      if (e != hipSuccess) {
+        if (c->stream_flags) (void)hipFree(c->stream_flags);
+        (void)hipHostFree(c->hsmall);
+        (void)hipStreamDestroy(c->stream);
+      }
+    }
     if (e != hipSuccess) {
       (void)hipGetLastError();
       delete c;
       for (Ctx* q : d->pool) {
         (void)hipStreamDestroy(q->stream);
         (void)hipHostFree(q->hsmall);
+        (void)hipFree(q->stream_flags);
         delete q;
       }
       delete d;
