@@ -351,7 +351,7 @@ int copy_out_and_sync(Ctx* c, void* dst, const void* dsrc, size_t bytes) {
 int status_out_and_sync(Ctx* c, int32_t* status, const int32_t* d_status, size_t n) {
   int rc = copy_out_and_sync(c, status, d_status, 4 * n);
   if (rc) return rc;
-  if (n <= WSTREAM_MAX_ITEMS && !is_device_ptr(status))
+  if (n <= WPOST2_MAX_ITEMS && !is_device_ptr(status))
     for (size_t i = 0; i < n; i++)
       if (status[i] == BLS_ERR_STREAM_TIMEOUT) return fail(BLSGPU_E_HIP, "a workgroup hand-over on the device ran out of its bounded wait");
   return 0;
@@ -749,7 +749,7 @@ bool launch_hash_g2_small(hipStream_t stream, size_t n, const uint8_t* d_msgs, c
 // The hand-over flags of the kernels whose workgroups pass data to each other inside one launch (kernels.cuh k_pairing_stream,
 // k_pairing_post2): a buffer of the context that those kernels alone write, and a value per launch that no earlier launch used.
 static int stream_epoch_next(Ctx* c) {
-  const size_t fb = (size_t)WSTREAM_MAX_ITEMS * WSTREAM_FLAGS * 4;
+  const size_t fb = (size_t)WPOST2_MAX_ITEMS * WSTREAM_FLAGS * 4;
   if (!c->stream_flags) {
     HIPCK(hipMalloc((void**)&c->stream_flags, fb));
     c->stream_epoch = 0;
@@ -761,10 +761,10 @@ static int stream_epoch_next(Ctx* c) {
   c->stream_epoch++;
   return 0;
 }
-// the late part of the cut check alone (its lines are in the record): for up to WSTREAM_MAX_ITEMS items with the Miller loop on two
+// the late part of the cut check alone (its lines are in the record): for up to WPOST2_MAX_ITEMS items with the Miller loop on two
 // workgroups per item (kernels.cuh k_pairing_post2)
 int launch_post(Ctx* c, size_t n, uint32_t* d_rec, int32_t* d_status) {
-  if (knobs().post_split != 0 && n <= WSTREAM_MAX_ITEMS) {
+  if (knobs().post_split != 0 && n <= WPOST2_MAX_ITEMS) {
     int rc = stream_epoch_next(c);
     if (rc) return rc;
     KL(KID_PAIRING_POST, k_pairing_post2, dim3((unsigned)n, 2), dim3(WIDE_ENGINE_BLOCK), n, d_rec, d_status, c->stream_flags, c->stream_epoch);
@@ -1649,7 +1649,7 @@ static int bind_device(int device, int ndev) {
     if (e == hipSuccess) {
       // the hand-over flags of the single-verdict kernels (stream_epoch_next): here, not on first use -- an allocation inside a
       // call costs that call a few hundred microseconds
-      const size_t fb = (size_t)WSTREAM_MAX_ITEMS * WSTREAM_FLAGS * 4;
+      const size_t fb = (size_t)WPOST2_MAX_ITEMS * WSTREAM_FLAGS * 4;
       e = hipMalloc((void**)&c->stream_flags, fb);
       if (e == hipSuccess) e = hipMemset(c->stream_flags, 0, fb);
       if (e == hipSuccess) c->stream_epoch = 1;         // cleared: the first launch publishes with 2

@@ -345,13 +345,14 @@ __global__ void k_pairing_post(size_t n, const uint32_t* rec, int32_t* status);
 // per item in a buffer that ONLY these kernels write; epoch: a value no earlier launch on that buffer used (never 0).  n <= WSTREAM_MAX_ITEMS:
 // the workgroups of an item must be resident together.
 #define WSTREAM_FLAGS 32              // one per four line steps: a chunk's flag is its first step / 4
-#define WSTREAM_MAX_ITEMS 64
+#define WSTREAM_MAX_ITEMS 64             // k_pairing_stream: three workgroups per item
+#define WPOST2_MAX_ITEMS 128            // k_pairing_post2: two per item (the flag buffer has room for this many items)
 #define WSTREAM_SPIN_LIMIT (1u << 21)      // polls (~1 us each) before the consumer gives up: status BLS_ERR_STREAM_TIMEOUT
 #define BLS_ERR_STREAM_TIMEOUT (-2)        // = BLSGPU_E_HIP: a device-side failure, not a verdict
 __global__ void k_pairing_stream(size_t n, uint32_t* rec, int32_t* status, uint32_t* flags, uint32_t epoch);
 // k_pairing_post with its Miller loop on two workgroups (programs POST_LO / POST_HI: the last 41 iterations from 1 beside the first
 // 22 and 41 squarings): grid (n, 2), workgroup (i, 0) hands its accumulator to workgroup (i, 1) through the record; same flags,
-// epoch and bound on n as k_pairing_stream
+// and epoch as k_pairing_stream; n <= WPOST2_MAX_ITEMS
 __global__ void k_pairing_post2(size_t n, uint32_t* rec, int32_t* status, uint32_t* flags, uint32_t epoch);
 // the last levels of a point sum on the engine: workgroup b <- the sum of points [16 b, 16 b + 16) (RAW_PROJ in and out)
 template <int G>

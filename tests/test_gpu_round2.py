@@ -673,8 +673,8 @@ def test_streamed_split_and_plain_cut_checks_agree():
     lines cannot be had early -- the summed key of MultiSignature::verify / verify_secure (Bls12381G1Impl), H(m) of a Bls12381G2Impl
     verification -- with the lines travelling while the Miller loop runs (k_pairing_stream; BLSGPU_STREAM_LINES=0: two launches), and
     the late part of every other cut check with its Miller loop on two workgroups (k_pairing_post2; BLSGPU_POST_SPLIT=0: one).  Both
-    are the default up to 64 items: the same verdicts for valid and tampered inputs at one item, at the forms' upper bound and just
-    beyond it, both orientations, repeated on one context (the hand-over flags are reused with a fresh value per launch).  Child
+    are the default up to 64 / 128 items: the same verdicts for valid and tampered inputs at one item, at the forms' upper bounds and just
+    beyond them, both orientations, repeated on one context (the hand-over flags are reused with a fresh value per launch).  Child
     processes: the knobs are read once."""
     import subprocess
     import sys
@@ -697,7 +697,7 @@ def test_streamed_split_and_plain_cut_checks_agree():
         "agg2 = api.point_sum(2, sg2m)\n"
         "out.append([api.multi_verify(2, api.POP, pk2m, agg2, msg), api.multi_verify(2, api.POP, pk2m[:-1], agg2, msg)])\n"
         "for sg in (2, 1):\n"
-        "    for m in (1, 3, 64, 65):\n"
+        "    for m in (1, 3, 64, 65, 128, 129):\n"
         "        ms = [hashlib.sha256(b'item %%d' %% i).digest() for i in range(m)]\n"
         "        pkm, sgm = api.sign_batch(sg, api.POP, sks[:m], ms)\n"
         "        ms[m // 2] = ms[m // 2] + b'!'\n"
@@ -712,7 +712,7 @@ def test_streamed_split_and_plain_cut_checks_agree():
         res[name] = eval(r.stdout.strip().splitlines()[-1])
     want = [[0, 1, 1]] * 3 + [[0, 0, 1], [0, 1]]
     for sg in (2, 1):
-        for m in (1, 3, 64, 65):
+        for m in (1, 3, 64, 65, 128, 129):
             want.append([1 if i == m // 2 else 0 for i in range(m)])
     for name, _ in variants:
         assert res[name] == want, name
