@@ -155,7 +155,7 @@ struct Knobs {
   long msm_c = 0, msm_ch = 0, msm2_c = 0, msm2_ch = 0, msm2_q = 0;          // 0: the library's own choice
   long msm2_tables = 1;       // verify_secure: weighted window tables of every key, built while the host hashes (0: off)
   long stream_lines = 1;      // a check whose lines cannot be had early runs them BESIDE its Miller loop (k_pairing_stream; 0: two launches)
-  long post_split = 1;        // the late part of a cut check runs its Miller loop on two workgroups (k_pairing_post2; 0: one)
+  long post_split = 3;        // the late part of a cut check runs its Miller loop on this many workgroups (k_pairing_post2: 3, 2; 0 or 1: one)
   long host_trace = 0, strict_env = 0, ab_knobs = 0;
   long ws_keep_mb = 4096;     // a context's line workspace above this many MiB is released when the call that grew it returns
   // A/B
@@ -172,7 +172,7 @@ const KnobSpec KNOB_TABLE[] = {
     {"BLSGPU_MSM2_C", &Knobs::msm2_c, 4, 16, false},                    {"BLSGPU_MSM2_CH", &Knobs::msm2_ch, 1, 1 << 16, false},
     {"BLSGPU_MSM2_Q", &Knobs::msm2_q, 1, 8, false},                     {"BLSGPU_HOST_TRACE", &Knobs::host_trace, 0, 1, false},
     {"BLSGPU_WS_KEEP_MB", &Knobs::ws_keep_mb, 0, 1L << 20, false},        {"BLSGPU_MSM2_TABLES", &Knobs::msm2_tables, 0, 1, false},
-    {"BLSGPU_STREAM_LINES", &Knobs::stream_lines, 0, 1, false},        {"BLSGPU_POST_SPLIT", &Knobs::post_split, 0, 1, false},
+    {"BLSGPU_STREAM_LINES", &Knobs::stream_lines, 0, 1, false},        {"BLSGPU_POST_SPLIT", &Knobs::post_split, 0, 3, false},
     {"BLSGPU_STRICT_ENV", &Knobs::strict_env, 0, 1, false},             {"BLSGPU_AB_KNOBS", &Knobs::ab_knobs, 0, 1, false},
     {"BLSGPU_MILLER_CHUNK", &Knobs::miller_chunk, 0, 65536, true},      {"BLSGPU_MILLER_V1", &Knobs::miller_v1, 0, 1, true},
     {"BLSGPU_ROW_PAD", &Knobs::row_pad, 0, 4096, true},                 {"BLSGPU_WIDE_MODE", &Knobs::wide_mode, 1, 2, true},
@@ -764,10 +764,12 @@ static int stream_epoch_next(Ctx* c) {
 // the late part of the cut check alone (its lines are in the record): for up to WPOST2_MAX_ITEMS items with the Miller loop on two
 // workgroups per item (kernels.cuh k_pairing_post2)
 int launch_post(Ctx* c, size_t n, uint32_t* d_rec, int32_t* d_status) {
-  if (knobs().post_split != 0 && n <= WPOST2_MAX_ITEMS) {
+  if (knobs().post_split >= 2 && n <= WPOST2_MAX_ITEMS) {
     int rc = stream_epoch_next(c);
     if (rc) return rc;
-    KL(KID_PAIRING_POST, k_pairing_post2, dim3((unsigned)n, 2), dim3(WIDE_ENGINE_BLOCK), n, d_rec, d_status, c->stream_flags, c->stream_epoch);
+    // three workgroups per item while every item can have three CUs at once, two up to WPOST2_MAX_ITEMS
+    const unsigned parts = (knobs().post_split >= 3 && n <= WSTREAM_MAX_ITEMS) ? 3u : 2u;
+    KL(KID_PAIRING_POST, k_pairing_post2, dim3((unsigned)n, parts), dim3(WIDE_ENGINE_BLOCK), n, d_rec, d_status, c->stream_flags, c->stream_epoch);
     return 0;
   }
   KL(KID_PAIRING_POST, k_pairing_post, dim3((unsigned)n), dim3(WIDE_ENGINE_BLOCK), n, (const uint32_t*)d_rec, d_status);

@@ -331,8 +331,9 @@ __global__ void k_hash_to_g1_engine(size_t n, const uint8_t* msgs, const uint64_
 #define WREC_F1 12       // G1Impl: Miller function of (signature, -[c] g2), the pair that balances the uncleared P0 (k_pairing_pre, part 1)
 #define WREC_L 24        // pair 0's 68 unscaled lines, 6 values each (k_pairing_pre, part 0)
 #define WREC_Q1 (24 + 6 * 68)   // Bls12381G2Impl only: pair 1's G2 point (the signature), Jacobian: 6 values
-#define WREC_F2 (WREC_Q1 + 6)    // the split Miller loop's hand-over (k_pairing_post2): the second workgroup's Fp12 accumulator
-#define WREC_VALUES (WREC_F2 + 12)
+#define WREC_F2 (WREC_Q1 + 6)    // the split Miller loop's hand-over slots (k_pairing_post2, k_pairing_stream): the later parts' Fp12 values, 12 each
+#define WREC_F2_SLOTS 2
+#define WREC_VALUES (WREC_F2 + 12 * WREC_F2_SLOTS)
 #define WREC_WORDS (16 * WREC_VALUES)
 template <int SG>
 __global__ void k_prepare_keys(size_t n, const uint8_t* pks, const uint8_t* sigs, const uint8_t* hashes, int fmt, int parts, uint32_t* rec, int32_t* status);
@@ -350,9 +351,10 @@ __global__ void k_pairing_post(size_t n, const uint32_t* rec, int32_t* status);
 #define WSTREAM_SPIN_LIMIT (1u << 21)      // polls (~1 us each) before the consumer gives up: status BLS_ERR_STREAM_TIMEOUT
 #define BLS_ERR_STREAM_TIMEOUT (-2)        // = BLSGPU_E_HIP: a device-side failure, not a verdict
 __global__ void k_pairing_stream(size_t n, uint32_t* rec, int32_t* status, uint32_t* flags, uint32_t epoch);
-// k_pairing_post with its Miller loop on two workgroups (programs POST_LO / POST_HI: the last 41 iterations from 1 beside the first
-// 22 and 41 squarings): grid (n, 2), workgroup (i, 0) hands its accumulator to workgroup (i, 1) through the record; same flags,
-// and epoch as k_pairing_stream; n <= WPOST2_MAX_ITEMS
+// k_pairing_post with its Miller loop on two or three workgroups: grid (n, 2) -- programs POST_LO / POST_HI, the last 41 iterations
+// from 1 beside the first 22 and 41 squarings -- or grid (n, 3) -- POST3_LO / POST3_MID / POST3_HI: 36 iterations, 18 and 36 squarings, 9
+// and 54 --; the workgroups with the lower block indices hand their accumulators to the last one through the record; same flags
+// and epoch as k_pairing_stream; n <= WPOST2_MAX_ITEMS (grid (n, 3): WSTREAM_MAX_ITEMS)
 __global__ void k_pairing_post2(size_t n, uint32_t* rec, int32_t* status, uint32_t* flags, uint32_t epoch);
 // the last levels of a point sum on the engine: workgroup b <- the sum of points [16 b, 16 b + 16) (RAW_PROJ in and out)
 template <int G>
@@ -3659,7 +3661,7 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_post(size_t n, co
 // chunk.  The two workgroups sit on different CUs -- as a rule on different XCDs with their own L2 -- so it is the device-scope
 // release / acquire pair (L2 write-back on one side, invalidation on the other) that makes the lines visible, not the barrier.
 // The poll is bounded: a consumer whose producer never arrives ends with BLS_ERR_STREAM_TIMEOUT instead of holding its CU.
-static_assert((WIDE_STEPS + 3) / 4 < WSTREAM_FLAGS, "a flag per four line steps, the last one for the Fp12 hand-over");
+static_assert((WIDE_STEPS + 3) / 4 + WREC_F2_SLOTS <= WSTREAM_FLAGS, "a flag per four line steps, the last ones for the Fp12 hand-over slots");
 struct wide_stream_hook {
   wide_lds_t<wide_tb_f12>* S;
   uint32_t* r;
@@ -3690,15 +3692,16 @@ struct wide_stream_hook {
     if (threadIdx.x == 0) __hip_atomic_store(flags + k, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
   __device__ __forceinline__ bool operator()(uint32_t kind, uint32_t first, uint32_t count) const {
-    if (kind == WOP_PUBF - WOP_FPINV || kind == WOP_ACQF - WOP_FPINV) {       // an Fp12 value: array `first` of the value store <-> WREC_F2
+    if (kind == WOP_PUBF - WOP_FPINV || kind == WOP_ACQF - WOP_FPINV) {       // an Fp12 value: array `first` of the value store <-> hand-over slot `count`
       const int l = (int)(threadIdx.x & 15u), v = (int)(threadIdx.x >> 4);
+      const uint32_t slot = count < WREC_F2_SLOTS ? count : 0u, at = 16 * (WREC_F2 + 12 * slot), k = WSTREAM_FLAGS - 1 - slot;
       if (kind == WOP_PUBF - WOP_FPINV) {
-        if (v < 12) r[16 * (WREC_F2 + v) + l] = S->V[first + v][l];
-        announce(WSTREAM_FLAGS - 1);
+        if (v < 12) r[at + 16 * v + l] = S->V[first + v][l];
+        announce(k);
         return true;
       }
-      if (!wait_for(WSTREAM_FLAGS - 1)) return false;
-      if (v < 12) S->V[first + v][l] = r[16 * (WREC_F2 + v) + l];
+      if (!wait_for(k)) return false;
+      if (v < 12) S->V[first + v][l] = r[at + 16 * v + l];
       return true;
     }
     const int s0 = (int)first, ns = (int)count;
@@ -3772,30 +3775,39 @@ __global__ void __launch_bounds__(WIDE_ENGINE_BLOCK) k_pairing_post2(size_t n, u
   __shared__ wide_lds_t<wide_tb_f12> S;
   const size_t item = blockIdx.x;
   if (item >= n) return;
-  if (status[item] != BLS_OK) return;                   // as in k_pairing_stream: the same in both workgroups of the item
+  if (status[item] != BLS_OK) return;                   // as in k_pairing_stream: the same in all workgroups of the item
   wide_consts K;
   wide_init(K);
   uint32_t* r = rec + item * WREC_WORDS;
   const wide_stream_hook hook = {&S, r, flags + item * WSTREAM_FLAGS, epoch};
-  const bool lo = blockIdx.y == 0;
-  if (lo) wide_stage(S, WIDE_PROG_POST_LO, WIDE_PROG_POST_LO_LEN);
-  else wide_stage(S, WIDE_PROG_POST_HI, WIDE_PROG_POST_HI_LEN);
+  // gridDim.y = 2 or 3 workgroups per item; the LAST block index is part 0 (it waits for the others, which are placed first)
+  const int part = (int)(gridDim.y - 1 - blockIdx.y);
+  const uint32_t* prog;
+  int len;
+  if (gridDim.y == 3) {
+    prog = part == 0 ? WIDE_PROG_POST3_HI : (part == 1 ? WIDE_PROG_POST3_MID : WIDE_PROG_POST3_LO);
+    len = part == 0 ? WIDE_PROG_POST3_HI_LEN : (part == 1 ? WIDE_PROG_POST3_MID_LEN : WIDE_PROG_POST3_LO_LEN);
+  } else {
+    prog = part == 0 ? WIDE_PROG_POST_HI : WIDE_PROG_POST_LO;
+    len = part == 0 ? WIDE_PROG_POST_HI_LEN : WIDE_PROG_POST_LO_LEN;
+  }
+  wide_stage(S, prog, len);
   const int l = (int)(threadIdx.x & 15u), v = (int)(threadIdx.x >> 4);
   if (v < 3) S.V[WV_P + v][l] = r[16 * (WREC_P0 + v) + l];
   if (v == 3) S.V[WV_P + 3][l] = 0u;
   if (v >= 4) S.V[WV_F + v - 4][l] = (v == 4 && l < FP_NL) ? FP_ONE[l] : 0u;   // f = 1
-  if (!lo && v < 12) S.V[WV_W + v][l] = r[16 * (WREC_F1 + v) + l];
+  if (part == 0 && v < 12) S.V[WV_W + v][l] = r[16 * (WREC_F1 + v) + l];
   for (int t = threadIdx.x; t < WIDE_STEPS * 6 * 16; t += WIDE_ENGINE_BLOCK) {
     const int st = t / 96, w = t % 96;
     S.V[WV_L + 12 * st + (w >> 4)][w & 15] = r[16 * WREC_L + 96 * st + w];
   }
   if (threadIdx.x == 0) S.flag = 1;
   __syncthreads();
-  if (lo) {
-    wide_exec(S, WIDE_PROG_POST_LO_LEN, K, hook);
+  if (part != 0) {
+    wide_exec(S, len, K, hook);
     return;
   }
-  if (!wide_exec(S, WIDE_PROG_POST_HI_LEN, K, hook)) {
+  if (!wide_exec(S, len, K, hook)) {
     if (threadIdx.x == 0) status[item] = BLS_ERR_STREAM_TIMEOUT;
     return;
   }

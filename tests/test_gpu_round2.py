@@ -672,7 +672,7 @@ def test_streamed_split_and_plain_cut_checks_agree():
     """The single-verdict checks in the forms that hand data between workgroups of one launch, against the plain ones: the checks whose
     lines cannot be had early -- the summed key of MultiSignature::verify / verify_secure (Bls12381G1Impl), H(m) of a Bls12381G2Impl
     verification -- with the lines travelling while the Miller loop runs (k_pairing_stream; BLSGPU_STREAM_LINES=0: two launches), and
-    the late part of every other cut check with its Miller loop on two workgroups (k_pairing_post2; BLSGPU_POST_SPLIT=0: one).  Both
+    the late part of every other cut check with its Miller loop on three or two workgroups (k_pairing_post2; BLSGPU_POST_SPLIT=2: two, 0: one).  Both
     are the default up to 64 / 128 items: the same verdicts for valid and tampered inputs at one item, at the forms' upper bounds and just
     beyond them, both orientations, repeated on one context (the hand-over flags are reused with a fresh value per launch).  Child
     processes: the knobs are read once."""
@@ -704,8 +704,8 @@ def test_streamed_split_and_plain_cut_checks_agree():
         "        out.append(list(api.verify_batch(sg, api.POP, pkm, sgm, ms)))\n"
         "print(repr(out))\n") % (util.ROOT, os.path.join(util.ROOT, 'tests'))
     res = {}
-    variants = (('default', {}), ('two_launches', {'BLSGPU_STREAM_LINES': '0'}), ('one_workgroup', {'BLSGPU_POST_SPLIT': '0'}),
-                ('plain', {'BLSGPU_STREAM_LINES': '0', 'BLSGPU_POST_SPLIT': '0'}))
+    variants = (('default', {}), ('two_launches', {'BLSGPU_STREAM_LINES': '0'}), ('two_workgroups', {'BLSGPU_POST_SPLIT': '2'}),
+                ('one_workgroup', {'BLSGPU_POST_SPLIT': '0'}), ('plain', {'BLSGPU_STREAM_LINES': '0', 'BLSGPU_POST_SPLIT': '0'}))
     for name, env in variants:
         r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (name, r.stderr[-2000:])

@@ -116,7 +116,7 @@ def sim_program(ops, lay, steps, V, hook=None):
             hook(name, d, x, V)
             continue
         if name in ('ACQF', 'PUBF'):
-            hook(name, lay.ref(d), V)
+            hook(name, lay.ref(d), V, x) if name in getattr(hook, 'slots', ()) else hook(name, lay.ref(d), V)
             continue
         op = by[name]
         base = {DST: lay.ref(d), SA: lay.ref(x), SB: lay.ref(y), TMP: lay.base['TMP'], CONST: cb}
@@ -232,28 +232,33 @@ def check_programs():
         sim_program(OPS, lay, dict(PROGRAMS)['POST_HI_S'], V5h, consumer)
         assert lo_chunks == sorted(lo_chunks) and min(lo_chunks) == g.miller_line_steps(g.SPLIT_S - 1, 0)[0]
         assert sorted(order) == sorted(wire) and unflat(V5h[B['T']:B['T'] + 12]) == want, 'streamed cut programs'
-        # one Miller loop on two workgroups: POST_LO accumulates the last SPLIT_AT iterations from 1 and publishes, POST_HI runs the
-        # first ones, squares SPLIT_AT times, takes the partner's value and finishes the check
-        box = {}
-        V6, V7 = [0] * lay.count, [0] * lay.count
-        for Vx in (V6, V7):
-            Vx[B['F']:B['F'] + 12] = flat(c.F12_ONE)
-            Vx[B['P']:B['P'] + 4] = V3p
-            for stp in range(NSTEPS):
-                o = B['L'] + 12 * stp
-                Vx[o:o + 6] = V1[o:o + 6]
-        V7[B['W']:B['W'] + 12] = V2[B['F']:B['F'] + 12]
+        # one Miller loop on two or three workgroups: the later parts accumulate their iterations from 1, square and publish; the first
+        # part takes their values from the hand-over slots and finishes the check
+        for names in (('POST_HI', 'POST_LO'), ('POST3_HI', 'POST3_MID', 'POST3_LO')):
+            box = {}
 
-        def pubf(name, at, V):
-            assert name == 'PUBF' and not box
-            box['f'] = V[at:at + 12]
-
-        def acqf(name, at, V):
-            assert name == 'ACQF'
-            V[at:at + 12] = box['f']
-        sim_program(OPS, lay, dict(PROGRAMS)['POST_LO'], V6, pubf)
-        sim_program(OPS, lay, dict(PROGRAMS)['POST_HI'], V7, acqf)
-        assert unflat(V7[B['T']:B['T'] + 12]) == want, 'split Miller loop programs'
+            def handover(name, at, V, slot):
+                if name == 'PUBF':
+                    assert slot not in box
+                    box[slot] = V[at:at + 12]
+                else:
+                    V[at:at + 12] = box.pop(slot)
+            handover.slots = ('ACQF', 'PUBF')
+            stores = []
+            for nm in names:
+                Vx = [0] * lay.count
+                Vx[B['F']:B['F'] + 12] = flat(c.F12_ONE)
+                Vx[B['P']:B['P'] + 4] = V3p
+                for stp in range(NSTEPS):
+                    o = B['L'] + 12 * stp
+                    Vx[o:o + 6] = V1[o:o + 6]
+                stores.append(Vx)
+            stores[0][B['W']:B['W'] + 12] = V2[B['F']:B['F'] + 12]
+            for nm, Vx in list(zip(names, stores))[:0:-1]:
+                sim_program(OPS, lay, dict(PROGRAMS)[nm], Vx, handover)
+            assert sorted(box) == list(range(len(names) - 1)), 'every later part publishes into its own slot'
+            sim_program(OPS, lay, dict(PROGRAMS)[names[0]], stores[0], handover)
+            assert not box and unflat(stores[0][B['T']:B['T'] + 12]) == want, 'split Miller loop programs %s' % names[0]
     # the fold tree's sixteen-way product
     vals = [tuple((rng.randrange(P), rng.randrange(P)) for _ in range(6)) for _ in range(16)]
     Vt = [0] * lay.count

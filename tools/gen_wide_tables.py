@@ -1004,7 +1004,8 @@ CONJ_F = [('CONJ', 'F', 'F', 'F')]                 # x < 0: the Miller function 
 # One Miller loop on two workgroups (kernels.cuh k_pairing_post2): the accumulator after all iterations is (f_hi)^(2^SPLIT_AT) f_lo, f_hi the
 # accumulation over iterations 62..SPLIT_AT and f_lo the one over the last SPLIT_AT iterations started from 1 -- squaring is
 # multiplicative.  A squaring alone is half an iteration (1.9 of 3.8 us), so the first workgroup runs 22 iterations and 41 squarings
-# (~170 us) while the second runs 41 iterations (~160 us) instead of one workgroup running 63 (~250 us).
+# (~170 us) while the second runs 41 iterations (~160 us) instead of one workgroup running 63 (~250 us); three workgroups (SPLIT3 below)
+# come to ~140 us, and with more the squarings alone (63 x 2 us) are the floor.
 SPLIT_AT = 41
 
 
@@ -1030,15 +1031,21 @@ def prog_miller_part(i_from, i_to):
     return st
 
 
-def prog_post_hi():
-    """first workgroup: f_hi, its SPLIT_AT squarings, then f_lo from the partner (built-in ACQF: into U) and the rest of POST"""
-    return (prog_pprep((0,)) + prog_miller_part(62, SPLIT_AT) + [('SQR', 'F', 'F', 'F')] * SPLIT_AT + [('ACQF', 'U', 0, 0), ('MUL', 'F', 'F', 'U'), ('MUL', 'F', 'F', 'W')]
-            + CONJ_F + prog_easy() + prog_final_hard())
+SPLIT3 = (54, 36)                # the same on three workgroups: 9 iterations and 54 squarings, 18 and 36, 36 (~140 us each)
 
 
-def prog_post_lo():
-    """second workgroup: f_lo, handed over with the built-in PUBF"""
-    return prog_pprep((0,)) + prog_miller_part(SPLIT_AT - 1, 0) + [('PUBF', 'F', 0, 0)]
+def prog_post_part(points, part):
+    """POST with its Miller loop cut at the iterations `points` (descending): part k runs iterations b[k] - 1 .. b[k + 1] of b = [63] + points
+    + [0] on an accumulator started from 1 and squares b[k + 1] more times (the product of the parts is the whole loop's value).  Part 0
+    then takes the other parts' values from its partners (built-in ACQF slot -> U) and goes on with the rest of POST; the others hand
+    theirs over (built-in PUBF, slot = part - 1)"""
+    b = [63] + list(points) + [0]
+    st = prog_pprep((0,)) + prog_miller_part(b[part] - 1, b[part + 1]) + [('SQR', 'F', 'F', 'F')] * b[part + 1]
+    if part:
+        return st + [('PUBF', 'F', part - 1, 0)]
+    for slot in range(len(points)):
+        st += [('ACQF', 'U', slot, 0), ('MUL', 'F', 'F', 'U')]
+    return st + [('MUL', 'F', 'F', 'W')] + CONJ_F + prog_easy() + prog_final_hard()
 
 
 def prog_f12_inv():
@@ -1098,8 +1105,12 @@ PROGRAMS = [('FINAL_HARD', prog_final_hard()),
              + [('ACQF', 'U', 0, 0), ('MUL', 'F', 'F', 'U'), ('MUL', 'F', 'F', 'W')] + CONJ_F + prog_easy() + prog_final_hard()),
             ('POST_LO_S', prog_pprep((0,)) + prog_miller_stream(SPLIT_S - 1, 0) + [('PUBF', 'F', 0, 0)]),
             # POST with its Miller loop on two workgroups (k_pairing_post2)
-            ('POST_HI', prog_post_hi()),
-            ('POST_LO', prog_post_lo()),
+            ('POST_HI', prog_post_part((SPLIT_AT,), 0)),
+            ('POST_LO', prog_post_part((SPLIT_AT,), 1)),
+            # ... and on three (the default while a batch leaves every item three CUs)
+            ('POST3_HI', prog_post_part(SPLIT3, 0)),
+            ('POST3_MID', prog_post_part(SPLIT3, 1)),
+            ('POST3_LO', prog_post_part(SPLIT3, 2)),
             ('F12_TREE16', prog_f12_tree16()),
             ('HORNER', prog_horner())]
 
@@ -1182,9 +1193,9 @@ def emit_set(out, ops, lay, programs, prefix, vprefix, trait, has_inv):
         names.append('ACQ')
         out.append('#define WOP_PUB %d     // hand line steps [dst, dst + a) of L to the partner workgroup' % len(names))
         names.append('PUB')
-        out.append('#define WOP_ACQF %d    // wait for the partner workgroup\'s Fp12 value and copy it into array dst' % len(names))
+        out.append('#define WOP_ACQF %d    // wait for the Fp12 value in hand-over slot a of a partner workgroup and copy it into array dst' % len(names))
         names.append('ACQF')
-        out.append('#define WOP_PUBF %d    // hand the Fp12 value in array dst to the partner workgroup' % len(names))
+        out.append('#define WOP_PUBF %d    // hand the Fp12 value in array dst to the partner workgroup through hand-over slot a' % len(names))
         names.append('PUBF')
     out.append('// value store (indices of 16-word values)')
     for k, v in lay.base.items():
